@@ -1,0 +1,245 @@
+/* jatts_hip.h -- C ABI of libjatts_hip.so: the MI355X (gfx950) kernels behind the
+ * jatts stage-4 hot path (text2mel `model.inference` + HiFi-GAN `Vocoder.decode`).
+ *
+ * The reference (unilight/jatts) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md §8b); each entry point below names the reference code whose arithmetic
+ * it replaces (paths under /root/reference/jatts/).  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; every pointer is DEVICE memory owned
+ *    by the caller unless marked HOST.  No allocation, no ownership transfer.
+ *  - All launches are asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - Return 0 on success, negative on error; jatts_last_error() gives the text.
+ *  - Activations are packed ragged, time-major: X[row][ld] where sequence b owns rows
+ *    cu_rows[b]*len_mul .. cu_rows[b+1]*len_mul-1.  cu_rows has n_seq+1 int32 entries.
+ *    `max_len` is the HOST-known max of (cu_rows[b+1]-cu_rows[b]) and only sizes grids.
+ *  - dtype: JATTS_F16 = f16 operands on v_mfma_f32_32x32x16_f16 with f32 accumulate
+ *    (fast mode); JATTS_F32 = f32 operands on v_mfma_f32_32x32x2_f32 (exact-f32 parity
+ *    mode).  Biases, residual streams and reductions are always f32.
+ */
+#ifndef JATTS_HIP_H_
+#define JATTS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JATTS_ABI_VERSION 1
+
+#define JATTS_F32 0
+#define JATTS_F16 1
+
+#define JATTS_ACT_NONE 0
+#define JATTS_ACT_RELU 1
+#define JATTS_ACT_TANH 2
+#define JATTS_ACT_SWISH 3
+
+#define JATTS_PRE_NONE 0
+#define JATTS_PRE_LRELU 1
+
+#define JATTS_OK 0
+#define JATTS_ERR_ARG (-1)
+#define JATTS_ERR_HIP (-2)
+#define JATTS_ERR_UNSUPPORTED (-3)
+
+int jatts_abi_version(void);
+const char* jatts_last_error(void);
+/* Device name / arch string of the current device (HOST buffer). */
+int jatts_device_info(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------
+ * Ragged geometry shared by the sequence kernels.
+ * ------------------------------------------------------------------------------- */
+typedef struct jatts_ragged {
+  const int32_t* cu_rows; /* device, n_seq+1 */
+  int32_t n_seq;
+  int32_t max_len; /* host-known max base length */
+  int32_t len_mul; /* rows per base row (HiFi-GAN stage rate); 1 elsewhere */
+} jatts_ragged;
+
+/* ---------------------------------------------------------------------------------
+ * Conv1d / Linear as MFMA implicit GEMM.
+ * Replaces torch.nn.Conv1d / Linear / ConvTranspose1d call sites on the path:
+ *   modules/transformer/multi_layer_conv.py:52-63 (FFN w_1/w_2),
+ *   modules/transformer/attention.py:39-61,93,184 (linear_q/k/v/out/pos),
+ *   modules/conformer/convolution.py:66,77 (pointwise convs),
+ *   modules/duration_predictor.py:78-84, variance_predictor.py:75-80 (predictor convs),
+ *   models/fastspeech2.py:641 (feat_out), modules/pre_postnets.py:183-185 (postnet),
+ *   parallel_wavegan HiFiGANGenerator input_conv / upsamples (vocoder.py:64).
+ *
+ *   y[t, n] = resid[t, n] + alpha * act( bias[n] + sum_{tap, c} W[n, tap, c] *
+ *                                pre( in_scale * sum_i x_i[t + tap*dil - pad, c] ) )
+ * with rows outside the sequence reading as zero.  W is given in MFMA fragment order
+ * (jatts_conv_weight_index).  c_in must be a multiple of 16.
+ * ------------------------------------------------------------------------------- */
+typedef struct jatts_conv_desc {
+  jatts_ragged rg;
+  int32_t dtype;       /* operand type of x_i and w */
+  int32_t n_in;        /* 1..3 inputs summed */
+  const void* x[3];    /* [rows][ldx] */
+  int32_t ldx;
+  float in_scale;
+  int32_t pre_act;     /* JATTS_PRE_* applied while staging */
+  float pre_slope;
+  const void* w;       /* packed weights */
+  int32_t c_in;        /* multiple of 16 */
+  int32_t n_out;       /* true output channels (packed rows = round_up(n_out, 32)) */
+  int32_t k_w;         /* taps */
+  int32_t dil;
+  int32_t pad;         /* input offset: tap 0 reads row t - pad */
+  const float* bias;   /* [n_out] or NULL */
+  int32_t act;         /* JATTS_ACT_* */
+  float alpha;
+  const float* resid;  /* f32 [rows][ldr] or NULL */
+  int32_t ldr;
+  void* y;             /* [rows][ldy] (or [n][ldy] when y_transposed) */
+  int32_t ldy;
+  int32_t y_is_f32;    /* 1: y is f32 regardless of dtype */
+  int32_t y_transposed;/* 1: y[n*ldy + row] (used for V^T) */
+} jatts_conv_desc;
+
+int jatts_conv1d(const jatts_conv_desc* d, void* stream);
+
+/* Index of W[n][tap][c] inside the packed buffer (HOST helper, pure function):
+ * fragments ordered [tap][c/16][n/32][lane = 32*((c%16)/8) + n%32][c%8].
+ * n_pad = round_up(n_out, 32). */
+int64_t jatts_conv_weight_index(int32_t n, int32_t tap, int32_t c, int32_t n_pad, int32_t c_in);
+
+/* ---------------------------------------------------------------------------------
+ * HiFi-GAN ResBlock dilation unit, fused (the dominant kernel):
+ *   y = x + conv_k,1( lrelu( conv_k,d( lrelu(x) ) + b1 ) ) + b2
+ * parallel_wavegan.layers.HiFiGANResidualBlock.forward [third party; call site
+ * jatts/vocoder/vocoder.py:64].  x, y: [rows][channels]; w1/w2 packed as above with
+ * c_in = n_out = channels.  y must not alias x.  Optional MRF accumulation:
+ * acc_mode 1: acc = y, 2: acc += y (f32 [rows][channels]).
+ * channels in {32, 64, 128, 256, 512}.
+ * ------------------------------------------------------------------------------- */
+typedef struct jatts_resunit_desc {
+  jatts_ragged rg;
+  int32_t dtype;
+  int32_t channels;
+  int32_t k_w;
+  int32_t dil;
+  float slope;
+  const void* x;
+  void* y;
+  const void* w1;
+  const float* b1;
+  const void* w2;
+  const float* b2;
+} jatts_resunit_desc;
+
+int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);
+
+/* Output stage: y[t] = tanh( b + sum_{tap,c} w[tap][c] * lrelu( in_scale * sum_i x_i[t+tap-pad][c] ) )
+ * (HiFiGANGenerator.output_conv: LeakyReLU(0.01) -> Conv1d(C,1,k) -> Tanh).  w: f32 [k_w][c_in]. */
+int jatts_hifigan_output(const jatts_ragged* rg, int32_t dtype, const void* const* x, int32_t n_in,
+                         float in_scale, float slope, int32_t c_in, int32_t k_w, const float* w,
+                         float bias, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Legacy relative-position multi-head self-attention (fused, flash style).
+ * Replaces LegacyRelPositionMultiHeadedAttention.forward core
+ * (modules/transformer/attention.py:164-206 incl. rel_shift :142-162 and
+ * forward_attention :63-93) for one unmasked sequence each:
+ *   score[i,j] = ( q_i.k_j + ku[j] + BD'[i,j] ) * scale
+ *   BD'[i,j]  = g[i][T-1-i+j]    (j <= i)
+ *             = 0                (j == i+1)
+ *             = g[i+1][j-i-2]    (j >  i+1)      (the view-reinterpretation wrap)
+ * where g[row][h][m] = (q_row,h + pos_bias_v_h) . p_h[m] is produced by jatts_conv1d and
+ * ku[row][h] = pos_bias_u_h . k_row,h by jatts_rowdot.  out = softmax(score) V.
+ * d_k must be a multiple of 32.
+ * ------------------------------------------------------------------------------- */
+typedef struct jatts_relattn_desc {
+  jatts_ragged rg;
+  int32_t dtype;
+  int32_t n_heads;
+  int32_t d_k;
+  const void* q;  int32_t ldq;   /* [rows][ldq], head h at column h*d_k */
+  const void* k;  int32_t ldk;
+  const void* vt; int32_t ldvt;  /* V^T: [(h*d_k + d)][ldvt], column = global row */
+  const void* g;  int32_t ldg;   /* g[row][h][m], row stride n_heads*ldg; NULL = no rel-pos */
+  const float* ku;               /* [rows][n_heads] or NULL */
+  float scale;
+  void* out; int32_t ldo;        /* [rows][ldo], head h at column h*d_k */
+} jatts_relattn_desc;
+
+int jatts_relpos_attention(const jatts_relattn_desc* d, void* stream);
+
+/* out[row][h] = sum_d x[row][h*d_k + d] * vec[h][d]   (pos_bias_u . k ; pos_bias_v . p) */
+int jatts_rowdot(int32_t dtype, const void* x, int32_t ldx, int64_t rows, int32_t n_heads,
+                 int32_t d_k, const float* vec, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Row-wise kernels (HBM bound).
+ * ------------------------------------------------------------------------------- */
+/* Embedding lookup * scale (encoder.py:133-137 + positional_encoding.py:232): f32 out. */
+int jatts_embed_scale(const int64_t* ids, int64_t rows, const float* table, int32_t dim,
+                      float scale, float* out, void* stream);
+
+/* LayerNorm over the last dim (modules/transformer/layer_norm.py:12-42, eps 1e-12):
+ * x (in_dtype) -> y (out_dtype); gamma/beta f32. */
+int jatts_layernorm(const void* x, int32_t in_dtype, int32_t ldx, void* y, int32_t out_dtype,
+                    int32_t ldy, int64_t rows, int32_t dim, const float* gamma,
+                    const float* beta, float eps, void* stream);
+
+/* y[row][c] = x[row][c] * scale[c] + shift[c]  (f32 in, `out_dtype` out; cols >= dim and
+ * < ldy are zero-filled).  Vocoder.decode normalisation (vocoder/vocoder.py:56-61),
+ * f32 -> operand casts. */
+int jatts_affine_cast(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                      int64_t rows, int32_t dim, const float* scale, const float* shift,
+                      void* stream);
+
+/* Conformer conv-module core (modules/conformer/convolution.py:67-75):
+ *   h = GLU(x[:, :C], x[:, C:]) ; y = swish( dwconv_k(h) * bn_scale + bn_shift )
+ * x: [rows][2C], y: [rows][C] (dtype); w_dw f32 [C][k]; BatchNorm(eval) and the
+ * depthwise bias folded into bn_scale/bn_shift by the host. */
+int jatts_glu_dwconv_bn_swish(const jatts_ragged* rg, int32_t dtype, const void* x, void* y,
+                              int32_t channels, int32_t k_w, const float* w_dw,
+                              const float* bn_scale, const float* bn_shift, void* stream);
+
+/* Predictor head: v[row] = x[row,:].w + b  (duration_predictor.py:85, variance_predictor.py:80).
+ * If dur_out != NULL also dur_out[row] = clamp(round(exp(v) - offset), 0) as int64
+ * (duration_predictor.py:87-90; round half to even). */
+int jatts_predictor_head(int32_t dtype, const void* x, int32_t ldx, int64_t rows, int32_t dim,
+                         const float* w, float b, float* v_out, int64_t* dur_out, float offset,
+                         void* stream);
+
+/* hs[row][c] += sum_k p[row+k-pad] wp[c][k] + bp[c] + sum_k e[row+k-pad] we[c][k] + be[c]
+ * (pitch_embed / energy_embed Conv1d(1, adim, k), models/fastspeech2.py:614-616). */
+int jatts_variance_embed_add(const jatts_ragged* rg, float* hs, int32_t dim, const float* p,
+                             const float* wp, const float* bp, int32_t kp, const float* e,
+                             const float* we, const float* be, int32_t ke, void* stream);
+
+/* hs[row][:] += vec[seq(row)][:]  (speaker embedding add, fastspeech2.py:591-597,751-753) */
+int jatts_add_seq_vector(const jatts_ragged* rg, float* hs, int32_t dim, const float* vec,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Length regulator (modules/length_regulator.py:70-97), bit-exact integer path.
+ * Step 1: d_eff = (alpha == 1) ? d : (int64) rint((float)d * alpha)   [half-to-even],
+ *         cum[row] = inclusive prefix sum of d_eff inside each sequence, olens[b] = total.
+ *         force_ones != 0 sets every d_eff to 1 (the whole-batch-zero rule, :85-94; the
+ *         host decides after reading olens).
+ * Step 2: out[cu_out[b] + f][:] = x[cu_rows[b] + idx][:], idx = #{t : cum[t] <= f};
+ *         frame_index (optional) receives idx as int64.
+ * ------------------------------------------------------------------------------- */
+int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, int32_t force_ones,
+                       int64_t* d_eff, int64_t* cum, int64_t* olens, void* stream);
+int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, const int32_t* cu_out,
+                    int32_t max_out_len, const float* x, int32_t dim, float* out,
+                    int64_t* frame_index, void* stream);
+
+/* Gaussian upsampling (modules/length_regulator.py:111-154), one unmasked sequence each:
+ * out[f] = softmax_t( -delta (f - c_t)^2 ) @ hs,  c_t = cumsum(d)_t - d_t/2 (float math). */
+int jatts_gaussian_upsample(const jatts_ragged* rg_in, const int64_t* d, const int32_t* cu_out,
+                            int32_t max_out_len, const float* hs, int32_t dim, float delta,
+                            float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JATTS_HIP_H_ */

@@ -1,0 +1,117 @@
+"""ctypes binding of libjatts_hip.so (declared in include/jatts_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails this
+module raises.  The library is built in-tree by ``jatts_amd.build.build()``
+(``make -C jatts_amd/csrc``) into ``jatts_amd/lib/libjatts_hip.so``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjatts_hip.so")
+
+F32, F16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
+PRE_NONE, PRE_LRELU = 0, 1
+
+
+class Ragged(C.Structure):
+    _fields_ = [("cu_rows", C.c_void_p), ("n_seq", C.c_int32), ("max_len", C.c_int32),
+                ("len_mul", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("rg", Ragged), ("dtype", C.c_int32), ("n_in", C.c_int32), ("x", C.c_void_p * 3),
+        ("ldx", C.c_int32), ("in_scale", C.c_float), ("pre_act", C.c_int32), ("pre_slope", C.c_float),
+        ("w", C.c_void_p), ("c_in", C.c_int32), ("n_out", C.c_int32), ("k_w", C.c_int32),
+        ("dil", C.c_int32), ("pad", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
+        ("alpha", C.c_float), ("resid", C.c_void_p), ("ldr", C.c_int32), ("y", C.c_void_p),
+        ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32),
+    ]
+
+
+class ResUnitDesc(C.Structure):
+    _fields_ = [
+        ("rg", Ragged), ("dtype", C.c_int32), ("channels", C.c_int32), ("k_w", C.c_int32),
+        ("dil", C.c_int32), ("slope", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+    ]
+
+
+class RelAttnDesc(C.Structure):
+    _fields_ = [
+        ("rg", Ragged), ("dtype", C.c_int32), ("n_heads", C.c_int32), ("d_k", C.c_int32),
+        ("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32),
+        ("vt", C.c_void_p), ("ldvt", C.c_int32), ("g", C.c_void_p), ("ldg", C.c_int32),
+        ("ku", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/jatts_hip.h declares
+PROTOTYPES = {
+    "jatts_abi_version": (C.c_int, []),
+    "jatts_last_error": (C.c_char_p, []),
+    "jatts_device_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "jatts_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "jatts_conv_weight_index": (C.c_int64, [C.c_int32] * 5),
+    "jatts_hifigan_resunit": (C.c_int, [C.POINTER(ResUnitDesc), C.c_void_p]),
+    "jatts_hifigan_output": (C.c_int, [C.POINTER(Ragged), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                       C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+                                       C.c_void_p, C.c_void_p]),
+    "jatts_relpos_attention": (C.c_int, [C.POINTER(RelAttnDesc), C.c_void_p]),
+    "jatts_rowdot": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_embed_scale": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                    C.c_void_p]),
+    "jatts_layernorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "jatts_affine_cast": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_glu_dwconv_bn_swish": (C.c_int, [C.POINTER(Ragged), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_predictor_head": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "jatts_variance_embed_add": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_void_p]),
+    "jatts_add_seq_vector": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "jatts_lr_durations": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_float, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_lr_gather": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_gaussian_upsample": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class JattsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libjatts_hip.so (raises if absent: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JattsHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C jatts_amd/csrc`.  jatts_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so misses a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.jatts_abi_version() != 1:
+        raise JattsHipError("libjatts_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().jatts_last_error().decode(errors="replace")
+        raise JattsHipError(f"{what} failed (rc={rc}): {msg}")

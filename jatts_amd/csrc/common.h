@@ -1,0 +1,104 @@
+// Shared device helpers for the jatts MI355X (gfx950 / CDNA4) kernels.
+// Wave = 64 lanes.  Activations are packed, ragged, time-major: X[row][C] with
+// cu_rows[b] = first row of sequence b (no padding rows anywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/jatts_hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define JATTS_CHECK_LAUNCH()                                 \
+  do {                                                       \
+    hipError_t e_ = hipGetLastError();                       \
+    if (e_ != hipSuccess) return jatts_set_error(e_, __FILE__, __LINE__); \
+  } while (0)
+
+int jatts_set_error(hipError_t e, const char* file, int line);
+int jatts_set_error_msg(int code, const char* msg);
+
+// ---------------------------------------------------------------- element traits
+template <typename T> struct Elem;
+template <> struct Elem<f16> {
+  typedef f16x8 vec8;  // 8 contraction elements per lane per MFMA K-step
+  static constexpr int kBytes = 2;
+};
+template <> struct Elem<float> {
+  typedef f32x8 vec8;
+  static constexpr int kBytes = 4;
+};
+
+// One "K=16" step of a 32x32 output fragment.  Lane l supplies row/col (l&31) and
+// contraction elements 8*(l>>5) .. 8*(l>>5)+7 of both operands.
+//  f16 : v_mfma_f32_32x32x16_f16 (dense f16 MFMA rate, f32 accumulate)
+//  f32 : 8 x v_mfma_f32_32x32x2_f32 (exact f32 fma chain; the parity mode).  MFMA j
+//        consumes element j of each lane, i.e. k = 8*(l>>5)+j: both k-groups agree
+//        between A and B, and the order of the contraction sum is irrelevant.
+__device__ __forceinline__ void mma32(const f16x8& a, const f16x8& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(const f32x8& a, const f32x8& b, f32x16& c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+}
+// 16x16 output fragment, "K=32" step: lane supplies row/col (l&15) and contraction
+// elements 8*(l>>4) .. +7.
+__device__ __forceinline__ void mma16(const f16x8& a, const f16x8& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+}
+
+// C/D fragment maps (dtype independent on gfx950):
+//  32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), reg in [0,16)
+//  16x16: col = lane&15, row = 4*(lane>>4) + reg,                  reg in [0,4)
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// Apply the fused epilogue activation.
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case JATTS_ACT_RELU: return v > 0.f ? v : 0.f;
+    case JATTS_ACT_TANH: return tanhf(v);
+    case JATTS_ACT_SWISH: return v / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+// Sequence lookup for a ragged launch: tile -> (sequence, first local row).
+// cu_tiles[b] = number of tiles before sequence b (n_seq+1 entries).
+__device__ __forceinline__ int find_seq(const int32_t* __restrict__ cu_tiles, int n_seq, int tile) {
+  int lo = 0, hi = n_seq;  // invariant: cu_tiles[lo] <= tile < cu_tiles[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (cu_tiles[mid] <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

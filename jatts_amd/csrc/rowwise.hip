@@ -1,0 +1,475 @@
+// HBM-bound row-wise kernels of the jatts hot path (gfx950): embedding, LayerNorm,
+// affine/cast, conformer GLU+depthwise+BN+Swish, predictor heads, variance embeddings,
+// length regulator (bit-exact integer path), Gaussian upsampling, HiFi-GAN output conv.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------- embedding
+__global__ void embed_scale_kernel(const int64_t* ids, int64_t rows, const float* table, int dim,
+                                   float scale, float* out) {
+  const int64_t row = blockIdx.x;
+  const float* src = table + ids[row] * (int64_t)dim;
+  float* dst = out + row * (int64_t)dim;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) dst[c] = src[c] * scale;
+}
+
+// ------------------------------------------------------------------------- layernorm
+// One wave per row; two-pass mean/variance on register-resident values (torch semantics:
+// biased variance, y = (x - mean) * rsqrt(var + eps) * gamma + beta).
+constexpr int LN_MAXV = 32;  // dim <= 64 * 32 = 2048
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, int ldx, TO* y, int ldy, int64_t rows,
+                                                        int dim, const float* gamma, const float* beta,
+                                                        float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const TI* xr = x + row * (int64_t)ldx;
+  float v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < dim ? to_f32(xr[c]) : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    const float t = c < dim ? v[i] - mean : 0.f;
+    q += t * t;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+  TO* yr = y + row * (int64_t)ldy;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < dim) yr[c] = from_f32<TO>((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  }
+}
+
+// ----------------------------------------------------------------------- affine + cast
+template <typename TO>
+__global__ void affine_cast_kernel(const float* x, int ldx, TO* y, int ldy, int64_t rows, int dim,
+                                   const float* scale, const float* shift) {
+  const int64_t total = rows * (int64_t)ldy;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ldy;
+    const int c = (int)(i - r * ldy);
+    float v = 0.f;
+    if (c < dim) {
+      v = x[r * ldx + c];
+      if (scale) v = v * scale[c];
+      if (shift) v = v + shift[c];
+    }
+    y[i] = from_f32<TO>(v);
+  }
+}
+
+// ------------------------------------------------ GLU -> depthwise conv -> BN -> Swish
+constexpr int DW_TT = 64;  // time steps per block
+constexpr int DW_CB = 64;  // channels per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void glu_dw_kernel(jatts_ragged rg, const T* x, T* y, int C, int K,
+                                                     const float* w, const float* sc, const float* sh) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* hs = reinterpret_cast<float*>(smem);  // [(DW_TT + K - 1)][DW_CB + 1]
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int t0 = blockIdx.x * DW_TT;
+  if (t0 >= L) return;
+  const int c0 = blockIdx.z * DW_CB;
+  const int pad = (K - 1) / 2;
+  const int rows = DW_TT + K - 1;
+  const int P = DW_CB + 1;
+  for (int u = threadIdx.x; u < rows * DW_CB; u += 256) {
+    const int r = u / DW_CB, cc = u - r * DW_CB;
+    const int pos = t0 - pad + r, c = c0 + cc;
+    float h = 0.f;
+    if (pos >= 0 && pos < L && c < C) {
+      const T* xr = x + (int64_t)(row0 + pos) * (2 * C);
+      const float a = to_f32(xr[c]), g = to_f32(xr[C + c]);
+      h = a / (1.f + __expf(-g));  // a * sigmoid(g)
+    }
+    hs[r * P + cc] = h;
+  }
+  __syncthreads();
+  const int cc = threadIdx.x & (DW_CB - 1), tg = threadIdx.x / DW_CB;  // 4 time groups of 16
+  const int c = c0 + cc;
+  if (c >= C) return;
+  const float s = sc[c], t = sh[c];
+  const float* wr = w + (int64_t)c * K;
+  for (int i = 0; i < DW_TT / 4; ++i) {
+    const int tl = tg * (DW_TT / 4) + i;
+    if (t0 + tl >= L) break;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += wr[k] * hs[(tl + k) * P + cc];
+    const float v = acc * s + t;
+    y[(int64_t)(row0 + t0 + tl) * C + c] = from_f32<T>(v / (1.f + __expf(-v)));
+  }
+}
+
+// --------------------------------------------------------------------- predictor head
+template <typename T>
+__global__ __launch_bounds__(256) void predictor_head_kernel(const T* x, int ldx, int64_t rows, int dim,
+                                                             const float* w, float b, float* v_out,
+                                                             int64_t* dur_out, float offset) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int c = lane; c < dim; c += 64) s += to_f32(x[row * ldx + c]) * w[c];
+  s = wave_sum(s) + b;
+  if (lane == 0) {
+    if (v_out) v_out[row] = s;
+    if (dur_out) {
+      // duration_predictor.py:87-90: clamp(round(exp(x) - offset), min=0).long()
+      float dlin = rintf(expf(s) - offset);
+      dlin = dlin > 0.f ? dlin : 0.f;
+      dur_out[row] = (int64_t)dlin;
+    }
+  }
+}
+
+// ------------------------------------------------------- pitch / energy embedding add
+__global__ void variance_embed_kernel(jatts_ragged rg, float* hs, int dim, const float* p, const float* wp,
+                                      const float* bp, int kp, const float* e, const float* we,
+                                      const float* be, int ke) {
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int t = blockIdx.x;
+  if (t >= L) return;
+  const int pp = (kp - 1) / 2, pe = (ke - 1) / 2;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float acc = bp[c] + be[c];
+    for (int k = 0; k < kp; ++k) {
+      const int q = t + k - pp;
+      if (q >= 0 && q < L) acc += p[row0 + q] * wp[c * kp + k];
+    }
+    for (int k = 0; k < ke; ++k) {
+      const int q = t + k - pe;
+      if (q >= 0 && q < L) acc += e[row0 + q] * we[c * ke + k];
+    }
+    hs[(int64_t)(row0 + t) * dim + c] += acc;
+  }
+}
+
+__global__ void add_seq_vector_kernel(jatts_ragged rg, float* hs, int dim, const float* vec) {
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int t = blockIdx.x;
+  if (t >= L) return;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) hs[(int64_t)(row0 + t) * dim + c] += vec[(int64_t)b * dim + c];
+}
+
+// -------------------------------------------------------------------- length regulator
+// One 256-thread block per sequence: alpha rounding + inclusive scan (int64, exact).
+__global__ __launch_bounds__(256) void lr_durations_kernel(jatts_ragged rg, const int64_t* d, float alpha,
+                                                           int force_ones, int64_t* d_eff, int64_t* cum,
+                                                           int64_t* olens) {
+  __shared__ int64_t part[256];
+  const int b = blockIdx.x;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int per = (L + 255) / 256;
+  const int lo = threadIdx.x * per, hi = min(L, lo + per);
+  int64_t s = 0;
+  for (int t = lo; t < hi; ++t) {
+    int64_t v = d[row0 + t];
+    if (force_ones) v = 1;
+    else if (alpha != 1.0f) v = (int64_t)rintf((float)v * alpha);  // torch.round(ds.float()*alpha).long()
+    d_eff[row0 + t] = v;
+    s += v;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan
+    int64_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int64_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (int t = lo; t < hi; ++t) {
+    run += d_eff[row0 + t];
+    cum[row0 + t] = run;
+  }
+  if (threadIdx.x == 255) olens[b] = part[255];
+}
+
+// One wave per output frame: idx = #{t : cum[t] <= f} (upper bound), then copy the row.
+__global__ __launch_bounds__(256) void lr_gather_kernel(jatts_ragged rg, const int64_t* cum,
+                                                        const int32_t* cu_out, const float* x, int dim,
+                                                        float* out, int64_t* frame_index) {
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int Lin = rg.cu_rows[b + 1] - row0;
+  const int o0 = cu_out[b];
+  const int Lout = cu_out[b + 1] - o0;
+  const int lane = threadIdx.x & 63;
+  for (int i = 0; i < 4; ++i) {
+    const int f = (blockIdx.x * 4 + i) * 4 + (threadIdx.x >> 6);
+    if (f >= Lout) return;
+    int lo = 0, hi = Lin;  // first t with cum[t] > f
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[row0 + mid] <= (int64_t)f) lo = mid + 1; else hi = mid;
+    }
+    const float* src = x + (int64_t)(row0 + lo) * dim;
+    float* dst = out + (int64_t)(o0 + f) * dim;
+    for (int c = lane; c < dim; c += 64) dst[c] = src[c];
+    if (frame_index && lane == 0) frame_index[o0 + f] = lo;
+  }
+}
+
+// ------------------------------------------------------------------ gaussian upsampling
+// One wave per output frame; softmax over the text axis in two passes (T_text is small).
+__global__ __launch_bounds__(256) void gaussian_upsample_kernel(jatts_ragged rg, const int64_t* d,
+                                                                const int32_t* cu_out, const float* hs,
+                                                                int dim, float delta, float* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cs = reinterpret_cast<float*>(smem);  // centres c_t, [Lin]
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int Lin = rg.cu_rows[b + 1] - row0;
+  const int o0 = cu_out[b];
+  const int Lout = cu_out[b + 1] - o0;
+  if ((int)blockIdx.x * 4 >= Lout) return;
+  if (threadIdx.x == 0) {  // c = cumsum(d) - d/2 in float (length_regulator.py:143)
+    int64_t run = 0;
+    for (int t = 0; t < Lin; ++t) {
+      const int64_t dv = d[row0 + t];
+      run += dv;
+      cs[t] = (float)run - (float)dv / 2.f;
+    }
+  }
+  __syncthreads();
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= Lout) return;
+  const int lane = threadIdx.x & 63;
+  float mx = -INFINITY;
+  for (int t = lane; t < Lin; t += 64) {
+    const float df = (float)f - cs[t];
+    mx = fmaxf(mx, -delta * df * df);
+  }
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int t = lane; t < Lin; t += 64) {
+    const float df = (float)f - cs[t];
+    den += expf(-delta * df * df - mx);
+  }
+  den = wave_sum(den);
+  float* dst = out + (int64_t)(o0 + f) * dim;
+  for (int c = lane; c < dim; c += 64) {
+    float acc = 0.f;
+    for (int t = 0; t < Lin; ++t) {
+      const float df = (float)f - cs[t];
+      acc += expf(-delta * df * df - mx) * hs[(int64_t)(row0 + t) * dim + c];
+    }
+    dst[c] = acc / den;
+  }
+}
+
+// ------------------------------------------------------------------ HiFi-GAN output conv
+constexpr int OUT_TT = 256;
+
+template <typename T>
+__global__ __launch_bounds__(256) void hifigan_output_kernel(jatts_ragged rg, const T* x0, const T* x1,
+                                                             const T* x2, int n_in, float in_scale,
+                                                             float slope, int C, int K, const float* w,
+                                                             float bias, float* y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int P = C + 1;
+  float* xs = reinterpret_cast<float*>(smem);  // [(OUT_TT + K - 1)][C + 1]
+  float* ws = xs + (OUT_TT + K - 1) * P;       // [K][C]
+  const int b = blockIdx.y;
+  const int64_t row0 = (int64_t)rg.cu_rows[b] * rg.len_mul;
+  const int L = (rg.cu_rows[b + 1] - rg.cu_rows[b]) * rg.len_mul;
+  const int t0 = blockIdx.x * OUT_TT;
+  if (t0 >= L) return;
+  const int pad = (K - 1) / 2;
+  for (int u = threadIdx.x; u < K * C; u += 256) ws[u] = w[u];
+  const int rows = OUT_TT + K - 1;
+  for (int u = threadIdx.x; u < rows * C; u += 256) {
+    const int r = u / C, c = u - r * C;
+    const int pos = t0 - pad + r;
+    float v = 0.f;
+    if (pos >= 0 && pos < L) {
+      const int64_t o = (row0 + pos) * C + c;
+      v = to_f32(x0[o]);
+      if (n_in > 1) v += to_f32(x1[o]);
+      if (n_in > 2) v += to_f32(x2[o]);
+      v = lrelu(v * in_scale, slope);
+    }
+    xs[r * P + c] = v;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t0 + t >= L) return;
+  float acc = bias;
+  for (int k = 0; k < K; ++k) {
+    const float* xr = xs + (t + k) * P;
+    const float* wr = ws + k * C;
+    for (int c = 0; c < C; ++c) acc += wr[c] * xr[c];
+  }
+  y[row0 + t0 + t] = tanhf(acc);
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int jatts_embed_scale(const int64_t* ids, int64_t rows, const float* table, int32_t dim,
+                                 float scale, float* out, void* stream) {
+  if (!ids || !table || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "embed_scale: null pointer");
+  if (rows <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(embed_scale_kernel, dim3((unsigned)rows), dim3(128), 0, S_, ids, rows, table, dim, scale, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_layernorm(const void* x, int32_t in_dtype, int32_t ldx, void* y, int32_t out_dtype,
+                               int32_t ldy, int64_t rows, int32_t dim, const float* gamma,
+                               const float* beta, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta) return jatts_set_error_msg(JATTS_ERR_ARG, "layernorm: null pointer");
+  if (dim > 64 * LN_MAXV) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "layernorm: dim > 2048");
+  if (rows <= 0) return JATTS_OK;
+  dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+#define LN_GO(TI, TO) \
+  hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, blk, 0, S_, (const TI*)x, ldx, (TO*)y, ldy, rows, dim, gamma, beta, eps)
+  if (in_dtype == JATTS_F32 && out_dtype == JATTS_F32) LN_GO(float, float);
+  else if (in_dtype == JATTS_F32 && out_dtype == JATTS_F16) LN_GO(float, f16);
+  else if (in_dtype == JATTS_F16 && out_dtype == JATTS_F16) LN_GO(f16, f16);
+  else if (in_dtype == JATTS_F16 && out_dtype == JATTS_F32) LN_GO(f16, float);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "layernorm: unknown dtype");
+#undef LN_GO
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_affine_cast(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                                 int64_t rows, int32_t dim, const float* scale, const float* shift,
+                                 void* stream) {
+  if (!x || !y) return jatts_set_error_msg(JATTS_ERR_ARG, "affine_cast: null pointer");
+  if (rows <= 0) return JATTS_OK;
+  const int64_t total = rows * (int64_t)ldy;
+  dim3 grid((unsigned)min((int64_t)4096, (total + 255) / 256));
+  if (out_dtype == JATTS_F16)
+    hipLaunchKernelGGL(affine_cast_kernel<f16>, grid, dim3(256), 0, S_, x, ldx, (f16*)y, ldy, rows, dim, scale, shift);
+  else if (out_dtype == JATTS_F32)
+    hipLaunchKernelGGL(affine_cast_kernel<float>, grid, dim3(256), 0, S_, x, ldx, (float*)y, ldy, rows, dim, scale, shift);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "affine_cast: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_glu_dwconv_bn_swish(const jatts_ragged* rg, int32_t dtype, const void* x, void* y,
+                                         int32_t channels, int32_t k_w, const float* w_dw,
+                                         const float* bn_scale, const float* bn_shift, void* stream) {
+  if (!rg || !x || !y || !w_dw || !bn_scale || !bn_shift) return jatts_set_error_msg(JATTS_ERR_ARG, "glu_dwconv: null pointer");
+  if (!(k_w & 1)) return jatts_set_error_msg(JATTS_ERR_ARG, "glu_dwconv: k_w must be odd");
+  if (rg->max_len <= 0) return JATTS_OK;
+  dim3 grid((unsigned)((rg->max_len + DW_TT - 1) / DW_TT), (unsigned)rg->n_seq, (unsigned)((channels + DW_CB - 1) / DW_CB));
+  const size_t lds = (size_t)(DW_TT + k_w - 1) * (DW_CB + 1) * sizeof(float);
+  if (dtype == JATTS_F16)
+    hipLaunchKernelGGL(glu_dw_kernel<f16>, grid, dim3(256), lds, S_, *rg, (const f16*)x, (f16*)y, channels, k_w, w_dw, bn_scale, bn_shift);
+  else if (dtype == JATTS_F32)
+    hipLaunchKernelGGL(glu_dw_kernel<float>, grid, dim3(256), lds, S_, *rg, (const float*)x, (float*)y, channels, k_w, w_dw, bn_scale, bn_shift);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "glu_dwconv: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_predictor_head(int32_t dtype, const void* x, int32_t ldx, int64_t rows, int32_t dim,
+                                    const float* w, float b, float* v_out, int64_t* dur_out, float offset,
+                                    void* stream) {
+  if (!x || !w) return jatts_set_error_msg(JATTS_ERR_ARG, "predictor_head: null pointer");
+  if (rows <= 0) return JATTS_OK;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == JATTS_F16)
+    hipLaunchKernelGGL(predictor_head_kernel<f16>, grid, dim3(256), 0, S_, (const f16*)x, ldx, rows, dim, w, b, v_out, dur_out, offset);
+  else if (dtype == JATTS_F32)
+    hipLaunchKernelGGL(predictor_head_kernel<float>, grid, dim3(256), 0, S_, (const float*)x, ldx, rows, dim, w, b, v_out, dur_out, offset);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "predictor_head: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_variance_embed_add(const jatts_ragged* rg, float* hs, int32_t dim, const float* p,
+                                        const float* wp, const float* bp, int32_t kp, const float* e,
+                                        const float* we, const float* be, int32_t ke, void* stream) {
+  if (!rg || !hs || !p || !wp || !bp || !e || !we || !be) return jatts_set_error_msg(JATTS_ERR_ARG, "variance_embed_add: null pointer");
+  if (rg->max_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(variance_embed_kernel, dim3((unsigned)rg->max_len, (unsigned)rg->n_seq), dim3(128), 0, S_, *rg, hs, dim, p, wp, bp, kp, e, we, be, ke);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_add_seq_vector(const jatts_ragged* rg, float* hs, int32_t dim, const float* vec,
+                                    void* stream) {
+  if (!rg || !hs || !vec) return jatts_set_error_msg(JATTS_ERR_ARG, "add_seq_vector: null pointer");
+  if (rg->max_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(add_seq_vector_kernel, dim3((unsigned)rg->max_len, (unsigned)rg->n_seq), dim3(128), 0, S_, *rg, hs, dim, vec);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, int32_t force_ones,
+                                  int64_t* d_eff, int64_t* cum, int64_t* olens, void* stream) {
+  if (!rg || !d || !d_eff || !cum || !olens) return jatts_set_error_msg(JATTS_ERR_ARG, "lr_durations: null pointer");
+  if (rg->n_seq <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(lr_durations_kernel, dim3((unsigned)rg->n_seq), dim3(256), 0, S_, *rg, d, alpha, force_ones, d_eff, cum, olens);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, const int32_t* cu_out,
+                               int32_t max_out_len, const float* x, int32_t dim, float* out,
+                               int64_t* frame_index, void* stream) {
+  if (!rg_in || !cum || !cu_out || !x || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "lr_gather: null pointer");
+  if (max_out_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(lr_gather_kernel, dim3((unsigned)((max_out_len + 15) / 16), (unsigned)rg_in->n_seq), dim3(256), 0, S_, *rg_in, cum, cu_out, x, dim, out, frame_index);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_gaussian_upsample(const jatts_ragged* rg_in, const int64_t* d, const int32_t* cu_out,
+                                       int32_t max_out_len, const float* hs, int32_t dim, float delta,
+                                       float* out, void* stream) {
+  if (!rg_in || !d || !cu_out || !hs || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "gaussian_upsample: null pointer");
+  if (max_out_len <= 0) return JATTS_OK;
+  const size_t lds = (size_t)rg_in->max_len * sizeof(float);
+  if (lds > 64 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "gaussian_upsample: text too long");
+  hipLaunchKernelGGL(gaussian_upsample_kernel, dim3((unsigned)((max_out_len + 3) / 4), (unsigned)rg_in->n_seq), dim3(256), lds, S_, *rg_in, d, cu_out, hs, dim, delta, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_hifigan_output(const jatts_ragged* rg, int32_t dtype, const void* const* x, int32_t n_in,
+                                    float in_scale, float slope, int32_t c_in, int32_t k_w, const float* w,
+                                    float bias, float* y, void* stream) {
+  if (!rg || !x || !x[0] || !w || !y || n_in < 1 || n_in > 3) return jatts_set_error_msg(JATTS_ERR_ARG, "hifigan_output: bad arguments");
+  if (rg->max_len <= 0) return JATTS_OK;
+  const int64_t maxL = (int64_t)rg->max_len * rg->len_mul;
+  dim3 grid((unsigned)((maxL + OUT_TT - 1) / OUT_TT), (unsigned)rg->n_seq);
+  const size_t lds = ((size_t)(OUT_TT + k_w - 1) * (c_in + 1) + (size_t)k_w * c_in) * sizeof(float);
+  if (lds > 64 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "hifigan_output: c_in*k_w too large");
+  const void* x1 = n_in > 1 ? x[1] : nullptr;
+  const void* x2 = n_in > 2 ? x[2] : nullptr;
+  if (dtype == JATTS_F16)
+    hipLaunchKernelGGL(hifigan_output_kernel<f16>, grid, dim3(256), lds, S_, *rg, (const f16*)x[0], (const f16*)x1, (const f16*)x2, n_in, in_scale, slope, c_in, k_w, w, bias, y);
+  else if (dtype == JATTS_F32)
+    hipLaunchKernelGGL(hifigan_output_kernel<float>, grid, dim3(256), lds, S_, *rg, (const float*)x[0], (const float*)x1, (const float*)x2, n_in, in_scale, slope, c_in, k_w, w, bias, y);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "hifigan_output: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}

@@ -1,0 +1,299 @@
+"""Tensor-level wrappers over the C ABI (jatts_amd/_abi.py).
+
+PyTorch is used here only as plumbing: device memory (torch tensors), the current
+HIP stream and dtype bookkeeping.  Every wrapper validates shapes, fills the POD
+descriptor and launches asynchronously on ``torch.cuda.current_stream()``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32  # noqa: F401
+
+_TORCH = {F32: torch.float32, F16: torch.float16}
+
+
+def torch_dtype(code):
+    return _TORCH[code]
+
+
+def code_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, col0=0):
+    if t is None:
+        return None
+    return t.data_ptr() + col0 * t.element_size()
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _abi.JattsHipError("jatts_amd kernels need device tensors (no CPU fallback)")
+    return t
+
+
+class RaggedBatch:
+    """Packed ragged batch geometry: sequence b owns rows cu[b]..cu[b+1]-1."""
+
+    def __init__(self, lens, device):
+        self.lens = [int(v) for v in lens]
+        cu = [0]
+        for v in self.lens:
+            cu.append(cu[-1] + v)
+        self.cu_host = cu
+        self.total = cu[-1]
+        self.n_seq = len(self.lens)
+        self.max_len = max(self.lens) if self.lens else 0
+        self.device = device
+        self.cu = torch.tensor(cu, dtype=torch.int32, device=device)
+
+    def struct(self, len_mul=1):
+        return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul)
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def pack_conv_weight(w, dtype_code):
+    """(n_out, c_in, k) -> MFMA fragment order [tap][c/16][n/32][lane][8] (include/jatts_hip.h).
+
+    c_in is zero-padded to a multiple of 16 and n_out to a multiple of 32.  Pure
+    permutation + cast: done once per checkpoint at prepare time.
+    """
+    n, c, k = w.shape
+    n_pad, c_pad = round_up(n, 32), round_up(c, 16)
+    wp = torch.zeros(n_pad, c_pad, k, dtype=torch.float32, device=w.device)
+    wp[:n, :c] = w.float()
+    wp = wp.permute(2, 0, 1).reshape(k, n_pad // 32, 32, c_pad // 16, 2, 8)
+    wp = wp.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)
+    return wp.to(torch_dtype(dtype_code))
+
+
+def convtranspose_as_conv(w, stride, padding):
+    """ConvTranspose1d weight (c_in, c_out, K) -> polyphase Conv1d weight
+    (stride*c_out, c_in, taps) + input offset `pad`, such that the conv output row j,
+    viewed as [stride][c_out], equals output steps j*stride .. j*stride+stride-1."""
+    c_in, c_out, K = w.shape
+    qs = [(r, q) for r in range(stride) for q in range(-K, K + 1) if 0 <= stride * q + r + padding < K]
+    qmin, qmax = min(q for _, q in qs), max(q for _, q in qs)
+    taps = qmax - qmin + 1
+    wc = torch.zeros(stride * c_out, c_in, taps, dtype=w.dtype, device=w.device)
+    for r, q in qs:
+        kk = stride * q + r + padding
+        wc[r * c_out:(r + 1) * c_out, :, qmax - q] = w[:, :, kk].t()
+    return wc, qmax
+
+
+def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
+           alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
+           in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None):
+    """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors."""
+    lib = _abi.load()
+    if isinstance(xs, torch.Tensor):
+        xs = [xs]
+    x0 = _dev(xs[0])
+    rows = rb.total * len_mul
+    tdt = torch_dtype(dtype)
+    for x in xs:
+        if x.dtype != tdt or not x.is_contiguous():
+            raise ValueError(f"conv1d: inputs must be contiguous {tdt}")
+    ldx = ldx if ldx is not None else x0.shape[-1]
+    if x0.numel() < rows * ldx or x_col0 + c_in > ldx:
+        raise ValueError("conv1d: input too small for the ragged geometry")
+    if pad is None:
+        pad = (k_w - 1) // 2 * dil
+    n_pad = round_up(n_out, 32)
+    if w_packed.dtype != tdt or w_packed.numel() != n_pad * c_in * k_w:
+        raise ValueError("conv1d: packed weight has wrong dtype/size")
+    odt = torch.float32 if out_f32 else tdt
+    if out is None:
+        if transposed:
+            out = torch.empty(n_out, rows if out_ld is None else out_ld, dtype=odt, device=x0.device)
+        else:
+            out = torch.empty(rows if out_rows is None else out_rows, out_ld or n_out, dtype=odt, device=x0.device)
+    if out.dtype != odt:
+        raise ValueError("conv1d: output dtype mismatch")
+    ldy = out.shape[-1] if out_ld is None else out_ld
+    d = _abi.ConvDesc()
+    d.rg = rb.struct(len_mul)
+    d.dtype, d.n_in = dtype, len(xs)
+    for i, x in enumerate(xs):
+        d.x[i] = _ptr(x, x_col0)
+    d.ldx, d.in_scale = ldx, in_scale
+    d.pre_act = _abi.PRE_LRELU if pre_lrelu is not None else _abi.PRE_NONE
+    d.pre_slope = pre_lrelu or 0.0
+    d.w, d.c_in, d.n_out, d.k_w, d.dil, d.pad = w_packed.data_ptr(), c_in, n_out, k_w, dil, pad
+    d.bias = _ptr(bias)
+    d.act, d.alpha = act, alpha
+    if resid is not None:
+        if resid.dtype != torch.float32:
+            raise ValueError("conv1d: residual must be f32")
+        d.resid, d.ldr = resid.data_ptr(), resid.shape[-1]
+    d.y, d.ldy = _ptr(out, out_col0), ldy
+    d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
+    _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")
+    return out
+
+
+def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype):
+    lib = _abi.load()
+    d = _abi.ResUnitDesc()
+    d.rg = rb.struct(len_mul)
+    d.dtype, d.channels, d.k_w, d.dil, d.slope = dtype, channels, k_w, dil, slope
+    rows = rb.total * len_mul
+    if x.numel() != rows * channels or y.numel() != rows * channels or x.dtype != torch_dtype(dtype):
+        raise ValueError("hifigan_resunit: bad buffer size/dtype")
+    d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
+    d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    _abi.check(lib.jatts_hifigan_resunit(C.byref(d), _stream()), "jatts_hifigan_resunit")
+    return y
+
+
+def hifigan_output(rb, len_mul, xs, in_scale, slope, c_in, k_w, w, bias, dtype):
+    lib = _abi.load()
+    rows = rb.total * len_mul
+    y = torch.empty(rows, dtype=torch.float32, device=xs[0].device)
+    arr = (C.c_void_p * len(xs))(*[_dev(x).data_ptr() for x in xs])
+    rg = rb.struct(len_mul)
+    _abi.check(lib.jatts_hifigan_output(C.byref(rg), dtype, arr, len(xs), in_scale, slope, c_in, k_w,
+                                        w.data_ptr(), float(bias), y.data_ptr(), _stream()),
+               "jatts_hifigan_output")
+    return y
+
+
+def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d_k, dtype,
+                     q_col0=0, k_col0=0):
+    lib = _abi.load()
+    out = torch.empty(rb.total, n_heads * d_k, dtype=torch_dtype(dtype), device=q.device)
+    d = _abi.RelAttnDesc()
+    d.rg = rb.struct()
+    d.dtype, d.n_heads, d.d_k = dtype, n_heads, d_k
+    d.q, d.ldq = _ptr(_dev(q), q_col0), ldq
+    d.k, d.ldk = _ptr(k, k_col0), ldk
+    d.vt, d.ldvt = vt.data_ptr(), ldvt
+    d.g, d.ldg = _ptr(g), ldg
+    d.ku = _ptr(ku)
+    d.scale = scale
+    d.out, d.ldo = out.data_ptr(), n_heads * d_k
+    _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
+    return out
+
+
+def rowdot(x, ldx, rows, n_heads, d_k, vec, col0=0):
+    lib = _abi.load()
+    out = torch.empty(rows, n_heads, dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_rowdot(code_of(x), _ptr(_dev(x), col0), ldx, rows, n_heads, d_k, vec.data_ptr(),
+                                out.data_ptr(), _stream()), "jatts_rowdot")
+    return out
+
+
+def embed_scale(ids, table, scale):
+    lib = _abi.load()
+    out = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=ids.device)
+    _abi.check(lib.jatts_embed_scale(_dev(ids).data_ptr(), ids.numel(), table.data_ptr(), table.shape[1],
+                                     float(scale), out.data_ptr(), _stream()), "jatts_embed_scale")
+    return out
+
+
+def layernorm(x, gamma, beta, out_dtype, eps=1e-12, out=None):
+    lib = _abi.load()
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty(rows, dim, dtype=torch_dtype(out_dtype), device=x.device)
+    _abi.check(lib.jatts_layernorm(_dev(x).data_ptr(), code_of(x), dim, out.data_ptr(), out_dtype, dim, rows,
+                                   dim, gamma.data_ptr(), beta.data_ptr(), eps, _stream()), "jatts_layernorm")
+    return out
+
+
+def affine_cast(x, out_dtype, scale=None, shift=None, ldy=None):
+    lib = _abi.load()
+    rows, dim = x.shape
+    ldy = ldy or dim
+    out = torch.empty(rows, ldy, dtype=torch_dtype(out_dtype), device=x.device)
+    _abi.check(lib.jatts_affine_cast(_dev(x).data_ptr(), dim, out.data_ptr(), out_dtype, ldy, rows, dim,
+                                     _ptr(scale), _ptr(shift), _stream()), "jatts_affine_cast")
+    return out
+
+
+def glu_dwconv_bn_swish(rb, x, channels, k_w, w_dw, bn_scale, bn_shift, dtype):
+    lib = _abi.load()
+    y = torch.empty(rb.total, channels, dtype=torch_dtype(dtype), device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_glu_dwconv_bn_swish(C.byref(rg), dtype, _dev(x).data_ptr(), y.data_ptr(), channels,
+                                             k_w, w_dw.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(),
+                                             _stream()), "jatts_glu_dwconv_bn_swish")
+    return y
+
+
+def predictor_head(x, w, b, want_duration=False, offset=1.0):
+    lib = _abi.load()
+    rows, dim = x.shape
+    v = torch.empty(rows, dtype=torch.float32, device=x.device)
+    dur = torch.empty(rows, dtype=torch.int64, device=x.device) if want_duration else None
+    _abi.check(lib.jatts_predictor_head(code_of(x), _dev(x).data_ptr(), dim, rows, dim, w.data_ptr(), float(b),
+                                        v.data_ptr(), _ptr(dur), offset, _stream()), "jatts_predictor_head")
+    return (v, dur) if want_duration else v
+
+
+def variance_embed_add(rb, hs, p, wp, bp, e, we, be):
+    lib = _abi.load()
+    rg = rb.struct()
+    _abi.check(lib.jatts_variance_embed_add(C.byref(rg), _dev(hs).data_ptr(), hs.shape[1], p.data_ptr(),
+                                            wp.data_ptr(), bp.data_ptr(), wp.shape[-1], e.data_ptr(),
+                                            we.data_ptr(), be.data_ptr(), we.shape[-1], _stream()),
+               "jatts_variance_embed_add")
+    return hs
+
+
+def add_seq_vector(rb, hs, vec):
+    lib = _abi.load()
+    rg = rb.struct()
+    _abi.check(lib.jatts_add_seq_vector(C.byref(rg), _dev(hs).data_ptr(), hs.shape[1], vec.data_ptr(),
+                                        _stream()), "jatts_add_seq_vector")
+    return hs
+
+
+def lr_durations(rb, d, alpha=1.0, force_ones=False):
+    lib = _abi.load()
+    d_eff = torch.empty_like(d)
+    cum = torch.empty_like(d)
+    olens = torch.empty(rb.n_seq, dtype=torch.int64, device=d.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_lr_durations(C.byref(rg), _dev(d).data_ptr(), float(alpha), int(force_ones),
+                                      d_eff.data_ptr(), cum.data_ptr(), olens.data_ptr(), _stream()),
+               "jatts_lr_durations")
+    return d_eff, cum, olens
+
+
+def lr_gather(rb_in, cum, rb_out, x, want_index=False):
+    lib = _abi.load()
+    dim = x.shape[1]
+    out = torch.empty(rb_out.total, dim, dtype=torch.float32, device=x.device)
+    idx = torch.empty(rb_out.total, dtype=torch.int64, device=x.device) if want_index else None
+    rg = rb_in.struct()
+    _abi.check(lib.jatts_lr_gather(C.byref(rg), cum.data_ptr(), rb_out.cu.data_ptr(), rb_out.max_len,
+                                   _dev(x).data_ptr(), dim, out.data_ptr(), _ptr(idx), _stream()),
+               "jatts_lr_gather")
+    return (out, idx) if want_index else out
+
+
+def gaussian_upsample(rb_in, d, rb_out, hs, delta=0.1):
+    lib = _abi.load()
+    dim = hs.shape[1]
+    out = torch.empty(rb_out.total, dim, dtype=torch.float32, device=hs.device)
+    rg = rb_in.struct()
+    _abi.check(lib.jatts_gaussian_upsample(C.byref(rg), _dev(d).data_ptr(), rb_out.cu.data_ptr(),
+                                           rb_out.max_len, hs.data_ptr(), dim, delta, out.data_ptr(),
+                                           _stream()), "jatts_gaussian_upsample")
+    return out

@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library loads and exports every symbol include/jatts_hip.h declares; host-side
+packing / polyphase / schema / sharding logic.  No compute calls (no GPU here)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "jatts_hip.h")).read()
+    declared = set(re.findall(r"\b(jatts_[a-z0-9_]+)\s*\(", hdr))
+    from jatts_amd import _abi
+    assert declared == set(_abi.PROTOTYPES), declared ^ set(_abi.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.jatts_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_field_order():
+    hdr = open(os.path.join(ROOT, "include", "jatts_hip.h")).read()
+    from jatts_amd import _abi
+    for cname, cls in (("jatts_ragged", _abi.Ragged), ("jatts_conv_desc", _abi.ConvDesc),
+                       ("jatts_resunit_desc", _abi.ResUnitDesc), ("jatts_relattn_desc", _abi.RelAttnDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = re.findall(r"([a-z_0-9]+)(?:\[\d+\])?\s*;", body)
+        assert names == [f[0] for f in cls._fields_], (cname, names)
+
+
+def test_weight_packing_matches_c_index(lib):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(0)
+    for (n, c, k) in [(40, 48, 3), (32, 16, 1), (1, 80, 7), (700, 192, 1)]:
+        w = torch.randn(n, c, k, generator=g)
+        wp = hip.pack_conv_weight(w, hip.F32)
+        n_pad, c_pad = hip.round_up(n, 32), hip.round_up(c, 16)
+        assert wp.numel() == n_pad * c_pad * k
+        for _ in range(50):
+            i, j, t = (int(torch.randint(0, m, (1,), generator=g)) for m in (n, c, k))
+            assert wp[lib.jatts_conv_weight_index(i, t, j, n_pad, c_pad)] == w[i, j, t]
+        assert float(wp.abs().sum()) == pytest.approx(float(w.abs().sum()), rel=1e-5)  # padding is zero
+
+
+@pytest.mark.parametrize("s,K", [(8, 16), (2, 4), (5, 10), (4, 8), (3, 6)])
+def test_polyphase_convtranspose_equals_torch(s, K):
+    """ConvTranspose1d == stride-1 conv producing [stride][c_out] phases (the HIP path's formulation)."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(s)
+    cin, cout, L = 6, 4, 11
+    w, b, x = torch.randn(cin, cout, K, generator=g), torch.randn(cout, generator=g), torch.randn(1, cin, L, generator=g)
+    p = s // 2 + s % 2
+    ref = F.conv_transpose1d(x, w, b, stride=s, padding=p, output_padding=s % 2)
+    wc, pad = hip.convtranspose_as_conv(w, s, p)
+    taps = wc.shape[-1]
+    y = F.conv1d(F.pad(x, (pad, taps - 1 - pad)), wc, b.repeat(s))[0].t().reshape(L * s, cout).t()
+    assert ref.shape[-1] == L * s and float((y - ref[0]).abs().max()) < 1e-5
+
+
+def test_state_dict_schema_equals_reference(golden_dir):
+    """Key names, order and shapes of jatts.models.FastSpeech2.state_dict() (captured from the reference)."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.synthetic import FS2_JSUT, FS2_SMALL
+    for name, cfg, idim, kw in (("fs2_jsut.npz", FS2_JSUT, 45, {}), ("fs2_small.npz", FS2_SMALL, 20, {}),
+                                ("fs2_small_spk.npz", FS2_SMALL, 20, {"spk_embed_dim": 16})):
+        keys = json.loads(str(np.load(os.path.join(golden_dir, name))["keys"]))
+        sd = FastSpeech2(idim=idim, **cfg, **kw).state_dict()
+        assert [k for k, _ in keys] == list(sd.keys())
+        assert all(tuple(s) == tuple(sd[k].shape) for k, s in keys)
+
+
+def test_hifigan_loads_weight_norm_checkpoints():
+    from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state
+    from jatts_amd.vocoder import HiFiGANGenerator
+    params = dict(HIFIGAN_V1_24K, channels=32)
+    sd = synth_hifigan_state(params)
+    wn = {}
+    for k, v in sd.items():
+        if k.endswith(".weight"):
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+            wn[k + "_g"], wn[k + "_v"] = norm, v * 0.5
+        else:
+            wn[k] = v
+    g = HiFiGANGenerator(**params)
+    g.load_state_dict(wn)
+    for k, v in sd.items():
+        assert torch.allclose(g.state_dict()[k], v, atol=1e-6), k
+    assert g.hop == 300
+
+
+def test_unsupported_configs_raise_like_the_reference():
+    from jatts_amd.models import FastSpeech2
+    with pytest.raises(ValueError):  # reference: NameError on the dead transformer branch
+        FastSpeech2(idim=10, odim=80)
+    import jatts_amd.models as M
+    assert getattr(M, "FastSpeech2") is FastSpeech2  # registry contract of tts_decode.py:139
+
+
+def test_shard_utterances_is_a_balanced_partition():
+    from jatts_amd.hostlogic import shard_utterances
+    lens = [5, 100, 7, 64, 64, 3, 90, 12, 1]
+    parts = shard_utterances(lens, 4)
+    assert sorted(i for p in parts for i in p) == list(range(len(lens)))
+    assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert parts == shard_utterances(lens, 4)

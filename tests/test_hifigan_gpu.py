@@ -1,0 +1,65 @@
+"""GPU parity: HiFi-GAN generator + Vocoder.decode against the CPU oracle (oracle/hifigan_oracle.py,
+PARITY UNPINNED for the generator — see its header) and the pinned normalisation golden.
+
+Tolerances: fp32 mode max|y - oracle| <= 2e-4 on tanh outputs in [-1,1]; fp16 mode <= 2e-2.
+Size-independent properties at scale: output length = T*hop, |y| <= 1, batch == per-utterance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import maxdiff, relerr
+from jatts_amd.synthetic import HIFIGAN_V1_22K, HIFIGAN_V1_24K, synth_hifigan_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(params, channels=128):
+    return dict(params, channels=channels)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp16", 2e-2)])
+@pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K), _small(HIFIGAN_V1_24K, 256)], ids=["22k", "24k"])
+def test_generator_matches_oracle(cuda, lib, prec, tol, params):
+    from jatts_amd import hip
+    from jatts_amd.vocoder import HiFiGANGenerator
+    from oracle.hifigan_oracle import hifigan_generate
+    sd = synth_hifigan_state(params, seed=3, std=0.08)
+    g = HiFiGANGenerator(**params)
+    g.load_state_dict(sd)
+    g = g.to(cuda).set_precision(prec)
+    gen = torch.Generator().manual_seed(0)
+    lens = [21, 8]
+    mels = [torch.randn(n, 80, generator=gen) for n in lens]
+    rb = hip.RaggedBatch(lens, cuda)
+    taps = {}
+    y = g.inference_batch(rb, torch.cat(mels).to(cuda), taps=taps)
+    hop = g.hop
+    assert y.shape == (sum(lens) * hop,)
+    o = 0
+    for n, c in zip(lens, mels):
+        otaps = {}
+        ref = hifigan_generate(sd, c, params["upsample_scales"], params["resblock_dilations"], taps=otaps)
+        got = y[o * hop:(o + n) * hop]
+        e = maxdiff(got, ref)
+        assert e <= tol, f"{prec}: max|d| = {e:.3e} (input_conv rel {relerr(taps['input_conv'][o:o+n], otaps['input_conv']):.2e})"
+        assert float(got.abs().max()) <= 1.0
+        o += n
+    # single-utterance API (parallel_wavegan contract: (T*hop, 1))
+    y1 = g.inference(mels[1])
+    assert y1.shape == (lens[1] * hop, 1)
+    assert maxdiff(y1.view(-1), y[lens[0] * hop:]) <= 1e-6
+
+
+def test_vocoder_decode_contract_and_normalisation(cuda, lib, golden_dir):
+    from jatts_amd.vocoder import Vocoder
+    z = np.load(golden_dir + "/vocoder_decode.npz")
+    params = _small(HIFIGAN_V1_24K, 64)
+    voc = Vocoder(synth_hifigan_state(params, seed=1, std=0.05),
+                  {"sampling_rate": 24000, "generator_type": "HiFiGANGenerator", "generator_params": params},
+                  {"mean": z["voc_mean"], "scale": z["voc_scale"]}, cuda,
+                  trg_stats={"mean": z["trg_mean"], "scale": z["trg_scale"]})
+    c = torch.tensor(z["c"]).to(cuda)
+    assert maxdiff(voc.normalized(c), z["c_norm"]) <= 1e-5      # vocoder.py:56-61, pinned on the reference
+    y, sr = voc.decode(c)
+    assert sr == 24000 and y.dim() == 1 and y.numel() == c.shape[0] * 300 and y.is_cuda

@@ -1,0 +1,403 @@
+"""GPU parity: every C-ABI kernel against the CPU oracle's arithmetic on seeded inputs.
+
+Tolerances (written here, per the north star):
+  fp32 mode (exact-f32 MFMA): relative L2 error <= 2e-5 (summation-order differences only).
+  fp16 mode (f16 operands, f32 accumulate): operands are rounded to f16 first, the oracle
+  computes in f32 on the SAME rounded operands -> relative L2 error <= 2e-3.
+  Integer/index work (length regulator, durations given log-durations): bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import maxdiff, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 2e-5, "fp16": 2e-3}
+
+
+def _dt(prec):
+    from jatts_amd import hip
+    return hip.F32 if prec == "fp32" else hip.F16
+
+
+def _round(t, prec):
+    return t.half().float() if prec == "fp16" else t
+
+
+def _ragged(lens, dev):
+    from jatts_amd import hip
+    return hip.RaggedBatch(lens, dev)
+
+
+def _ref_conv(x, w, b, lens, dil, pad, k, pre_slope=None, act=None):
+    """Per-sequence conv on time-major rows; y[t] = sum W[n,c,tap] x[t + tap*dil - pad]."""
+    outs, o = [], 0
+    for L in lens:
+        xs = x[o:o + L].t().unsqueeze(0).double()
+        if pre_slope is not None:
+            xs = F.leaky_relu(xs, pre_slope)
+        right = (k - 1) * dil - pad
+        xs = F.pad(xs, (pad, right))
+        y = F.conv1d(xs, w.double(), None if b is None else b.double(), dilation=dil)[0].t()
+        outs.append(y)
+        o += L
+    y = torch.cat(outs)
+    if act == "relu":
+        y = torch.relu(y)
+    elif act == "tanh":
+        y = torch.tanh(y)
+    return y
+
+
+CONV_CASES = [
+    # c_in, n_out, k, dil, lens, act, resid, transposed, pre, n_in
+    (64, 128, 3, 1, [37, 256, 5], "relu", False, False, None, 1),
+    (384, 1536, 3, 1, [128, 77], "relu", False, False, None, 1),
+    (1536, 384, 3, 1, [128, 300], None, True, False, None, 1),
+    (80, 256, 5, 1, [90, 41], "tanh", False, False, None, 1),
+    (256, 80, 5, 1, [90, 41], None, True, False, None, 1),
+    (384, 80, 1, 1, [100], None, False, False, None, 1),
+    (384, 384, 1, 1, [33, 65], None, False, True, None, 1),
+    (80, 512, 7, 1, [50, 20], None, False, False, None, 1),
+    (32, 32, 11, 5, [400, 17], None, False, False, 0.1, 1),
+    (64, 48, 3, 3, [70], None, False, False, 0.1, 3),
+    (192, 700, 1, 1, [64, 130], None, False, False, None, 1),
+    (16, 1, 3, 1, [19], None, False, False, None, 1),
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d(cuda, lib, prec, case):
+    from jatts_amd import hip
+    c_in, n_out, k, dil, lens, act, resid, transposed, pre, n_in = case
+    g = torch.Generator().manual_seed(hash(case[:4]) & 0xFFFF)
+    R = sum(lens)
+    xs = [_round(torch.randn(R, c_in, generator=g), prec) for _ in range(n_in)]
+    w = _round(torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k), prec)
+    b = torch.randn(n_out, generator=g)
+    res = torch.randn(R, n_out, generator=g) if resid else None
+    pad = (k - 1) // 2 * dil
+    in_scale = 1.0 / n_in
+    xsum = sum(xs) * in_scale
+    if prec == "fp16" and (n_in > 1 or pre is not None):
+        # the kernel sums in f32, applies lrelu, then rounds the staged operand to f16
+        xsum = (F.leaky_relu(xsum, pre) if pre is not None else xsum).half().float()
+        ref = _ref_conv(xsum, w, b, lens, dil, pad, k, None, act)
+    else:
+        ref = _ref_conv(xsum, w, b, lens, dil, pad, k, pre, act)
+    alpha = 0.5 if resid else 1.0
+    ref = ref * alpha + (res.double() if resid else 0)
+    dt = _dt(prec)
+    rb = _ragged(lens, cuda)
+    tdt = hip.torch_dtype(dt)
+    wp = hip.pack_conv_weight(w.to(cuda), dt)
+    y = hip.conv1d(rb, [x.to(cuda).to(tdt) for x in xs], wp, c_in, n_out, k, dtype=dt, dil=dil, bias=b.to(cuda),
+                   act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], alpha=alpha,
+                   resid=None if res is None else res.to(cuda), out_f32=True, transposed=transposed,
+                   pre_lrelu=pre, in_scale=in_scale)
+    torch.cuda.synchronize()
+    y = y.t() if transposed else y
+    e = relerr(y, ref)
+    assert e <= TOL[prec], f"conv1d {case} {prec}: rel err {e:.3e}"
+
+
+def _ref_unit(x, w1, b1, w2, b2, lens, k, d, slope, round16):
+    outs, o = [], 0
+    for L in lens:
+        xs = x[o:o + L].t().unsqueeze(0).double()
+        a = F.leaky_relu(xs, slope)
+        if round16:
+            a = a.half().double()
+        h = F.conv1d(a, w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+        h = F.leaky_relu(h, slope)
+        if round16:
+            h = h.half().double()
+        y = F.conv1d(h, w2.double(), b2.double(), padding=(k - 1) // 2) + xs
+        outs.append(y[0].t())
+        o += L
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("C,k,d,lens", [
+    (32, 3, 1, [700, 3, 250]), (32, 11, 5, [600, 31]), (64, 7, 3, [513]), (128, 3, 5, [300, 40]),
+    (128, 11, 1, [129]), (256, 7, 5, [150, 64]), (256, 11, 5, [70]), (512, 3, 3, [45]),
+])
+def test_hifigan_resunit(cuda, lib, prec, C, k, d, lens):
+    from jatts_amd import hip
+    if prec == "fp32" and C == 512:
+        pytest.skip("C=512 fp32 uses the generic two-launch path (LDS)")
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + d)
+    R = sum(lens)
+    x = _round(torch.randn(R, C, generator=g), prec)
+    w1 = _round(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), prec)
+    w2 = _round(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), prec)
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    ref = _ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, prec == "fp16")
+    dt = _dt(prec)
+    tdt = hip.torch_dtype(dt)
+    rb = _ragged(lens, cuda)
+    xd = x.to(cuda).to(tdt)
+    y = torch.full_like(xd, float("nan"))
+    hip.hifigan_resunit(rb, 1, xd, y, hip.pack_conv_weight(w1.to(cuda), dt), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), dt), b2.to(cuda), C, k, d, 0.1, dt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all(), "unwritten / non-finite outputs"
+    e = relerr(y.float(), ref)
+    assert e <= TOL[prec], f"resunit C={C} k={k} d={d} {prec}: rel err {e:.3e}"
+
+
+def test_hifigan_resunit_len_mul(cuda, lib):
+    """len_mul scales the ragged geometry (HiFi-GAN stages reuse one cu_rows array)."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(3)
+    lens, mul, C, k, d = [5, 9], 8, 32, 3, 3
+    R = sum(lens) * mul
+    x = torch.randn(R, C, generator=g)
+    w1, w2 = torch.randn(C, C, k, generator=g) * 0.1, torch.randn(C, C, k, generator=g) * 0.1
+    b1, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = _ref_unit(x, w1, b1, w2, b2, [n * mul for n in lens], k, d, 0.1, False)
+    rb = _ragged(lens, cuda)
+    y = torch.empty(R, C, device=cuda)
+    hip.hifigan_resunit(rb, mul, x.to(cuda), y, hip.pack_conv_weight(w1.to(cuda), hip.F32), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), hip.F32), b2.to(cuda), C, k, d, 0.1, hip.F32)
+    assert relerr(y, ref) <= TOL["fp32"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("H,dk,lens,rel", [(2, 32, [24, 9, 33], True), (2, 192, [130, 64], True),
+                                          (2, 96, [65], True), (4, 64, [100, 1, 17], False)])
+def test_relpos_attention(cuda, lib, prec, H, dk, lens, rel):
+    from jatts_amd import hip
+    from oracle.fs2_oracle import rel_shift_legacy
+    g = torch.Generator().manual_seed(H * dk + len(lens))
+    A, R, Tm = H * dk, sum(lens), max(lens)
+    ldg = hip.round_up(Tm, 32)
+    q = _round(torch.randn(R, A, generator=g), prec)
+    k = _round(torch.randn(R, A, generator=g), prec)
+    v = _round(torch.randn(R, A, generator=g), prec)
+    gm = _round(torch.randn(R, H, ldg, generator=g), prec)  # g[row][h][m]
+    ku = torch.randn(R, H, generator=g)
+    scale = 1.0 / math.sqrt(dk)
+    outs, o = [], 0
+    for T in lens:
+        qs, ks, vs = (t[o:o + T].view(T, H, dk).transpose(0, 1).double() for t in (q, k, v))
+        s = qs @ ks.transpose(1, 2) + ku[o:o + T].t().double().unsqueeze(1)
+        if rel:
+            s = s + rel_shift_legacy(gm[o:o + T, :, :T].permute(1, 0, 2).double())
+        p = torch.softmax(s * scale, -1)
+        if prec == "fp16":
+            pass  # P is rounded to f16 inside the kernel: covered by the tolerance
+        outs.append((p @ vs).transpose(0, 1).reshape(T, A))
+        o += T
+    ref = torch.cat(outs)
+    dt = _dt(prec)
+    tdt = hip.torch_dtype(dt)
+    rb = _ragged(lens, cuda)
+    vt = v.t().contiguous().to(cuda).to(tdt)
+    out = hip.relpos_attention(rb, q.to(cuda).to(tdt), A, k.to(cuda).to(tdt), A, vt, R,
+                               gm.reshape(R, H * ldg).to(cuda).to(tdt) if rel else None, ldg,
+                               ku.to(cuda), scale, H, dk, dt)
+    e = relerr(out.float(), ref)
+    assert e <= (5e-5 if prec == "fp32" else 3e-3), f"attention {H}x{dk} {prec}: rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("in16,out16", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("dim", [64, 256, 384])
+def test_layernorm(cuda, lib, in16, out16, dim):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(37, dim, generator=g) * 3 + 1
+    if in16:
+        x = x.half().float()
+    gamma, beta = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    ref = F.layer_norm(x.double(), (dim,), gamma.double(), beta.double(), 1e-12)
+    xd = x.to(cuda).half() if in16 else x.to(cuda)
+    y = hip.layernorm(xd, gamma.to(cuda), beta.to(cuda), hip.F16 if out16 else hip.F32)
+    assert relerr(y.float(), ref) <= (1e-3 if out16 else 1e-5)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("C,K,lens", [(64, 7, [24, 9, 70]), (384, 31, [100, 15]), (100, 15, [33])])
+def test_glu_dwconv_bn_swish(cuda, lib, prec, C, K, lens):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(C + K)
+    R = sum(lens)
+    x = _round(torch.randn(R, 2 * C, generator=g), prec)
+    w = torch.randn(C, K, generator=g) * 0.3
+    s, t = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    outs, o = [], 0
+    for L in lens:
+        h = F.glu(x[o:o + L].double(), dim=-1).t().unsqueeze(0)
+        y = F.conv1d(h, w.double().unsqueeze(1), None, padding=(K - 1) // 2, groups=C)[0].t() * s.double() + t.double()
+        outs.append(y * torch.sigmoid(y))
+        o += L
+    ref = torch.cat(outs)
+    dt = _dt(prec)
+    y = hip.glu_dwconv_bn_swish(_ragged(lens, cuda), x.to(cuda).to(hip.torch_dtype(dt)), C, K, w.to(cuda),
+                                s.to(cuda), t.to(cuda), dt)
+    assert relerr(y.float(), ref) <= (1e-5 if prec == "fp32" else 1e-3)
+
+
+def test_predictor_head_and_durations(cuda, lib):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(500, 256, generator=g)
+    w = torch.randn(256, generator=g) * 0.1
+    v, d = hip.predictor_head(x.to(cuda), w.to(cuda), 0.7, want_duration=True)
+    ref = x.double() @ w.double() + 0.7
+    assert maxdiff(v, ref) <= 1e-4
+    # duration_predictor.py:87-90 on the kernel's own log-durations: bit-exact except within 1e-4 of a .5 boundary
+    lin = torch.exp(v.cpu().double()) - 1.0
+    want = torch.clamp(torch.round(lin), min=0).long()
+    near = (lin - torch.floor(lin) - 0.5).abs() < 1e-4
+    assert torch.equal(d.cpu()[~near], want[~near])
+    assert d.dtype == torch.int64 and int(d.min()) >= 0
+
+
+@pytest.mark.parametrize("alpha", [1.0, 1.5, 0.7, 2.5])
+def test_length_regulator_bit_exact(cuda, lib, alpha):
+    """Bit-exact against the C oracle (itself pinned on the reference KATs)."""
+    from jatts_amd import hip
+    from oracle import lr_oracle as LR
+    g = torch.Generator().manual_seed(int(alpha * 10))
+    lens = [128, 1, 37, 300, 64]
+    dim = 24
+    d = torch.cat([torch.randint(0, 9, (n,), generator=g) for n in lens])
+    d[128] = 2  # the length-1 utterance must produce frames
+    x = torch.randn(sum(lens), dim, generator=g)
+    rb = _ragged(lens, cuda)
+    d_eff, cum, olens = hip.lr_durations(rb, d.to(cuda), alpha)
+    o = 0
+    want_olens = []
+    for n in lens:
+        de, ol = LR.effective_durations(d[o:o + n].numpy()[None], [n], alpha)
+        assert np.array_equal(d_eff[o:o + n].cpu().numpy(), de[0])
+        assert np.array_equal(cum[o:o + n].cpu().numpy(), np.cumsum(de[0]))
+        want_olens.append(int(ol[0]))
+        o += n
+    assert olens.tolist() == want_olens
+    rbo = _ragged(want_olens, cuda)
+    out, fidx = hip.lr_gather(rb, cum, rbo, x.to(cuda), want_index=True)
+    o = oo = 0
+    for n, m in zip(lens, want_olens):
+        idx = LR.frame_index(d_eff[o:o + n].cpu().numpy())
+        assert np.array_equal(fidx[oo:oo + m].cpu().numpy(), idx)
+        assert torch.equal(out[oo:oo + m].cpu(), x[o:o + n][torch.as_tensor(idx)])  # pure gather: exact
+        o, oo = o + n, oo + m
+
+
+def test_length_regulator_golden_kats(cuda, lib, golden_dir):
+    """The reference's own LengthRegulator outputs (tests/golden/lr_kat.npz)."""
+    from jatts_amd import hip
+    z = np.load(golden_dir + "/lr_kat.npz")
+    for n in range(int(z["n_cases"])):
+        ds, alpha, xs, ref = z[f"c{n}_ds"], float(z[f"c{n}_alpha"]), z[f"c{n}_xs"], z[f"c{n}_out"]
+        B, T = ds.shape
+        rb = _ragged([T] * B, cuda)
+        d = torch.tensor(ds).reshape(-1).to(cuda)
+        d_eff, cum, olens = hip.lr_durations(rb, d, alpha)
+        if sum(olens.tolist()) == 0:  # whole-batch-zero rule, length_regulator.py:85-94 (host decides)
+            d_eff, cum, olens = hip.lr_durations(rb, d, alpha, force_ones=True)
+        ol = olens.tolist()
+        assert max(ol) == ref.shape[1], (n, ol, ref.shape)
+        x = torch.tensor(xs).reshape(B * T, -1).to(cuda)
+        out = hip.lr_gather(rb, cum, _ragged(ol, cuda), x).cpu().numpy()
+        o = 0
+        for b in range(B):
+            assert np.array_equal(out[o:o + ol[b]], ref[b, :ol[b]]), (n, b)
+            assert not ref[b, ol[b]:].any()  # pad_list zero padding
+            o += ol[b]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_hifigan_output_conv(cuda, lib, prec):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(1)
+    lens, mul, C, K = [7, 3], 16, 32, 7
+    R = sum(lens) * mul
+    xs = [_round(torch.randn(R, C, generator=g), prec) for _ in range(3)]
+    w = torch.randn(K, C, generator=g) * 0.1
+    outs, o = [], 0
+    for n in lens:
+        L = n * mul
+        a = F.leaky_relu(sum(x[o:o + L] for x in xs).double() / 3.0, 0.01).t().unsqueeze(0)
+        y = torch.tanh(F.conv1d(a, w.t().double().unsqueeze(0), torch.tensor([0.3]).double(), padding=3))
+        outs.append(y.reshape(-1))
+        o += L
+    ref = torch.cat(outs)
+    dt = _dt(prec)
+    y = hip.hifigan_output(_ragged(lens, cuda), mul, [x.to(cuda).to(hip.torch_dtype(dt)) for x in xs], 1.0 / 3.0,
+                           0.01, C, K, w.to(cuda), 0.3, dt)
+    assert maxdiff(y, ref) <= 2e-5
+
+
+def test_small_rowwise_kernels(cuda, lib):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(2)
+    # embedding * scale
+    table = torch.randn(20, 64, generator=g)
+    ids = torch.randint(0, 20, (50,), generator=g)
+    y = hip.embed_scale(ids.to(cuda), table.to(cuda), 8.0)
+    assert torch.equal(y.cpu(), table[ids] * 8.0)
+    # affine cast with zero-filled padding columns
+    x = torch.randn(9, 80, generator=g)
+    s, t = torch.randn(80, generator=g), torch.randn(80, generator=g)
+    y = hip.affine_cast(x.to(cuda), hip.F32, scale=s.to(cuda), shift=t.to(cuda), ldy=96)
+    assert maxdiff(y[:, :80], x * s + t) <= 1e-6 and not y[:, 80:].any()
+    # variance embedding add, k = 1 and k = 9
+    lens = [11, 4]
+    rb = _ragged(lens, cuda)
+    for kp in (1, 9):
+        hs = torch.randn(15, 32, generator=g)
+        p, e = torch.randn(15, generator=g), torch.randn(15, generator=g)
+        wp, we = torch.randn(32, kp, generator=g), torch.randn(32, kp, generator=g)
+        bp, be = torch.randn(32, generator=g), torch.randn(32, generator=g)
+        ref, o = hs.clone().double(), 0
+        for n in lens:
+            for (sig, w_, b_) in ((p, wp, bp), (e, we, be)):
+                c = F.conv1d(sig[o:o + n].double().view(1, 1, n), w_.double().unsqueeze(1), b_.double(),
+                             padding=(kp - 1) // 2)[0].t()
+                ref[o:o + n] += c
+            o += n
+        out = hip.variance_embed_add(rb, hs.to(cuda), p.to(cuda), wp.to(cuda), bp.to(cuda), e.to(cuda),
+                                     we.to(cuda), be.to(cuda))
+        assert maxdiff(out, ref) <= 1e-5
+    # per-sequence vector add, rowdot
+    hs = torch.randn(15, 32, generator=g)
+    vec = torch.randn(2, 32, generator=g)
+    out = hip.add_seq_vector(rb, hs.to(cuda), vec.to(cuda))
+    ref = hs.clone()
+    ref[:11] += vec[0]
+    ref[11:] += vec[1]
+    assert maxdiff(out, ref) <= 1e-6
+    x = torch.randn(15, 64, generator=g)
+    v = torch.randn(2, 32, generator=g)
+    out = hip.rowdot(x.to(cuda), 64, 15, 2, 32, v.to(cuda))
+    assert maxdiff(out, torch.einsum("rhd,hd->rh", x.view(15, 2, 32), v)) <= 1e-5
+
+
+def test_gaussian_upsample(cuda, lib):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(4)
+    lens = [12, 5]
+    d = torch.randint(1, 6, (17,), generator=g)
+    hs = torch.randn(17, 16, generator=g)
+    outs, o, olens = [], 0, []
+    for n in lens:
+        ds = d[o:o + n].double()
+        T = int(ds.sum())
+        t = torch.arange(T).double()
+        c = ds.cumsum(0) - ds / 2
+        p = torch.softmax(-0.1 * (t[:, None] - c[None]) ** 2, dim=1)
+        outs.append(p @ hs[o:o + n].double())
+        olens.append(T)
+        o += n
+    out = hip.gaussian_upsample(_ragged(lens, cuda), d.to(cuda), _ragged(olens, cuda), hs.to(cuda))
+    assert maxdiff(out, torch.cat(outs)) <= 1e-5

@@ -1,0 +1,111 @@
+"""CPU: the oracle against the golden vectors captured from the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_state, load_golden, maxdiff
+from oracle import fs2_oracle as O
+from oracle import hifigan_oracle as HO
+from oracle import lr_oracle as LR
+
+
+@pytest.mark.parametrize("name,seed,heads", [("fs2_small.npz", 0, 2), ("fs2_jsut.npz", 0, 2)])
+def test_fs2_oracle_matches_reference(name, seed, heads):
+    z, keys = load_golden(name)
+    sd = golden_state(keys, seed)
+    u = 0
+    while f"u{u}_text" in z.files:
+        text = torch.tensor(z[f"u{u}_text"])
+        alpha = float(z[f"u{u}_alpha"]) if f"u{u}_alpha" in z.files else 1.0
+        taps = {}
+        o = O.fs2_inference(sd, text, heads, alpha=alpha, taps=taps)
+        assert np.array_equal(o["duration"].numpy(), z[f"u{u}_duration"])
+        # same torch build + same thread-independent kernels: bit-exact here; 1e-5 leaves room for BLAS threading
+        assert maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-5
+        assert maxdiff(o["pitch"], z[f"u{u}_pitch"]) <= 1e-5
+        assert maxdiff(o["energy"], z[f"u{u}_energy"]) <= 1e-5
+        if f"u{u}_encoder_out" in z.files:
+            assert maxdiff(taps["encoder_out"], z[f"u{u}_encoder_out"]) <= 1e-5
+            assert maxdiff(taps["layer0"], z[f"u{u}_enc_layer0"]) <= 1e-5
+            assert maxdiff(taps["decoder_out"], z[f"u{u}_decoder_out"]) <= 1e-5
+            assert maxdiff(o["before"], z[f"u{u}_before"]) <= 1e-5
+            assert maxdiff(o["log_duration"], z[f"u{u}_log_duration"].reshape(-1)) <= 1e-5
+        u += 1
+    assert u >= 2
+
+
+def test_fs2_oracle_speaker_embedding():
+    z, keys = load_golden("fs2_small_spk.npz")
+    sd = golden_state(keys, 1)
+    for u in range(2):
+        o = O.fs2_inference(sd, torch.tensor(z[f"u{u}_text"]), 2, spembs=torch.tensor(z[f"u{u}_spemb"]))
+        assert np.array_equal(o["duration"].numpy(), z[f"u{u}_duration"])
+        assert maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-5
+
+
+def test_rel_shift_closed_form_equals_view_trick():
+    g = torch.Generator().manual_seed(0)
+    for T in (1, 2, 3, 7, 16):
+        bd = torch.randn(2, T, T, generator=g)
+        assert torch.equal(O.rel_shift_legacy(bd), O.rel_shift_closed_form(bd))
+
+
+def test_length_regulator_kats():
+    """C oracle vs the reference LengthRegulator outputs (incl. SURVEY §8 A9 KATs)."""
+    z, _ = load_golden("lr_kat.npz")
+    for n in range(int(z["n_cases"])):
+        ds, alpha, xs, ref = z[f"c{n}_ds"], float(z[f"c{n}_alpha"]), z[f"c{n}_xs"], z[f"c{n}_out"]
+        B, T = ds.shape
+        out, olens = LR.gather(xs, ds, [T] * B, alpha)
+        assert out.shape == ref.shape, (n, out.shape, ref.shape)
+        assert np.array_equal(out, ref), n
+    assert list(LR.frame_index([2, 0, 3, 1, 0])) == [0, 0, 2, 2, 2, 3]
+    d, _ = LR.effective_durations(np.array([[2, 0, 3, 1, 0]]), [5], 1.5)
+    assert list(LR.frame_index(d[0])) == [0, 0, 0, 2, 2, 2, 2, 3, 3]
+    d, _ = LR.effective_durations(np.zeros((1, 5), dtype=np.int64), [5])
+    assert list(LR.frame_index(d[0])) == [0, 1, 2, 3, 4]
+
+
+def test_length_regulate_torch_matches_c_oracle():
+    g = torch.Generator().manual_seed(5)
+    for alpha in (1.0, 0.5, 1.5, 2.5):
+        d = torch.randint(0, 7, (50,), generator=g)
+        x = torch.randn(50, 4, generator=g)
+        y, d_eff = O.length_regulate(x, d, alpha)
+        out, olens = LR.gather(x.numpy()[None], d.numpy()[None], [50], alpha)
+        assert np.array_equal(out[0], y.numpy())
+
+
+def test_vocoder_decode_normalisation_golden():
+    z, _ = load_golden("vocoder_decode.npz")
+    c = HO.vocoder_normalize(torch.tensor(z["c"]), torch.tensor(z["trg_mean"]), torch.tensor(z["trg_scale"]),
+                             torch.tensor(z["voc_mean"]), torch.tensor(z["voc_scale"]))
+    assert maxdiff(c, z["c_norm"]) <= 1e-6
+
+
+def test_hifigan_oracle_structure():
+    """Structural invariants of the (unpinned) HiFi-GAN restatement: length, range, weight-norm folding."""
+    sd = HO.random_hifigan_state(channels=64, upsample_scales=(4, 2), upsample_kernel_sizes=(8, 4), std=0.1)
+    c = torch.randn(9, 80)
+    y = HO.hifigan_generate(sd, c, (4, 2))
+    assert y.shape == (9 * 8,) and float(y.abs().max()) <= 1.0
+    wn = {}
+    for k, v in sd.items():
+        if k.endswith(".weight"):
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+            wn[k[:-6] + "weight_g"], wn[k[:-6] + "weight_v"] = norm, v * 3.0
+        else:
+            wn[k] = v
+    y2 = HO.hifigan_generate(wn, c, (4, 2))
+    assert maxdiff(y, y2) <= 1e-5
+
+
+def test_masks_golden():
+    from jatts_amd.hostlogic import make_non_pad_mask, make_pad_mask
+
+    z, _ = load_golden("mask_kat.npz")
+    for n in range(int(z["n_cases"])):
+        lens = z[f"m{n}_lens"].tolist()
+        assert np.array_equal(make_pad_mask(lens).numpy(), z[f"m{n}_pad"])
+        assert np.array_equal(make_non_pad_mask(lens).numpy(), z[f"m{n}_nonpad"])
