@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
             const int64_t o = (int64_t)(n0 + e) * d.ldy + row;
             if (d.y_is_f32) ((float*)d.y)[o] = v[e]; else ((T*)d.y)[o] = from_f32<T>(v[e]);
           }
-        } else if (n0 + 3 < d.n_out) {
+        } else if (n0 + 3 < d.n_out && (d.ldy & 3) == 0) {
           const int64_t o = row * d.ldy + n0;
           if (d.y_is_f32 || sizeof(T) == 4) {
             *reinterpret_cast<f32x4*>((float*)d.y + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -372,8 +372,6 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   if (d->n_in < 1 || d->n_in > 3 || d->k_w < 1 || d->dil < 1 || d->n_out < 1 || d->rg.n_seq < 1 || d->rg.len_mul < 1)
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: bad geometry");
   if (d->rg.max_len <= 0) return JATTS_OK;
-  if (!d->y_transposed && d->ldy % 4)
-    return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: ldy must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const bool narrow = d->n_out <= 64;
   if (d->dtype == JATTS_F16) {

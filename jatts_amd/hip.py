@@ -26,6 +26,39 @@ def code_of(t):
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+# ---- optional live kernel timing (HIP events on the launch stream); used by bench.py only
+_PROF = None
+
+
+def profile_begin():
+    global _PROF
+    _PROF = []
+
+
+def profile_end():
+    """-> list of (tag, meta, milliseconds); synchronises the device."""
+    global _PROF
+    recs, _PROF = _PROF or [], None
+    torch.cuda.synchronize()
+    return [(tag, meta, a.elapsed_time(b)) for tag, meta, a, b in recs]
+
+
+class _Timed:
+    def __init__(self, tag, meta):
+        self.tag, self.meta = tag, meta
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROF.append((self.tag, self.meta, self.a, b))
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -142,7 +175,8 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
         d.resid, d.ldr = resid.data_ptr(), resid.shape[-1]
     d.y, d.ldy = _ptr(out, out_col0), ldy
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
-    _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")
+    with _Timed("conv1d", (c_in, n_out, k_w, rows)):
+        _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")
     return out
 
 
@@ -156,7 +190,8 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
         raise ValueError("hifigan_resunit: bad buffer size/dtype")
     d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
     d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
-    _abi.check(lib.jatts_hifigan_resunit(C.byref(d), _stream()), "jatts_hifigan_resunit")
+    with _Timed("resunit", (channels, k_w, dil, rows)):
+        _abi.check(lib.jatts_hifigan_resunit(C.byref(d), _stream()), "jatts_hifigan_resunit")
     return y
 
 
@@ -186,7 +221,8 @@ def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d
     d.ku = _ptr(ku)
     d.scale = scale
     d.out, d.ldo = out.data_ptr(), n_heads * d_k
-    _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
+    with _Timed("relattn", (n_heads, d_k, rb.total)):
+        _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
     return out
 
 

@@ -116,28 +116,33 @@ HIFIGAN_V1_22K = dict(  # parallel_wavegan HiFiGANGenerator defaults [recalled]:
 HIFIGAN_V1_24K = dict(HIFIGAN_V1_22K, upsample_scales=(5, 5, 4, 3), upsample_kernel_sizes=(10, 10, 8, 6))
 
 
-def synth_hifigan_state(params, seed=0, std=0.02):
-    """Generator weights ~ N(0, std) (the public recipe's reset_parameters uses 0.01),
-    weight norm already folded; biases ~ N(0, std)."""
+def synth_hifigan_state(params, seed=0, gain=1.0):
+    """Generator weights, weight norm already folded.  Every conv is N(0, g/sqrt(fan_in)) so that
+    activations stay O(1..10) through the 4 stages (a single global std either vanishes or
+    explodes through ~40 convs): g = gain for input/upsample/convs1, 0.3*gain for convs2 (keeps
+    the residual stream from doubling per unit), 0.5*gain for the output conv; biases N(0, 0.02)."""
     sd = {}
     ch, k = params["channels"], params["kernel_size"]
 
-    def rn(name, *shape):
+    def rn(name, shape, fan_in=None, g=1.0):
+        std = 0.02 if fan_in is None else g * gain / math.sqrt(fan_in)
         sd[name] = torch.randn(shape, generator=_gen(name, seed)) * std
 
-    rn("input_conv.weight", ch, params["in_channels"], k)
-    rn("input_conv.bias", ch)
+    rn("input_conv.weight", (ch, params["in_channels"], k), params["in_channels"] * k)
+    rn("input_conv.bias", (ch,))
     nb = len(params["resblock_kernel_sizes"])
     c = ch
-    for i, uk in enumerate(params["upsample_kernel_sizes"]):
-        rn(f"upsamples.{i}.1.weight", c, c // 2, uk)
-        rn(f"upsamples.{i}.1.bias", c // 2)
+    for i, (us, uk) in enumerate(zip(params["upsample_scales"], params["upsample_kernel_sizes"])):
+        rn(f"upsamples.{i}.1.weight", (c, c // 2, uk), c * uk / us)
+        rn(f"upsamples.{i}.1.bias", (c // 2,))
         c //= 2
         for j, rk in enumerate(params["resblock_kernel_sizes"]):
             for d in range(len(params["resblock_dilations"][j])):
-                for cv in ("convs1", "convs2") if params.get("use_additional_convs", True) else ("convs1",):
-                    rn(f"blocks.{i * nb + j}.{cv}.{d}.1.weight", c, c, rk)
-                    rn(f"blocks.{i * nb + j}.{cv}.{d}.1.bias", c)
-    rn("output_conv.1.weight", params["out_channels"], c, k)
-    rn("output_conv.1.bias", params["out_channels"])
+                rn(f"blocks.{i * nb + j}.convs1.{d}.1.weight", (c, c, rk), c * rk)
+                rn(f"blocks.{i * nb + j}.convs1.{d}.1.bias", (c,))
+                if params.get("use_additional_convs", True):
+                    rn(f"blocks.{i * nb + j}.convs2.{d}.1.weight", (c, c, rk), c * rk, 0.3)
+                    rn(f"blocks.{i * nb + j}.convs2.{d}.1.bias", (c,))
+    rn("output_conv.1.weight", (params["out_channels"], c, k), c * k, 0.5)
+    rn("output_conv.1.bias", (params["out_channels"],))
     return sd

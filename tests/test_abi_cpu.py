@@ -77,7 +77,7 @@ def test_state_dict_schema_equals_reference(golden_dir):
 def test_hifigan_loads_weight_norm_checkpoints():
     from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state
     from jatts_amd.vocoder import HiFiGANGenerator
-    params = dict(HIFIGAN_V1_24K, channels=32)
+    params = dict(HIFIGAN_V1_24K, channels=256)
     sd = synth_hifigan_state(params)
     wn = {}
     for k, v in sd.items():
