@@ -48,7 +48,7 @@ def cpu_baseline(fs2_sd, voc_sd, voc_params, text, heads):
     from oracle.fs2_oracle import fs2_inference
     from oracle.hifigan_oracle import hifigan_generate
 
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)  # oversubscribing a 256-thread host makes torch CPU slower
     torch.set_num_threads(cores)
     with torch.no_grad():
         t0 = time.time()
@@ -187,7 +187,11 @@ def main():
         "roofline": roof,
         "resunit_ms_per_step": tot_unit_ms / a.steps,
         "other_kernel_ms_per_step": {k: v / a.steps for k, v in other.items()},
-        "resunit_by_shape": sorted(units, key=lambda u: -u["total_ms"])[:12],
+        "resunit_by_shape": sorted(units, key=lambda u: -u["total_ms"]),
+        "conv1d_by_shape": sorted(
+            [dict(c_in=m[0], n_out=m[1], k=m[2], rows=m[3], launches_per_step=len(v) / a.steps,
+                  ms_per_step=sum(v) / a.steps, tflops=2.0 * m[0] * m[1] * m[2] * m[3] * len(v) / sum(v) / 1e9)
+             for (t, m), v in fam.items() if t == "conv1d"], key=lambda u: -u["ms_per_step"])[:14],
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(fs2_sd, voc_sd, vp, synth_texts(1, a.cpu_t_text, vocab, seed=1)[0], 2)

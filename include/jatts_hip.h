@@ -73,7 +73,7 @@ typedef struct jatts_ragged {
  *   y[t, n] = resid[t, n] + alpha * act( bias[n] + sum_{tap, c} W[n, tap, c] *
  *                                pre( in_scale * sum_i x_i[t + tap*dil - pad, c] ) )
  * with rows outside the sequence reading as zero.  W is given in MFMA fragment order
- * (jatts_conv_weight_index).  c_in must be a multiple of 16.
+ * (jatts_conv_weight_index).  c_in must be a multiple of 32 (zero-pad channels otherwise).
  * ------------------------------------------------------------------------------- */
 typedef struct jatts_conv_desc {
   jatts_ragged rg;
@@ -85,7 +85,7 @@ typedef struct jatts_conv_desc {
   int32_t pre_act;     /* JATTS_PRE_* applied while staging */
   float pre_slope;
   const void* w;       /* packed weights */
-  int32_t c_in;        /* multiple of 16 */
+  int32_t c_in;        /* multiple of 32 */
   int32_t n_out;       /* true output channels (packed rows = round_up(n_out, 32)) */
   int32_t k_w;         /* taps */
   int32_t dil;
@@ -113,9 +113,8 @@ int64_t jatts_conv_weight_index(int32_t n, int32_t tap, int32_t c, int32_t n_pad
  *   y = x + conv_k,1( lrelu( conv_k,d( lrelu(x) ) + b1 ) ) + b2
  * parallel_wavegan.layers.HiFiGANResidualBlock.forward [third party; call site
  * jatts/vocoder/vocoder.py:64].  x, y: [rows][channels]; w1/w2 packed as above with
- * c_in = n_out = channels.  y must not alias x.  Optional MRF accumulation:
- * acc_mode 1: acc = y, 2: acc += y (f32 [rows][channels]).
- * channels in {32, 64, 128, 256, 512}.
+ * c_in = n_out = channels.  y must not alias x.  channels in {32, 64, 128, 256, 512}
+ * (f32 mode: up to 256); other widths go through two jatts_conv1d launches.
  * ------------------------------------------------------------------------------- */
 typedef struct jatts_resunit_desc {
   jatts_ragged rg;

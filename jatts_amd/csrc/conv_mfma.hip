@@ -11,6 +11,8 @@
 // straight from L2 -- no LDS staging, no bank conflicts.  Activation tiles (+halo) are
 // staged once per channel chunk in LDS with a (row bytes + 16) pitch: the 16-lane groups of
 // ds_read_b128 then hit 16 distinct 16-B slots (pitch/16 is odd) -> conflict free.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -40,41 +42,65 @@ template <> struct Vec8IO<float> {
 // Source row for LDS row r is local position pos0 + r of a sequence of length L starting at
 // global row seq_row0; positions outside [0, L) give zeros.  Up to 3 inputs are summed,
 // scaled and passed through the optional leaky-ReLU before conversion to T.
-template <typename T>
+// Loads are issued in batches of UB per thread BEFORE any of them is consumed: a one-load-
+// per-iteration loop serialises a full L2/HBM round trip per 16 bytes (measured: the staging
+// phases were as long as the MFMA phases).
+template <typename T, int UB = 8>
 __device__ __forceinline__ void stage_rows(char* lds, int pitch, int rows, int nch, int pos0, int L,
                                            int64_t seq_row0, const T* const* x, int n_in, int ldx,
                                            int c0, float in_scale, int pre_act, float slope) {
   typedef typename Elem<T>::vec8 V8;
   const int upr = nch >> 3;  // 8-element units per row
   const int total = rows * upr;
-  for (int u = threadIdx.x; u < total; u += blockDim.x) {
-    const int r = u / upr, cu = u - r * upr;
-    const int pos = pos0 + r;
-    V8 v;
-    if (pos >= 0 && pos < L) {
-      const int64_t off = (seq_row0 + pos) * (int64_t)ldx + c0 + cu * 8;
-      v = Vec8IO<T>::ldg(x[0] + off);
-      if (n_in > 1 || in_scale != 1.f || pre_act != JATTS_PRE_NONE) {
-        float f[8];
+  const bool plain = n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE;
+  for (int base = threadIdx.x; base < total; base += blockDim.x * UB) {
+    V8 v[UB];
+    int64_t off[UB];
+    int dst[UB];
+    bool ok[UB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = to_f32(v[e]);
-        for (int i = 1; i < n_in; ++i) {
-          V8 w = Vec8IO<T>::ldg(x[i] + off);
+    for (int j = 0; j < UB; ++j) {
+      const int u = base + j * blockDim.x;
+      const int r = u / upr, cu = u - r * upr;
+      const int pos = pos0 + r;
+      ok[j] = u < total && pos >= 0 && pos < L;
+      dst[j] = u < total ? r * pitch + cu * 8 * (int)sizeof(T) : -1;
+      off[j] = (seq_row0 + pos) * (int64_t)ldx + c0 + cu * 8;
+      if (ok[j]) v[j] = Vec8IO<T>::ldg(x[0] + off[j]);
+      else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += to_f32(w[e]);
-        }
+        for (int e = 0; e < 8; ++e) v[j][e] = from_f32<T>(0.f);
+      }
+    }
+    if (!plain) {
+      V8 w1[UB], w2[UB];
+      if (n_in > 1) {
+#pragma unroll
+        for (int j = 0; j < UB; ++j)
+          if (ok[j]) w1[j] = Vec8IO<T>::ldg(x[1] + off[j]);
+      }
+      if (n_in > 2) {
+#pragma unroll
+        for (int j = 0; j < UB; ++j)
+          if (ok[j]) w2[j] = Vec8IO<T>::ldg(x[2] + off[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        if (!ok[j]) continue;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float t = f[e] * in_scale;
+          float t = to_f32(v[j][e]);
+          if (n_in > 1) t += to_f32(w1[j][e]);
+          if (n_in > 2) t += to_f32(w2[j][e]);
+          t *= in_scale;
           if (pre_act == JATTS_PRE_LRELU) t = lrelu(t, slope);
-          v[e] = from_f32<T>(t);
+          v[j][e] = from_f32<T>(t);
         }
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
     }
-    Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T), v);
+#pragma unroll
+    for (int j = 0; j < UB; ++j)
+      if (dst[j] >= 0) Vec8IO<T>::sts(lds + dst[j], v[j]);
   }
 }
 
@@ -82,32 +108,67 @@ __device__ __forceinline__ void stage_rows(char* lds, int pitch, int rows, int n
 //  w        : packed weights; fragment (tap, kc, nf) at ((tap*KC16 + kc)*NFR + nf)*512 elements
 //  kc_base  : first global 16-channel step covered by the LDS tile, kc_cnt steps staged
 //  act      : LDS tile, row `col + tap*dil` holds the sample feeding output column `col`
-template <typename T, int NF, int NT>
+// Software pipeline (hipcc otherwise waits vmcnt(0)/lgkmcnt right at each MFMA, and with one
+// wave per SIMD nothing else hides the L2 / LDS latency): weight fragments travel through a
+// register ring D iterations ahead of their use (global -> VGPR, fully coalesced 1 KiB wave
+// loads), activation fragments are read from LDS one iteration ahead.  The loop is unrolled
+// by D so every ring slot is a compile-time register index, and the body is STRAIGHT-LINE
+// (no guards): k_w * kc_cnt must be a multiple of D, and the producers clamp at the last
+// fragment instead of branching, so the tail prefetches are harmless in-bounds re-reads.
+template <typename T, int NF, int NT, int D>
 __device__ __forceinline__ void conv_stage(f32x16 (&acc)[NF][NT], const T* __restrict__ w, int KC16,
                                            int NFR, int nf0, int kc_base, int kc_cnt, int k_w, int dil,
                                            const char* act, int pitch, int col0, int lane) {
   typedef typename Elem<T>::vec8 V8;
+  static_assert(D % 2 == 0, "ring depth must be even");
   const int g = lane >> 5;
-  const char* bptr0 = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * g) * sizeof(T);
-  for (int tap = 0; tap < k_w; ++tap) {
-    const char* bptr = bptr0 + (size_t)(tap * dil) * pitch;
-    const T* wtap = w + ((size_t)(tap * KC16 + kc_base) * NFR) * 512 + (size_t)lane * 8;
-#pragma unroll 2
-    for (int kk = 0; kk < kc_cnt; ++kk) {
-      V8 a[NF], b[NT];
+  const int n_it = k_w * kc_cnt;
+  const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * g) * sizeof(T);
+  const T* wbase = w + (size_t)lane * 8;
+  int nfo[NF];  // fragment offsets (clamped: duplicates are never stored)
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        int nf = nf0 + f;
-        nf = nf < NFR ? nf : NFR - 1;  // clamp: duplicates are never stored
-        a[f] = Vec8IO<T>::ldg(wtap + ((size_t)kk * NFR + nf) * 512);
-      }
+  for (int f = 0; f < NF; ++f) nfo[f] = (nf0 + f < NFR ? nf0 + f : NFR - 1) * 512;
+  const int last_tap = k_w - 1;
+
+  int wp_tap = 0, wp_kk = 0;  // weight producer position
+  auto fetch_w = [&](V8(&dst)[NF]) {
+    const T* p = wbase + ((size_t)(wp_tap * KC16 + kc_base + wp_kk) * NFR) * 512;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        b[t] = Vec8IO<T>::lds(bptr + (size_t)(t * 32) * pitch + (size_t)(kk * 16) * sizeof(T));
+    for (int f = 0; f < NF; ++f) dst[f] = Vec8IO<T>::ldg(p + nfo[f]);
+    const int nk = wp_kk + 1;
+    const bool wrap = nk == kc_cnt;
+    wp_kk = wrap ? 0 : nk;
+    wp_tap = min(wp_tap + (wrap ? 1 : 0), last_tap);
+  };
+  int bp_tap = 0, bp_kk = 0;  // activation producer position
+  auto fetch_b = [&](V8(&dst)[NT]) {
+    const char* p = bbase + (size_t)(bp_tap * dil) * pitch + (size_t)(bp_kk * 16) * sizeof(T);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dst[t] = Vec8IO<T>::lds(p + (size_t)(t * 32) * pitch);
+    const int nk = bp_kk + 1;
+    const bool wrap = nk == kc_cnt;
+    bp_kk = wrap ? 0 : nk;
+    bp_tap = min(bp_tap + (wrap ? 1 : 0), last_tap);
+  };
+
+  V8 ring[D][NF];
+  V8 bb[2][NT];
+#pragma unroll
+  for (int j = 0; j < D; ++j) fetch_w(ring[j]);
+  fetch_b(bb[0]);
+  // sched_barrier(0): LLVM's scheduler otherwise sinks every prefetch back next to its use
+  __builtin_amdgcn_sched_barrier(0);
+  for (int it0 = 0; it0 < n_it; it0 += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      fetch_b(bb[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mma32(a[f], b[t], acc[f][t]);
+        for (int t = 0; t < NT; ++t) mma32(ring[j][f], bb[j & 1][t], acc[f][t]);
+      fetch_w(ring[j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -154,8 +215,8 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
     stage_rows<T>(smem, pitch, rows, nch, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, c0, d.in_scale,
                   d.pre_act, d.pre_slope);
     __syncthreads();
-    conv_stage<T, NF, NT>(acc, (const T*)d.w, KC16, NFR, nf0, c0 >> 4, nch >> 4, d.k_w, d.dil, smem, pitch,
-                          col0, lane);
+    conv_stage<T, NF, NT, 2>(acc, (const T*)d.w, KC16, NFR, nf0, c0 >> 4, nch >> 4, d.k_w, d.dil, smem,
+                             pitch, col0, lane);
     __syncthreads();
   }
 
@@ -234,6 +295,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   constexpr int NF = C / (WN * 32);
   constexpr int KC16 = C / 16, NFR = C / 32;
   constexpr int pitch = C * (int)sizeof(T) + 16;
+  constexpr int RD = sizeof(T) == 4 ? 2 : (KC16 < 8 ? KC16 : 8);  // weight ring depth; divides K*KC16
   static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
   const int K = d.k_w, dil = d.dil;
   const int p2 = (K - 1) / 2, p1 = p2 * dil;
@@ -252,12 +314,22 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   const int nf0 = wn * NF;
 
   const int rx = WGCOLS + 2 * p1;   // x tile rows: row r <-> position t0 - p2 - p1 + r
-  const int rh = WGCOLS + K - 1;    // h tile rows: row j <-> position t0 - p2 + j
+  // h tile: WGCOLS + K - 1 rows, row j <-> position t0 - p2 + j.  It OVERLAYS the x tile (dead once
+  // stage 1 has finished everywhere): half the LDS -> 2-3 workgroups per CU, so one workgroup's
+  // staging / epilogues overlap another's MFMA phase.
   char* xs = smem;
-  char* hs = smem + (size_t)rx * pitch;
+  char* hs = smem;
 
   const T* xin[3] = {(const T*)d.x, nullptr, nullptr};
   stage_rows<T>(xs, pitch, rx, C, t0 - p2 - p1, L, seq_row0, xin, 1, C, 0, 1.f, JATTS_PRE_LRELU, d.slope);
+  __syncthreads();
+
+  f32x16 acc[NF][NT];
+  zero_acc<NF, NT>(acc);
+  conv_stage<T, NF, NT, RD>(acc, (const T*)d.w1, KC16, NFR, nf0, 0, KC16, K, dil, xs, pitch, col0, lane);
+
+  // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
+  __syncthreads();  // every wave is done reading x: the tile may now be overwritten by h
   // rows of h past the computed columns are only read by discarded output columns
   for (int u = threadIdx.x; u < (K - 1) * (C / 8); u += blockDim.x) {
     const int r = WGCOLS + u / (C / 8), cu = u % (C / 8);
@@ -266,13 +338,6 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
     for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
     Vec8IO<T>::sts(hs + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T), z);
   }
-  __syncthreads();
-
-  f32x16 acc[NF][NT];
-  zero_acc<NF, NT>(acc);
-  conv_stage<T, NF, NT>(acc, (const T*)d.w1, KC16, NFR, nf0, 0, KC16, K, dil, xs, pitch, col0, lane);
-
-  // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = col0 + t * 32 + (lane & 31);
@@ -301,7 +366,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   __syncthreads();
 
   zero_acc<NF, NT>(acc);
-  conv_stage<T, NF, NT>(acc, (const T*)d.w2, KC16, NFR, nf0, 0, KC16, K, 1, hs, pitch, col0, lane);
+  conv_stage<T, NF, NT, RD>(acc, (const T*)d.w2, KC16, NFR, nf0, 0, KC16, K, 1, hs, pitch, col0, lane);
 
   // epilogue 2: y = x + acc + b2 for the tt_out valid columns
   const T* xg = (const T*)d.x;
@@ -342,7 +407,8 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   const int tt_out = WGCOLS - 2 * p2;
   if (tt_out < 8) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: kernel too wide for tile");
   const size_t pitch = C * sizeof(T) + 16;
-  const size_t lds = (size_t)(WGCOLS + 2 * p1 + WGCOLS + K - 1) * pitch;
+  const size_t rows_x = WGCOLS + 2 * p1, rows_h = WGCOLS + K - 1;
+  const size_t lds = (rows_x > rows_h ? rows_x : rows_h) * pitch;  // h overlays x
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: tile exceeds 160 KiB LDS");
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
@@ -367,7 +433,7 @@ extern "C" int64_t jatts_conv_weight_index(int32_t n, int32_t tap, int32_t c, in
 
 extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   if (!d || !d->x[0] || !d->w || !d->y || !d->rg.cu_rows) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: null pointer");
-  if (d->c_in <= 0 || d->c_in % 16) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: c_in must be a positive multiple of 16");
+  if (d->c_in <= 0 || d->c_in % 32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: c_in must be a positive multiple of 32");
   if (d->ldx % 8) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: ldx must be a multiple of 8");
   if (d->n_in < 1 || d->n_in > 3 || d->k_w < 1 || d->dil < 1 || d->n_out < 1 || d->rg.n_seq < 1 || d->rg.len_mul < 1)
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: bad geometry");
@@ -390,12 +456,23 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
   if (d->rg.max_len <= 0) return JATTS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) {
-    switch (d->channels) {
-      case 32: return launch_resunit<f16, 32, 256, 1, 2>(*d, s);
-      case 64: return launch_resunit<f16, 64, 256, 1, 2>(*d, s);
-      case 128: return launch_resunit<f16, 128, 128, 2, 2>(*d, s);
-      case 256: return launch_resunit<f16, 256, 64, 4, 2>(*d, s);
-      case 512: return launch_resunit<f16, 512, 32, 4, 1>(*d, s);
+    // tile variants: <C, workgroup columns, waves along n, 32-col fragments per wave>.
+    // JATTS_RESUNIT_VARIANT (tuning knob, read once) selects alternative tilings for sweeps.
+    static const int variant = [] { const char* e = getenv("JATTS_RESUNIT_VARIANT"); return e ? atoi(e) : 0; }();
+    switch (d->channels * 10 + variant) {
+      case 320: return launch_resunit<f16, 32, 256, 1, 2>(*d, s);
+      case 321: return launch_resunit<f16, 32, 256, 1, 4>(*d, s);
+      case 322: return launch_resunit<f16, 32, 128, 1, 4>(*d, s);
+      case 640: return launch_resunit<f16, 64, 256, 1, 2>(*d, s);
+      case 641: return launch_resunit<f16, 64, 256, 1, 4>(*d, s);
+      case 642: return launch_resunit<f16, 64, 128, 1, 4>(*d, s);
+      case 1280: return launch_resunit<f16, 128, 128, 2, 2>(*d, s);
+      case 1281: return launch_resunit<f16, 128, 128, 2, 4>(*d, s);
+      case 1282: return launch_resunit<f16, 128, 256, 2, 4>(*d, s);
+      case 2560: return launch_resunit<f16, 256, 64, 4, 2>(*d, s);
+      case 2561: return launch_resunit<f16, 256, 128, 4, 4>(*d, s);
+      case 2562: return launch_resunit<f16, 256, 128, 4, 2>(*d, s);
+      case 5120: case 5121: case 5122: return launch_resunit<f16, 512, 32, 4, 1>(*d, s);
     }
   } else if (d->dtype == JATTS_F32) {
     switch (d->channels) {

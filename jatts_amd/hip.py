@@ -101,11 +101,11 @@ def round_up(v, m):
 def pack_conv_weight(w, dtype_code):
     """(n_out, c_in, k) -> MFMA fragment order [tap][c/16][n/32][lane][8] (include/jatts_hip.h).
 
-    c_in is zero-padded to a multiple of 16 and n_out to a multiple of 32.  Pure
+    c_in is zero-padded to a multiple of 32 and n_out to a multiple of 32.  Pure
     permutation + cast: done once per checkpoint at prepare time.
     """
     n, c, k = w.shape
-    n_pad, c_pad = round_up(n, 32), round_up(c, 16)
+    n_pad, c_pad = round_up(n, 32), round_up(c, 32)
     wp = torch.zeros(n_pad, c_pad, k, dtype=torch.float32, device=w.device)
     wp[:n, :c] = w.float()
     wp = wp.permute(2, 0, 1).reshape(k, n_pad // 32, 32, c_pad // 16, 2, 8)

@@ -43,7 +43,7 @@ class PackedConv:
             w = w * scale.view(-1, 1, 1)
             b = (b * scale if b is not None else torch.zeros_like(scale)) + shift
         self.n_out, c, self.k = w.shape
-        self.c_in = hip.round_up(c, 16)
+        self.c_in = hip.round_up(c, 32)
         self.w = hip.pack_conv_weight(w.to(device), dtype)
         self.b = None if b is None else b.to(device).contiguous()
 

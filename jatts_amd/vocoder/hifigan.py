@@ -39,8 +39,8 @@ class HiFiGANGenerator(torch.nn.Module):
         self.upsample_kernel_sizes = tuple(int(k) for k in upsample_kernel_sizes)
         self.resblock_kernel_sizes = tuple(int(k) for k in resblock_kernel_sizes)
         self.resblock_dilations = tuple(tuple(int(d) for d in ds) for ds in resblock_dilations)
-        if channels % (16 << len(self.upsample_scales)):
-            raise NotImplementedError("channels / 2**n_upsamples must be a multiple of 16 (MFMA K step)")
+        if channels % (32 << len(self.upsample_scales)):
+            raise NotImplementedError("channels / 2**n_upsamples must be a multiple of 32 (MFMA tile)")
         self.hop = 1
         for s in self.upsample_scales:
             self.hop *= s

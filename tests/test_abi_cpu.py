@@ -39,7 +39,7 @@ def test_weight_packing_matches_c_index(lib):
     for (n, c, k) in [(40, 48, 3), (32, 16, 1), (1, 80, 7), (700, 192, 1)]:
         w = torch.randn(n, c, k, generator=g)
         wp = hip.pack_conv_weight(w, hip.F32)
-        n_pad, c_pad = hip.round_up(n, 32), hip.round_up(c, 16)
+        n_pad, c_pad = hip.round_up(n, 32), hip.round_up(c, 32)
         assert wp.numel() == n_pad * c_pad * k
         for _ in range(50):
             i, j, t = (int(torch.randint(0, m, (1,), generator=g)) for m in (n, c, k))
@@ -77,7 +77,7 @@ def test_state_dict_schema_equals_reference(golden_dir):
 def test_hifigan_loads_weight_norm_checkpoints():
     from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state
     from jatts_amd.vocoder import HiFiGANGenerator
-    params = dict(HIFIGAN_V1_24K, channels=256)
+    params = dict(HIFIGAN_V1_24K, channels=512)
     sd = synth_hifigan_state(params)
     wn = {}
     for k, v in sd.items():

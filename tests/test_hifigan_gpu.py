@@ -19,7 +19,7 @@ def _small(params, channels=128):
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp16", 2e-2)])
-@pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K, 512), _small(HIFIGAN_V1_24K, 256)], ids=["22k", "24k"])
+@pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K, 512), _small(HIFIGAN_V1_24K, 512)], ids=["22k", "24k"])
 def test_generator_matches_oracle(cuda, lib, prec, tol, params):
     from jatts_amd import hip
     from jatts_amd.vocoder import HiFiGANGenerator
@@ -54,7 +54,7 @@ def test_generator_matches_oracle(cuda, lib, prec, tol, params):
 def test_vocoder_decode_contract_and_normalisation(cuda, lib, golden_dir):
     from jatts_amd.vocoder import Vocoder
     z = np.load(golden_dir + "/vocoder_decode.npz")
-    params = _small(HIFIGAN_V1_24K, 256)
+    params = _small(HIFIGAN_V1_24K, 512)
     voc = Vocoder(synth_hifigan_state(params, seed=1),
                   {"sampling_rate": 24000, "generator_type": "HiFiGANGenerator", "generator_params": params},
                   {"mean": z["voc_mean"], "scale": z["voc_scale"]}, cuda,

@@ -67,7 +67,8 @@ CONV_CASES = [
     (32, 32, 11, 5, [400, 17], None, False, False, 0.1, 1),
     (64, 48, 3, 3, [70], None, False, False, 0.1, 3),
     (192, 700, 1, 1, [64, 130], None, False, False, None, 1),
-    (16, 1, 3, 1, [19], None, False, False, None, 1),
+    (32, 1, 3, 1, [19], None, False, False, None, 1),
+    (96, 64, 7, 1, [40, 9], None, False, False, None, 1),
 ]
 
 
@@ -97,7 +98,9 @@ def test_conv1d(cuda, lib, prec, case):
     rb = _ragged(lens, cuda)
     tdt = hip.torch_dtype(dt)
     wp = hip.pack_conv_weight(w.to(cuda), dt)
-    y = hip.conv1d(rb, [x.to(cuda).to(tdt) for x in xs], wp, c_in, n_out, k, dtype=dt, dil=dil, bias=b.to(cuda),
+    c_pad = hip.round_up(c_in, 32)  # the ABI wants c_in % 32 == 0: zero-pad channels like the product does
+    xs = [F.pad(x, (0, c_pad - c_in)) for x in xs]
+    y = hip.conv1d(rb, [x.to(cuda).to(tdt).contiguous() for x in xs], wp, c_pad, n_out, k, dtype=dt, dil=dil, bias=b.to(cuda),
                    act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], alpha=alpha,
                    resid=None if res is None else res.to(cuda), out_f32=True, transposed=transposed,
                    pre_lrelu=pre, in_scale=in_scale)

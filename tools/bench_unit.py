@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused HiFi-GAN dilation-unit kernel at bench-sized shapes.
+    python tools/bench_unit.py [--C 128 --k 11 --dil 1 --iters 10] [--all]
+Prints avg ms, TFLOP/s and algorithmic GB/s per shape (HIP events on the launch stream)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from jatts_amd import hip  # noqa: E402
+
+
+def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
+    dev = torch.device("cuda:0")
+    rb = hip.RaggedBatch([T] * B, dev)
+    rows = B * T * rate
+    tdt = hip.torch_dtype(dtype)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).to(tdt)
+    y = torch.empty_like(x)
+    w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype)
+    w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype)
+    b1 = torch.zeros(C, device=dev)
+    b2 = torch.zeros(C, device=dev)
+    for _ in range(2):
+        hip.hifigan_resunit(rb, rate, x, y, w1, b1, w2, b2, C, k, d, 0.1, dtype)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        hip.hifigan_resunit(rb, rate, x, y, w1, b1, w2, b2, C, k, d, 0.1, dtype)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    flops = 4.0 * C * C * k * rows
+    byts = 2.0 * rows * C * x.element_size()
+    print(f"C={C:4d} k={k:2d} d={d} rows={rows:9d}  {ms:7.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  {byts / ms / 1e6:7.1f} GB/s")
+    return ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--C", type=int, default=128)
+    ap.add_argument("--k", type=int, default=11)
+    ap.add_argument("--dil", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--all", action="store_true")
+    a = ap.parse_args()
+    rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
+    if a.all:
+        tot = 0.0
+        for C in (256, 128, 64, 32):
+            for k in (3, 7, 11):
+                for d in (1, 3, 5):
+                    tot += run(C, k, d, rates[C], a.iters)
+        print(f"sum over the 36 units of one generator pass: {tot:.2f} ms")
+    else:
+        run(a.C, a.k, a.dil, rates[a.C], a.iters)
+
+
+if __name__ == "__main__":
+    main()
