@@ -73,7 +73,7 @@ typedef struct jatts_ragged {
  *   y[t, n] = resid[t, n] + alpha * act( bias[n] + sum_{tap, c} W[n, tap, c] *
  *                                pre( in_scale * sum_i x_i[t + tap*dil - pad, c] ) )
  * with rows outside the sequence reading as zero.  W is given in MFMA fragment order
- * (jatts_conv_weight_index).  c_in must be a multiple of 32 (zero-pad channels otherwise).
+ * (jatts_conv_weight_index).  c_in must be a multiple of 64 (zero-pad channels otherwise).
  * ------------------------------------------------------------------------------- */
 typedef struct jatts_conv_desc {
   jatts_ragged rg;
@@ -85,7 +85,7 @@ typedef struct jatts_conv_desc {
   int32_t pre_act;     /* JATTS_PRE_* applied while staging */
   float pre_slope;
   const void* w;       /* packed weights */
-  int32_t c_in;        /* multiple of 32 */
+  int32_t c_in;        /* multiple of 64 */
   int32_t n_out;       /* true output channels (packed rows = round_up(n_out, 32)) */
   int32_t k_w;         /* taps */
   int32_t dil;

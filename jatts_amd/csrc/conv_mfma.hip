@@ -13,6 +13,10 @@
 // ds_read_b128 then hit 16 distinct 16-B slots (pitch/16 is odd) -> conflict free.
 #include <stdlib.h>
 
+#ifndef JATTS_ABLATE
+#define JATTS_ABLATE 0  // profiling-only ablations of the fused unit (tools/ablate_unit.sh); 0 = product
+#endif
+
 #include "common.h"
 
 namespace {
@@ -104,70 +108,235 @@ __device__ __forceinline__ void stage_rows(char* lds, int pitch, int rows, int n
   }
 }
 
-// acc[f][t] += sum over (tap, 16-channel steps) of W-fragment x activation-fragment.
-//  w        : packed weights; fragment (tap, kc, nf) at ((tap*KC16 + kc)*NFR + nf)*512 elements
-//  kc_base  : first global 16-channel step covered by the LDS tile, kc_cnt steps staged
-//  act      : LDS tile, row `col + tap*dil` holds the sample feeding output column `col`
-// Software pipeline (hipcc otherwise waits vmcnt(0)/lgkmcnt right at each MFMA, and with one
-// wave per SIMD nothing else hides the L2 / LDS latency): weight fragments travel through a
-// register ring D iterations ahead of their use (global -> VGPR, fully coalesced 1 KiB wave
-// loads), activation fragments are read from LDS one iteration ahead.  The loop is unrolled
-// by D so every ring slot is a compile-time register index, and the body is STRAIGHT-LINE
-// (no guards): k_w * kc_cnt must be a multiple of D, and the producers clamp at the last
-// fragment instead of branching, so the tail prefetches are harmless in-bounds re-reads.
+// Split staging for the double-buffered conv pipeline: issue() starts the global loads of one
+// channel chunk into registers (no wait), commit() combines / activates them and writes the LDS
+// tile.  Between the two the workgroup computes the previous chunk, so the HBM/L2 latency of the
+// activation stream hides under the MFMA phase (async-stage split).
+template <typename T, int MAXU, int NIN>
+struct StageRegs {
+  typedef typename Elem<T>::vec8 V8;
+  V8 v[NIN][MAXU];
+};
+
+template <typename T, int MAXU, int NIN>
+__device__ __forceinline__ void stage_issue(StageRegs<T, MAXU, NIN>& sr, int rows, int pos0, int L, int64_t seq_row0,
+                                            const T* const* x, int n_in, int ldx, int c0) {
+  constexpr int UPR = 8;  // 64-channel chunk = 8 units of 8 elements per row
+  const int total = rows * UPR;
+#pragma unroll
+  for (int j = 0; j < MAXU; ++j) {
+    const int u = threadIdx.x + j * blockDim.x;
+    const int r = u / UPR, cu = u % UPR;
+    const int pos = pos0 + r;
+    const bool ok = u < total && pos >= 0 && pos < L;
+    const int64_t off = (seq_row0 + pos) * (int64_t)ldx + c0 + cu * 8;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (i < n_in && ok) sr.v[i][j] = Vec8IO<T>::ldg(x[i] + off);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sr.v[i][j][e] = from_f32<T>(0.f);
+      }
+    }
+  }
+}
+
+template <typename T, int MAXU, int NIN>
+__device__ __forceinline__ void stage_commit(StageRegs<T, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in,
+                                             float in_scale, int pre_act, float slope) {
+  constexpr int UPR = 8;
+  const int total = rows * UPR;
+  const bool plain = n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE;
+#pragma unroll
+  for (int j = 0; j < MAXU; ++j) {
+    const int u = threadIdx.x + j * blockDim.x;
+    if (u >= total) continue;
+    const int r = u / UPR, cu = u % UPR;
+    typename Elem<T>::vec8 o = sr.v[0][j];
+    if (!plain) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = to_f32(sr.v[0][j][e]);
+        if (NIN > 1 && n_in > 1) t += to_f32(sr.v[NIN > 1 ? 1 : 0][j][e]);
+        if (NIN > 2 && n_in > 2) t += to_f32(sr.v[NIN > 2 ? 2 : 0][j][e]);
+        t *= in_scale;
+        if (pre_act == JATTS_PRE_LRELU) t = lrelu(t, slope);
+        o[e] = from_f32<T>(t);
+      }
+    }
+    Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T), o);
+  }
+}
+
+// ---------------------------------------------------------------- pipelined MFMA inner loop
+// Work is organised in GROUPS of KCG consecutive 16-channel steps of one tap.  The packed weight
+// layout ([tap][c/16][n/32][lane][8]) makes the KCG fragments of a group contiguous (stride
+// NFR*512 elements), so inside a group every address is base + immediate.  A register ring of
+// KCG slots holds the current group's weight fragments; slot kk is refilled with fragment kk of
+// the NEXT group right after its MFMAs (global -> VGPR, one coalesced 1 KiB wave load per
+// fragment, KCG iterations ahead of use).  Activation fragments are read from LDS one step ahead
+// (double buffer bb).  hipcc would otherwise wait vmcnt(0)/lgkmcnt right at each MFMA, and its
+// scheduler sinks prefetches back next to their uses: sched_barrier(0) pins the issue points.
+// Per MFMA the loop now carries ~2 non-MFMA instructions (was ~8 with per-iteration producer
+// bookkeeping), which is what a single wave per SIMD can hide behind a 32-cycle MFMA.
+template <typename T, int NF>
+struct WFrags {
+  int nfo[NF];  // element offset of this wave's n-fragments inside one 16-channel step
+  int stride;   // elements between consecutive 16-channel steps (NFR * 512)
+  __device__ __forceinline__ void init(int NFR, int nf0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) nfo[f] = (nf0 + f < NFR ? nf0 + f : NFR - 1) * 512;  // clamped: never stored
+    stride = NFR * 512;
+  }
+};
+
+template <typename T, int NF, int KCG>
+__device__ __forceinline__ void ring_fill(typename Elem<T>::vec8 (&ring)[KCG][NF], const WFrags<T, NF>& wf,
+                                          const T* base) {
+#pragma unroll
+  for (int kk = 0; kk < KCG; ++kk)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) ring[kk][f] = Vec8IO<T>::ldg(base + (size_t)kk * wf.stride + wf.nfo[f]);
+}
+
+template <typename T, int NT>
+__device__ __forceinline__ void fetch_b(typename Elem<T>::vec8 (&dst)[NT], const char* p, int pitch) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) dst[t] = Vec8IO<T>::lds(p + (size_t)(t * 32) * pitch);
+}
+
+// One group: acc += W[group] x act.  On entry ring = this group's fragments and bb[0] = the
+// activation fragments of its first step; on exit ring = next group's fragments (from
+// next_base) and bb[0] = first step of the next group (from bnext).  bcur / bnext are the
+// lane-adjusted LDS addresses of step 0 of this / the next group (steps are 32*sizeof(T)/2..
+// 16 channels = 16*sizeof(T) bytes apart).
+template <typename T, int NF, int NT, int KCG>
+__device__ __forceinline__ void conv_group(f32x16 (&acc)[NF][NT], typename Elem<T>::vec8 (&ring)[KCG][NF],
+                                           typename Elem<T>::vec8 (&bb)[2][NT], const WFrags<T, NF>& wf,
+                                           const T* next_base, const char* bcur, const char* bnext, int pitch) {
+  static_assert(KCG % 2 == 0, "group size must be even (bb parity)");
+#pragma unroll
+  for (int kk = 0; kk < KCG; ++kk) {
+    if (kk + 1 < KCG) fetch_b<T, NT>(bb[(kk + 1) & 1], bcur + (size_t)(kk + 1) * 16 * sizeof(T), pitch);
+    else fetch_b<T, NT>(bb[0], bnext, pitch);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) mma32(ring[kk][f], bb[kk & 1][t], acc[f][t]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) ring[kk][f] = Vec8IO<T>::ldg(next_base + (size_t)kk * wf.stride + wf.nfo[f]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// A whole conv over an LDS activation tile that holds ALL input channels (fused unit): groups run
+// tap-major and are LINEAR in the packed weights.  KC16 = C/16 steps per tap, GPT = KC16/KCG.
+template <typename T, int NF, int NT, int KC16, int KCG>
+__device__ __forceinline__ void conv_full(f32x16 (&acc)[NF][NT], const T* __restrict__ w, int NFR, int nf0, int k_w,
+                                          int dil, const char* act, int pitch, int col0, int lane) {
+  typedef typename Elem<T>::vec8 V8;
+  constexpr int GPT = KC16 / KCG;
+  static_assert(GPT * KCG == KC16, "group size must divide the steps per tap");
+  WFrags<T, NF> wf;
+  wf.init(NFR, nf0);
+  const T* wl = w + (size_t)lane * 8;
+  const size_t gstride = (size_t)KCG * wf.stride;  // elements per group
+  const int n_groups = k_w * GPT;
+  const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * (lane >> 5)) * sizeof(T);
+  V8 ring[KCG][NF], bb[2][NT];
+  ring_fill<T, NF, KCG>(ring, wf, wl);
+  fetch_b<T, NT>(bb[0], bbase, pitch);
+  __builtin_amdgcn_sched_barrier(0);
+  int g = 0;
+  for (int tap = 0; tap < k_w; ++tap) {
+    const char* btap = bbase + (size_t)(tap * dil) * pitch;
+    const char* btap_next = bbase + (size_t)(min(tap + 1, k_w - 1) * dil) * pitch;
+#pragma unroll
+    for (int h = 0; h < GPT; ++h, ++g) {
+      const T* nb = wl + (size_t)min(g + 1, n_groups - 1) * gstride;  // clamp: harmless re-read at the end
+      const char* bcur = btap + (size_t)(h * KCG) * 16 * sizeof(T);
+      const char* bnext = h + 1 < GPT ? btap + (size_t)((h + 1) * KCG) * 16 * sizeof(T) : btap_next;
+      conv_group<T, NF, NT, KCG>(acc, ring, bb, wf, nb, bcur, bnext, pitch);
+    }
+  }
+}
+
+// Weight-fragment register ring for the generic conv (chunked activations).  Fragments are consumed
+// in the order  for chunk: for tap: for kk  and the producer runs D iterations ahead of the consumer
+// ACROSS chunk boundaries, so the loads for the next chunk are in flight while the activation tile
+// is re-staged and the workgroup sits in its barriers.  Past the last fragment the producer clamps.
+template <typename T, int NF, int D>
+struct WRing {
+  typedef typename Elem<T>::vec8 V8;
+  V8 r[D][NF];
+  const T* wbase;
+  int nfo[NF];
+  int KC16, NFR, k_w, kc_per, n_chunks;
+  int p_chunk, p_tap, p_kk;
+
+  __device__ __forceinline__ void init(const T* w, int KC16_, int NFR_, int nf0, int k_w_, int kc_per_,
+                                       int n_chunks_, int lane) {
+    wbase = w + (size_t)lane * 8;
+    KC16 = KC16_; NFR = NFR_; k_w = k_w_; kc_per = kc_per_; n_chunks = n_chunks_;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) nfo[f] = (nf0 + f < NFR ? nf0 + f : NFR - 1) * 512;  // clamped: never stored
+    p_chunk = p_tap = p_kk = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) fetch(r[j]);
+  }
+  __device__ __forceinline__ void fetch(V8 (&dst)[NF]) {
+    const T* p = wbase + ((size_t)(p_tap * KC16 + p_chunk * kc_per + p_kk) * NFR) * 512;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) dst[f] = Vec8IO<T>::ldg(p + nfo[f]);
+    const int nk = p_kk + 1;
+    const bool wk = nk == kc_per;
+    p_kk = wk ? 0 : nk;
+    const int nt = p_tap + (wk ? 1 : 0);
+    const bool wt = nt == k_w;
+    p_tap = wt ? 0 : nt;
+    const int nc = p_chunk + (wt ? 1 : 0);
+    const bool end = nc == n_chunks;  // clamp at the last fragment of the last chunk
+    p_chunk = end ? n_chunks - 1 : nc;
+    p_tap = end ? k_w - 1 : p_tap;
+    p_kk = end ? kc_per - 1 : p_kk;
+  }
+};
+
+// One chunk: consumes k_w*kc_per ring entries (a multiple of D, so every ring slot is a compile-time
+// register index and the body is straight-line); activation fragments one step ahead from LDS.
 template <typename T, int NF, int NT, int D>
-__device__ __forceinline__ void conv_stage(f32x16 (&acc)[NF][NT], const T* __restrict__ w, int KC16,
-                                           int NFR, int nf0, int kc_base, int kc_cnt, int k_w, int dil,
-                                           const char* act, int pitch, int col0, int lane) {
+__device__ __forceinline__ void conv_stage(f32x16 (&acc)[NF][NT], WRing<T, NF, D>& ring, int kc_per, int k_w,
+                                           int dil, const char* act, int pitch, int col0, int lane) {
   typedef typename Elem<T>::vec8 V8;
   static_assert(D % 2 == 0, "ring depth must be even");
   const int g = lane >> 5;
-  const int n_it = k_w * kc_cnt;
+  const int n_it = k_w * kc_per;
   const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * g) * sizeof(T);
-  const T* wbase = w + (size_t)lane * 8;
-  int nfo[NF];  // fragment offsets (clamped: duplicates are never stored)
-#pragma unroll
-  for (int f = 0; f < NF; ++f) nfo[f] = (nf0 + f < NFR ? nf0 + f : NFR - 1) * 512;
   const int last_tap = k_w - 1;
-
-  int wp_tap = 0, wp_kk = 0;  // weight producer position
-  auto fetch_w = [&](V8(&dst)[NF]) {
-    const T* p = wbase + ((size_t)(wp_tap * KC16 + kc_base + wp_kk) * NFR) * 512;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) dst[f] = Vec8IO<T>::ldg(p + nfo[f]);
-    const int nk = wp_kk + 1;
-    const bool wrap = nk == kc_cnt;
-    wp_kk = wrap ? 0 : nk;
-    wp_tap = min(wp_tap + (wrap ? 1 : 0), last_tap);
-  };
-  int bp_tap = 0, bp_kk = 0;  // activation producer position
-  auto fetch_b = [&](V8(&dst)[NT]) {
+  int bp_tap = 0, bp_kk = 0;  // activation producer position (clamps at the end)
+  auto fetch_bb = [&](V8(&dst)[NT]) {
     const char* p = bbase + (size_t)(bp_tap * dil) * pitch + (size_t)(bp_kk * 16) * sizeof(T);
 #pragma unroll
     for (int t = 0; t < NT; ++t) dst[t] = Vec8IO<T>::lds(p + (size_t)(t * 32) * pitch);
     const int nk = bp_kk + 1;
-    const bool wrap = nk == kc_cnt;
+    const bool wrap = nk == kc_per;
     bp_kk = wrap ? 0 : nk;
     bp_tap = min(bp_tap + (wrap ? 1 : 0), last_tap);
   };
-
-  V8 ring[D][NF];
   V8 bb[2][NT];
-#pragma unroll
-  for (int j = 0; j < D; ++j) fetch_w(ring[j]);
-  fetch_b(bb[0]);
-  // sched_barrier(0): LLVM's scheduler otherwise sinks every prefetch back next to its use
+  fetch_bb(bb[0]);
   __builtin_amdgcn_sched_barrier(0);
   for (int it0 = 0; it0 < n_it; it0 += D) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      fetch_b(bb[(j + 1) & 1]);
+      fetch_bb(bb[(j + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mma32(ring[j][f], bb[j & 1][t], acc[f][t]);
-      fetch_w(ring[j]);
+        for (int t = 0; t < NT; ++t) mma32(ring.r[j][f], bb[j & 1][t], acc[f][t]);
+      ring.fetch(ring.r[j]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -186,7 +355,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NF][NT]) {
 // ------------------------------------------------------------------ generic conv kernel
 constexpr int KCH = 64;  // channels staged per LDS chunk
 
-template <typename T, int NF, int NT, int WN, int WT>
+template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
 __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32;
@@ -210,14 +379,36 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
   f32x16 acc[NF][NT];
   zero_acc<NF, NT>(acc);
 
-  for (int c0 = 0; c0 < d.c_in; c0 += KCH) {
-    const int nch = min(KCH, d.c_in - c0);
-    stage_rows<T>(smem, pitch, rows, nch, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, c0, d.in_scale,
-                  d.pre_act, d.pre_slope);
+  // staged 8-element units per thread in the async pipeline (halo <= 32 rows; larger halos take
+  // the synchronous single-buffer path)
+  constexpr int MAXU = ((BT + 32) * 8 + WN * WT * 64 - 1) / (WN * WT * 64);
+  constexpr int RD = KCH / 16;  // ring depth 4: k_w * (KCH/16) is always a multiple of it
+  WRing<T, NF, RD> ring;
+  const int n_chunks = d.c_in / KCH;
+  ring.init((const T*)d.w, KC16, NFR, nf0, d.k_w, KCH / 16, n_chunks, lane);
+  if constexpr (ASYNC) {
+    const size_t buf_bytes = (size_t)rows * pitch;
+    StageRegs<T, MAXU, NIN> sr;
+    stage_issue<T, MAXU, NIN>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0);
+    stage_commit<T, MAXU, NIN>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     __syncthreads();
-    conv_stage<T, NF, NT, 2>(acc, (const T*)d.w, KC16, NFR, nf0, c0 >> 4, nch >> 4, d.k_w, d.dil, smem,
-                             pitch, col0, lane);
-    __syncthreads();
+    for (int ci = 0; ci < n_chunks; ++ci) {
+      const bool more = ci + 1 < n_chunks;
+      if (more) stage_issue<T, MAXU, NIN>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCH);
+      conv_stage<T, NF, NT, RD>(acc, ring, KCH / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0,
+                                lane);
+      if (more) stage_commit<T, MAXU, NIN>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in,
+                                           d.in_scale, d.pre_act, d.pre_slope);
+      __syncthreads();
+    }
+  } else {
+    for (int ci = 0; ci < n_chunks; ++ci) {
+      stage_rows<T>(smem, pitch, rows, KCH, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, ci * KCH, d.in_scale,
+                    d.pre_act, d.pre_slope);
+      __syncthreads();
+      conv_stage<T, NF, NT, RD>(acc, ring, KCH / 16, d.k_w, d.dil, smem, pitch, col0, lane);
+      __syncthreads();
+    }
   }
 
   // epilogue: lane owns column (lane&31) and channel quads n0 + {0..3}
@@ -234,14 +425,25 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
         const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
         if (n0 >= d.n_out) continue;
         float v[4];
+        const bool full = n0 + 3 < d.n_out;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f}, rq = {0.f, 0.f, 0.f, 0.f};
+        if (full) {  // 16-byte bias / residual loads (n0 % 4 == 0)
+          if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n0);
+          if (d.resid && (d.ldr & 3) == 0) rq = *reinterpret_cast<const f32x4*>(d.resid + row * d.ldr + n0);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int n = n0 + e;
           float s = acc[f][t][4 * q + e];
           if (n < d.n_out) {
-            if (d.bias) s += d.bias[n];
-            s = apply_act(s, d.act) * d.alpha;
-            if (d.resid) s += d.resid[row * d.ldr + n];
+            if (full) {
+              s = apply_act(s + bq[e], d.act) * d.alpha;
+              if (d.resid) s += (d.ldr & 3) == 0 ? rq[e] : d.resid[row * d.ldr + n];
+            } else {
+              if (d.bias) s += d.bias[n];
+              s = apply_act(s, d.act) * d.alpha;
+              if (d.resid) s += d.resid[row * d.ldr + n];
+            }
           }
           v[e] = s;
         }
@@ -266,18 +468,22 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
           }
         }
       }
+      // keep the epilogue's live ranges short: without this hipcc hoists every bias / residual
+      // load of the tile to the top and the kernel loses a wave of occupancy
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-template <typename T, int NF, int NT, int WN, int WT>
-int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
+template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
+int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + BT - 1) / BT), (unsigned)d.rg.n_seq, (unsigned)((d.n_out + BN - 1) / BN));
-  const size_t lds = (size_t)(BT + (d.k_w - 1) * d.dil) * (KCH * sizeof(T) + 16);
+  const size_t rows = (size_t)BT + (size_t)(d.k_w - 1) * d.dil;
+  const size_t lds = (ASYNC ? 2 : 1) * rows * (KCH * sizeof(T) + 16);
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: halo too large for LDS");
-  auto kern = conv1d_kernel<T, NF, NT, WN, WT>;
+  auto kern = conv1d_kernel<T, NF, NT, WN, WT, NIN, ASYNC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
@@ -287,15 +493,24 @@ int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
   return JATTS_OK;
 }
 
+template <typename T, int NF, int NT, int WN, int WT>
+int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
+  const bool small_halo = (d.k_w - 1) * d.dil <= 32;
+  const bool multi_chunk = d.c_in > KCH;  // a single chunk has nothing to overlap with
+  if (small_halo && multi_chunk && d.n_in == 1) return launch_conv_k<T, NF, NT, WN, WT, 1, true>(d, s);
+  if (small_halo && multi_chunk && sizeof(T) == 2) return launch_conv_k<T, NF, NT, WN, WT, 3, true>(d, s);
+  return launch_conv_k<T, NF, NT, WN, WT, 3, false>(d, s);
+}
+
 // ------------------------------------------------------------ fused HiFi-GAN dilation unit
-template <typename T, int C, int WGCOLS, int WN, int NT>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8>
 __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(jatts_resunit_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
   constexpr int NF = C / (WN * 32);
   constexpr int KC16 = C / 16, NFR = C / 32;
   constexpr int pitch = C * (int)sizeof(T) + 16;
-  constexpr int RD = sizeof(T) == 4 ? 2 : (KC16 < 8 ? KC16 : 8);  // weight ring depth; divides K*KC16
+  constexpr int KCG = sizeof(T) == 4 ? 2 : (KC16 < KCGMAX ? KC16 : KCGMAX);  // ring depth = group size
   static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
   const int K = d.k_w, dil = d.dil;
   const int p2 = (K - 1) / 2, p1 = p2 * dil;
@@ -321,12 +536,14 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   char* hs = smem;
 
   const T* xin[3] = {(const T*)d.x, nullptr, nullptr};
-  stage_rows<T>(xs, pitch, rx, C, t0 - p2 - p1, L, seq_row0, xin, 1, C, 0, 1.f, JATTS_PRE_LRELU, d.slope);
+  if (JATTS_ABLATE != 2)
+    stage_rows<T>(xs, pitch, rx, C, t0 - p2 - p1, L, seq_row0, xin, 1, C, 0, 1.f,
+                  JATTS_ABLATE == 1 ? JATTS_PRE_NONE : JATTS_PRE_LRELU, d.slope);
   __syncthreads();
 
   f32x16 acc[NF][NT];
   zero_acc<NF, NT>(acc);
-  conv_stage<T, NF, NT, RD>(acc, (const T*)d.w1, KC16, NFR, nf0, 0, KC16, K, dil, xs, pitch, col0, lane);
+  if (JATTS_ABLATE != 6) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
 
   // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
   __syncthreads();  // every wave is done reading x: the tile may now be overwritten by h
@@ -357,7 +574,8 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
         }
         char* p = hs + (size_t)col * pitch + (size_t)n0 * sizeof(T);
         if (sizeof(T) == 2) {
-          *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+          if (JATTS_ABLATE != 5 || to_f32(o[0]) == 12345.678f)
+            *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
         } else {
           *reinterpret_cast<f32x4*>(p) = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
         }
@@ -366,11 +584,16 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   __syncthreads();
 
   zero_acc<NF, NT>(acc);
-  conv_stage<T, NF, NT, RD>(acc, (const T*)d.w2, KC16, NFR, nf0, 0, KC16, K, 1, hs, pitch, col0, lane);
+  if (JATTS_ABLATE != 6) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
 
-  // epilogue 2: y = x + acc + b2 for the tt_out valid columns
+  // epilogue 2: y = x + acc + b2 for the tt_out valid columns.  The tile is assembled in LDS (the
+  // h region is dead once every wave has left stage 2) and written with row-contiguous 16-byte
+  // stores: the MFMA fragment layout would otherwise scatter each 128-byte line over 8 separate
+  // 8-byte store instructions, which measured 1.4 ms of a 2.7 ms launch (profiles/r01_notes.md).
   const T* xg = (const T*)d.x;
   T* yg = (T*)d.y;
+  __syncthreads();
+  char* ys = smem;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = col0 + t * 32 + (lane & 31);
@@ -383,24 +606,44 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
       for (int q = 0; q < 4; ++q) {
         const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
         const f32x4 bb = *reinterpret_cast<const f32x4*>(d.b2 + n0);
+        char* p = ys + (size_t)col * pitch + (size_t)n0 * sizeof(T);
         if (sizeof(T) == 2) {
-          const f16x4 xr = *reinterpret_cast<const f16x4*>((const f16*)xg + rowoff + n0);
+          f16x4 xr = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+          if (JATTS_ABLATE != 3) xr = *reinterpret_cast<const f16x4*>((const f16*)xg + rowoff + n0);
           f16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (f16)(acc[f][t][4 * q + e] + bb[e] + (float)xr[e]);
-          *reinterpret_cast<f16x4*>((f16*)yg + rowoff + n0) = o;
+          *reinterpret_cast<f16x4*>(p) = o;
         } else {
           const f32x4 xr = *reinterpret_cast<const f32x4*>((const float*)xg + rowoff + n0);
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e] + bb[e] + xr[e];
-          *reinterpret_cast<f32x4*>((float*)yg + rowoff + n0) = o;
+          *reinterpret_cast<f32x4*>(p) = o;
         }
       }
   }
+  __syncthreads();
+  {
+    constexpr int UPR = C / 8;
+    const int vrows = min(tt_out, L - t0);
+    const int total = vrows * UPR;
+    for (int u = threadIdx.x; u < total; u += blockDim.x) {
+      const int r = u / UPR, cu = u - r * UPR;
+      const typename Elem<T>::vec8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
+      T* dst = yg + (seq_row0 + t0 + r) * (int64_t)C + cu * 8;
+      if (JATTS_ABLATE != 4 || to_f32(v[0]) == 12345.678f) {
+        if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
+        else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
+        }
+      }
+    }
+  }
 }
 
-template <typename T, int C, int WGCOLS, int WN, int NT>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8>
 int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   constexpr int WT = WGCOLS / (NT * 32);
   const int K = d.k_w, p2 = (K - 1) / 2, p1 = p2 * d.dil;
@@ -408,11 +651,13 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   if (tt_out < 8) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: kernel too wide for tile");
   const size_t pitch = C * sizeof(T) + 16;
   const size_t rows_x = WGCOLS + 2 * p1, rows_h = WGCOLS + K - 1;
-  const size_t lds = (rows_x > rows_h ? rows_x : rows_h) * pitch;  // h overlays x
+  size_t lds = (rows_x > rows_h ? rows_x : rows_h) * pitch;  // h overlays x
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: tile exceeds 160 KiB LDS");
+  static const int pad_lds = [] { const char* e = getenv("JATTS_RESUNIT_PADLDS"); return e ? atoi(e) : 0; }();
+  if (pad_lds && lds < (size_t)pad_lds) lds = pad_lds;  // experiment knob: force fewer workgroups per CU
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
-  auto kern = resunit_kernel<T, C, WGCOLS, WN, NT>;
+  auto kern = resunit_kernel<T, C, WGCOLS, WN, NT, KCGMAX>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
@@ -433,15 +678,19 @@ extern "C" int64_t jatts_conv_weight_index(int32_t n, int32_t tap, int32_t c, in
 
 extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   if (!d || !d->x[0] || !d->w || !d->y || !d->rg.cu_rows) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: null pointer");
-  if (d->c_in <= 0 || d->c_in % 32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: c_in must be a positive multiple of 32");
+  if (d->c_in <= 0 || d->c_in % 64) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: c_in must be a positive multiple of 64");
   if (d->ldx % 8) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: ldx must be a multiple of 8");
   if (d->n_in < 1 || d->n_in > 3 || d->k_w < 1 || d->dil < 1 || d->n_out < 1 || d->rg.n_seq < 1 || d->rg.len_mul < 1)
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: bad geometry");
   if (d->rg.max_len <= 0) return JATTS_OK;
   hipStream_t s = (hipStream_t)stream;
   const bool narrow = d->n_out <= 64;
+  // JATTS_CONV_VARIANT (tuning knob): 0 = 128n x 128t tile (64 accumulators/lane, 2-3 workgroups/CU;
+  // measured 1.7x faster end to end), 1 = 128n x 256t register tile (1 workgroup/CU)
+  static const int variant = [] { const char* e = getenv("JATTS_CONV_VARIANT"); return e ? atoi(e) : 0; }();
   if (d->dtype == JATTS_F16) {
-    return narrow ? launch_conv<f16, 2, 2, 1, 4>(*d, s) : launch_conv<f16, 2, 4, 2, 2>(*d, s);
+    if (narrow) return launch_conv<f16, 2, 2, 1, 4>(*d, s);
+    return variant == 1 ? launch_conv<f16, 2, 4, 2, 2>(*d, s) : launch_conv<f16, 2, 2, 2, 2>(*d, s);
   } else if (d->dtype == JATTS_F32) {
     return narrow ? launch_conv<float, 2, 2, 1, 4>(*d, s) : launch_conv<float, 2, 2, 2, 2>(*d, s);
   }
@@ -460,18 +709,15 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
     // JATTS_RESUNIT_VARIANT (tuning knob, read once) selects alternative tilings for sweeps.
     static const int variant = [] { const char* e = getenv("JATTS_RESUNIT_VARIANT"); return e ? atoi(e) : 0; }();
     switch (d->channels * 10 + variant) {
-      case 320: return launch_resunit<f16, 32, 256, 1, 2>(*d, s);
-      case 321: return launch_resunit<f16, 32, 256, 1, 4>(*d, s);
-      case 322: return launch_resunit<f16, 32, 128, 1, 4>(*d, s);
+      case 320: case 321: case 322: return launch_resunit<f16, 32, 256, 1, 2>(*d, s);
       case 640: return launch_resunit<f16, 64, 256, 1, 2>(*d, s);
-      case 641: return launch_resunit<f16, 64, 256, 1, 4>(*d, s);
-      case 642: return launch_resunit<f16, 64, 128, 1, 4>(*d, s);
-      case 1280: return launch_resunit<f16, 128, 128, 2, 2>(*d, s);
-      case 1281: return launch_resunit<f16, 128, 128, 2, 4>(*d, s);
-      case 1282: return launch_resunit<f16, 128, 256, 2, 4>(*d, s);
-      case 2560: return launch_resunit<f16, 256, 64, 4, 2>(*d, s);
-      case 2561: return launch_resunit<f16, 256, 128, 4, 4>(*d, s);
-      case 2562: return launch_resunit<f16, 256, 128, 4, 2>(*d, s);
+      case 641: case 642: return launch_resunit<f16, 64, 256, 1, 2, 2>(*d, s);
+      case 1280: return launch_resunit<f16, 128, 128, 2, 2, 8>(*d, s);
+      case 1281: return launch_resunit<f16, 128, 128, 2, 2, 4>(*d, s);
+      case 1282: return launch_resunit<f16, 128, 128, 2, 2, 2>(*d, s);
+      case 2560: return launch_resunit<f16, 256, 64, 4, 2, 8>(*d, s);
+      case 2561: return launch_resunit<f16, 256, 64, 4, 2, 4>(*d, s);
+      case 2562: return launch_resunit<f16, 256, 64, 4, 2, 2>(*d, s);
       case 5120: case 5121: case 5122: return launch_resunit<f16, 512, 32, 4, 1>(*d, s);
     }
   } else if (d->dtype == JATTS_F32) {

@@ -98,14 +98,15 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
-def pack_conv_weight(w, dtype_code):
+def pack_conv_weight(w, dtype_code, c_mult=64):
     """(n_out, c_in, k) -> MFMA fragment order [tap][c/16][n/32][lane][8] (include/jatts_hip.h).
 
-    c_in is zero-padded to a multiple of 32 and n_out to a multiple of 32.  Pure
-    permutation + cast: done once per checkpoint at prepare time.
+    c_in is zero-padded to a multiple of ``c_mult`` (64 for jatts_conv1d, whose LDS chunks are 64
+    channels; 32 for the fused HiFi-GAN unit, which takes c_in == channels) and n_out to a
+    multiple of 32.  Pure permutation + cast: done once per checkpoint at prepare time.
     """
     n, c, k = w.shape
-    n_pad, c_pad = round_up(n, 32), round_up(c, 32)
+    n_pad, c_pad = round_up(n, 32), round_up(c, c_mult)
     wp = torch.zeros(n_pad, c_pad, k, dtype=torch.float32, device=w.device)
     wp[:n, :c] = w.float()
     wp = wp.permute(2, 0, 1).reshape(k, n_pad // 32, 32, c_pad // 16, 2, 8)

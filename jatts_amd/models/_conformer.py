@@ -33,7 +33,7 @@ def legacy_rel_pos_table(n, d, table_len):
 class PackedConv:
     """A Conv1d/Linear weight packed for jatts_conv1d."""
 
-    def __init__(self, w, b, dtype, device, scale=None, shift=None):
+    def __init__(self, w, b, dtype, device, scale=None, shift=None, c_mult=64):
         # w: (n, c, k) or (n, c); optional per-output-channel affine folded in (BatchNorm eval)
         w = w.detach().float()
         if w.dim() == 2:
@@ -43,8 +43,8 @@ class PackedConv:
             w = w * scale.view(-1, 1, 1)
             b = (b * scale if b is not None else torch.zeros_like(scale)) + shift
         self.n_out, c, self.k = w.shape
-        self.c_in = hip.round_up(c, 32)
-        self.w = hip.pack_conv_weight(w.to(device), dtype)
+        self.c_in = hip.round_up(c, c_mult)
+        self.w = hip.pack_conv_weight(w.to(device), dtype, c_mult)
         self.b = None if b is None else b.to(device).contiguous()
 
 
@@ -57,6 +57,8 @@ class ConformerRunner:
             self.n_layers += 1
         self.A = g("encoders.0.norm_mha.weight").shape[0]
         self.dk = self.A // n_heads
+        if self.A % 64 or self.dk % 32:
+            raise NotImplementedError("attention_dim must be a multiple of 64 and d_k a multiple of 32 (MFMA tiles)")
         f32 = lambda t: t.detach().float().to(device).contiguous()  # noqa: E731
         self.layers = []
         for i in range(self.n_layers):
@@ -146,7 +148,7 @@ class ConformerRunner:
             ku = hip.rowdot(qk, 2 * A, rb.total, H, dk, L["u"], col0=A)                          # u . k_j
             g = torch.empty(rb.total, H * ldg, dtype=hip.torch_dtype(self.dtype), device=x.device)
             for h in range(H):  # g[row][h][m] = q_row,h . p_h[m] + v_h . p_h[m]
-                hip.conv1d(rb, qk, heads[h], dk, ldg, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
+                hip.conv1d(rb, qk, heads[h], hip.round_up(dk, 64), ldg, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
                            x_col0=h * dk, out=g, out_ld=H * ldg, out_col0=h * ldg)
         ctx = hip.relpos_attention(rb, qk, 2 * A, qk, 2 * A, vt, rb.total, g, ldg, ku, 1.0 / math.sqrt(dk),
                                    H, dk, self.dtype, q_col0=0, k_col0=A)

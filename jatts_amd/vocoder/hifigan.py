@@ -108,6 +108,8 @@ class HiFiGANGenerator(torch.nn.Module):
         P["in"] = PackedConv(sd["input_conv.weight"], sd["input_conv.bias"], dt, dev)
         nb = len(self.resblock_kernel_sizes)
         P["ups"], P["blocks"] = [], []
+        supported = {hip.F16: (32, 64, 128, 256, 512), hip.F32: (32, 64, 128, 256)}[dt]
+        P["unit_channels"] = supported
         for i, (s, uk) in enumerate(zip(self.upsample_scales, self.upsample_kernel_sizes)):
             w = sd[f"upsamples.{i}.1.weight"].detach().float()
             wc, pad = hip.convtranspose_as_conv(w, s, s // 2 + s % 2)
@@ -118,8 +120,9 @@ class HiFiGANGenerator(torch.nn.Module):
                 units = []
                 for di, d in enumerate(self.resblock_dilations[j]):
                     q = f"blocks.{i * nb + j}."
-                    c1 = PackedConv(sd[q + f"convs1.{di}.1.weight"], sd[q + f"convs1.{di}.1.bias"], dt, dev)
-                    c2 = PackedConv(sd[q + f"convs2.{di}.1.weight"], sd[q + f"convs2.{di}.1.bias"], dt, dev)
+                    cm = 32 if w.shape[1] in supported else 64  # fused unit takes c_in == channels
+                    c1 = PackedConv(sd[q + f"convs1.{di}.1.weight"], sd[q + f"convs1.{di}.1.bias"], dt, dev, c_mult=cm)
+                    c2 = PackedConv(sd[q + f"convs2.{di}.1.weight"], sd[q + f"convs2.{di}.1.bias"], dt, dev, c_mult=cm)
                     units.append((c1, c2, rk, d))
                 stage.append(units)
             P["blocks"].append(stage)
@@ -142,7 +145,7 @@ class HiFiGANGenerator(torch.nn.Module):
         if taps is not None:
             taps["input_conv"] = x.float()
         xs, in_scale, rate = [x], 1.0, 1
-        supported = {hip.F16: (32, 64, 128, 256, 512), hip.F32: (32, 64, 128, 256)}[dt]
+        supported = P["unit_channels"]
         for i, (pc, pad, s, c_out) in enumerate(P["ups"]):
             rows = rb.total * rate
             up = hip.conv1d(rb, xs, pc.w, pc.c_in, pc.n_out, pc.k, dtype=dt, bias=pc.b, pad=pad,

@@ -36,10 +36,10 @@ def test_ctypes_structs_match_header_field_order():
 def test_weight_packing_matches_c_index(lib):
     from jatts_amd import hip
     g = torch.Generator().manual_seed(0)
-    for (n, c, k) in [(40, 48, 3), (32, 16, 1), (1, 80, 7), (700, 192, 1)]:
+    for (n, c, k) in [(40, 48, 3), (32, 16, 1), (1, 80, 7), (700, 192, 1), (64, 64, 11)]:
         w = torch.randn(n, c, k, generator=g)
         wp = hip.pack_conv_weight(w, hip.F32)
-        n_pad, c_pad = hip.round_up(n, 32), hip.round_up(c, 32)
+        n_pad, c_pad = hip.round_up(n, 32), hip.round_up(c, 64)
         assert wp.numel() == n_pad * c_pad * k
         for _ in range(50):
             i, j, t = (int(torch.randint(0, m, (1,), generator=g)) for m in (n, c, k))

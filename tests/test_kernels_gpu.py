@@ -98,7 +98,7 @@ def test_conv1d(cuda, lib, prec, case):
     rb = _ragged(lens, cuda)
     tdt = hip.torch_dtype(dt)
     wp = hip.pack_conv_weight(w.to(cuda), dt)
-    c_pad = hip.round_up(c_in, 32)  # the ABI wants c_in % 32 == 0: zero-pad channels like the product does
+    c_pad = hip.round_up(c_in, 64)  # the ABI wants c_in % 64 == 0: zero-pad channels like the product does
     xs = [F.pad(x, (0, c_pad - c_in)) for x in xs]
     y = hip.conv1d(rb, [x.to(cuda).to(tdt).contiguous() for x in xs], wp, c_pad, n_out, k, dtype=dt, dil=dil, bias=b.to(cuda),
                    act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], alpha=alpha,
@@ -148,8 +148,8 @@ def test_hifigan_resunit(cuda, lib, prec, C, k, d, lens):
     rb = _ragged(lens, cuda)
     xd = x.to(cuda).to(tdt)
     y = torch.full_like(xd, float("nan"))
-    hip.hifigan_resunit(rb, 1, xd, y, hip.pack_conv_weight(w1.to(cuda), dt), b1.to(cuda),
-                        hip.pack_conv_weight(w2.to(cuda), dt), b2.to(cuda), C, k, d, 0.1, dt)
+    hip.hifigan_resunit(rb, 1, xd, y, hip.pack_conv_weight(w1.to(cuda), dt, 32), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), dt, 32), b2.to(cuda), C, k, d, 0.1, dt)
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all(), "unwritten / non-finite outputs"
     e = relerr(y.float(), ref)
@@ -168,8 +168,8 @@ def test_hifigan_resunit_len_mul(cuda, lib):
     ref = _ref_unit(x, w1, b1, w2, b2, [n * mul for n in lens], k, d, 0.1, False)
     rb = _ragged(lens, cuda)
     y = torch.empty(R, C, device=cuda)
-    hip.hifigan_resunit(rb, mul, x.to(cuda), y, hip.pack_conv_weight(w1.to(cuda), hip.F32), b1.to(cuda),
-                        hip.pack_conv_weight(w2.to(cuda), hip.F32), b2.to(cuda), C, k, d, 0.1, hip.F32)
+    hip.hifigan_resunit(rb, mul, x.to(cuda), y, hip.pack_conv_weight(w1.to(cuda), hip.F32, 32), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), hip.F32, 32), b2.to(cuda), C, k, d, 0.1, hip.F32)
     assert relerr(y, ref) <= TOL["fp32"]
 
 

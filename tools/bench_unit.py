@@ -20,8 +20,8 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     g = torch.Generator(device="cpu").manual_seed(0)
     x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).to(tdt)
     y = torch.empty_like(x)
-    w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype)
-    w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype)
+    w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype, 32)
+    w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype, 32)
     b1 = torch.zeros(C, device=dev)
     b2 = torch.zeros(C, device=dev)
     for _ in range(2):
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--dil", type=int, default=1)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--all", action="store_true")
+    ap.add_argument("--batch", type=int, default=64)
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
     if a.all:
@@ -57,7 +58,7 @@ def main():
                     tot += run(C, k, d, rates[C], a.iters)
         print(f"sum over the 36 units of one generator pass: {tot:.2f} ms")
     else:
-        run(a.C, a.k, a.dil, rates[a.C], a.iters)
+        run(a.C, a.k, a.dil, rates[a.C], a.iters, B=a.batch)
 
 
 if __name__ == "__main__":
