@@ -129,6 +129,12 @@ typedef struct jatts_resunit_desc {
   const float* b1;
   const void* w2;
   const float* b2;
+  /* optional MRF mix fused into the (coalesced) output pass: y = out_scale * (unit(x) + add0 + add1);
+   * used by the last unit of the last ResBlock so that the mean over ResBlocks
+   * (HiFiGANGenerator.forward: cs / num_blocks) is written once.  NULL = plain unit. */
+  const void* add0;
+  const void* add1;
+  float out_scale;
 } jatts_resunit_desc;
 
 int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);

@@ -36,6 +36,7 @@ class ResUnitDesc(C.Structure):
         ("rg", Ragged), ("dtype", C.c_int32), ("channels", C.c_int32), ("k_w", C.c_int32),
         ("dil", C.c_int32), ("slope", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("add0", C.c_void_p), ("add1", C.c_void_p), ("out_scale", C.c_float),
     ]
 
 

@@ -630,8 +630,17 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
     const int total = vrows * UPR;
     for (int u = threadIdx.x; u < total; u += blockDim.x) {
       const int r = u / UPR, cu = u - r * UPR;
-      const typename Elem<T>::vec8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
-      T* dst = yg + (seq_row0 + t0 + r) * (int64_t)C + cu * 8;
+      typename Elem<T>::vec8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
+      const int64_t goff = (seq_row0 + t0 + r) * (int64_t)C + cu * 8;
+      if (d.add0) {  // fused MRF mean over ResBlocks (coalesced 16-byte reads)
+        const typename Elem<T>::vec8 a0 = Vec8IO<T>::ldg((const T*)d.add0 + goff);
+        typename Elem<T>::vec8 a1 = a0;
+        if (d.add1) a1 = Vec8IO<T>::ldg((const T*)d.add1 + goff);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[e]) + (d.add1 ? to_f32(a1[e]) : 0.f)) * d.out_scale);
+      }
+      T* dst = yg + goff;
       if (JATTS_ABLATE != 4 || to_f32(v[0]) == 12345.678f) {
         if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
         else {

@@ -181,7 +181,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     return out
 
 
-def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype):
+def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype, add=None, out_scale=1.0):
     lib = _abi.load()
     d = _abi.ResUnitDesc()
     d.rg = rb.struct(len_mul)
@@ -191,6 +191,13 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
         raise ValueError("hifigan_resunit: bad buffer size/dtype")
     d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
     d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    if add:
+        for a in add:
+            if a.numel() != rows * channels or a.dtype != x.dtype:
+                raise ValueError("hifigan_resunit: bad mix buffer")
+        d.add0 = add[0].data_ptr()
+        d.add1 = add[1].data_ptr() if len(add) > 1 else None
+    d.out_scale = out_scale
     with _Timed("resunit", (channels, k_w, dil, rows)):
         _abi.check(lib.jatts_hifigan_resunit(C.byref(d), _stream()), "jatts_hifigan_resunit")
     return y

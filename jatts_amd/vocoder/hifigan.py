@@ -155,12 +155,17 @@ class HiFiGANGenerator(torch.nn.Module):
             if taps is not None:
                 taps[f"up{i}"] = up.float()
             outs = []
-            for units in P["blocks"][i]:
+            blocks = P["blocks"][i]
+            fuse_mean = c_out in supported and len(blocks) in (2, 3)
+            for j, units in enumerate(blocks):
                 cur = up
-                for (c1, c2, rk, d) in units:
+                for di, (c1, c2, rk, d) in enumerate(units):
                     nxt = torch.empty_like(up)
                     if c_out in supported:
-                        hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt)
+                        last = fuse_mean and j == len(blocks) - 1 and di == len(units) - 1
+                        # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
+                        hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt,
+                                            add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0)
                     else:  # generic two-launch fallback for unusual channel counts
                         h = hip.conv1d(rb, cur, c1.w, c_out, c_out, rk, dtype=dt, bias=c1.b, dil=d,
                                        pre_lrelu=self.slope, len_mul=rate)
@@ -170,9 +175,12 @@ class HiFiGANGenerator(torch.nn.Module):
                         nxt = hip.affine_cast(y32, dt)
                     cur = nxt
                 outs.append(cur)
-            xs, in_scale = outs, 1.0 / len(outs)
+            if fuse_mean:
+                xs, in_scale = [outs[-1]], 1.0
+            else:
+                xs, in_scale = outs, 1.0 / len(outs)
             if taps is not None:
-                taps[f"mrf{i}"] = sum(o.float() for o in outs) * in_scale
+                taps[f"mrf{i}"] = sum(o.float() for o in xs) * in_scale
         return hip.hifigan_output(rb, rate, xs, in_scale, 0.01, xs[0].shape[1], self.kernel_size,
                                   P["out_w"], P["out_b"], dt)
 

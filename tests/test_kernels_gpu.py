@@ -156,6 +156,26 @@ def test_hifigan_resunit(cuda, lib, prec, C, k, d, lens):
     assert e <= TOL[prec], f"resunit C={C} k={k} d={d} {prec}: rel err {e:.3e}"
 
 
+def test_hifigan_resunit_fused_mrf_mean(cuda, lib):
+    """y = (unit(x) + add0 + add1) / 3 written by the unit's coalesced output pass."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(11)
+    lens, C, k, d = [300, 77], 64, 7, 3
+    R = sum(lens)
+    x, a0, a1 = (torch.randn(R, C, generator=g).half().float() for _ in range(3))
+    w1 = (torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).half().float()
+    w2 = (torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).half().float()
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    unit = _ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, True)
+    ref = (unit.half().double() + a0.double() + a1.double()) / 3.0
+    rb = _ragged(lens, cuda)
+    y = torch.empty(R, C, device=cuda, dtype=torch.float16)
+    hip.hifigan_resunit(rb, 1, x.to(cuda).half(), y, hip.pack_conv_weight(w1.to(cuda), hip.F16, 32), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), hip.F16, 32), b2.to(cuda), C, k, d, 0.1, hip.F16,
+                        add=[a0.to(cuda).half(), a1.to(cuda).half()], out_scale=1.0 / 3.0)
+    assert relerr(y.float(), ref) <= TOL["fp16"]
+
+
 def test_hifigan_resunit_len_mul(cuda, lib):
     """len_mul scales the ragged geometry (HiFi-GAN stages reuse one cu_rows array)."""
     from jatts_amd import hip
