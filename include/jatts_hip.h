@@ -170,6 +170,12 @@ typedef struct jatts_relattn_desc {
   const float* ku;               /* [rows][n_heads] or NULL */
   float scale;
   void* out; int32_t ldo;        /* [rows][ldo], head h at column h*d_k */
+  /* rel_mode 0/1: legacy map above (LegacyRelPositionMultiHeadedAttention).
+   * rel_mode 2: RelPositionMultiHeadedAttention (attention.py:209-305, new rel_shift :237-261, used
+   * by VITS): BD'[i,j] = g[i][rel_center - i + j] for every j (no wrap); g has 2*cap-1 columns
+   * whose column m encodes relative position rel_center - m, rel_center = cap - 1. */
+  int32_t rel_mode;
+  int32_t rel_center;
 } jatts_relattn_desc;
 
 int jatts_relpos_attention(const jatts_relattn_desc* d, void* stream);
@@ -218,6 +224,15 @@ int jatts_predictor_head(int32_t dtype, const void* x, int32_t ldx, int64_t rows
 int jatts_variance_embed_add(const jatts_ragged* rg, float* hs, int32_t dim, const float* p,
                              const float* wp, const float* bp, int32_t kp, const float* e,
                              const float* we, const float* be, int32_t ke, void* stream);
+
+/* WaveNet gated activation (modules/wavenet/residual_block.py:143-160):
+ *   y[row][c] = tanh(x[row][c] + g[seq][c]) * sigmoid(x[row][C + c] + g[seq][C + c]),  g optional.
+ * x: [rows][2C] (dtype), gseq: f32 [n_seq][2C] or NULL, y: [rows][C] (dtype). */
+int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, const void* x, const float* gseq,
+                             void* y, int32_t channels, void* stream);
+
+/* y[row][c] = x[row][C-1-c]  (FlipFlow, modules/vits/flow.py:17-40); f32, x != y. */
+int jatts_flip_channels(const float* x, float* y, int64_t rows, int32_t channels, void* stream);
 
 /* hs[row][:] += vec[seq(row)][:]  (speaker embedding add, fastspeech2.py:591-597,751-753) */
 int jatts_add_seq_vector(const jatts_ragged* rg, float* hs, int32_t dim, const float* vec,

@@ -46,6 +46,7 @@ class RelAttnDesc(C.Structure):
         ("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32),
         ("vt", C.c_void_p), ("ldvt", C.c_int32), ("g", C.c_void_p), ("ldg", C.c_int32),
         ("ku", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("rel_mode", C.c_int32), ("rel_center", C.c_int32),
     ]
 
 
@@ -76,6 +77,9 @@ PROTOTYPES = {
     "jatts_variance_embed_add": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p]),
+    "jatts_gated_tanh_sigmoid": (C.c_int, [C.POINTER(Ragged), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_void_p]),
+    "jatts_flip_channels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "jatts_add_seq_vector": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "jatts_lr_durations": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_float, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

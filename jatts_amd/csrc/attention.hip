@@ -112,8 +112,12 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
         if (j < Tn) {
           if (d.ku) s += d.ku[(int64_t)(row0 + j) * H + h];
           if (gg && qi < Tn) {
-            if (j <= qi) s += to_f32(gg[((int64_t)(row0 + qi) * H + h) * d.ldg + (Tn - 1 - qi + j)]);
-            else if (j > qi + 1) s += to_f32(gg[((int64_t)(row0 + qi + 1) * H + h) * d.ldg + (j - qi - 2)]);
+            if (d.rel_mode == 2) {  // new rel_shift: plain diagonal map, no wrap
+              s += to_f32(gg[((int64_t)(row0 + qi) * H + h) * d.ldg + (d.rel_center - qi + j)]);
+            } else {                // legacy rel_shift (view-reinterpretation wrap)
+              if (j <= qi) s += to_f32(gg[((int64_t)(row0 + qi) * H + h) * d.ldg + (Tn - 1 - qi + j)]);
+              else if (j > qi + 1) s += to_f32(gg[((int64_t)(row0 + qi + 1) * H + h) * d.ldg + (j - qi - 2)]);
+            }
           }
           s *= d.scale;
         } else {

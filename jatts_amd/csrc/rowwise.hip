@@ -171,6 +171,32 @@ __global__ void add_seq_vector_kernel(jatts_ragged rg, float* hs, int dim, const
   for (int c = threadIdx.x; c < dim; c += blockDim.x) hs[(int64_t)(row0 + t) * dim + c] += vec[(int64_t)b * dim + c];
 }
 
+// ------------------------------------------------------------ WaveNet gate, channel flip
+template <typename T>
+__global__ void gated_kernel(jatts_ragged rg, const T* x, const float* gseq, T* y, int C) {
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int t = blockIdx.x;
+  if (t >= L) return;
+  const T* xr = x + (int64_t)(row0 + t) * (2 * C);
+  const float* g = gseq ? gseq + (int64_t)b * (2 * C) : nullptr;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = to_f32(xr[c]), s = to_f32(xr[C + c]);
+    if (g) { a += g[c]; s += g[C + c]; }
+    y[(int64_t)(row0 + t) * C + c] = from_f32<T>(tanhf(a) / (1.f + expf(-s)));
+  }
+}
+
+__global__ void flip_kernel(const float* x, float* y, int64_t rows, int C) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    y[i] = x[r * C + (C - 1 - c)];
+  }
+}
+
 // -------------------------------------------------------------------- length regulator
 // One 256-thread block per sequence: alpha rounding + inclusive scan (int64, exact).
 __global__ __launch_bounds__(256) void lr_durations_kernel(jatts_ragged rg, const int64_t* d, float alpha,
@@ -410,6 +436,29 @@ extern "C" int jatts_variance_embed_add(const jatts_ragged* rg, float* hs, int32
   if (!rg || !hs || !p || !wp || !bp || !e || !we || !be) return jatts_set_error_msg(JATTS_ERR_ARG, "variance_embed_add: null pointer");
   if (rg->max_len <= 0) return JATTS_OK;
   hipLaunchKernelGGL(variance_embed_kernel, dim3((unsigned)rg->max_len, (unsigned)rg->n_seq), dim3(128), 0, S_, *rg, hs, dim, p, wp, bp, kp, e, we, be, ke);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, const void* x, const float* gseq,
+                                        void* y, int32_t channels, void* stream) {
+  if (!rg || !x || !y) return jatts_set_error_msg(JATTS_ERR_ARG, "gated_tanh_sigmoid: null pointer");
+  if (rg->max_len <= 0) return JATTS_OK;
+  dim3 grid((unsigned)rg->max_len, (unsigned)rg->n_seq);
+  if (dtype == JATTS_F16)
+    hipLaunchKernelGGL(gated_kernel<f16>, grid, dim3(128), 0, S_, *rg, (const f16*)x, gseq, (f16*)y, channels);
+  else if (dtype == JATTS_F32)
+    hipLaunchKernelGGL(gated_kernel<float>, grid, dim3(128), 0, S_, *rg, (const float*)x, gseq, (float*)y, channels);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "gated_tanh_sigmoid: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_flip_channels(const float* x, float* y, int64_t rows, int32_t channels, void* stream) {
+  if (!x || !y || x == y) return jatts_set_error_msg(JATTS_ERR_ARG, "flip_channels: bad pointers");
+  if (rows <= 0) return JATTS_OK;
+  const int64_t total = rows * channels;
+  hipLaunchKernelGGL(flip_kernel, dim3((unsigned)min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, S_, x, y, rows, channels);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -131,7 +131,7 @@ def convtranspose_as_conv(w, stride, padding):
 
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
-           in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None):
+           in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
@@ -173,7 +173,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     if resid is not None:
         if resid.dtype != torch.float32:
             raise ValueError("conv1d: residual must be f32")
-        d.resid, d.ldr = resid.data_ptr(), resid.shape[-1]
+        d.resid, d.ldr = _ptr(resid, resid_col0), resid.shape[-1]
     d.y, d.ldy = _ptr(out, out_col0), ldy
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
     with _Timed("conv1d", (c_in, n_out, k_w, rows)):
@@ -216,7 +216,7 @@ def hifigan_output(rb, len_mul, xs, in_scale, slope, c_in, k_w, w, bias, dtype):
 
 
 def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d_k, dtype,
-                     q_col0=0, k_col0=0):
+                     q_col0=0, k_col0=0, rel_mode=1, rel_center=0):
     lib = _abi.load()
     out = torch.empty(rb.total, n_heads * d_k, dtype=torch_dtype(dtype), device=q.device)
     d = _abi.RelAttnDesc()
@@ -229,6 +229,7 @@ def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d
     d.ku = _ptr(ku)
     d.scale = scale
     d.out, d.ldo = out.data_ptr(), n_heads * d_k
+    d.rel_mode, d.rel_center = rel_mode, rel_center
     with _Timed("relattn", (n_heads, d_k, rb.total)):
         _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
     return out
@@ -298,6 +299,23 @@ def variance_embed_add(rb, hs, p, wp, bp, e, we, be):
                                             we.data_ptr(), be.data_ptr(), we.shape[-1], _stream()),
                "jatts_variance_embed_add")
     return hs
+
+
+def gated_tanh_sigmoid(rb, x, gseq, channels, dtype):
+    lib = _abi.load()
+    y = torch.empty(rb.total, channels, dtype=torch_dtype(dtype), device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_gated_tanh_sigmoid(C.byref(rg), dtype, _dev(x).data_ptr(), _ptr(gseq), y.data_ptr(),
+                                            channels, _stream()), "jatts_gated_tanh_sigmoid")
+    return y
+
+
+def flip_channels(x):
+    lib = _abi.load()
+    y = torch.empty_like(x)
+    _abi.check(lib.jatts_flip_channels(_dev(x).data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream()),
+               "jatts_flip_channels")
+    return y
 
 
 def add_seq_vector(rb, hs, vec):

@@ -30,6 +30,17 @@ def legacy_rel_pos_table(n, d, table_len):
     return pe
 
 
+def rel_pos_table_new(cap, d):
+    """RelPositionalEncoding (positional_encoding.py:265-309): row m encodes relative position
+    cap-1-m, m in [0, 2cap-1); independent of the reference's table length."""
+    pos = torch.arange(cap - 1, -cap, -1.0, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(2 * cap - 1, d, dtype=torch.float32)
+    pe[:, 0::2] = torch.sin(pos * div_term)
+    pe[:, 1::2] = torch.cos(pos * div_term)
+    return pe
+
+
 class PackedConv:
     """A Conv1d/Linear weight packed for jatts_conv1d."""
 
@@ -49,8 +60,12 @@ class PackedConv:
 
 
 class ConformerRunner:
-    def __init__(self, sd, prefix, n_heads, dtype, device):
+    def __init__(self, sd, prefix, n_heads, dtype, device, rel_style="legacy"):
+        """rel_style: "legacy" = LegacyRelPositionalEncoding + LegacyRelPositionMultiHeadedAttention
+        (FastSpeech2 / Matcha, fastspeech2.py fallback), "new" = RelPositionalEncoding +
+        RelPositionMultiHeadedAttention (VITS text encoder and decoder)."""
         self.dtype, self.device, self.H = dtype, device, n_heads
+        self.rel_style = rel_style
         g = lambda k: sd[prefix + k]  # noqa: E731
         self.n_layers = 0
         while (prefix + f"encoders.{self.n_layers}.norm_mha.weight") in sd:
@@ -108,18 +123,22 @@ class ConformerRunner:
         cap = hip.round_up(t_max, 128)
         if cap in self._pos_cache:
             return cap, self._pos_cache[cap]
-        n_valid = min(cap, self.pe_len)
-        pe = torch.zeros(cap, self.A, dtype=torch.float32)
-        pe[:n_valid] = legacy_rel_pos_table(n_valid, self.A, self.pe_len)
+        if self.rel_style == "new":
+            pe = rel_pos_table_new(cap, self.A)          # (2cap-1, A)
+        else:
+            n_valid = min(cap, self.pe_len)
+            pe = torch.zeros(cap, self.A, dtype=torch.float32)
+            pe[:n_valid] = legacy_rel_pos_table(n_valid, self.A, self.pe_len)
+        n_pos = pe.shape[0]
         pe_t = hip.affine_cast(pe.to(self.device), self.dtype)
-        rb = hip.RaggedBatch([cap], self.device)
+        rb = hip.RaggedBatch([n_pos], self.device)
         per_layer = []
         for L in self.layers:
             if not L["rel"]:
                 per_layer.append(None)
                 continue
             P = hip.conv1d(rb, pe_t, L["pos"].w, L["pos"].c_in, self.A, 1, dtype=self.dtype)  # (cap, A)
-            cv = hip.rowdot(P, self.A, cap, self.H, self.dk, L["vb"]).t().contiguous()        # (H, cap)
+            cv = hip.rowdot(P, self.A, n_pos, self.H, self.dk, L["vb"]).t().contiguous()      # (H, n_pos)
             # per-head weight operand of the BD GEMM (n = position m, contraction d_k): pure re-layout
             heads = [hip.pack_conv_weight(P[:, h * self.dk:(h + 1) * self.dk].float().unsqueeze(-1), self.dtype)
                      for h in range(self.H)]
@@ -143,15 +162,20 @@ class ConformerRunner:
         vt = hip.conv1d(rb, xn, L["v"].w, A, A, 1, dtype=self.dtype, bias=L["v"].b, transposed=True)  # (A, R)
         g = ku = None
         ldg = 0
+        rel_mode, rel_center = 1, 0
         if L["rel"]:
-            ldg, (heads, cv) = pos
+            cap, (heads, cv) = pos
+            n_pos = cv.shape[1]                       # cap (legacy) or 2cap-1 (new)
+            ldg = hip.round_up(n_pos, 32)
+            if self.rel_style == "new":
+                rel_mode, rel_center = 2, cap - 1
             ku = hip.rowdot(qk, 2 * A, rb.total, H, dk, L["u"], col0=A)                          # u . k_j
             g = torch.empty(rb.total, H * ldg, dtype=hip.torch_dtype(self.dtype), device=x.device)
             for h in range(H):  # g[row][h][m] = q_row,h . p_h[m] + v_h . p_h[m]
-                hip.conv1d(rb, qk, heads[h], hip.round_up(dk, 64), ldg, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
+                hip.conv1d(rb, qk, heads[h], hip.round_up(dk, 64), n_pos, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
                            x_col0=h * dk, out=g, out_ld=H * ldg, out_col0=h * ldg)
         ctx = hip.relpos_attention(rb, qk, 2 * A, qk, 2 * A, vt, rb.total, g, ldg, ku, 1.0 / math.sqrt(dk),
-                                   H, dk, self.dtype, q_col0=0, k_col0=A)
+                                   H, dk, self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center)
         hip.conv1d(rb, ctx, L["o"].w, A, A, 1, dtype=self.dtype, bias=L["o"].b, resid=x, out=x, out_f32=True)
 
     def _convmod(self, rb, x, L):

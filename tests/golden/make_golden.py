@@ -44,6 +44,80 @@ def import_reference():
     return FastSpeech2
 
 
+def import_reference_vits():
+    """VITS needs no-op stubs for numba / conformer / diffusers (none executes at inference)."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _T:
+        def __getitem__(self, k):
+            return self
+
+        def __call__(self, *a, **k):
+            return self
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return self
+
+        def __getattr__(self, k):
+            return _Any()
+
+    t = _T()
+    stub("numba", jit=lambda *a, **k: (lambda f: f), float64=t, float32=t, int8=t, int32=t, int64=t, boolean=t)
+    stub("conformer", ConformerBlock=object)
+    for n in ("diffusers", "diffusers.models", "diffusers.models.activations", "diffusers.models.attention",
+              "diffusers.models.attention_processor", "diffusers.models.lora", "diffusers.utils",
+              "diffusers.utils.torch_utils", "diffusers.models.embeddings", "diffusers.models.normalization"):
+        stub(n).__getattr__ = lambda k: _Any
+    from jatts.models.vits import VITS
+
+    return VITS
+
+
+VITS_SMALL = dict(odim=80, adim=64, aheads=2, text_encoder_blocks=2, text_encoder_attention_heads=2, dlayers=2,
+                  dunits=128, flow_flows=2, flow_layers=2, posterior_encoder_layers=2, duration_predictor_chans=64,
+                  spk_embed_dim=16)
+
+
+def run_vits(VITS, texts):
+    model = VITS(idim=20, **VITS_SMALL).eval()
+    ref_sd = model.state_dict()
+    sd = synth_state_dict(ref_sd, 2)
+    # the reference zero-initialises the coupling projections (residual_coupling.py:173-174): give the
+    # golden model non-trivial ones so the flow is actually exercised
+    model.load_state_dict(sd)
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]),
+           "config": json.dumps(VITS_SMALL)}
+    real_randn_like = torch.randn_like
+    for u, text in enumerate(texts):
+        spemb = torch.randn(16, generator=torch.Generator().manual_seed(200 + u))
+        holder = {}
+
+        def fake_randn_like(t, *a, **k):
+            holder["noise"] = torch.randn(t.shape, generator=torch.Generator().manual_seed(300 + u))
+            return holder["noise"]
+
+        torch.randn_like = fake_randn_like
+        try:
+            with torch.no_grad():
+                r = model.inference(text, spembs=spemb)
+        finally:
+            torch.randn_like = real_randn_like
+        out[f"u{u}_text"] = np_(text)
+        out[f"u{u}_spemb"] = np_(spemb)
+        out[f"u{u}_noise"] = np_(holder["noise"][0].t())  # (T_feats, A)
+        out[f"u{u}_feat_gen"] = np_(r["feat_gen"])
+        out[f"u{u}_duration"] = np_(r["duration"])
+    return out, model
+
+
 def np_(t):
     return t.detach().cpu().numpy()
 
@@ -217,6 +291,20 @@ def main():
         print(f"jsut u{u}: oracle-vs-ref mel max|d| =",
               float((o["feat_gen"] - torch.tensor(full[f"u{u}_feat_gen"])).abs().max()),
               "frames", full[f"u{u}_feat_gen"].shape[0])
+    # --- mel-VITS (small config, speaker embedding, injected noise)
+    VITS = import_reference_vits()
+    from oracle.vits_oracle import vits_inference
+    g = torch.Generator().manual_seed(5)
+    texts = [torch.randint(1, 20, (n,), generator=g) for n in (14, 27)]
+    vz, vmodel = run_vits(VITS, texts)
+    np.savez_compressed(os.path.join(HERE, "vits_small.npz"), **vz)
+    vsd = vmodel.state_dict()
+    for u, t in enumerate(texts):
+        o = vits_inference(vsd, t, 2, 2, torch.tensor(vz[f"u{u}_spemb"]), torch.tensor(vz[f"u{u}_noise"]))
+        print(f"vits u{u}: oracle-vs-ref mel max|d| =",
+              float((o["feat_gen"] - torch.tensor(vz[f"u{u}_feat_gen"])).abs().max()),
+              "dur equal:", bool((o["duration"].numpy() == vz[f"u{u}_duration"]).all()),
+              "frames", vz[f"u{u}_feat_gen"].shape[0])
     np.savez_compressed(os.path.join(HERE, "lr_kat.npz"), **lr_cases())
     np.savez_compressed(os.path.join(HERE, "mask_kat.npz"), **mask_cases())
     np.savez_compressed(os.path.join(HERE, "vocoder_decode.npz"), **vocoder_decode_case())

@@ -231,6 +231,57 @@ def test_relpos_attention(cuda, lib, prec, H, dk, lens, rel):
     assert e <= (5e-5 if prec == "fp32" else 3e-3), f"attention {H}x{dk} {prec}: rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_relpos_attention_new_style(cuda, lib, prec):
+    """rel_mode 2 (RelPositionMultiHeadedAttention, attention.py:237-261): BD'[i,j] = g[i][center - i + j]."""
+    from jatts_amd import hip
+    from oracle.vits_oracle import rel_shift_new
+    g = torch.Generator().manual_seed(21)
+    H, dk, lens, cap = 2, 32, [40, 17, 64], 128
+    A, R = H * dk, sum(lens)
+    ncol = 2 * cap - 1
+    ldg = hip.round_up(ncol, 32)
+    q, k, v = (_round(torch.randn(R, A, generator=g), prec) for _ in range(3))
+    gm = _round(torch.randn(R, H, ldg, generator=g), prec)
+    ku = torch.randn(R, H, generator=g)
+    scale = 1.0 / math.sqrt(dk)
+    outs, o = [], 0
+    for T in lens:
+        qs, ks, vs = (t[o:o + T].view(T, H, dk).transpose(0, 1).double() for t in (q, k, v))
+        # columns cap-T .. cap+T-2 of the wide table are this utterance's 2T-1 relative positions
+        bd = gm[o:o + T, :, cap - T: cap + T - 1].permute(1, 0, 2).double()
+        s = qs @ ks.transpose(1, 2) + ku[o:o + T].t().double().unsqueeze(1) + rel_shift_new(bd)
+        outs.append((torch.softmax(s * scale, -1) @ vs).transpose(0, 1).reshape(T, A))
+        o += T
+    ref = torch.cat(outs)
+    dt = _dt(prec)
+    tdt = hip.torch_dtype(dt)
+    out = hip.relpos_attention(_ragged(lens, cuda), q.to(cuda).to(tdt), A, k.to(cuda).to(tdt), A,
+                               v.t().contiguous().to(cuda).to(tdt), R, gm.reshape(R, H * ldg).to(cuda).to(tdt), ldg,
+                               ku.to(cuda), scale, H, dk, dt, rel_mode=2, rel_center=cap - 1)
+    assert relerr(out.float(), ref) <= (5e-5 if prec == "fp32" else 3e-3)
+
+
+def test_gated_activation_and_flip(cuda, lib):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(22)
+    lens, C = [9, 30], 48
+    R = sum(lens)
+    x = torch.randn(R, 2 * C, generator=g)
+    gs = torch.randn(2, 2 * C, generator=g)
+    rb = _ragged(lens, cuda)
+    y = hip.gated_tanh_sigmoid(rb, x.to(cuda), gs.to(cuda), C, hip.F32)
+    xg = x.clone().double()
+    xg[:9] += gs[0].double()
+    xg[9:] += gs[1].double()
+    assert maxdiff(y, torch.tanh(xg[:, :C]) * torch.sigmoid(xg[:, C:])) <= 1e-5
+    y0 = hip.gated_tanh_sigmoid(rb, x.to(cuda).half(), None, C, hip.F16)
+    xh = x.half().double()
+    assert maxdiff(y0.float(), torch.tanh(xh[:, :C]) * torch.sigmoid(xh[:, C:])) <= 2e-3
+    z = torch.randn(R, C, generator=g)
+    assert torch.equal(hip.flip_channels(z.to(cuda)).cpu(), torch.flip(z, [1]))
+
+
 @pytest.mark.parametrize("in16,out16", [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize("dim", [64, 256, 384])
 def test_layernorm(cuda, lib, in16, out16, dim):

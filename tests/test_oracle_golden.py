@@ -44,6 +44,24 @@ def test_fs2_oracle_speaker_embedding():
         assert maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-5
 
 
+def test_vits_oracle_matches_reference():
+    """mel-VITS (A16): oracle vs the real reference with injected noise (tests/golden/vits_small.npz)."""
+    import json
+    from oracle.vits_oracle import rel_shift_new, vits_inference
+    z, keys = load_golden("vits_small.npz")
+    sd = golden_state(keys, 2)
+    assert json.loads(str(z["config"]))["spk_embed_dim"] == 16
+    for u in range(2):
+        o = vits_inference(sd, torch.tensor(z[f"u{u}_text"]), 2, 2, torch.tensor(z[f"u{u}_spemb"]),
+                           torch.tensor(z[f"u{u}_noise"]))
+        assert np.array_equal(o["duration"].numpy(), z[f"u{u}_duration"])
+        assert maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-5
+    # new rel_shift == the diagonal index map the HIP kernel uses
+    bd = torch.randn(2, 5, 9)
+    want = torch.stack([torch.stack([bd[:, i, 4 - i + j] for j in range(5)], -1) for i in range(5)], 1)
+    assert torch.equal(rel_shift_new(bd), want)
+
+
 def test_rel_shift_closed_form_equals_view_trick():
     g = torch.Generator().manual_seed(0)
     for T in (1, 2, 3, 7, 16):
