@@ -231,6 +231,16 @@ int jatts_variance_embed_add(const jatts_ragged* rg, float* hs, int32_t dim, con
 int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, const void* x, const float* gseq,
                              void* y, int32_t channels, void* stream);
 
+/* y[row][:] = x[row][:] / max(||x[row]||_2, eps)  (torch.nn.functional.normalize on speaker embeddings,
+ * models/fastspeech2.py:751, vits.py:706); f32 in, `out_dtype` out, columns >= dim and < ldy zero-filled. */
+int jatts_l2_normalize(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int64_t rows,
+                       int32_t dim, float eps, void* stream);
+
+/* VITS prior sampling (models/vits.py:478-480): z[row][c] = stats[row][c] + noise[row][c] *
+ * exp(stats[row][C + c]) * noise_scale;  stats: f32 [rows][2C] (m_p | logs_p), noise/z: f32 [rows][C]. */
+int jatts_gaussian_sample(const float* stats, const float* noise, float* z, int64_t rows, int32_t channels,
+                          float noise_scale, void* stream);
+
 /* y[row][c] = x[row][C-1-c]  (FlipFlow, modules/vits/flow.py:17-40); f32, x != y. */
 int jatts_flip_channels(const float* x, float* y, int64_t rows, int32_t channels, void* stream);
 

@@ -79,6 +79,10 @@ PROTOTYPES = {
                                            C.c_int32, C.c_void_p]),
     "jatts_gated_tanh_sigmoid": (C.c_int, [C.POINTER(Ragged), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p]),
+    "jatts_l2_normalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                     C.c_float, C.c_void_p]),
+    "jatts_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                        C.c_void_p]),
     "jatts_flip_channels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "jatts_add_seq_vector": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "jatts_lr_durations": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_float, C.c_int32, C.c_void_p,

@@ -188,6 +188,28 @@ __global__ void gated_kernel(jatts_ragged rg, const T* x, const float* gseq, T* 
   }
 }
 
+template <typename TO>
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int ldx, TO* y, int ldy, int64_t rows, int dim,
+                                                     float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int c = lane; c < dim; c += 64) { const float v = x[row * ldx + c]; s += v * v; }
+  const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), eps);
+  for (int c = lane; c < ldy; c += 64) y[row * ldy + c] = from_f32<TO>(c < dim ? x[row * ldx + c] * inv : 0.f);
+}
+
+__global__ void gaussian_sample_kernel(const float* stats, const float* noise, float* z, int64_t rows, int C,
+                                       float noise_scale) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    z[i] = stats[r * 2 * C + c] + noise[i] * expf(stats[r * 2 * C + C + c]) * noise_scale;
+  }
+}
+
 __global__ void flip_kernel(const float* x, float* y, int64_t rows, int C) {
   const int64_t total = rows * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -450,6 +472,31 @@ extern "C" int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, c
   else if (dtype == JATTS_F32)
     hipLaunchKernelGGL(gated_kernel<float>, grid, dim3(128), 0, S_, *rg, (const float*)x, gseq, (float*)y, channels);
   else return jatts_set_error_msg(JATTS_ERR_ARG, "gated_tanh_sigmoid: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_l2_normalize(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int64_t rows,
+                                  int32_t dim, float eps, void* stream) {
+  if (!x || !y) return jatts_set_error_msg(JATTS_ERR_ARG, "l2_normalize: null pointer");
+  if (rows <= 0) return JATTS_OK;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (out_dtype == JATTS_F16)
+    hipLaunchKernelGGL(l2norm_kernel<f16>, grid, dim3(256), 0, S_, x, ldx, (f16*)y, ldy, rows, dim, eps);
+  else if (out_dtype == JATTS_F32)
+    hipLaunchKernelGGL(l2norm_kernel<float>, grid, dim3(256), 0, S_, x, ldx, (float*)y, ldy, rows, dim, eps);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "l2_normalize: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_gaussian_sample(const float* stats, const float* noise, float* z, int64_t rows, int32_t channels,
+                                     float noise_scale, void* stream) {
+  if (!stats || !noise || !z) return jatts_set_error_msg(JATTS_ERR_ARG, "gaussian_sample: null pointer");
+  if (rows <= 0) return JATTS_OK;
+  const int64_t total = rows * channels;
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, S_,
+                     stats, noise, z, rows, channels, noise_scale);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -310,6 +310,26 @@ def gated_tanh_sigmoid(rb, x, gseq, channels, dtype):
     return y
 
 
+def l2_normalize(x, out_dtype, ldy=None, eps=1e-12):
+    """F.normalize(x, dim=1) (eps 1e-12) -> out_dtype, zero-padded to ldy columns."""
+    lib = _abi.load()
+    rows, dim = x.shape
+    ldy = ldy or dim
+    y = torch.empty(rows, ldy, dtype=torch_dtype(out_dtype), device=x.device)
+    _abi.check(lib.jatts_l2_normalize(_dev(x).data_ptr(), dim, y.data_ptr(), out_dtype, ldy, rows, dim, eps,
+                                      _stream()), "jatts_l2_normalize")
+    return y
+
+
+def gaussian_sample(stats, noise, noise_scale):
+    lib = _abi.load()
+    rows, c2 = stats.shape
+    z = torch.empty(rows, c2 // 2, dtype=torch.float32, device=stats.device)
+    _abi.check(lib.jatts_gaussian_sample(_dev(stats).data_ptr(), noise.data_ptr(), z.data_ptr(), rows, c2 // 2,
+                                         float(noise_scale), _stream()), "jatts_gaussian_sample")
+    return z
+
+
 def flip_channels(x):
     lib = _abi.load()
     y = torch.empty_like(x)

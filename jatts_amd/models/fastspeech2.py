@@ -226,10 +226,9 @@ class FastSpeech2(torch.nn.Module):
         if self.spk_embed_dim is not None:
             if spembs is None:
                 raise ValueError("spembs required (spk_embed_dim is set)")
-            sp = torch.nn.functional.normalize(spembs.to(dev).float().reshape(len(lens), -1))
             rbs = hip.RaggedBatch([1] * len(lens), dev)
             c_in = P["proj"].c_in
-            sp_t = hip.affine_cast(sp.contiguous(), dt, ldy=c_in)
+            sp_t = hip.l2_normalize(spembs.to(dev).float().reshape(len(lens), -1).contiguous(), dt, ldy=c_in)
             vec = hip.conv1d(rbs, sp_t, P["proj"].w, c_in, A, 1, dtype=dt, bias=P["proj"].b, out_f32=True)
             hip.add_seq_vector(rb, hs, vec)
         hs_t = hip.affine_cast(hs, dt)

@@ -211,9 +211,8 @@ class VITS(torch.nn.Module):
         spembs = spembs.to(dev).float().reshape(B, -1).contiguous()
         rbs = hip.RaggedBatch([1] * B, dev)
         pj = P["proj"]
-        spn = torch.nn.functional.normalize(spembs)
-        vec = hip.conv1d(rbs, hip.affine_cast(spn.contiguous(), dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt,
-                         bias=pj.b, out_f32=True)
+        vec = hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b,
+                         out_f32=True)
         hip.add_seq_vector(rb, hs, vec)
         logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hip.affine_cast(hs, dt)), P["dur"].w, P["dur"].b,
                                           want_duration=True)
@@ -234,8 +233,7 @@ class VITS(torch.nn.Module):
             nz = torch.randn(rbo.total, A, device=dev)
         else:
             nz = torch.cat([n.reshape(-1, A) for n in noise]).to(dev).float().contiguous()
-        # z_p = m_p + eps * exp(logs_p) * noise_scale (vits.py:478-480): O(R*A) elementwise plumbing
-        z = (up[:, :A] + nz * torch.exp(up[:, A:]) * noise_scale).contiguous()
+        z = hip.gaussian_sample(up, nz, noise_scale)   # z_p = m_p + eps * exp(logs_p) * noise_scale (vits.py:478-480)
         if taps is not None:
             taps["z_p"] = z.clone()
         # global conditioning vectors g = conv1x1_glo(spembs) per flow layer (residual_block.py:150-154)
