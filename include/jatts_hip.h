@@ -36,6 +36,7 @@ extern "C" {
 #define JATTS_ACT_RELU 1
 #define JATTS_ACT_TANH 2
 #define JATTS_ACT_SWISH 3
+#define JATTS_ACT_MISH 4
 
 #define JATTS_PRE_NONE 0
 #define JATTS_PRE_LRELU 1
@@ -230,6 +231,19 @@ int jatts_variance_embed_add(const jatts_ragged* rg, float* hs, int32_t dim, con
  * x: [rows][2C] (dtype), gseq: f32 [n_seq][2C] or NULL, y: [rows][C] (dtype). */
 int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, const void* x, const float* gseq,
                              void* y, int32_t channels, void* stream);
+
+/* GroupNorm over (channels/groups x time) of each utterance + Mish (+ per-utterance vector), the body of
+ * Matcha's Block1D / ResnetBlock1D (modules/matchatts/decoder.py:66-97):
+ *   y[t][c] = mish( (x[t][c] - mean_g) * rstd_g * gamma[c] + beta[c] ) + addvec[seq][c]
+ * x: [rows][C] (in_dtype); y: [rows][C] (out_dtype); addvec: f32 [n_seq][C] or NULL. */
+int jatts_groupnorm_mish(const jatts_ragged* rg, const void* x, int32_t in_dtype, void* y, int32_t out_dtype,
+                         int32_t channels, int32_t groups, const float* gamma, const float* beta, float eps,
+                         const float* addvec, void* stream);
+
+/* SnakeBeta (modules/matchatts/transformer.py:84-102): y = x + inv_beta[c] * sin(x * alpha[c])^2 with
+ * alpha = exp(log_alpha), inv_beta = 1 / (exp(log_beta) + 1e-9) precomputed by the host. */
+int jatts_snakebeta(int32_t dtype, const void* x, void* y, int64_t rows, int32_t channels, const float* alpha,
+                    const float* inv_beta, void* stream);
 
 /* y[row][:] = x[row][:] / max(||x[row]||_2, eps)  (torch.nn.functional.normalize on speaker embeddings,
  * models/fastspeech2.py:751, vits.py:706); f32 in, `out_dtype` out, columns >= dim and < ldy zero-filled. */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
 F32, F16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH = 0, 1, 2, 3, 4
 PRE_NONE, PRE_LRELU = 0, 1
 
 
@@ -79,6 +79,10 @@ PROTOTYPES = {
                                            C.c_int32, C.c_void_p]),
     "jatts_gated_tanh_sigmoid": (C.c_int, [C.POINTER(Ragged), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p]),
+    "jatts_groupnorm_mish": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "jatts_snakebeta": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "jatts_l2_normalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_float, C.c_void_p]),
     "jatts_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,

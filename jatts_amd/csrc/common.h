@@ -77,6 +77,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case JATTS_ACT_RELU: return v > 0.f ? v : 0.f;
     case JATTS_ACT_TANH: return tanhf(v);
     case JATTS_ACT_SWISH: return v / (1.f + __expf(-v));
+    case JATTS_ACT_MISH: return v * tanhf(v > 20.f ? v : log1pf(expf(v)));  // torch softplus threshold 20
     default: return v;
   }
 }

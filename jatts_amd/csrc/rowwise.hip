@@ -188,6 +188,57 @@ __global__ void gated_kernel(jatts_ragged rg, const T* x, const float* gseq, T* 
   }
 }
 
+// ------------------------------------------------------------ GroupNorm + Mish, SnakeBeta
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void groupnorm_mish_kernel(jatts_ragged rg, const T* x, TO* y, int C, int groups,
+                                                            const float* gamma, const float* beta, float eps,
+                                                            const float* addvec) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  if (L <= 0) return;
+  const int gc = C / groups;
+  const int c0 = g * gc;
+  const int n = L * gc;
+  const T* xb = x + (int64_t)row0 * C + c0;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += to_f32(xb[(int64_t)(i / gc) * C + (i % gc)]);
+  const float mean = block_sum_256(s, red) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = to_f32(xb[(int64_t)(i / gc) * C + (i % gc)]) - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(block_sum_256(q, red) / (float)n + eps);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i / gc, c = c0 + i % gc;
+    float v = (to_f32(xb[(int64_t)r * C + (i % gc)]) - mean) * rstd * gamma[c] + beta[c];
+    v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+    if (addvec) v += addvec[(int64_t)b * C + c];
+    y[(int64_t)(row0 + r) * C + c] = from_f32<TO>(v);
+  }
+}
+
+template <typename T>
+__global__ void snakebeta_kernel(const T* x, T* y, int64_t rows, int C, const float* alpha, const float* inv_beta) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float v = to_f32(x[i]);
+    const float sn = sinf(v * alpha[c]);
+    y[i] = from_f32<T>(v + inv_beta[c] * sn * sn);
+  }
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int ldx, TO* y, int ldy, int64_t rows, int dim,
                                                      float eps) {
@@ -472,6 +523,40 @@ extern "C" int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, c
   else if (dtype == JATTS_F32)
     hipLaunchKernelGGL(gated_kernel<float>, grid, dim3(128), 0, S_, *rg, (const float*)x, gseq, (float*)y, channels);
   else return jatts_set_error_msg(JATTS_ERR_ARG, "gated_tanh_sigmoid: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_groupnorm_mish(const jatts_ragged* rg, const void* x, int32_t in_dtype, void* y, int32_t out_dtype,
+                                    int32_t channels, int32_t groups, const float* gamma, const float* beta, float eps,
+                                    const float* addvec, void* stream) {
+  if (!rg || !x || !y || !gamma || !beta) return jatts_set_error_msg(JATTS_ERR_ARG, "groupnorm_mish: null pointer");
+  if (groups < 1 || channels % groups) return jatts_set_error_msg(JATTS_ERR_ARG, "groupnorm_mish: channels % groups != 0");
+  if (rg->max_len <= 0) return JATTS_OK;
+  dim3 grid((unsigned)groups, (unsigned)rg->n_seq), blk(256);
+#define GN_GO(TI, TO) \
+  hipLaunchKernelGGL((groupnorm_mish_kernel<TI, TO>), grid, blk, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec)
+  if (in_dtype == JATTS_F32 && out_dtype == JATTS_F32) GN_GO(float, float);
+  else if (in_dtype == JATTS_F32 && out_dtype == JATTS_F16) GN_GO(float, f16);
+  else if (in_dtype == JATTS_F16 && out_dtype == JATTS_F16) GN_GO(f16, f16);
+  else if (in_dtype == JATTS_F16 && out_dtype == JATTS_F32) GN_GO(f16, float);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "groupnorm_mish: unknown dtype");
+#undef GN_GO
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_snakebeta(int32_t dtype, const void* x, void* y, int64_t rows, int32_t channels, const float* alpha,
+                               const float* inv_beta, void* stream) {
+  if (!x || !y || !alpha || !inv_beta) return jatts_set_error_msg(JATTS_ERR_ARG, "snakebeta: null pointer");
+  if (rows <= 0) return JATTS_OK;
+  const int64_t total = rows * channels;
+  dim3 grid((unsigned)min((int64_t)4096, (total + 255) / 256));
+  if (dtype == JATTS_F16)
+    hipLaunchKernelGGL(snakebeta_kernel<f16>, grid, dim3(256), 0, S_, (const f16*)x, (f16*)y, rows, channels, alpha, inv_beta);
+  else if (dtype == JATTS_F32)
+    hipLaunchKernelGGL(snakebeta_kernel<float>, grid, dim3(256), 0, S_, (const float*)x, (float*)y, rows, channels, alpha, inv_beta);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "snakebeta: unknown dtype");
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _abi
-from ._abi import ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32  # noqa: F401
+from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32  # noqa: F401
 
 _TORCH = {F32: torch.float32, F16: torch.float16}
 
@@ -307,6 +307,24 @@ def gated_tanh_sigmoid(rb, x, gseq, channels, dtype):
     rg = rb.struct()
     _abi.check(lib.jatts_gated_tanh_sigmoid(C.byref(rg), dtype, _dev(x).data_ptr(), _ptr(gseq), y.data_ptr(),
                                             channels, _stream()), "jatts_gated_tanh_sigmoid")
+    return y
+
+
+def groupnorm_mish(rb, x, channels, groups, gamma, beta, out_dtype, eps=1e-5, addvec=None):
+    lib = _abi.load()
+    y = torch.empty(rb.total, channels, dtype=torch_dtype(out_dtype), device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_groupnorm_mish(C.byref(rg), _dev(x).data_ptr(), code_of(x), y.data_ptr(), out_dtype, channels,
+                                        groups, gamma.data_ptr(), beta.data_ptr(), eps, _ptr(addvec), _stream()),
+               "jatts_groupnorm_mish")
+    return y
+
+
+def snakebeta(x, alpha, inv_beta):
+    lib = _abi.load()
+    y = torch.empty_like(x)
+    _abi.check(lib.jatts_snakebeta(code_of(x), _dev(x).data_ptr(), y.data_ptr(), x.shape[0], x.shape[1],
+                                   alpha.data_ptr(), inv_beta.data_ptr(), _stream()), "jatts_snakebeta")
     return y
 
 

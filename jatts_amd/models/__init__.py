@@ -2,3 +2,4 @@
 ``getattr(jatts_amd.models, config["model_type"])(**config["model_params"])``."""
 from .fastspeech2 import FastSpeech2  # noqa: F401
 from .vits import VITS  # noqa: F401
+from .matchatts import MatchaTTS, MatchaTTS_MAS  # noqa: F401

@@ -1,0 +1,419 @@
+"""Matcha-TTS on the MI355X HIP path — drop-ins for ``jatts.models.MatchaTTS_MAS`` (tts2 recipes, Gaussian
+upsampling, SURVEY §8 A14-A15 / BASELINE config 3) and ``jatts.models.MatchaTTS`` (tts1 variant: hard
+length regulator, no aligner).
+
+Same constructor kwargs (reference models/matchatts_mas.py:52-114), same state_dict schema (conformer
+encoder + duration predictor + encoder_proj + [alignment module] + CFM U-Net ``decoder.estimator.*`` with
+diffusers-style ``attn1.to_q/to_k/to_v/to_out.0`` keys), same ``inference(text, ..., n_timesteps,
+temperature)`` contract (:552-642).  ``noise`` can be injected for parity (the reference draws
+torch.randn_like inside CFM.inference, flow_matching.py:64).
+
+Per Euler step the U-Net runs as: Conv1d k3 (MFMA) -> GroupNorm+Mish(+time vector) kernel -> ... ->
+LayerNorm -> fused SDPA (the attention kernel without relative-position terms) -> SnakeBeta FF (MFMA +
+elementwise) -> stride-2 conv as a 2-tap conv on the paired-row view -> ConvTranspose as polyphase conv;
+the Euler update x += dt * v is the epilogue of the final 1x1 projection.
+"""
+import logging
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from .. import hip
+from ..hip import ACT_MISH, ACT_NONE, ACT_SWISH
+from . import _schema as S
+from ._conformer import ConformerRunner, PackedConv
+from .fastspeech2 import _Predictor
+
+GN_EPS = 1e-5  # torch.nn.GroupNorm / LayerNorm defaults (decoder.py:71, transformer.py:213)
+
+
+def _split_in(w, sizes):
+    """Split a conv weight (o, sum(sizes), k) along the input channels."""
+    out, o = [], 0
+    for n in sizes:
+        out.append(w[:, o:o + n])
+        o += n
+    return out
+
+
+class _Resnet:
+    """ResnetBlock1D (decoder.py:80-97) with its input given as a list of channel groups (concat-free)."""
+
+    def __init__(self, sd, p, in_sizes, dt, dev):
+        f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
+        w1 = sd[p + "block1.block.0.weight"].detach().float()
+        wr = sd[p + "res_conv.weight"].detach().float()
+        self.c_out = w1.shape[0]
+        self.in_sizes = in_sizes
+        self.conv1 = [PackedConv(w, sd[p + "block1.block.0.bias"] if i == 0 else None, dt, dev)
+                      for i, w in enumerate(_split_in(w1, in_sizes))]
+        self.res = [PackedConv(w, sd[p + "res_conv.bias"] if i == 0 else None, dt, dev)
+                    for i, w in enumerate(_split_in(wr, in_sizes))]
+        self.gn1 = (f32(sd[p + "block1.block.1.weight"]), f32(sd[p + "block1.block.1.bias"]))
+        self.conv2 = PackedConv(sd[p + "block2.block.0.weight"], sd[p + "block2.block.0.bias"], dt, dev)
+        self.gn2 = (f32(sd[p + "block2.block.1.weight"]), f32(sd[p + "block2.block.1.bias"]))
+        self.mlp = PackedConv(sd[p + "mlp.1.weight"], sd[p + "mlp.1.bias"], dt, dev)
+
+    def run(self, rb, rbs, xs, tmish, dt):
+        """xs: list of operand-dtype tensors (rows, ld_i) matching in_sizes; tmish: (n_seq, Ct) = mish(time emb).
+        Returns f32 (rows, c_out)."""
+        C = self.c_out
+        h = None
+        for x, cv in zip(xs, self.conv1):
+            h = hip.conv1d(rb, x, cv.w, cv.c_in, C, 3, dtype=dt, bias=cv.b, resid=h, out=h, out_f32=True,
+                           ldx=x.shape[1])
+        tv = hip.conv1d(rbs, tmish, self.mlp.w, self.mlp.c_in, C, 1, dtype=dt, bias=self.mlp.b, out_f32=True)
+        h = hip.groupnorm_mish(rb, h, C, 8, self.gn1[0], self.gn1[1], dt, GN_EPS, addvec=tv)
+        h = hip.conv1d(rb, h, self.conv2.w, self.conv2.c_in, C, 3, dtype=dt, bias=self.conv2.b)
+        out = hip.groupnorm_mish(rb, h, C, 8, self.gn2[0], self.gn2[1], hip.F32, GN_EPS)
+        for x, cv in zip(xs, self.res):
+            hip.conv1d(rb, x, cv.w, cv.c_in, C, 1, dtype=dt, bias=cv.b, resid=out, out=out, out_f32=True, ldx=x.shape[1])
+        return out
+
+
+class _TBlock:
+    """BasicTransformerBlock (transformer.py:276-364): LN -> self-attention -> +x ; LN -> SnakeBeta FF -> +x."""
+
+    def __init__(self, sd, p, heads, dt, dev):
+        f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
+        self.heads = heads
+        self.n1 = (f32(sd[p + "norm1.weight"]), f32(sd[p + "norm1.bias"]))
+        self.n3 = (f32(sd[p + "norm3.weight"]), f32(sd[p + "norm3.bias"]))
+        wq, wk = sd[p + "attn1.to_q.weight"], sd[p + "attn1.to_k.weight"]
+        self.inner = wq.shape[0]
+        self.dh = self.inner // heads
+        if self.dh % 32:
+            raise NotImplementedError("attention head dim must be a multiple of 32")
+        self.qk = PackedConv(torch.cat([wq, wk], 0), None, dt, dev)
+        self.v = PackedConv(sd[p + "attn1.to_v.weight"], None, dt, dev)
+        self.o = PackedConv(sd[p + "attn1.to_out.0.weight"], sd[p + "attn1.to_out.0.bias"], dt, dev)
+        self.ff1 = PackedConv(sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"], dt, dev)
+        self.ff2 = PackedConv(sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"], dt, dev)
+        self.alpha = f32(torch.exp(sd[p + "ff.net.0.alpha"].detach().float()))
+        self.inv_beta = f32(1.0 / (torch.exp(sd[p + "ff.net.0.beta"].detach().float()) + 1e-9))
+
+    def run(self, rb, x, dt):
+        """x: f32 (rows, C), updated in place."""
+        C, I = x.shape[1], self.inner
+        n = hip.layernorm(x, self.n1[0], self.n1[1], dt, GN_EPS)
+        qk = hip.conv1d(rb, n, self.qk.w, self.qk.c_in, 2 * I, 1, dtype=dt)
+        vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True)
+        a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, rb.total, None, 0, None, self.dh ** -0.5, self.heads,
+                                 self.dh, dt, q_col0=0, k_col0=I, rel_mode=0)
+        hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)
+        n = hip.layernorm(x, self.n3[0], self.n3[1], dt, GN_EPS)
+        u = hip.conv1d(rb, n, self.ff1.w, self.ff1.c_in, self.ff1.n_out, 1, dtype=dt, bias=self.ff1.b)
+        u = hip.snakebeta(u, self.alpha, self.inv_beta)
+        hip.conv1d(rb, u, self.ff2.w, self.ff2.c_in, C, 1, dtype=dt, bias=self.ff2.b, resid=x, out=x, out_f32=True)
+
+
+class _MatchaBase(torch.nn.Module):
+    _MAS = True
+
+    def __init__(
+        self, idim: int, odim: int, adim: int = 384, aheads: int = 4, elayers: int = 6, eunits: int = 1536,
+        positionwise_layer_type: str = "conv1d", positionwise_conv_kernel_size: int = 1, use_scaled_pos_enc: bool = True,
+        use_batch_norm: bool = True, encoder_normalize_before: bool = True, encoder_concat_after: bool = False,
+        reduction_factor: int = 1, encoder_type: str = "transformer", transformer_enc_dropout_rate: float = 0.1,
+        transformer_enc_positional_dropout_rate: float = 0.1, transformer_enc_attn_dropout_rate: float = 0.1,
+        conformer_rel_pos_type: str = "legacy", conformer_pos_enc_layer_type: str = "rel_pos",
+        conformer_self_attn_layer_type: str = "rel_selfattn", conformer_activation_type: str = "swish",
+        use_macaron_style_in_conformer: bool = True, use_cnn_in_conformer: bool = True, zero_triu: bool = False,
+        conformer_enc_kernel_size: int = 7, conformer_dec_kernel_size: int = 31, decoder_channels=(256, 256),
+        decoder_dropout: float = 0.05, decoder_attention_head_dim: int = 64, decoder_n_blocks: int = 1,
+        decoder_num_mid_blocks: int = 2, decoder_num_heads: int = 2, decoder_act_fn: str = "snakebeta",
+        duration_predictor_type: str = "deterministic", duration_predictor_layers: int = 2,
+        duration_predictor_chans: int = 384, duration_predictor_kernel_size: int = 3,
+        duration_predictor_dropout_rate: float = 0.1, spks: Optional[int] = None, spk_embed_dim: Optional[int] = None,
+        spk_embed_integration_type: str = "add", use_gst: bool = False, gst_tokens: int = 10, gst_heads: int = 4,
+        gst_conv_layers: int = 6, gst_conv_chans_list: Sequence[int] = (32, 32, 64, 64, 128, 128),
+        gst_conv_kernel_size: int = 3, gst_conv_stride: int = 2, gst_gru_layers: int = 1, gst_gru_units: int = 128,
+        init_type: str = "xavier_uniform", init_enc_alpha: float = 1.0, use_masking: bool = False,
+        use_weighted_masking: bool = False, **unused,
+    ):
+        super().__init__()
+        if encoder_type != "conformer":
+            raise ValueError(f"{encoder_type} is not supported (only 'conformer'; the transformer branch is dead code)")
+        if conformer_rel_pos_type != "legacy" or zero_triu or encoder_concat_after or not encoder_normalize_before:
+            raise NotImplementedError("only the reference defaults: legacy rel-pos, normalize_before, no concat_after")
+        if duration_predictor_type != "deterministic" or use_gst or reduction_factor != 1:
+            raise NotImplementedError("stochastic duration predictor / GST / reduction_factor > 1 are not supported")
+        if decoder_act_fn != "snakebeta":
+            raise NotImplementedError("only decoder_act_fn='snakebeta' (the recipes' setting)")
+        if len(decoder_channels) != 2:
+            raise NotImplementedError("decoder_channels must have two levels (one down/up-sampling), as in the recipes")
+        self.idim, self.odim, self.adim, self.aheads = idim, odim, adim, aheads
+        self.dec_heads, self.dec_channels = decoder_num_heads, tuple(decoder_channels)
+        self.n_blocks, self.n_mid = decoder_n_blocks, decoder_num_mid_blocks
+        self.spk_embed_dim = spk_embed_dim if (spk_embed_dim is not None and spk_embed_dim > 0) else None
+        if self.spk_embed_dim is not None and spk_embed_integration_type != "add":
+            raise NotImplementedError("spk_embed_integration_type='concat' is not supported")
+        spec = S.new_spec()
+        spec["encoder.embed.0.weight"] = ((idim, adim), "param")
+        S.conformer_spec(spec, "encoder.", adim, aheads, eunits, elayers, positionwise_layer_type,
+                         positionwise_conv_kernel_size, use_macaron_style_in_conformer, use_cnn_in_conformer,
+                         conformer_enc_kernel_size)
+        if spks is not None and spks > 1:
+            spec["sid_emb.weight"] = ((spks, adim), "param")
+        self.spks = spks if (spks is not None and spks > 1) else None
+        if self.spk_embed_dim is not None:
+            S._lin(spec, "projection", adim, self.spk_embed_dim)
+        S._lin(spec, "encoder_proj", odim, adim)
+        S.predictor_spec(spec, "duration_predictor.", adim, duration_predictor_layers, duration_predictor_chans,
+                         duration_predictor_kernel_size)
+        if self._MAS:
+            for nm, o, i, k in (("t_conv1", adim, adim, 3), ("t_conv2", adim, adim, 1), ("f_conv1", adim, odim, 3),
+                                ("f_conv2", adim, adim, 3), ("f_conv3", adim, adim, 1)):
+                S._conv(spec, "alignment_module." + nm, o, i, k)
+        # CFM estimator (decoder.py:243-411)
+        e = "decoder.estimator."
+        in_ch = 2 * odim
+        ch = self.dec_channels
+        ted = ch[0] * 4
+        inner = decoder_num_heads * decoder_attention_head_dim
+        S._lin(spec, e + "time_mlp.linear_1", ted, in_ch)
+        S._lin(spec, e + "time_mlp.linear_2", ted, ted)
+
+        def resnet(p, ci, co):
+            S._lin(spec, p + "mlp.1", co, ted)
+            S._conv(spec, p + "block1.block.0", co, ci, 3)
+            S._norm(spec, p + "block1.block.1", co)
+            S._conv(spec, p + "block2.block.0", co, co, 3)
+            S._norm(spec, p + "block2.block.1", co)
+            S._conv(spec, p + "res_conv", co, ci, 1)
+
+        def tblock(p, dim):
+            S._norm(spec, p + "norm1", dim)
+            for nm in ("to_q", "to_k", "to_v"):
+                S._lin(spec, p + "attn1." + nm, inner, dim, bias=False)
+            S._lin(spec, p + "attn1.to_out.0", dim, inner)
+            S._norm(spec, p + "norm3", dim)
+            spec[p + "ff.net.0.alpha"] = ((4 * dim,), "param")
+            spec[p + "ff.net.0.beta"] = ((4 * dim,), "param")
+            S._lin(spec, p + "ff.net.0.proj", 4 * dim, dim)
+            S._lin(spec, p + "ff.net.2", dim, 4 * dim)
+
+        oc = in_ch
+        for i in range(len(ch)):
+            ic, oc = oc, ch[i]
+            resnet(e + f"down_blocks.{i}.0.", ic, oc)
+            for j in range(decoder_n_blocks):
+                tblock(e + f"down_blocks.{i}.1.{j}.", oc)
+            S._conv(spec, e + f"down_blocks.{i}.2" + (".conv" if i < len(ch) - 1 else ""), oc, oc, 3)
+        for i in range(decoder_num_mid_blocks):
+            resnet(e + f"mid_blocks.{i}.0.", ch[-1], ch[-1])
+            for j in range(decoder_n_blocks):
+                tblock(e + f"mid_blocks.{i}.1.{j}.", ch[-1])
+        up = ch[::-1] + (ch[0],)
+        for i in range(len(up) - 1):
+            resnet(e + f"up_blocks.{i}.0.", 2 * up[i], up[i + 1])
+            for j in range(decoder_n_blocks):
+                tblock(e + f"up_blocks.{i}.1.{j}.", up[i + 1])
+            if i < len(up) - 2:
+                spec[e + f"up_blocks.{i}.2.conv.weight"] = ((up[i + 1], up[i + 1], 4), "param")  # ConvTranspose1d
+                spec[e + f"up_blocks.{i}.2.conv.bias"] = ((up[i + 1],), "param")
+            else:
+                S._conv(spec, e + f"up_blocks.{i}.2", up[i + 1], up[i + 1], 3)
+        S._conv(spec, e + "final_block.block.0", up[-1], up[-1], 3)
+        S._norm(spec, e + "final_block.block.1", up[-1])
+        S._conv(spec, e + "final_proj", odim, up[-1], 1)
+        S.build_from_spec(self, spec)
+        self.precision = "fp16"
+        self._prep = None
+        self.eval()
+
+    def set_precision(self, precision):
+        if precision not in ("fp16", "fp32"):
+            raise ValueError(precision)
+        if precision != self.precision:
+            self.precision, self._prep = precision, None
+        return self
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def _prepare(self):
+        dev = self.encoder_proj.weight.device
+        if dev.type != "cuda":
+            raise hip._abi.JattsHipError("jatts_amd Matcha-TTS runs on the GPU only (no CPU fallback); call .to('cuda')")
+        key = (self.precision, str(dev))
+        if self._prep is not None and self._prep["key"] == key:
+            return self._prep
+        hip._abi.load()
+        dt = hip.F16 if self.precision == "fp16" else hip.F32
+        sd = self.state_dict()
+        f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
+        P = {"key": key, "dtype": dt, "dev": dev}
+        P["emb"] = f32(sd["encoder.embed.0.weight"])
+        P["enc"] = ConformerRunner(sd, "encoder.", self.aheads, dt, dev)  # legacy rel-pos (matchatts_mas.py:196-218)
+        P["dur"] = _Predictor(sd, "duration_predictor.", dt, dev)
+        P["eproj"] = PackedConv(sd["encoder_proj.weight"], sd["encoder_proj.bias"], dt, dev)
+        if self.spk_embed_dim is not None:
+            P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
+        if self.spks is not None:
+            P["sid_emb"] = f32(sd["sid_emb.weight"])
+        e = "decoder.estimator."
+        od, ch = self.odim, self.dec_channels
+        P["t1"] = PackedConv(sd[e + "time_mlp.linear_1.weight"], sd[e + "time_mlp.linear_1.bias"], dt, dev)
+        P["t2"] = PackedConv(sd[e + "time_mlp.linear_2.weight"], sd[e + "time_mlp.linear_2.bias"], dt, dev)
+        tb = lambda p: [_TBlock(sd, p + f"1.{j}.", self.dec_heads, dt, dev) for j in range(self.n_blocks)]  # noqa: E731
+        P["d0"] = (_Resnet(sd, e + "down_blocks.0.0.", [od, od], dt, dev), tb(e + "down_blocks.0."))
+        wd = sd[e + "down_blocks.0.2.conv.weight"].detach().float()        # Conv1d(C, C, 3, stride 2, pad 1)
+        C0 = wd.shape[0]
+        w2 = torch.zeros(C0, 2 * C0, 2)
+        w2[:, C0:, 0] = wd[:, :, 0]   # tap 0 reads paired row j-1: its second half is x[2j-1]
+        w2[:, :C0, 1] = wd[:, :, 1]   # tap 1 reads paired row j: x[2j] | x[2j+1]
+        w2[:, C0:, 1] = wd[:, :, 2]
+        P["down"] = PackedConv(w2, sd[e + "down_blocks.0.2.conv.bias"], dt, dev)
+        P["d1"] = (_Resnet(sd, e + "down_blocks.1.0.", [ch[0]], dt, dev), tb(e + "down_blocks.1."))
+        P["d1c"] = PackedConv(sd[e + "down_blocks.1.2.weight"], sd[e + "down_blocks.1.2.bias"], dt, dev)
+        P["mid"] = [(_Resnet(sd, e + f"mid_blocks.{i}.0.", [ch[1]], dt, dev), tb(e + f"mid_blocks.{i}."))
+                    for i in range(self.n_mid)]
+        P["u0"] = (_Resnet(sd, e + "up_blocks.0.0.", [ch[1], ch[1]], dt, dev), tb(e + "up_blocks.0."))
+        wu, pad = hip.convtranspose_as_conv(sd[e + "up_blocks.0.2.conv.weight"].detach().float(), 2, 1)
+        P["up"] = (PackedConv(wu, sd[e + "up_blocks.0.2.conv.bias"].detach().float().repeat(2), dt, dev), pad)
+        P["u1"] = (_Resnet(sd, e + "up_blocks.1.0.", [ch[0], ch[0]], dt, dev), tb(e + "up_blocks.1."))
+        P["u1c"] = PackedConv(sd[e + "up_blocks.1.2.weight"], sd[e + "up_blocks.1.2.bias"], dt, dev)
+        P["fb"] = (PackedConv(sd[e + "final_block.block.0.weight"], sd[e + "final_block.block.0.bias"], dt, dev),
+                   f32(sd[e + "final_block.block.1.weight"]), f32(sd[e + "final_block.block.1.bias"]))
+        P["fp"] = PackedConv(sd[e + "final_proj.weight"], sd[e + "final_proj.bias"], dt, dev)
+        self._prep = P
+        return P
+
+    # one U-Net evaluation; x_t / mu_t: operand dtype (R, ld) with odim valid columns; x32: f32 state (R, odim)
+    def _estimator_step(self, P, rb, rb2, rbs, x32, mu_t, temb_rows, dt_step):
+        dt = P["dtype"]
+        od = self.odim
+        ld_in = P["d0"][0].conv1[0].c_in
+        x_t = hip.affine_cast(x32, dt, ldy=ld_in)
+        t1 = hip.conv1d(rbs, temb_rows, P["t1"].w, P["t1"].c_in, P["t1"].n_out, 1, dtype=dt, bias=P["t1"].b, act=ACT_SWISH)
+        tm = hip.conv1d(rbs, t1, P["t2"].w, P["t2"].c_in, P["t2"].n_out, 1, dtype=dt, bias=P["t2"].b, act=ACT_MISH)
+
+        def stage(blk, rbx, xs):
+            res, tbs = blk
+            h = res.run(rbx, rbs, xs, tm, dt)
+            for t in tbs:
+                t.run(rbx, h, dt)
+            return h
+
+        h0 = stage(P["d0"], rb, [x_t, mu_t])                     # (R, C0) f32; skip connection 0
+        h0_t = hip.affine_cast(h0, dt)
+        C0 = h0.shape[1]
+        dn = P["down"]
+        h = hip.conv1d(rb2, h0_t.view(-1, 2 * C0), dn.w, dn.c_in, C0, 2, dtype=dt, bias=dn.b, pad=1)   # (R/2, C0)
+        h1 = stage(P["d1"], rb2, [h])                            # skip connection 1
+        h1_t = hip.affine_cast(h1, dt)
+        c = P["d1c"]
+        h = hip.conv1d(rb2, h1_t, c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
+        for blk in P["mid"]:
+            h = hip.affine_cast(stage(blk, rb2, [h]), dt)
+        h = stage(P["u0"], rb2, [h, h1_t])
+        up, pad = P["up"]
+        C1 = h.shape[1]
+        h = hip.conv1d(rb2, hip.affine_cast(h, dt), up.w, up.c_in, 2 * C1, up.k, dtype=dt, bias=up.b, pad=pad)
+        h = h.view(-1, C1)                                        # (R, C1): polyphase rows are already interleaved
+        h = stage(P["u1"], rb, [h, h0_t])
+        c = P["u1c"]
+        h = hip.conv1d(rb, hip.affine_cast(h, dt), c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
+        fbc, g, b = P["fb"]
+        h = hip.conv1d(rb, h, fbc.w, fbc.c_in, fbc.n_out, 3, dtype=dt, bias=fbc.b)
+        h = hip.groupnorm_mish(rb, h, fbc.n_out, 8, g, b, dt, GN_EPS)
+        fp = P["fp"]
+        # Euler update fused into the projection epilogue: x += dt * (W h + b)   (flow_matching.py:86-88)
+        hip.conv1d(rb, h, fp.w, fp.c_in, od, 1, dtype=dt, bias=fp.b, alpha=dt_step, resid=x32, out=x32, out_f32=True)
+
+    @torch.no_grad()
+    def inference_batch(self, texts, n_timesteps: int = 10, temperature: float = 0.667, spembs=None, sids=None,
+                        noise=None, durations=None, taps=None):
+        P = self._prepare()
+        dt, dev, A, od = P["dtype"], P["dev"], self.adim, self.odim
+        B = len(texts)
+        lens = [int(t.numel()) for t in texts]
+        rb = hip.RaggedBatch(lens, dev)
+        ids = torch.cat([t.reshape(-1) for t in texts]).to(device=dev, dtype=torch.int64)
+        if int(ids.max()) >= self.idim or int(ids.min()) < 0:
+            raise IndexError("token id out of range")
+        hs = P["enc"].run(rb, hip.embed_scale(ids, P["emb"], math.sqrt(A)))
+        rbs = hip.RaggedBatch([1] * B, dev)
+        if self.spks is not None:
+            hip.add_seq_vector(rb, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
+        if self.spk_embed_dim is not None:
+            pj = P["proj"]
+            sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
+            hip.add_seq_vector(rb, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
+        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hip.affine_cast(hs, dt)), P["dur"].w, P["dur"].b,
+                                          want_duration=True)
+        d_used = d_pred
+        if durations is not None:
+            d_used = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
+        d_eff, cum, olens_t = hip.lr_durations(rb, d_used)
+        olens = olens_t.tolist()                                   # host sync: output sizes
+        if sum(olens) == 0:
+            logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
+            d_eff, cum, olens_t = hip.lr_durations(rb, d_used, force_ones=True)
+            olens = olens_t.tolist()
+        olens = [n - n % 2 for n in olens]                         # matchatts_mas.py:521-526: even lengths
+        if min(olens) <= 0:
+            raise RuntimeError("an utterance has fewer than 2 output frames")
+        rbo = hip.RaggedBatch(olens, dev)
+        if self._MAS:   # GaussianUpsampling (length_regulator.py:111-154); frame f only depends on f and d
+            up = hip.gaussian_upsample(rb, d_eff, rbo, hs)
+        else:           # MatchaTTS (tts1): hard LengthRegulator (matchatts.py:427)
+            up = hip.lr_gather(rb, cum, rbo, hs)
+        ep = P["eproj"]
+        mu = hip.conv1d(rbo, hip.affine_cast(up, dt), ep.w, ep.c_in, od, 1, dtype=dt, bias=ep.b, out_f32=True)
+        if taps is not None:
+            taps["mu"] = mu.clone()
+        if noise is None:
+            nz = torch.randn(rbo.total, od, device=dev)
+        else:
+            nz = torch.cat([n[:m].reshape(-1, od) for n, m in zip(noise, olens)]).to(dev).float().contiguous()
+        x = hip.affine_cast(nz, hip.F32, scale=torch.full((od,), float(temperature), device=dev))
+        mu_t = hip.affine_cast(mu, dt, ldy=P["d0"][0].conv1[1].c_in)
+        rb2 = hip.RaggedBatch([n // 2 for n in olens], dev)
+        # Euler schedule exactly as flow_matching.py:68-93 (float32 accumulation of t)
+        t_span = torch.linspace(0, 1, n_timesteps + 1)
+        t, dt_s = t_span[0], t_span[1] - t_span[0]
+        half = od  # SinusoidalPosEmb(in_channels = 2*odim): half_dim = odim
+        freq = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+        c_t = P["t1"].c_in
+        for step in range(1, n_timesteps + 1):
+            emb = 1000.0 * t * freq
+            temb = torch.zeros(B, c_t)
+            temb[:, :2 * half] = torch.cat((emb.sin(), emb.cos()))
+            self._estimator_step(P, rbo, rb2, rbs, x, mu_t, temb.to(dev).to(hip.torch_dtype(dt)), float(dt_s))
+            t = t + dt_s
+            if step < n_timesteps:
+                dt_s = t_span[step + 1] - t
+        return dict(feat_gen=x, olens=olens, feats_rb=rbo, text_rb=rb, duration=d_pred, log_duration=logd)
+
+    def inference(self, text, feats=None, durations=None, spembs=None, sids=None, lids=None, n_timesteps: int = 10,
+                  temperature: float = 0.667, use_teacher_forcing: bool = False, noise=None):
+        """Same contract as jatts.models.MatchaTTS_MAS.inference (matchatts_mas.py:552-642) for feats=None."""
+        if feats is not None or use_teacher_forcing:
+            raise NotImplementedError("alignment / teacher-forcing branches are training-time paths")
+        r = self.inference_batch([text], n_timesteps=n_timesteps, temperature=temperature,
+                                 spembs=None if spembs is None else spembs.unsqueeze(0), sids=sids,
+                                 noise=None if noise is None else [noise])
+        out = dict(feat_gen=r["feat_gen"], duration=r["duration"])
+        if self._MAS:
+            out.update(log_p_attn=None, ds=None)
+        return out
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training pass (CFM loss) is outside the stage-4 hot path")
+
+
+class MatchaTTS_MAS(_MatchaBase):
+    _MAS = True
+
+
+class MatchaTTS(_MatchaBase):
+    """tts1 variant (reference models/matchatts.py): external-duration training, hard LengthRegulator."""
+    _MAS = False

@@ -57,6 +57,17 @@ def pin_duration_head(sd, frames_per_token, prefix="duration_predictor."):
     return sd
 
 
+def matcha_golden_tweaks(sd):
+    """Adjustments applied on top of synth_state_dict for the Matcha golden model (shared by
+    tests/golden/make_golden.py and the tests): SnakeBeta's log-scale alpha/beta get a visible range
+    and the duration head a +1.3 bias (about 3 frames per token) so the U-Net sees useful lengths."""
+    for k in sd:
+        if k.endswith(".alpha") or k.endswith(".beta"):
+            sd[k] = sd[k] * 5.0
+    sd["duration_predictor.linear.bias"] = sd["duration_predictor.linear.bias"] + 1.3
+    return sd
+
+
 def synth_texts(n_utts, t_text, vocab=45, seed=1, ragged_min=None):
     """Token id sequences ~ U{1..vocab-1} (0 is <blank>/pad).  ``ragged_min`` draws
     lengths ~ U{ragged_min..t_text}."""

@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-from jatts_amd.synthetic import FS2_JSUT, FS2_SMALL, synth_state_dict  # noqa: E402
+from jatts_amd.synthetic import FS2_JSUT, FS2_SMALL, matcha_golden_tweaks, synth_state_dict  # noqa: E402
 
 
 def import_reference():
@@ -79,6 +79,77 @@ def import_reference_vits():
     from jatts.models.vits import VITS
 
     return VITS
+
+
+def import_reference_matcha():
+    """MatchaTTS_MAS with diffusers' Attention / LoRACompatibleLinear replaced by a standard SDPA module
+    (diffusers is absent; see oracle/matcha_oracle.py: that piece is parity-unpinned)."""
+    import torch.nn as nn
+
+    class Attention(nn.Module):
+        def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                     upcast_attention=False):
+            super().__init__()
+            inner = heads * dim_head
+            self.heads, self.scale = heads, dim_head ** -0.5
+            self.to_q = nn.Linear(query_dim, inner, bias=bias)
+            self.to_k = nn.Linear(query_dim, inner, bias=bias)
+            self.to_v = nn.Linear(query_dim, inner, bias=bias)
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+        def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+            B, T, _ = hidden_states.shape
+            sp = lambda t: t.view(B, T, self.heads, -1).transpose(1, 2)  # noqa: E731
+            q, k, v = sp(self.to_q(hidden_states)), sp(self.to_k(hidden_states)), sp(self.to_v(hidden_states))
+            a = torch.softmax(q @ k.transpose(-1, -2) * self.scale, dim=-1)
+            return self.to_out[0]((a @ v).transpose(1, 2).reshape(B, T, -1))
+
+    ident = lambda c: c  # noqa: E731
+    sys.modules["diffusers.models.attention_processor"].Attention = Attention
+    sys.modules["diffusers.models.lora"].LoRACompatibleLinear = nn.Linear
+    sys.modules["diffusers.utils.torch_utils"].maybe_allow_in_graph = ident
+    for n in ("GEGLU", "GELU", "AdaLayerNorm", "AdaLayerNormZero", "ApproximateGELU"):
+        setattr(sys.modules["diffusers.models.attention"], n, type(n, (nn.Module,), {}))
+    for m in [k for k in sys.modules if k.startswith("jatts.modules.matchatts") or k == "jatts.models.matchatts_mas"]:
+        del sys.modules[m]
+    from jatts.models.matchatts_mas import MatchaTTS_MAS
+
+    return MatchaTTS_MAS
+
+
+MATCHA_SMALL = dict(odim=80, adim=64, aheads=2, elayers=2, eunits=128, positionwise_layer_type="conv1d",
+                    positionwise_conv_kernel_size=3, encoder_type="conformer", duration_predictor_layers=2,
+                    duration_predictor_chans=64, duration_predictor_kernel_size=3, conformer_enc_kernel_size=7,
+                    decoder_channels=[128, 128], decoder_attention_head_dim=64, decoder_n_blocks=1,
+                    decoder_num_mid_blocks=2, decoder_num_heads=2, decoder_act_fn="snakebeta")
+
+
+def run_matcha(Matcha, texts, n_timesteps=4, temperature=0.667):
+    model = Matcha(idim=20, **MATCHA_SMALL).eval()
+    ref_sd = model.state_dict()
+    sd = matcha_golden_tweaks(synth_state_dict(ref_sd, 3))
+    model.load_state_dict(sd)
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "config": json.dumps(MATCHA_SMALL),
+           "n_timesteps": np.int64(n_timesteps), "temperature": np.float32(temperature)}
+    real = torch.randn_like
+    for u, text in enumerate(texts):
+        holder = {}
+
+        def fake(t, *a, **k):
+            holder["noise"] = torch.randn(t.shape, generator=torch.Generator().manual_seed(400 + u))
+            return holder["noise"]
+
+        torch.randn_like = fake
+        try:
+            with torch.no_grad():
+                r = model.inference(text, n_timesteps=n_timesteps, temperature=temperature)
+        finally:
+            torch.randn_like = real
+        out[f"u{u}_text"] = np_(text)
+        out[f"u{u}_noise"] = np_(holder["noise"][0].t())   # (T', odim)
+        out[f"u{u}_feat_gen"] = np_(r["feat_gen"])
+        out[f"u{u}_duration"] = np_(r["duration"])
+    return out, model, sd
 
 
 VITS_SMALL = dict(odim=80, adim=64, aheads=2, text_encoder_blocks=2, text_encoder_attention_heads=2, dlayers=2,
@@ -305,6 +376,19 @@ def main():
               float((o["feat_gen"] - torch.tensor(vz[f"u{u}_feat_gen"])).abs().max()),
               "dur equal:", bool((o["duration"].numpy() == vz[f"u{u}_duration"]).all()),
               "frames", vz[f"u{u}_feat_gen"].shape[0])
+    # --- Matcha-TTS (MAS variant), small config, injected noise
+    Matcha = import_reference_matcha()
+    from oracle.matcha_oracle import matcha_inference
+    g = torch.Generator().manual_seed(6)
+    texts = [torch.randint(1, 20, (n,), generator=g) for n in (11, 19)]
+    mz, mmodel, msd = run_matcha(Matcha, texts)
+    np.savez_compressed(os.path.join(HERE, "matcha_small.npz"), **mz)
+    for u, t in enumerate(texts):
+        o = matcha_inference(mmodel.state_dict(), t, 2, 2, torch.tensor(mz[f"u{u}_noise"]), n_timesteps=4)
+        print(f"matcha u{u}: oracle-vs-ref mel max|d| =",
+              float((o["feat_gen"] - torch.tensor(mz[f"u{u}_feat_gen"])).abs().max()),
+              "dur equal:", bool((o["duration"].numpy() == mz[f"u{u}_duration"]).all()),
+              "frames", mz[f"u{u}_feat_gen"].shape[0], "absmax", float(np.abs(mz[f"u{u}_feat_gen"]).max()))
     np.savez_compressed(os.path.join(HERE, "lr_kat.npz"), **lr_cases())
     np.savez_compressed(os.path.join(HERE, "mask_kat.npz"), **mask_cases())
     np.savez_compressed(os.path.join(HERE, "vocoder_decode.npz"), **vocoder_decode_case())

@@ -74,6 +74,16 @@ def test_state_dict_schema_equals_reference(golden_dir):
         assert all(tuple(s) == tuple(sd[k].shape) for k, s in keys)
 
 
+def test_matcha_and_vits_schemas_equal_reference(golden_dir):
+    from jatts_amd.models import VITS, MatchaTTS_MAS
+    for name, cls in (("matcha_small.npz", MatchaTTS_MAS), ("vits_small.npz", VITS)):
+        z = np.load(os.path.join(golden_dir, name))
+        keys = json.loads(str(z["keys"]))
+        sd = cls(idim=20, **json.loads(str(z["config"]))).state_dict()
+        assert [k for k, _ in keys] == list(sd.keys()), name
+        assert all(tuple(s) == tuple(sd[k].shape) for k, s in keys), name
+
+
 def test_hifigan_loads_weight_norm_checkpoints():
     from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state
     from jatts_amd.vocoder import HiFiGANGenerator

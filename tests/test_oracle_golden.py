@@ -62,6 +62,20 @@ def test_vits_oracle_matches_reference():
     assert torch.equal(rel_shift_new(bd), want)
 
 
+def test_matcha_oracle_matches_reference():
+    """Matcha-TTS MAS (A14-A15): oracle vs the reference run with injected noise, 4 Euler steps."""
+    import json
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    from oracle.matcha_oracle import matcha_inference
+    z, keys = load_golden("matcha_small.npz")
+    sd = matcha_golden_tweaks(golden_state(keys, 3))
+    for u in range(2):
+        o = matcha_inference(sd, torch.tensor(z[f"u{u}_text"]), 2, 2, torch.tensor(z[f"u{u}_noise"]),
+                             n_timesteps=int(z["n_timesteps"]), temperature=float(z["temperature"]))
+        assert np.array_equal(o["duration"].numpy(), z[f"u{u}_duration"])
+        assert maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-5
+
+
 def test_rel_shift_closed_form_equals_view_trick():
     g = torch.Generator().manual_seed(0)
     for T in (1, 2, 3, 7, 16):
