@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Stage-4 decoding CLI — drop-in for ``jatts/bin/tts_decode.py`` (reference :30-274) on the MI355X path.
+
+Same flags (``--csv --stats --token-list --token-column --outdir --checkpoint [--config] [--verbose]``),
+same outputs (``<outdir>/wav/<sample_id>.wav`` as PCM_16 at the vocoder's sampling rate).  Differences,
+all additive: utterances are synthesised in ragged batches (``--batch-size``) instead of one by one; the
+per-utterance PNG (reference :240-244) is written only with ``--plot``; under ``torch.distributed.run``
+every rank decodes its own shard of the csv (no collective: the outputs are files).
+
+    python -m jatts_amd.bin.tts_decode --csv data/dev.csv --stats exp/stats.h5 --token-list exp/tokens.txt \\
+        --token-column phonemes --checkpoint exp/checkpoint-100000steps.pkl --outdir exp/results/dev
+"""
+import argparse
+import csv
+import logging
+import os
+import time
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+import jatts_amd.models
+from jatts_amd.hostlogic import shard_utterances
+from jatts_amd.vocoder import Vocoder
+
+
+class TokenIDConverter:
+    """Token list file: one symbol per line, id = line number (reference utils/token_id_converter.py:12-60)."""
+
+    def __init__(self, token_list, unk_symbol="<unk>"):
+        with open(token_list, "r", encoding="utf-8") as f:
+            self.token_list = [line.rstrip() for line in f]
+        self.token2id = {}
+        for i, t in enumerate(self.token_list):
+            if t in self.token2id:
+                raise RuntimeError(f'Symbol "{t}" is duplicated')
+            self.token2id[t] = i
+        if unk_symbol not in self.token2id:
+            raise RuntimeError(f"Unknown symbol '{unk_symbol}' doesn't exist in the token_list")
+        self.unk_id = self.token2id[unk_symbol]
+
+    def tokens2ids(self, tokens):
+        return [self.token2id.get(t, self.unk_id) for t in tokens]
+
+
+def read_stats(path, feat):
+    """``<feat>_mean`` / ``<feat>_scale`` (reference compute_statistics.py:94-103); .h5 needs h5py, .npz works everywhere."""
+    if str(path).endswith(".npz"):
+        z = np.load(path)
+        return {"mean": z[f"{feat}_mean"].astype(np.float32), "scale": z[f"{feat}_scale"].astype(np.float32)}
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("reading .h5 stats needs h5py; convert to .npz (<feat>_mean, <feat>_scale)") from e
+    with h5py.File(path, "r") as f:
+        return {"mean": f[f"{feat}_mean"][()].astype(np.float32), "scale": f[f"{feat}_scale"][()].astype(np.float32)}
+
+
+def write_wav_pcm16(path, y, sr):
+    """float [-1, 1] -> 16-bit PCM, as soundfile's 'PCM_16' does (lrint(x * 32767))."""
+    pcm = np.rint(np.clip(np.asarray(y, dtype=np.float64), -1.0, 1.0) * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(sr))
+        w.writeframes(pcm.tobytes())
+
+
+def read_items(csv_path, token_column, converter):
+    items = []
+    with open(csv_path, newline="") as f:
+        for row in csv.DictReader(f):
+            tokens = [p for p in row[token_column].split(" ") if p != ""]   # tts_dataset.py:108-116
+            row["token_indices"] = np.array(converter.tokens2ids(tokens), dtype=np.int64)
+            items.append(row)
+    return items
+
+
+def get_parser():
+    p = argparse.ArgumentParser(description="Decode with trained TTS model (MI355X HIP path).")
+    p.add_argument("--csv", required=True, type=str)
+    p.add_argument("--stats", required=True, type=str)
+    p.add_argument("--token-list", required=True, type=str)
+    p.add_argument("--token-column", required=True, type=str)
+    p.add_argument("--outdir", required=True, type=str)
+    p.add_argument("--checkpoint", required=True, type=str)
+    p.add_argument("--config", default=None, type=str)
+    p.add_argument("--verbose", type=int, default=1)
+    p.add_argument("--batch-size", type=int, default=64, help="utterances per ragged batch (extension)")
+    p.add_argument("--precision", default="fp16", choices=["fp16", "fp32"], help="MFMA operand precision (extension)")
+    p.add_argument("--plot", action="store_true", help="also write <outdir>/outs/<id>.png like the reference")
+    return p
+
+
+def main(argv=None):
+    args = get_parser().parse_args(argv)
+    level = logging.DEBUG if args.verbose > 1 else logging.INFO if args.verbose > 0 else logging.WARN
+    logging.basicConfig(level=level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    os.makedirs(os.path.join(args.outdir, "wav"), exist_ok=True)
+    if args.config is None:
+        args.config = os.path.join(os.path.dirname(args.checkpoint), "config.yml")
+    with open(args.config) as f:
+        config = yaml.load(f, Loader=yaml.Loader)
+    config.update(vars(args))
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise RuntimeError("jatts_amd needs an MI355X: there is no CPU fallback")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+
+    converter = TokenIDConverter(args.token_list)
+    items = read_items(args.csv, args.token_column, converter)
+    logging.info(f"Dataset size = {len(items)}.")
+    if world > 1:
+        mine = shard_utterances([len(it["token_indices"]) for it in items], world)[rank]
+        items = [items[i] for i in mine]
+
+    model_class = getattr(jatts_amd.models, config["model_type"])          # tts_decode.py:139
+    model = model_class(**config["model_params"])
+    model.load_state_dict(torch.load(args.checkpoint, map_location="cpu")["model"])
+    model = model.eval().to(device).set_precision(args.precision)
+    logging.info(f"Loaded model parameters from {args.checkpoint}.")
+
+    stats = read_stats(args.stats, config["out_feat_type"])                # tts_decode.py:160-164
+    if not config.get("vocoder", False):
+        raise NotImplementedError("Griffin-Lim fallback (no vocoder) is outside the HIP path")
+    vcfg = config["vocoder"]
+    if vcfg.get("vocoder_type", "") not in ("", "hifigan", "parallel_wavegan"):
+        raise NotImplementedError(f"vocoder_type {vcfg.get('vocoder_type')} is not on the HIP path")
+    vocoder = Vocoder(vcfg["checkpoint"], vcfg["config"], vcfg["stats"], device, trg_stats=stats)
+    vocoder.set_precision(args.precision)
+    hop = vocoder.model.hop
+    uses_spk = "spkemb" in config.get("feat_list", [])
+    kw = {}
+    if config["model_type"] in ("MatchaTTS", "MatchaTTS_MAS"):              # tts_decode.py:217-226
+        kw = {"temperature": config["temperature"], "n_timesteps": config["ode_steps"]}
+
+    order = sorted(range(len(items)), key=lambda i: -len(items[i]["token_indices"]))  # similar lengths together
+    n_frames, t0 = 0, time.time()
+    for s in range(0, len(order), args.batch_size):
+        batch = [items[i] for i in order[s:s + args.batch_size]]
+        texts = [torch.from_numpy(it["token_indices"]).to(device) for it in batch]
+        if uses_spk:
+            if "spkemb_path" not in batch[0]:
+                raise NotImplementedError("speaker embeddings must be precomputed (csv column spkemb_path -> .npy); "
+                                          "the SpeechBrain extractor is outside the hot path")
+            spk = torch.from_numpy(np.stack([np.load(it["spkemb_path"]) for it in batch])).float().to(device)
+            r = model.inference_batch(texts, spembs=spk, **kw)
+        else:
+            r = model.inference_batch(texts, **kw)
+        y = vocoder.decode_batch(r["feats_rb"], r["feat_gen"])
+        y_host = y.cpu().numpy()                                            # one device->host copy per batch
+        mel_host = r["feat_gen"].cpu().numpy() if args.plot else None
+        o = 0
+        for it, nf in zip(batch, r["olens"]):
+            sid = it.get("sample_id", it.get("id", str(o)))
+            write_wav_pcm16(os.path.join(args.outdir, "wav", f"{sid}.wav"), y_host[o * hop:(o + nf) * hop],
+                            vocoder.config["sampling_rate"])
+            if args.plot:
+                import matplotlib
+                matplotlib.use("Agg")
+                import matplotlib.pyplot as plt
+                os.makedirs(os.path.join(args.outdir, "outs"), exist_ok=True)
+                plt.figure(figsize=(8, 3))
+                plt.imshow(mel_host[o:o + nf].T, origin="lower", aspect="auto")
+                plt.savefig(os.path.join(args.outdir, "outs", f"{sid}.png"))
+                plt.close()
+            o += nf
+        n_frames += sum(r["olens"])
+    dt = time.time() - t0
+    logging.info("inference speed = %.1f frames / sec. (RTF = %.5f)" % (
+        n_frames / max(dt, 1e-9), dt / max(n_frames * hop / vocoder.config["sampling_rate"], 1e-9)))
+
+
+if __name__ == "__main__":
+    main()
