@@ -62,6 +62,20 @@ def cpu_baseline(fs2_sd, voc_sd, voc_params, text, heads):
                 seconds=t2 - t0, samples=int(y.numel()))
 
 
+def pmc_traffic(c, esz):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_bench.sh ->
+    tools/pmc_traffic.py; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes, same workload).  PMC
+    counters cannot be collected from inside this process, so the number is the last committed measurement."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    key = f"resunit_kernelI{'DF16_' if esz == 2 else 'f'}Li{c}E"
+    for name, v in json.load(open(path))["kernels"].items():
+        if key in name:
+            return v["hbm_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)"
+    return None, None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -162,7 +176,7 @@ def main():
     else:
         roof = dict(bound="hbm", achieved=dom_bytes / dom_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s")
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = None
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom_c, esz)
     roof["kernel"] = f"resunit_kernel<{'f16' if esz == 2 else 'float'}, C={dom_c}> (fused HiFi-GAN dilation unit)"
     roof["avg_launch_ms"] = dom_ms / sum(u["launches"] for u in dom)
     roof["arith_intensity_flop_per_byte"] = ai

@@ -82,6 +82,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Compile-time activation (one specialised epilogue per activation, selected by a uniform branch).
+template <int ACT> __device__ __forceinline__ float act_c(float v) { return apply_act(v, ACT); }
+
 // Sequence lookup for a ragged launch: tile -> (sequence, first local row).
 // cu_tiles[b] = number of tiles before sequence b (n_seq+1 entries).
 __device__ __forceinline__ int find_seq(const int32_t* __restrict__ cu_tiles, int n_seq, int tile) {

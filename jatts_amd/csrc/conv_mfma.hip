@@ -185,8 +185,8 @@ struct WFrags {
   int stride;   // elements between consecutive 16-channel steps (NFR * 512)
   __device__ __forceinline__ void init(int NFR, int nf0) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) nfo[f] = (nf0 + f < NFR ? nf0 + f : NFR - 1) * 512;  // clamped: never stored
-    stride = NFR * 512;
+    for (int f = 0; f < NF; ++f) nfo[f] = JATTS_ABLATE == 10 ? 0 : (nf0 + f < NFR ? nf0 + f : NFR - 1) * 512;  // clamped
+    stride = JATTS_ABLATE == 10 ? 0 : NFR * 512;
   }
 };
 
@@ -241,7 +241,7 @@ __device__ __forceinline__ void conv_full(f32x16 (&acc)[NF][NT], const T* __rest
   WFrags<T, NF> wf;
   wf.init(NFR, nf0);
   const T* wl = w + (size_t)lane * 8;
-  const size_t gstride = (size_t)KCG * wf.stride;  // elements per group
+  const size_t gstride = JATTS_ABLATE == 10 ? 0 : (size_t)KCG * wf.stride;  // elements per group
   const int n_groups = k_w * GPT;
   const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * (lane >> 5)) * sizeof(T);
   V8 ring[KCG][NF], bb[2][NT];
@@ -355,6 +355,58 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NF][NT]) {
 // ------------------------------------------------------------------ generic conv kernel
 constexpr int KCH = 64;  // channels staged per LDS chunk
 
+// Conv epilogue: y = act(acc + bias) * alpha + resid.  Lane owns column (lane&31) and the channel quads
+// n0 + {0..3}; quads fully inside n_out take the 16-byte bias / residual / store path, the ragged last quad
+// (n_out % 4 != 0) a scalar loop.
+template <typename T, int ACT, int NF, int NT>
+__device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (&acc)[NF][NT], int t0, int col0, int nf0,
+                                              int lane, int L, int64_t seq_row0) {
+  const int g = lane >> 5;
+  const bool vec_r = d.resid && (d.ldr & 3) == 0, vec_y = (d.ldy & 3) == 0 && !d.y_transposed;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int pos = t0 + col0 + t * 32 + (lane & 31);
+    if (pos >= L) continue;
+    const int64_t row = seq_row0 + pos;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
+        if (n0 >= d.n_out) continue;
+        const bool full = n0 + 3 < d.n_out;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f}, rq = {0.f, 0.f, 0.f, 0.f};
+        if (full) {
+          if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n0);
+          if (vec_r) rq = *reinterpret_cast<const f32x4*>(d.resid + row * d.ldr + n0);
+        }
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[f][t][4 * q + e] + bq[e]) * d.alpha + rq[e];
+        if (full && vec_y && (vec_r || !d.resid)) {
+          const int64_t o = row * d.ldy + n0;
+          if (d.y_is_f32 || sizeof(T) == 4) *reinterpret_cast<f32x4*>((float*)d.y + o) = v;
+          else *reinterpret_cast<f16x4*>((f16*)d.y + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + e;
+            if (n >= d.n_out) break;
+            float s = v[e];
+            if (!full) s = act_c<ACT>(acc[f][t][4 * q + e] + (d.bias ? d.bias[n] : 0.f)) * d.alpha;
+            if (d.resid && !(full && vec_r)) s += d.resid[row * d.ldr + n];
+            const int64_t o = d.y_transposed ? (int64_t)n * d.ldy + row : row * d.ldy + n;
+            if (d.y_is_f32) ((float*)d.y)[o] = s; else ((T*)d.y)[o] = from_f32<T>(s);
+          }
+        }
+      }
+      // keep the epilogue's live ranges short: without this hipcc hoists every bias / residual
+      // load of the tile to the top and the kernel loses a wave of occupancy
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
 __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -411,67 +463,15 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
     }
   }
 
-  // epilogue: lane owns column (lane&31) and channel quads n0 + {0..3}
-  const int g = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int pos = t0 + col0 + t * 32 + (lane & 31);
-    if (pos >= L) continue;
-    const int64_t row = seq_row0 + pos;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
-        if (n0 >= d.n_out) continue;
-        float v[4];
-        const bool full = n0 + 3 < d.n_out;
-        f32x4 bq = {0.f, 0.f, 0.f, 0.f}, rq = {0.f, 0.f, 0.f, 0.f};
-        if (full) {  // 16-byte bias / residual loads (n0 % 4 == 0)
-          if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n0);
-          if (d.resid && (d.ldr & 3) == 0) rq = *reinterpret_cast<const f32x4*>(d.resid + row * d.ldr + n0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + e;
-          float s = acc[f][t][4 * q + e];
-          if (n < d.n_out) {
-            if (full) {
-              s = apply_act(s + bq[e], d.act) * d.alpha;
-              if (d.resid) s += (d.ldr & 3) == 0 ? rq[e] : d.resid[row * d.ldr + n];
-            } else {
-              if (d.bias) s += d.bias[n];
-              s = apply_act(s, d.act) * d.alpha;
-              if (d.resid) s += d.resid[row * d.ldr + n];
-            }
-          }
-          v[e] = s;
-        }
-        if (d.y_transposed) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n0 + e >= d.n_out) break;
-            const int64_t o = (int64_t)(n0 + e) * d.ldy + row;
-            if (d.y_is_f32) ((float*)d.y)[o] = v[e]; else ((T*)d.y)[o] = from_f32<T>(v[e]);
-          }
-        } else if (n0 + 3 < d.n_out && (d.ldy & 3) == 0) {
-          const int64_t o = row * d.ldy + n0;
-          if (d.y_is_f32 || sizeof(T) == 4) {
-            *reinterpret_cast<f32x4*>((float*)d.y + o) = f32x4{v[0], v[1], v[2], v[3]};
-          } else {
-            *reinterpret_cast<f16x4*>((f16*)d.y + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          }
-        } else {
-          for (int e = 0; e < 4 && n0 + e < d.n_out; ++e) {
-            const int64_t o = row * d.ldy + n0 + e;
-            if (d.y_is_f32) ((float*)d.y)[o] = v[e]; else ((T*)d.y)[o] = from_f32<T>(v[e]);
-          }
-        }
-      }
-      // keep the epilogue's live ranges short: without this hipcc hoists every bias / residual
-      // load of the tile to the top and the kernel loses a wave of occupancy
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  // epilogue, specialised per activation by ONE uniform branch: a runtime switch inside the 64-element
+  // unrolled body inlined tanh/mish 128 times, the unroller gave up and the accumulators went to scratch
+  // (1.8x slower conv, profiles/r01_notes.md).
+  switch (d.act) {
+    case JATTS_ACT_RELU: conv_epilogue<T, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
+    case JATTS_ACT_TANH: conv_epilogue<T, JATTS_ACT_TANH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
+    case JATTS_ACT_SWISH: conv_epilogue<T, JATTS_ACT_SWISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
+    case JATTS_ACT_MISH: conv_epilogue<T, JATTS_ACT_MISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
+    default: conv_epilogue<T, JATTS_ACT_NONE, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
   }
 }
 
@@ -504,7 +504,7 @@ int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
 
 // ------------------------------------------------------------ fused HiFi-GAN dilation unit
 template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8>
-__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(jatts_resunit_desc d) {
+__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN * 32)) * NT * 16 <= 128) ? 2 : 1) void resunit_kernel(jatts_resunit_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
   constexpr int NF = C / (WN * 32);
@@ -536,14 +536,14 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   char* hs = smem;
 
   const T* xin[3] = {(const T*)d.x, nullptr, nullptr};
-  if (JATTS_ABLATE != 2)
+  if (JATTS_ABLATE != 2 && JATTS_ABLATE != 7 && JATTS_ABLATE != 12)
     stage_rows<T>(xs, pitch, rx, C, t0 - p2 - p1, L, seq_row0, xin, 1, C, 0, 1.f,
                   JATTS_ABLATE == 1 ? JATTS_PRE_NONE : JATTS_PRE_LRELU, d.slope);
   __syncthreads();
 
   f32x16 acc[NF][NT];
   zero_acc<NF, NT>(acc);
-  if (JATTS_ABLATE != 6) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
+  if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
 
   // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
   __syncthreads();  // every wave is done reading x: the tile may now be overwritten by h
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
         }
         char* p = hs + (size_t)col * pitch + (size_t)n0 * sizeof(T);
         if (sizeof(T) == 2) {
-          if (JATTS_ABLATE != 5 || to_f32(o[0]) == 12345.678f)
+          if ((JATTS_ABLATE != 5 && JATTS_ABLATE != 9) || to_f32(o[0]) == 12345.678f)
             *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
         } else {
           *reinterpret_cast<f32x4*>(p) = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
@@ -584,22 +584,21 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
   __syncthreads();
 
   zero_acc<NF, NT>(acc);
-  if (JATTS_ABLATE != 6) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
+  if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
 
-  // epilogue 2: y = x + acc + b2 for the tt_out valid columns.  The tile is assembled in LDS (the
-  // h region is dead once every wave has left stage 2) and written with row-contiguous 16-byte
-  // stores: the MFMA fragment layout would otherwise scatter each 128-byte line over 8 separate
-  // 8-byte store instructions, which measured 1.4 ms of a 2.7 ms launch (profiles/r01_notes.md).
+  // epilogue 2: y = x + acc + b2 for the tt_out valid columns.  acc + b2 is assembled in LDS (the h region
+  // is dead once every wave has left stage 2) and the residual is added in the row-contiguous 16-byte
+  // store pass below: in MFMA fragment order both the x re-read and the y store scatter every 128-byte
+  // line over 8 separate 8-byte accesses (1.4 ms of a 2.7 ms launch, profiles/r01_notes.md).
   const T* xg = (const T*)d.x;
   T* yg = (T*)d.y;
+  if (JATTS_ABLATE == 8) return;
   __syncthreads();
   char* ys = smem;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = col0 + t * 32 + (lane & 31);
-    const int pos = t0 + col;
-    if (col >= tt_out || pos >= L) continue;
-    const int64_t rowoff = (seq_row0 + pos) * (int64_t)C;
+    if (col >= tt_out || t0 + col >= L) continue;
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -608,44 +607,60 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64) void resunit_kernel(j
         const f32x4 bb = *reinterpret_cast<const f32x4*>(d.b2 + n0);
         char* p = ys + (size_t)col * pitch + (size_t)n0 * sizeof(T);
         if (sizeof(T) == 2) {
-          f16x4 xr = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-          if (JATTS_ABLATE != 3) xr = *reinterpret_cast<const f16x4*>((const f16*)xg + rowoff + n0);
           f16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)(acc[f][t][4 * q + e] + bb[e] + (float)xr[e]);
+          for (int e = 0; e < 4; ++e) o[e] = (f16)(acc[f][t][4 * q + e] + bb[e]);
           *reinterpret_cast<f16x4*>(p) = o;
         } else {
-          const f32x4 xr = *reinterpret_cast<const f32x4*>((const float*)xg + rowoff + n0);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e] + bb[e] + xr[e];
+          for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e] + bb[e];
           *reinterpret_cast<f32x4*>(p) = o;
         }
       }
   }
   __syncthreads();
   {
-    constexpr int UPR = C / 8;
+    constexpr int UPR = C / 8, UB = 4;
+    typedef typename Elem<T>::vec8 V8;
     const int vrows = min(tt_out, L - t0);
     const int total = vrows * UPR;
-    for (int u = threadIdx.x; u < total; u += blockDim.x) {
-      const int r = u / UPR, cu = u - r * UPR;
-      typename Elem<T>::vec8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
-      const int64_t goff = (seq_row0 + t0 + r) * (int64_t)C + cu * 8;
-      if (d.add0) {  // fused MRF mean over ResBlocks (coalesced 16-byte reads)
-        const typename Elem<T>::vec8 a0 = Vec8IO<T>::ldg((const T*)d.add0 + goff);
-        typename Elem<T>::vec8 a1 = a0;
-        if (d.add1) a1 = Vec8IO<T>::ldg((const T*)d.add1 + goff);
+    const int64_t g0 = (seq_row0 + t0) * (int64_t)C;  // the valid rows are contiguous in y: unit u <-> 8 elements at g0 + 8u
+    const bool has_add = d.add0 != nullptr, has_add1 = d.add1 != nullptr;
+    for (int u0 = threadIdx.x; u0 < total; u0 += UB * blockDim.x) {
+      V8 xr[UB], a0[UB], a1[UB];
+      // all global reads of the batch are issued before any is consumed (one round trip, not UB)
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[e]) + (d.add1 ? to_f32(a1[e]) : 0.f)) * d.out_scale);
+      for (int i = 0; i < UB; ++i) {
+        const int u = u0 + i * blockDim.x;
+        if (u < total) {
+          if (JATTS_ABLATE != 3) xr[i] = Vec8IO<T>::ldg(xg + g0 + (int64_t)u * 8);
+          if (has_add) a0[i] = Vec8IO<T>::ldg((const T*)d.add0 + g0 + (int64_t)u * 8);   // fused MRF mean over ResBlocks
+          if (has_add1) a1[i] = Vec8IO<T>::ldg((const T*)d.add1 + g0 + (int64_t)u * 8);
+        }
       }
-      T* dst = yg + goff;
-      if (JATTS_ABLATE != 4 || to_f32(v[0]) == 12345.678f) {
-        if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
-        else {
-          *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
-          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int u = u0 + i * blockDim.x;
+        if (u >= total) continue;
+        const int r = u / UPR, cu = u - r * UPR;
+        V8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
+        if (JATTS_ABLATE != 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(xr[i][e]));  // residual
+        }
+        if (has_add) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[i][e]) + (has_add1 ? to_f32(a1[i][e]) : 0.f)) * d.out_scale);
+        }
+        T* dst = yg + g0 + (int64_t)u * 8;
+        if ((JATTS_ABLATE != 4 && JATTS_ABLATE != 12) || to_f32(v[0]) == 12345.678f) {
+          if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
+          else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
+          }
         }
       }
     }
@@ -717,17 +732,25 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
     // tile variants: <C, workgroup columns, waves along n, 32-col fragments per wave>.
     // JATTS_RESUNIT_VARIANT (tuning knob, read once) selects alternative tilings for sweeps.
     static const int variant = [] { const char* e = getenv("JATTS_RESUNIT_VARIANT"); return e ? atoi(e) : 0; }();
+    // Default (variant 0) = the fastest tiling measured per shape (profiles/r01_notes.md): 4 time fragments
+    // per wave where the accumulators still allow 2 waves/SIMD -- every weight fragment fetched through the
+    // 64 B/clk vector L1 then feeds 4 MFMAs instead of 2, which is what bounds the 128/256-channel units.
+    const bool wide_k = d->k_w > 3;
     switch (d->channels * 10 + variant) {
-      case 320: case 321: case 322: return launch_resunit<f16, 32, 256, 1, 2>(*d, s);
-      case 640: return launch_resunit<f16, 64, 256, 1, 2>(*d, s);
-      case 641: case 642: return launch_resunit<f16, 64, 256, 1, 2, 2>(*d, s);
-      case 1280: return launch_resunit<f16, 128, 128, 2, 2, 8>(*d, s);
-      case 1281: return launch_resunit<f16, 128, 128, 2, 2, 4>(*d, s);
-      case 1282: return launch_resunit<f16, 128, 128, 2, 2, 2>(*d, s);
-      case 2560: return launch_resunit<f16, 256, 64, 4, 2, 8>(*d, s);
-      case 2561: return launch_resunit<f16, 256, 64, 4, 2, 4>(*d, s);
-      case 2562: return launch_resunit<f16, 256, 64, 4, 2, 2>(*d, s);
-      case 5120: case 5121: case 5122: return launch_resunit<f16, 512, 32, 4, 1>(*d, s);
+      case 320: return wide_k && d->k_w > 7 ? launch_resunit<f16, 32, 512, 1, 4, 2>(*d, s) : launch_resunit<f16, 32, 256, 1, 2>(*d, s);
+      case 321: return launch_resunit<f16, 32, 256, 1, 2>(*d, s);
+      case 323: return launch_resunit<f16, 32, 512, 1, 4, 2>(*d, s);
+      case 640: return wide_k ? launch_resunit<f16, 64, 512, 1, 4, 4>(*d, s) : launch_resunit<f16, 64, 256, 1, 2>(*d, s);
+      case 641: return launch_resunit<f16, 64, 256, 1, 2>(*d, s);
+      case 643: return launch_resunit<f16, 64, 256, 1, 4, 4>(*d, s);
+      case 644: return launch_resunit<f16, 64, 512, 1, 4, 4>(*d, s);
+      case 1280: case 1283: return launch_resunit<f16, 128, 256, 2, 4, 4>(*d, s);
+      case 1281: return launch_resunit<f16, 128, 128, 2, 2, 8>(*d, s);
+      case 1284: return launch_resunit<f16, 128, 128, 2, 4, 4>(*d, s);
+      case 2560: case 2563: return launch_resunit<f16, 256, 128, 4, 4, 4>(*d, s);
+      case 2561: return launch_resunit<f16, 256, 64, 4, 2, 8>(*d, s);
+      case 2564: return launch_resunit<f16, 256, 128, 4, 2, 4>(*d, s);
+      case 5120: return launch_resunit<f16, 512, 32, 4, 1>(*d, s);
     }
   } else if (d->dtype == JATTS_F32) {
     switch (d->channels) {
