@@ -140,6 +140,12 @@ typedef struct jatts_resunit_desc {
 
 int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);
 
+/* Profiling hook (not part of the reference interface): while `buf` is non-NULL, thread 0 of the first n_workgroups
+ * workgroups of every jatts_hifigan_resunit launch writes 16 uint64 to buf[16*wg ..]: {XCC_ID<<32 | HW_ID, s_memtime
+ * at start, x staged, conv1 done, h written, conv2 done, y assembled, y stored, then s_memrealtime (100 MHz) at start
+ * and end, 6 unused}.  buf: device memory of n_workgroups*128 bytes.  Pass NULL to switch tracing off (the default). */
+int jatts_debug_trace(void* buf, int64_t n_workgroups);
+
 /* Output stage: y[t] = tanh( b + sum_{tap,c} w[tap][c] * lrelu( in_scale * sum_i x_i[t+tap-pad][c] ) )
  * (HiFiGANGenerator.output_conv: LeakyReLU(0.01) -> Conv1d(C,1,k) -> Tanh).  w: f32 [k_w][c_in]. */
 int jatts_hifigan_output(const jatts_ragged* rg, int32_t dtype, const void* const* x, int32_t n_in,

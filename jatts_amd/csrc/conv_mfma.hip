@@ -498,13 +498,17 @@ int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
   const bool small_halo = (d.k_w - 1) * d.dil <= 32;
   const bool multi_chunk = d.c_in > KCH;  // a single chunk has nothing to overlap with
   if (small_halo && multi_chunk && d.n_in == 1) return launch_conv_k<T, NF, NT, WN, WT, 1, true>(d, s);
-  if (small_halo && multi_chunk && sizeof(T) == 2) return launch_conv_k<T, NF, NT, WN, WT, 3, true>(d, s);
+  if constexpr (sizeof(T) == 2) {
+    if (small_halo && multi_chunk) return launch_conv_k<T, NF, NT, WN, WT, 3, true>(d, s);
+  }
   return launch_conv_k<T, NF, NT, WN, WT, 3, false>(d, s);
 }
 
 // ------------------------------------------------------------ fused HiFi-GAN dilation unit
+static unsigned long long* g_trace = nullptr;  // profiling hook, see jatts_debug_trace
+static unsigned g_trace_cap = 0;
 template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8>
-__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN * 32)) * NT * 16 <= 128) ? 2 : 1) void resunit_kernel(jatts_resunit_desc d) {
+__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN * 32)) * NT * 16 <= 128) ? 2 : 1) void resunit_kernel(jatts_resunit_desc d, unsigned long long* trace, unsigned trace_cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
   constexpr int NF = C / (WN * 32);
@@ -512,6 +516,19 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
   constexpr int pitch = C * (int)sizeof(T) + 16;
   constexpr int KCG = sizeof(T) == 4 ? 2 : (KC16 < KCGMAX ? KC16 : KCGMAX);  // ring depth = group size
   static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
+  // Phase trace (profiling hook, jatts_debug_trace): thread 0 of the first trace_cap workgroups stamps s_memtime
+  // at every phase boundary: [hw id, start, staged, conv1, h written, conv2, y assembled, stored, realtime x2].
+  const unsigned wg_lin = blockIdx.x + blockIdx.y * gridDim.x;
+  const bool tracing = trace != nullptr && wg_lin < trace_cap && threadIdx.x == 0;
+#define JATTS_STAMP(i) do { if (tracing) trace[(size_t)wg_lin * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (tracing) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    trace[(size_t)wg_lin * 16] = ((unsigned long long)xcc << 32) | hwid;
+    trace[(size_t)wg_lin * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+  }
+  JATTS_STAMP(1);
   const int K = d.k_w, dil = d.dil;
   const int p2 = (K - 1) / 2, p1 = p2 * dil;
   const int tt_out = WGCOLS - 2 * p2;
@@ -540,11 +557,13 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
     stage_rows<T>(xs, pitch, rx, C, t0 - p2 - p1, L, seq_row0, xin, 1, C, 0, 1.f,
                   JATTS_ABLATE == 1 ? JATTS_PRE_NONE : JATTS_PRE_LRELU, d.slope);
   __syncthreads();
+  JATTS_STAMP(2);
 
   f32x16 acc[NF][NT];
   zero_acc<NF, NT>(acc);
   if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
 
+  JATTS_STAMP(3);
   // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
   __syncthreads();  // every wave is done reading x: the tile may now be overwritten by h
   // rows of h past the computed columns are only read by discarded output columns
@@ -582,10 +601,12 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
       }
   }
   __syncthreads();
+  JATTS_STAMP(4);
 
   zero_acc<NF, NT>(acc);
   if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
 
+  JATTS_STAMP(5);
   // epilogue 2: y = x + acc + b2 for the tt_out valid columns.  acc + b2 is assembled in LDS (the h region
   // is dead once every wave has left stage 2) and the residual is added in the row-contiguous 16-byte
   // store pass below: in MFMA fragment order both the x re-read and the y store scatter every 128-byte
@@ -620,6 +641,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
       }
   }
   __syncthreads();
+  JATTS_STAMP(6);
   {
     constexpr int UPR = C / 8, UB = 4;
     typedef typename Elem<T>::vec8 V8;
@@ -665,6 +687,9 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
       }
     }
   }
+  JATTS_STAMP(7);
+  if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+#undef JATTS_STAMP
 }
 
 template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8>
@@ -686,12 +711,18 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d);
+  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, g_trace, g_trace_cap);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
 
 }  // namespace
+
+extern "C" int jatts_debug_trace(void* buf, int64_t n_workgroups) {
+  g_trace = (unsigned long long*)buf;
+  g_trace_cap = buf ? (unsigned)n_workgroups : 0u;
+  return JATTS_OK;
+}
 
 extern "C" int64_t jatts_conv_weight_index(int32_t n, int32_t tap, int32_t c, int32_t n_pad, int32_t c_in) {
   const int64_t KC16 = c_in / 16, NFR = n_pad / 32;

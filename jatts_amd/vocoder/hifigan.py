@@ -11,6 +11,9 @@ Kernel schedule per batch: affine/cast -> input conv (MFMA implicit GEMM) -> per
 upsample stage [polyphase ConvTranspose as MFMA conv (LeakyReLU + MRF mean fused on the
 input side) -> 3 ResBlocks x 3 fused dilation units] -> output conv + tanh.
 """
+import contextlib
+import os
+
 import torch
 
 from .. import hip
@@ -132,6 +135,15 @@ class HiFiGANGenerator(torch.nn.Module):
         self._prep = P
         return P
 
+    # tuning knob (profiles/r01_notes.md): run the independent ResBlock chains of a stage on separate HIP streams
+    concurrent = os.environ.get("JATTS_HIFIGAN_STREAMS", "0") == "1"
+
+    def _side_streams(self, n):
+        pool = self.__dict__.setdefault("_streams", [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream())
+        return pool[:n]
+
     @torch.no_grad()
     def inference_batch(self, rb, mel, scale=None, shift=None, taps=None):
         """rb: RaggedBatch over mel frames; mel: f32 (rows, in_channels) packed.
@@ -157,24 +169,48 @@ class HiFiGANGenerator(torch.nn.Module):
             outs = []
             blocks = P["blocks"][i]
             fuse_mean = c_out in supported and len(blocks) in (2, 3)
+            # The ResBlocks of a stage are independent chains: with JATTS_HIFIGAN_STREAMS=1 all but the last run on
+            # side streams so that workgroups of memory-heavy (k=3) and MFMA-heavy (k=11) units share the CUs.
+            # Every buffer of the stage is allocated up front on the launch stream and held until the join.
+            side = self._side_streams(len(blocks) - 1) if (self.concurrent and c_out in supported) else []
+            main = torch.cuda.current_stream() if side else None
+            bufs = [[torch.empty_like(up), torch.empty_like(up)] for _ in blocks]
+            if side:
+                fork = torch.cuda.Event()
+                fork.record(main)
+            done = []
             for j, units in enumerate(blocks):
                 cur = up
-                for di, (c1, c2, rk, d) in enumerate(units):
-                    nxt = torch.empty_like(up)
-                    if c_out in supported:
-                        last = fuse_mean and j == len(blocks) - 1 and di == len(units) - 1
-                        # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
-                        hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt,
-                                            add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0)
-                    else:  # generic two-launch fallback for unusual channel counts
-                        h = hip.conv1d(rb, cur, c1.w, c_out, c_out, rk, dtype=dt, bias=c1.b, dil=d,
-                                       pre_lrelu=self.slope, len_mul=rate)
-                        r32 = cur.float()
-                        y32 = hip.conv1d(rb, h, c2.w, c_out, c_out, rk, dtype=dt, bias=c2.b,
-                                         pre_lrelu=self.slope, len_mul=rate, resid=r32, out_f32=True)
-                        nxt = hip.affine_cast(y32, dt)
-                    cur = nxt
+                st = side[j] if j < len(side) else None
+                if st is not None:
+                    st.wait_event(fork)
+                with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                    for di, (c1, c2, rk, d) in enumerate(units):
+                        nxt = bufs[j][di & 1]
+                        if c_out in supported:
+                            last = fuse_mean and j == len(blocks) - 1 and di == len(units) - 1
+                            if last:
+                                for ev in done:
+                                    torch.cuda.current_stream().wait_event(ev)
+                            # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
+                            hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt,
+                                                add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0)
+                        else:  # generic two-launch fallback for unusual channel counts
+                            h = hip.conv1d(rb, cur, c1.w, c_out, c_out, rk, dtype=dt, bias=c1.b, dil=d,
+                                           pre_lrelu=self.slope, len_mul=rate)
+                            r32 = cur.float()
+                            y32 = hip.conv1d(rb, h, c2.w, c_out, c_out, rk, dtype=dt, bias=c2.b,
+                                             pre_lrelu=self.slope, len_mul=rate, resid=r32, out_f32=True)
+                            nxt = hip.affine_cast(y32, dt)
+                        cur = nxt
+                    if st is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        done.append(ev)
                 outs.append(cur)
+            if side and not fuse_mean:
+                for ev in done:
+                    main.wait_event(ev)
             if fuse_mean:
                 xs, in_scale = [outs[-1]], 1.0
             else:
