@@ -28,6 +28,90 @@ __device__ __forceinline__ typename Elem<T>::vec8 load8(const T* p) {
 constexpr int QB = 64;  // queries per workgroup
 constexpr int KB = 64;  // keys per tile
 
+template <typename T>
+__device__ __forceinline__ void store8(char* p, const typename Elem<T>::vec8& v) {
+  if (sizeof(T) == 2) {
+    *reinterpret_cast<typename Elem<T>::vec8*>(p) = v;
+  } else {
+    *reinterpret_cast<f32x4*>(p) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    *reinterpret_cast<f32x4*>(p + 16) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  }
+}
+
+// 4 consecutive elements from an address that is only element-aligned (the rel-pos diagonal starts anywhere):
+// gfx950 under the amdhsa ABI runs in unaligned-access mode, so this is one 8/16-byte load.
+template <typename T>
+__device__ __forceinline__ void load4u(const T* p, float (&o)[4]) {
+  T v[4];
+  __builtin_memcpy(v, p, 4 * sizeof(T));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = to_f32(v[e]);
+}
+
+// One K / V^T tile in flight in registers: the global loads of tile t+1 are issued before the MFMAs of tile t
+// and land in LDS after them, so no wave ever waits on a tile load (the first version staged V^T with one
+// 2-byte load per element, each a serialized round trip: 1.1 ms per decoder layer, profiles/r01_notes.md).
+template <typename T, int DK>
+struct TileRegs {
+  static constexpr int N = DK / 32;  // 16-byte (8-element) chunks per thread for K and for V^T
+  typename Elem<T>::vec8 k[N], v[N];
+  float ku;
+};
+
+template <typename T, int DK>
+__device__ __forceinline__ void tile_load(TileRegs<T, DK>& tr, const jatts_relattn_desc& d, const T* kg, const T* vtg,
+                                          int row0, int h, int j0, int Tn, bool vt_vec) {
+  typedef typename Elem<T>::vec8 Vec;
+  constexpr int UPR = DK / 8;
+#pragma unroll
+  for (int i = 0; i < TileRegs<T, DK>::N; ++i) {
+    const int u = threadIdx.x + 256 * i;
+    {  // K rows: keys, 8 channels per chunk
+      const int r = u / UPR, cu = u - r * UPR, j = j0 + r;
+      Vec z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
+      tr.k[i] = (j >= 0 && j < Tn) ? load8<T>(kg + (int64_t)j * d.ldk + cu * 8) : z;
+    }
+    {  // V^T rows: channels, 8 keys per chunk
+      const int r = u >> 3, jc = j0 + 8 * (u & 7);
+      Vec z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
+      const T* src = vtg + (int64_t)r * d.ldvt + jc;
+      if (vt_vec) {
+        if (jc + 7 >= 0 && jc < Tn) z = load8<T>(src);   // aligned: (row0 + j0) % 8 == 0, ldvt % 8 == 0
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (jc + e < 0 || jc + e >= Tn) z[e] = from_f32<T>(0.f);   // never multiply P = 0 by stray bits
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (jc + e >= 0 && jc + e < Tn) z[e] = src[e];
+      }
+      tr.v[i] = z;
+    }
+  }
+  tr.ku = 0.f;
+  if (d.ku && threadIdx.x < KB) {
+    const int j = j0 + (int)threadIdx.x;
+    if (j >= 0 && j < Tn) tr.ku = d.ku[(int64_t)(row0 + j) * d.n_heads + h];
+  }
+}
+
+template <typename T, int DK>
+__device__ __forceinline__ void tile_store(const TileRegs<T, DK>& tr, char* ks, char* vs, float* kus, int KP, int VP) {
+  constexpr int UPR = DK / 8;
+#pragma unroll
+  for (int i = 0; i < TileRegs<T, DK>::N; ++i) {
+    const int u = threadIdx.x + 256 * i;
+    const int r = u / UPR, cu = u - r * UPR;
+    store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i]);
+    store8<T>(vs + (size_t)(u >> 3) * VP + (size_t)(u & 7) * 8 * sizeof(T), tr.v[i]);
+  }
+  if (threadIdx.x < KB) kus[threadIdx.x] = tr.ku;
+}
+
 template <typename T, int DK>
 __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,6 +122,7 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
   constexpr int NDF = DK / 16;                  // output d fragments
   char* ks = smem;
   char* vs = smem + KB * KP;
+  float* kus = reinterpret_cast<float*>(smem + KB * KP + DK * VP);
 
   const int b = blockIdx.y, h = blockIdx.z;
   const int row0 = d.rg.cu_rows[b];
@@ -53,6 +138,9 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
   const T* vtg = (const T*)d.vt + (int64_t)(h * DK) * d.ldvt + row0;
   const T* gg = d.g ? (const T*)d.g : nullptr;
   const int H = d.n_heads;
+  // Key tiles start where the packed V^T columns are 16-byte aligned: (row0 + j0) % 8 == 0, keys < 0 are masked.
+  const bool vt_vec = (d.ldvt & 7) == 0 && (reinterpret_cast<uintptr_t>(d.vt) & 31) == 0;
+  const int j_start = vt_vec ? -(row0 & 7) : 0;
 
   Vec qf[NKS];
 #pragma unroll
@@ -63,31 +151,49 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
   for (int f = 0; f < NDF; ++f) ot[f] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int j0 = 0; j0 < Tn; j0 += KB) {
-    // ---- stage K tile (rows = keys) and V^T tile (rows = d) ----
-    {
-      constexpr int UPR = DK / 8;
-      for (int u = threadIdx.x; u < KB * UPR; u += 256) {
-        const int r = u / UPR, cu = u - r * UPR;
-        Vec v;
-        if (j0 + r < Tn) v = load8<T>(kg + (int64_t)(j0 + r) * d.ldk + cu * 8);
-        else {
+  // rel-pos bias rows of this lane's query (legacy rel_shift reads row qi for j <= qi, row qi + 1 beyond)
+  const T* g_q = gg ? gg + ((int64_t)(row0 + qi_c) * H + h) * d.ldg : nullptr;
+  const T* g_q1 = gg ? gg + ((int64_t)(row0 + (qi_c + 1 < Tn ? qi_c + 1 : qi_c)) * H + h) * d.ldg : nullptr;
+
+  TileRegs<T, DK> tr;
+  tile_load<T, DK>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
+  for (int j0 = j_start; j0 < Tn; j0 += KB) {
+    tile_store<T, DK>(tr, ks, vs, kus, KP, VP);
+    __syncthreads();
+    if (j0 + KB < Tn) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0 + KB, Tn, vt_vec);
+
+    // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
+    float bd[4][4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
+    for (int f = 0; f < 4; ++f) {
+      const int jq = j0 + 16 * f + 4 * g;  // this lane's 4 consecutive keys jq .. jq+3 of fragment f
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bd[f][r] = 0.f;
+      if (gg && qi < Tn) {
+        const bool inside = jq >= 0 && jq + 3 < Tn;
+        if (d.rel_mode == 2) {  // new rel_shift: plain diagonal map, no wrap
+          const T* p = g_q + (d.rel_center - qi + jq);
+          if (inside) load4u<T>(p, bd[f]);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (jq + r >= 0 && jq + r < Tn) bd[f][r] = to_f32(p[r]);
+          }
+        } else {                // legacy rel_shift (view-reinterpretation wrap)
+          if (inside && jq + 3 <= qi) load4u<T>(g_q + (Tn - 1 - qi + jq), bd[f]);
+          else if (inside && jq > qi + 1) load4u<T>(g_q1 + (jq - qi - 2), bd[f]);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = jq + r;
+              if (j < 0 || j >= Tn) continue;
+              if (j <= qi) bd[f][r] = to_f32(g_q[Tn - 1 - qi + j]);
+              else if (j > qi + 1) bd[f][r] = to_f32(g_q1[j - qi - 2]);
+            }
+          }
         }
-        T* dst = reinterpret_cast<T*>(ks + (size_t)r * KP) + cu * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = v[e];
-      }
-      // V^T rows are contiguous in time in global memory; unaligned start -> scalar loads
-      for (int u = threadIdx.x; u < DK * KB; u += 256) {
-        const int r = u / KB, c = u - r * KB;
-        T v = from_f32<T>(0.f);
-        if (j0 + c < Tn) v = vtg[(int64_t)r * d.ldvt + j0 + c];
-        reinterpret_cast<T*>(vs + (size_t)r * VP)[c] = v;
       }
     }
-    __syncthreads();
 
     // ---- S^T fragments: st[f][r] = key (j0 + 16 f + 4 g + r)  x  query qc ----
     f32x4 st[4];
@@ -104,28 +210,16 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
     // ---- bias terms, scale, mask, online softmax ----
     float mx = -INFINITY;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f) {
+      const f32x4 kq = *reinterpret_cast<const f32x4*>(kus + 16 * f + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * f + 4 * g + r;
-        float s = st[f][r];
-        if (j < Tn) {
-          if (d.ku) s += d.ku[(int64_t)(row0 + j) * H + h];
-          if (gg && qi < Tn) {
-            if (d.rel_mode == 2) {  // new rel_shift: plain diagonal map, no wrap
-              s += to_f32(gg[((int64_t)(row0 + qi) * H + h) * d.ldg + (d.rel_center - qi + j)]);
-            } else {                // legacy rel_shift (view-reinterpretation wrap)
-              if (j <= qi) s += to_f32(gg[((int64_t)(row0 + qi) * H + h) * d.ldg + (Tn - 1 - qi + j)]);
-              else if (j > qi + 1) s += to_f32(gg[((int64_t)(row0 + qi + 1) * H + h) * d.ldg + (j - qi - 2)]);
-            }
-          }
-          s *= d.scale;
-        } else {
-          s = -INFINITY;
-        }
+        float s = (j >= 0 && j < Tn) ? (st[f][r] + kq[r] + bd[f][r]) * d.scale : -INFINITY;
         st[f][r] = s;
         mx = fmaxf(mx, s);
       }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
@@ -182,7 +276,7 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
 
 template <typename T, int DK>
 int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
-  const size_t lds = (size_t)KB * (DK * sizeof(T) + 16) + (size_t)DK * (KB * sizeof(T) + 16);
+  const size_t lds = (size_t)KB * (DK * sizeof(T) + 16) + (size_t)DK * (KB * sizeof(T) + 16) + KB * sizeof(float);
   dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
   auto kern = relattn_kernel<T, DK>;
   if (lds > 64 * 1024) {

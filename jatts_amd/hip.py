@@ -215,6 +215,12 @@ def hifigan_output(rb, len_mul, xs, in_scale, slope, c_in, k_w, w, bias, dtype):
     return y
 
 
+def vt_ld(total_rows):
+    """Leading dimension for a packed V^T buffer (channels x rows) that lets jatts_relpos_attention stage it
+    with aligned 16-byte loads: a multiple of 8 with 8 columns of slack past the last row."""
+    return round_up(total_rows, 8) + 8
+
+
 def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d_k, dtype,
                      q_col0=0, k_col0=0, rel_mode=1, rel_center=0):
     lib = _abi.load()

@@ -98,8 +98,9 @@ class _TBlock:
         C, I = x.shape[1], self.inner
         n = hip.layernorm(x, self.n1[0], self.n1[1], dt, GN_EPS)
         qk = hip.conv1d(rb, n, self.qk.w, self.qk.c_in, 2 * I, 1, dtype=dt)
-        vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True)
-        a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, rb.total, None, 0, None, self.dh ** -0.5, self.heads,
+        ldvt = hip.vt_ld(rb.total)
+        vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt)
+        a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, ldvt, None, 0, None, self.dh ** -0.5, self.heads,
                                  self.dh, dt, q_col0=0, k_col0=I, rel_mode=0)
         hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)
         n = hip.layernorm(x, self.n3[0], self.n3[1], dt, GN_EPS)

@@ -194,9 +194,11 @@ def test_hifigan_resunit_len_mul(cuda, lib):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("pad_vt", [False, True])   # True: hip.vt_ld layout -> aligned 16-byte V^T staging, tiles start at j < 0
 @pytest.mark.parametrize("H,dk,lens,rel", [(2, 32, [24, 9, 33], True), (2, 192, [130, 64], True),
-                                          (2, 96, [65], True), (4, 64, [100, 1, 17], False)])
-def test_relpos_attention(cuda, lib, prec, H, dk, lens, rel):
+                                          (2, 96, [65], True), (4, 64, [100, 1, 17], False),
+                                          (2, 64, [3, 70, 5, 129], True)])
+def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
     from jatts_amd import hip
     from oracle.fs2_oracle import rel_shift_legacy
     g = torch.Generator().manual_seed(H * dk + len(lens))
@@ -223,8 +225,10 @@ def test_relpos_attention(cuda, lib, prec, H, dk, lens, rel):
     dt = _dt(prec)
     tdt = hip.torch_dtype(dt)
     rb = _ragged(lens, cuda)
-    vt = v.t().contiguous().to(cuda).to(tdt)
-    out = hip.relpos_attention(rb, q.to(cuda).to(tdt), A, k.to(cuda).to(tdt), A, vt, R,
+    ldvt = hip.vt_ld(R) if pad_vt else R
+    vt = torch.full((A, ldvt), float("nan"), dtype=tdt, device=cuda)   # slack columns must never be used
+    vt[:, :R] = v.t().to(cuda).to(tdt)
+    out = hip.relpos_attention(rb, q.to(cuda).to(tdt), A, k.to(cuda).to(tdt), A, vt, ldvt,
                                gm.reshape(R, H * ldg).to(cuda).to(tdt) if rel else None, ldg,
                                ku.to(cuda), scale, H, dk, dt)
     e = relerr(out.float(), ref)
