@@ -407,6 +407,52 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
   }
 }
 
+// Coalesced epilogue for T-typed, row-major outputs without residual (projections, FFN w1, the polyphase upsampling
+// convs): act(acc + bias) * alpha is assembled as a [BT][BN] tile in LDS (the activation buffers are dead) and
+// written with row-contiguous 16-byte stores.  In fragment order every 128-byte output line is otherwise hit by
+// 8 separate 8-byte stores from lanes 32 rows apart.
+template <typename T, int ACT, int NF, int NT, int BN>
+__device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x16 (&acc)[NF][NT], char* smem, int t0,
+                                                  int col0, int nf_local0, int n_base, int lane, int L,
+                                                  int64_t seq_row0, int BT) {
+  constexpr int opitch = BN * (int)sizeof(T) + 16;
+  const int g = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + (lane & 31);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = (nf_local0 + f) * 32 + 8 * q + 4 * g;   // channel inside the workgroup's BN slab
+        if (n_base + nl >= d.n_out) continue;                   // n_out % 8 == 0: quads are all-or-nothing
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n_base + nl);
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(act_c<ACT>(acc[f][t][4 * q + e] + bq[e]) * d.alpha);
+        char* p = smem + (size_t)col * opitch + (size_t)nl * sizeof(T);
+        if (sizeof(T) == 2) *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+        else *reinterpret_cast<f32x4*>(p) = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+      }
+  }
+  __syncthreads();
+  const int vrows = min(BT, L - t0);
+  const int upr = min(BN, d.n_out - n_base) / 8;   // 8-element units per row
+  const int total = vrows * upr;
+  T* yg = (T*)d.y + (seq_row0 + t0) * (int64_t)d.ldy + n_base;
+  for (int u = threadIdx.x; u < total; u += blockDim.x) {
+    const int r = u / upr, cu = u - r * upr;
+    const typename Elem<T>::vec8 v = Vec8IO<T>::lds(smem + (size_t)r * opitch + (size_t)cu * 8 * sizeof(T));
+    T* dst = yg + (int64_t)r * d.ldy + cu * 8;
+    if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
+    else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
+    }
+  }
+}
+
 template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
 __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -466,6 +512,22 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
   // epilogue, specialised per activation by ONE uniform branch: a runtime switch inside the 64-element
   // unrolled body inlined tanh/mish 128 times, the unroller gave up and the accumulators went to scratch
   // (1.8x slower conv, profiles/r01_notes.md).
+  if constexpr (sizeof(T) == 2) {
+    const bool coalesced = !d.y_transposed && !d.y_is_f32 && !d.resid && (d.ldy & 7) == 0 && (d.n_out & 7) == 0 &&
+                           (reinterpret_cast<uintptr_t>(d.y) & 15) == 0;
+    if (coalesced) {   // the loop's last barrier has retired every read of the activation buffers
+      constexpr int BN = WN * NF * 32;
+      const int n_base = blockIdx.z * BN;
+      switch (d.act) {
+        case JATTS_ACT_RELU: conv_epilogue_lds<T, JATTS_ACT_RELU, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
+        case JATTS_ACT_TANH: conv_epilogue_lds<T, JATTS_ACT_TANH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
+        case JATTS_ACT_SWISH: conv_epilogue_lds<T, JATTS_ACT_SWISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
+        case JATTS_ACT_MISH: conv_epilogue_lds<T, JATTS_ACT_MISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
+        default: conv_epilogue_lds<T, JATTS_ACT_NONE, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
+      }
+      return;
+    }
+  }
   switch (d.act) {
     case JATTS_ACT_RELU: conv_epilogue<T, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
     case JATTS_ACT_TANH: conv_epilogue<T, JATTS_ACT_TANH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
@@ -481,7 +543,8 @@ int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + BT - 1) / BT), (unsigned)d.rg.n_seq, (unsigned)((d.n_out + BN - 1) / BN));
   const size_t rows = (size_t)BT + (size_t)(d.k_w - 1) * d.dil;
-  const size_t lds = (ASYNC ? 2 : 1) * rows * (KCH * sizeof(T) + 16);
+  size_t lds = (ASYNC ? 2 : 1) * rows * (KCH * sizeof(T) + 16);
+  if (sizeof(T) == 2 && lds < (size_t)BT * (BN * sizeof(T) + 16)) lds = (size_t)BT * (BN * sizeof(T) + 16);  // output tile
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: halo too large for LDS");
   auto kern = conv1d_kernel<T, NF, NT, WN, WT, NIN, ASYNC>;
   if (lds > 64 * 1024) {
