@@ -407,15 +407,15 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
   }
 }
 
-// Coalesced epilogue for T-typed, row-major outputs without residual (projections, FFN w1, the polyphase upsampling
-// convs): act(acc + bias) * alpha is assembled as a [BT][BN] tile in LDS (the activation buffers are dead) and
-// written with row-contiguous 16-byte stores.  In fragment order every 128-byte output line is otherwise hit by
-// 8 separate 8-byte stores from lanes 32 rows apart.
-template <typename T, int ACT, int NF, int NT, int BN>
+// Coalesced epilogue for row-major outputs (projections, FFN, the polyphase upsampling convs): act(acc + bias) * alpha
+// is assembled as a [BT][BN] tile of the OUTPUT type in LDS (the activation buffers are dead), then the f32 residual
+// is added and the tile written with row-contiguous 16-byte accesses.  In fragment order every 128-byte output line
+// is otherwise hit by 8 separate 8-byte stores (and residual loads) from lanes 32 rows apart.
+template <typename T, typename TO, int ACT, int NF, int NT, int BN>
 __device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x16 (&acc)[NF][NT], char* smem, int t0,
                                                   int col0, int nf_local0, int n_base, int lane, int L,
                                                   int64_t seq_row0, int BT) {
-  constexpr int opitch = BN * (int)sizeof(T) + 16;
+  constexpr int opitch = BN * (int)sizeof(TO) + 16;
   const int g = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -428,33 +428,41 @@ __device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x
         if (n_base + nl >= d.n_out) continue;                   // n_out % 8 == 0: quads are all-or-nothing
         f32x4 bq = {0.f, 0.f, 0.f, 0.f};
         if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n_base + nl);
-        T o[4];
+        f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(act_c<ACT>(acc[f][t][4 * q + e] + bq[e]) * d.alpha);
-        char* p = smem + (size_t)col * opitch + (size_t)nl * sizeof(T);
-        if (sizeof(T) == 2) *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
-        else *reinterpret_cast<f32x4*>(p) = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        for (int e = 0; e < 4; ++e) o[e] = act_c<ACT>(acc[f][t][4 * q + e] + bq[e]) * d.alpha;
+        char* p = smem + (size_t)col * opitch + (size_t)nl * sizeof(TO);
+        if (sizeof(TO) == 2) *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+        else *reinterpret_cast<f32x4*>(p) = o;
       }
   }
   __syncthreads();
   const int vrows = min(BT, L - t0);
   const int upr = min(BN, d.n_out - n_base) / 8;   // 8-element units per row
   const int total = vrows * upr;
-  T* yg = (T*)d.y + (seq_row0 + t0) * (int64_t)d.ldy + n_base;
+  TO* yg = (TO*)d.y + (seq_row0 + t0) * (int64_t)d.ldy + n_base;
+  const float* rg = d.resid ? d.resid + (seq_row0 + t0) * (int64_t)d.ldr + n_base : nullptr;
   for (int u = threadIdx.x; u < total; u += blockDim.x) {
     const int r = u / upr, cu = u - r * upr;
-    const typename Elem<T>::vec8 v = Vec8IO<T>::lds(smem + (size_t)r * opitch + (size_t)cu * 8 * sizeof(T));
-    T* dst = yg + (int64_t)r * d.ldy + cu * 8;
-    if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
-    else {
-      *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
+    const char* src = smem + (size_t)r * opitch + (size_t)cu * 8 * sizeof(TO);
+    TO* dst = yg + (int64_t)r * d.ldy + cu * 8;
+    if (sizeof(TO) == 2) {
+      *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(src);   // (no residual on this path)
+    } else {
+      f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+      if (rg) {
+        const float* rp = rg + (int64_t)r * d.ldr + cu * 8;
+        lo += *reinterpret_cast<const f32x4*>(rp);
+        hi += *reinterpret_cast<const f32x4*>(rp + 4);
+      }
+      *reinterpret_cast<f32x4*>(dst) = lo;
+      *reinterpret_cast<f32x4*>((float*)dst + 4) = hi;
     }
   }
 }
 
 template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
-__global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) {
+__global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d, int f32_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32;
   const int b = blockIdx.y;
@@ -513,20 +521,28 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d) 
   // unrolled body inlined tanh/mish 128 times, the unroller gave up and the accumulators went to scratch
   // (1.8x slower conv, profiles/r01_notes.md).
   if constexpr (sizeof(T) == 2) {
-    const bool coalesced = !d.y_transposed && !d.y_is_f32 && !d.resid && (d.ldy & 7) == 0 && (d.n_out & 7) == 0 &&
-                           (reinterpret_cast<uintptr_t>(d.y) & 15) == 0;
-    if (coalesced) {   // the loop's last barrier has retired every read of the activation buffers
-      constexpr int BN = WN * NF * 32;
-      const int n_base = blockIdx.z * BN;
-      switch (d.act) {
-        case JATTS_ACT_RELU: conv_epilogue_lds<T, JATTS_ACT_RELU, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
-        case JATTS_ACT_TANH: conv_epilogue_lds<T, JATTS_ACT_TANH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
-        case JATTS_ACT_SWISH: conv_epilogue_lds<T, JATTS_ACT_SWISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
-        case JATTS_ACT_MISH: conv_epilogue_lds<T, JATTS_ACT_MISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
-        default: conv_epilogue_lds<T, JATTS_ACT_NONE, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
-      }
+    // the loop's last barrier has retired every read of the activation buffers: reuse them as the output tile
+    constexpr int BN = WN * NF * 32;
+    const int n_base = blockIdx.z * BN;
+    const bool rowmajor = !d.y_transposed && (d.n_out & 7) == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0;
+#define JATTS_EPI(TO)                                                                                                  \
+  switch (d.act) {                                                                                                     \
+    case JATTS_ACT_RELU: conv_epilogue_lds<T, TO, JATTS_ACT_RELU, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;  \
+    case JATTS_ACT_TANH: conv_epilogue_lds<T, TO, JATTS_ACT_TANH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;  \
+    case JATTS_ACT_SWISH: conv_epilogue_lds<T, TO, JATTS_ACT_SWISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break; \
+    case JATTS_ACT_MISH: conv_epilogue_lds<T, TO, JATTS_ACT_MISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;  \
+    default: conv_epilogue_lds<T, TO, JATTS_ACT_NONE, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;              \
+  }
+    if (rowmajor && !d.y_is_f32 && !d.resid && (d.ldy & 7) == 0) {
+      JATTS_EPI(T)
       return;
     }
+    if (rowmajor && d.y_is_f32 && f32_tile && (d.ldy & 3) == 0 &&
+        (!d.resid || ((d.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(d.resid) & 15) == 0))) {
+      JATTS_EPI(float)
+      return;
+    }
+#undef JATTS_EPI
   }
   switch (d.act) {
     case JATTS_ACT_RELU: conv_epilogue<T, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
@@ -544,14 +560,23 @@ int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
   dim3 grid((unsigned)((maxL + BT - 1) / BT), (unsigned)d.rg.n_seq, (unsigned)((d.n_out + BN - 1) / BN));
   const size_t rows = (size_t)BT + (size_t)(d.k_w - 1) * d.dil;
   size_t lds = (ASYNC ? 2 : 1) * rows * (KCH * sizeof(T) + 16);
-  if (sizeof(T) == 2 && lds < (size_t)BT * (BN * sizeof(T) + 16)) lds = (size_t)BT * (BN * sizeof(T) + 16);  // output tile
+  // output tile of the coalesced epilogues (f16 kernels): T-typed always, f32 (row-major f32 outputs, e.g. the
+  // in-place residual-stream updates) when the conv is long enough that the bigger LDS footprint does not matter
+  int f32_tile = 0;
+  if (sizeof(T) == 2) {
+    if (lds < (size_t)BT * (BN * sizeof(T) + 16)) lds = (size_t)BT * (BN * sizeof(T) + 16);
+    if (d.y_is_f32 && !d.y_transposed) {
+      f32_tile = 1;
+      if (lds < (size_t)BT * (BN * 4 + 16)) lds = (size_t)BT * (BN * 4 + 16);
+    }
+  }
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: halo too large for LDS");
   auto kern = conv1d_kernel<T, NF, NT, WN, WT, NIN, ASYNC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d);
+  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, f32_tile);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -565,6 +590,90 @@ int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
     if (small_halo && multi_chunk) return launch_conv_k<T, NF, NT, WN, WT, 3, true>(d, s);
   }
   return launch_conv_k<T, NF, NT, WN, WT, 3, false>(d, s);
+}
+
+// Unit-kernel output pass: y = (acc + b2 tile in LDS) + x [+ MRF partners] with row-contiguous 16-byte accesses;
+// all global reads of a batch are issued before any is consumed (one round trip per batch, not per unit).
+template <typename T, int C, int UB, bool ADD>
+__device__ __forceinline__ void unit_store_pass(const jatts_resunit_desc& d, const char* ys, int pitch, int vrows,
+                                                const T* xg, T* yg, int64_t g0) {
+  typedef typename Elem<T>::vec8 V8;
+  constexpr int UPR = C / 8;
+  const int total = vrows * UPR;
+  const bool has_add1 = ADD && d.add1 != nullptr;
+  for (int u0 = threadIdx.x; u0 < total; u0 += UB * blockDim.x) {
+    V8 xr[UB], a0[ADD ? UB : 1], a1[ADD ? UB : 1];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int u = u0 + i * blockDim.x;
+      if (u < total) {
+        if (JATTS_ABLATE != 3) xr[i] = Vec8IO<T>::ldg(xg + g0 + (int64_t)u * 8);
+        if (ADD) {
+          a0[i] = Vec8IO<T>::ldg((const T*)d.add0 + g0 + (int64_t)u * 8);
+          if (has_add1) a1[i] = Vec8IO<T>::ldg((const T*)d.add1 + g0 + (int64_t)u * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int u = u0 + i * blockDim.x;
+      if (u >= total) continue;
+      const int r = u / UPR, cu = u - r * UPR;
+      V8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
+      if (JATTS_ABLATE != 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(xr[i][e]));  // residual
+      }
+      if (ADD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[i][e]) + (has_add1 ? to_f32(a1[i][e]) : 0.f)) * d.out_scale);
+      }
+      T* dst = yg + g0 + (int64_t)u * 8;
+      if ((JATTS_ABLATE != 4 && JATTS_ABLATE != 12) || to_f32(v[0]) == 12345.678f) {
+        if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
+        else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
+        }
+      }
+    }
+  }
+}
+
+// Unit-kernel staging: the WHOLE x tile (one input, LeakyReLU) in one batch of UB 16-byte loads per thread, all in
+// flight before the first is consumed.  The accumulators are not live yet, so the registers are free; the generic
+// 8-per-batch form paid 3 serial HBM round trips per tile (stage x = 29 % of a k=3 workgroup's lifetime, tools/trace_unit.py).
+template <typename T, int UB>
+__device__ __forceinline__ void stage_unit(char* lds, int pitch, int rows, int upr, int pos0, int L, int64_t seq_row0,
+                                           const T* x, int ldx, bool pre_lrelu, float slope) {
+  typedef typename Elem<T>::vec8 V8;
+  const int total = rows * upr;
+  for (int base = threadIdx.x; base < total; base += blockDim.x * UB) {
+    V8 v[UB];
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = base + j * blockDim.x;
+      const int r = u / upr, cu = u - r * upr;
+      const int pos = pos0 + r;
+      if (u < total && pos >= 0 && pos < L) v[j] = Vec8IO<T>::ldg(x + (seq_row0 + pos) * (int64_t)ldx + cu * 8);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = from_f32<T>(0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = base + j * blockDim.x;
+      if (u >= total) continue;
+      const int r = u / upr, cu = u - r * upr;
+      if (pre_lrelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = from_f32<T>(lrelu(to_f32(v[j][e]), slope));
+      }
+      Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T), v[j]);
+    }
+  }
 }
 
 // ------------------------------------------------------------ fused HiFi-GAN dilation unit
@@ -617,8 +726,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
 
   const T* xin[3] = {(const T*)d.x, nullptr, nullptr};
   if (JATTS_ABLATE != 2 && JATTS_ABLATE != 7 && JATTS_ABLATE != 12)
-    stage_rows<T>(xs, pitch, rx, C, t0 - p2 - p1, L, seq_row0, xin, 1, C, 0, 1.f,
-                  JATTS_ABLATE == 1 ? JATTS_PRE_NONE : JATTS_PRE_LRELU, d.slope);
+  {
+    constexpr int NTHR = WN * WT * 64;
+    constexpr int UBX = ((WGCOLS + 64) * (C / 8) + NTHR - 1) / NTHR;   // covers halos up to 32 rows a side in one batch
+    stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24))>(xs, pitch, rx, C / 8, t0 - p2 - p1, L, seq_row0, xin[0], C, JATTS_ABLATE != 1, d.slope);
+  }
   __syncthreads();
   JATTS_STAMP(2);
 
@@ -706,49 +818,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
   __syncthreads();
   JATTS_STAMP(6);
   {
-    constexpr int UPR = C / 8, UB = 4;
-    typedef typename Elem<T>::vec8 V8;
     const int vrows = min(tt_out, L - t0);
-    const int total = vrows * UPR;
     const int64_t g0 = (seq_row0 + t0) * (int64_t)C;  // the valid rows are contiguous in y: unit u <-> 8 elements at g0 + 8u
-    const bool has_add = d.add0 != nullptr, has_add1 = d.add1 != nullptr;
-    for (int u0 = threadIdx.x; u0 < total; u0 += UB * blockDim.x) {
-      V8 xr[UB], a0[UB], a1[UB];
-      // all global reads of the batch are issued before any is consumed (one round trip, not UB)
-#pragma unroll
-      for (int i = 0; i < UB; ++i) {
-        const int u = u0 + i * blockDim.x;
-        if (u < total) {
-          if (JATTS_ABLATE != 3) xr[i] = Vec8IO<T>::ldg(xg + g0 + (int64_t)u * 8);
-          if (has_add) a0[i] = Vec8IO<T>::ldg((const T*)d.add0 + g0 + (int64_t)u * 8);   // fused MRF mean over ResBlocks
-          if (has_add1) a1[i] = Vec8IO<T>::ldg((const T*)d.add1 + g0 + (int64_t)u * 8);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < UB; ++i) {
-        const int u = u0 + i * blockDim.x;
-        if (u >= total) continue;
-        const int r = u / UPR, cu = u - r * UPR;
-        V8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
-        if (JATTS_ABLATE != 3) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(xr[i][e]));  // residual
-        }
-        if (has_add) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[i][e]) + (has_add1 ? to_f32(a1[i][e]) : 0.f)) * d.out_scale);
-        }
-        T* dst = yg + g0 + (int64_t)u * 8;
-        if ((JATTS_ABLATE != 4 && JATTS_ABLATE != 12) || to_f32(v[0]) == 12345.678f) {
-          if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&v);
-          else {
-            *reinterpret_cast<f32x4*>(dst) = f32x4{to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3])};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{to_f32(v[4]), to_f32(v[5]), to_f32(v[6]), to_f32(v[7])};
-          }
-        }
-      }
-    }
+    constexpr bool keep_small = C <= 64;   // small-channel kernels live on occupancy (6 workgroups/CU): keep the batch short
+    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true>(d, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
+    else unit_store_pass<T, C, keep_small ? 4 : 8, false>(d, ys, pitch, vrows, xg, yg, g0);
   }
   JATTS_STAMP(7);
   if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();
