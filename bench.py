@@ -43,13 +43,13 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(fs2_sd, voc_sd, voc_params, texts, heads, budget_s=12.0):
+def cpu_baseline(fs2_sd, voc_sd, voc_params, texts, heads, budget_s=12.0, threads=None):
     """Reference stage-4 loop shape (tts_decode.py:203-255): one utterance at a time (B=1) on the host cores with
     the CPU oracle, repeated over the bench's utterances until ~budget_s seconds of CPU work have been timed."""
     from oracle.fs2_oracle import fs2_inference
     from oracle.hifigan_oracle import hifigan_generate
 
-    cores = min(32, os.cpu_count() or 1)  # oversubscribing a 256-thread host makes torch CPU slower
+    cores = threads or min(32, os.cpu_count() or 1)  # oversubscribing a 256-thread host makes torch CPU slower
     torch.set_num_threads(cores)
     n = samples = frames = 0
     t_fs2 = t_voc = 0.0
@@ -62,7 +62,7 @@ def cpu_baseline(fs2_sd, voc_sd, voc_params, texts, heads, budget_s=12.0):
             t2 = time.time()
             n, samples, frames = n + 1, samples + int(y.numel()), frames + int(r["feat_gen"].shape[0])
             t_fs2, t_voc = t_fs2 + (t1 - t0), t_voc + (t2 - t1)
-            if t_fs2 + t_voc >= budget_s and n >= 2:
+            if t_fs2 + t_voc >= budget_s and (n >= 2 or budget_s <= 0.0):
                 break
     secs = t_fs2 + t_voc
     return dict(value=samples / secs, unit="samples/s", cores=cores, kind="port",
@@ -121,13 +121,21 @@ def main():
     hop = voc.model.hop
     texts = [t.to(dev) for t in synth_texts(a.batch, a.t_text, vocab, seed=1 + rank)]
 
+    stage_ev = []   # per step: events at start / after text2mel / after vocoder / after the audio all-gather
+
     def step():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
         r = m.inference_batch(texts)
+        ev[1].record()
         y = voc.decode_batch(r["feats_rb"], r["feat_gen"])
+        ev[2].record()
         lens = [n * hop for n in r["olens"]]
         if world > 1:
             from jatts_amd.distributed import gather_audio
             gather_audio(y, lens)
+        ev[3].record()
+        stage_ev.append(ev)
         return y, lens
 
     for _ in range(a.warmup):
@@ -137,6 +145,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     hip.profile_begin()
+    stage_ev.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         y, lens = step()
@@ -213,6 +222,8 @@ def main():
                    "utterances_per_gpu": a.batch, "phonemes": a.t_text, "frames_per_utt": a.t_text * a.frames_per_token,
                    "hop": hop, "sampling_rate": sr, "parallelism": f"dp{world} (utterance sharding, audio all-gather)"},
         "rtf": dt / (total_samples / sr),
+        "stage_ms_per_step": {nme: sum(e[i].elapsed_time(e[i + 1]) for e in stage_ev) / len(stage_ev)
+                              for i, nme in enumerate(["text2mel", "vocoder", "audio_all_gather"])},
         "roofline": roof,
         "resunit_ms_per_step": tot_unit_ms / a.steps,
         "other_kernel_ms_per_step": {k: v / a.steps for k, v in other.items()},
@@ -226,6 +237,10 @@ def main():
         cb = cpu_baseline(fs2_sd, voc_sd, vp, synth_texts(64, a.cpu_t_text, vocab, seed=1), 2)
         out["cpu_baseline"] = cb
         out["cpu_baseline"]["rtf"] = cb["seconds"] / (cb["samples"] / sr)
+        # SURVEY 8d also asks for the recipe default OMP_NUM_THREADS=1 (path.sh:15): one utterance, one thread
+        c1 = cpu_baseline(fs2_sd, voc_sd, vp, synth_texts(1, a.cpu_t_text, vocab, seed=1), 2, budget_s=0.0, threads=1)
+        out["cpu_baseline"]["single_thread"] = {k: c1[k] for k in ("value", "unit", "cores", "sample", "seconds")}
+        out["cpu_baseline"]["single_thread"]["rtf"] = c1["seconds"] / (c1["samples"] / sr)
         out["speedup_vs_cpu_rtf"] = out["cpu_baseline"]["rtf"] / out["rtf"]
     else:
         out["cpu_baseline"] = None
