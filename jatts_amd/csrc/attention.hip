@@ -113,10 +113,12 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, DK>& tr, char* ks, 
 }
 
 template <typename T, int DK>
-__global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
+__global__ __launch_bounds__(256, (DK <= 192 && sizeof(T) == 2) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<T>::vec8 Vec;
-  constexpr int KP = DK * (int)sizeof(T) + 16;  // K tile pitch (bytes)
+  // K tile pitch: the score MFMAs read 16 key rows x 4 channel groups per ds_read_b128; with the pitch = 2 (mod 4)
+  // 16-byte units the hardware's 16-lane groups hit 16 distinct slots (+16 left 41 % of the LDS cycles in conflict)
+  constexpr int KP = DK * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
   constexpr int VP = KB * (int)sizeof(T) + 16;  // V^T tile pitch
   constexpr int NKS = DK / 32;                  // contraction steps for S
   constexpr int NDF = DK / 16;                  // output d fragments
@@ -198,10 +200,11 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
     // ---- S^T fragments: st[f][r] = key (j0 + 16 f + 4 g + r)  x  query qc ----
     f32x4 st[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      st[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; ++f) st[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < NKS; ++s) {
+    for (int s = 0; s < NKS; ++s) {   // 4 independent accumulator chains per contraction step
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
         const T* ap = reinterpret_cast<const T*>(ks + (size_t)(16 * f + qc) * KP) + 32 * s + 8 * g;
         Vec a = load8<T>(ap);
         mma16(a, qf[s], st[f]);
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void relattn_kernel(jatts_relattn_desc d) {
 
 template <typename T, int DK>
 int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
-  const size_t lds = (size_t)KB * (DK * sizeof(T) + 16) + (size_t)DK * (KB * sizeof(T) + 16) + KB * sizeof(float);
+  const size_t lds = (size_t)KB * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KB * sizeof(T) + 16) + KB * sizeof(float);
   dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
   auto kern = relattn_kernel<T, DK>;
   if (lds > 64 * 1024) {
