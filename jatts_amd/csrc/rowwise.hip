@@ -89,7 +89,7 @@ __global__ void affine_cast_kernel(const float* x, int ldx, TO* y, int ldy, int6
 constexpr int DW_TT = 64;  // time steps per block
 constexpr int DW_CB = 64;  // channels per block
 
-template <typename T>
+template <typename T, int KMAX>
 __global__ __launch_bounds__(256) void glu_dw_kernel(jatts_ragged rg, const T* x, T* y, int C, int K,
                                                      const float* w, const float* sc, const float* sh) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,6 +103,14 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(jatts_ragged rg, const T* x
   const int pad = (K - 1) / 2;
   const int rows = DW_TT + K - 1;
   const int P = DW_CB + 1;
+  // depthwise taps of this block's 64 channels, transposed to [k][channel] in LDS: the 64*K floats are contiguous
+  // in w (coalesced), whereas w[c*K + k] read per lane inside the tap loop is a 64-line gather per instruction
+  // (the kernel spent 88 % of its wave cycles waiting on those; profiles/r01_notes.md)
+  float* ws = hs + rows * P;
+  for (int u = threadIdx.x; u < DW_CB * K; u += 256) {
+    const int cc = u / K, k = u - cc * K;
+    ws[k * P + cc] = c0 + cc < C ? w[(int64_t)c0 * K + u] : 0.f;
+  }
   if ((C & 7) == 0) {
     // 16-byte loads of 8 channels of a and of g, 4 units per thread in flight before any is consumed (the
     // one-element-per-iteration form serialised a memory round trip per 2 bytes: 157 us per launch).
@@ -149,14 +157,31 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(jatts_ragged rg, const T* x
   const int c = c0 + cc;
   if (c >= C) return;
   const float s = sc[c], t = sh[c];
-  const float* wr = w + (int64_t)c * K;
-  for (int i = 0; i < DW_TT / 4; ++i) {
-    const int tl = tg * (DW_TT / 4) + i;
-    if (t0 + tl >= L) break;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc += wr[k] * hs[(tl + k) * P + cc];
-    const float v = acc * s + t;
-    y[(int64_t)(row0 + t0 + tl) * C + c] = from_f32<T>(v / (1.f + __expf(-v)));
+  constexpr int OPT = DW_TT / 4;  // outputs per thread: a register window of OPT + K - 1 inputs, each read from LDS once
+  if constexpr (KMAX > 0) {
+    float wreg[KMAX], win[OPT + KMAX - 1];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) wreg[k] = k < K ? ws[k * P + cc] : 0.f;
+#pragma unroll
+    for (int j = 0; j < OPT + KMAX - 1; ++j) win[j] = j < OPT + K - 1 ? hs[(tg * OPT + j) * P + cc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+      const int tl = tg * OPT + i;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) acc += wreg[k] * win[i + k];   // taps >= K carry weight 0
+      const float v = acc * s + t;
+      if (t0 + tl < L) y[(int64_t)(row0 + t0 + tl) * C + c] = from_f32<T>(v / (1.f + __expf(-v)));
+    }
+  } else {
+    for (int i = 0; i < OPT; ++i) {
+      const int tl = tg * OPT + i;
+      if (t0 + tl >= L) break;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += ws[k * P + cc] * hs[(tl + k) * P + cc];
+      const float v = acc * s + t;
+      y[(int64_t)(row0 + t0 + tl) * C + c] = from_f32<T>(v / (1.f + __expf(-v)));
+    }
   }
 }
 
@@ -600,11 +625,15 @@ extern "C" int jatts_glu_dwconv_bn_swish(const jatts_ragged* rg, int32_t dtype, 
   if (!(k_w & 1)) return jatts_set_error_msg(JATTS_ERR_ARG, "glu_dwconv: k_w must be odd");
   if (rg->max_len <= 0) return JATTS_OK;
   dim3 grid((unsigned)((rg->max_len + DW_TT - 1) / DW_TT), (unsigned)rg->n_seq, (unsigned)((channels + DW_CB - 1) / DW_CB));
-  const size_t lds = (size_t)(DW_TT + k_w - 1) * (DW_CB + 1) * sizeof(float);
-  if (dtype == JATTS_F16)
-    hipLaunchKernelGGL(glu_dw_kernel<f16>, grid, dim3(256), lds, S_, *rg, (const f16*)x, (f16*)y, channels, k_w, w_dw, bn_scale, bn_shift);
-  else if (dtype == JATTS_F32)
-    hipLaunchKernelGGL(glu_dw_kernel<float>, grid, dim3(256), lds, S_, *rg, (const float*)x, (float*)y, channels, k_w, w_dw, bn_scale, bn_shift);
+  const size_t lds = (size_t)(DW_TT + 2 * k_w - 1) * (DW_CB + 1) * sizeof(float);   // input tile + transposed taps
+  if (lds > 64 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "glu_dwconv: kernel too wide");
+#define DW_GO(TT, KM) hipLaunchKernelGGL((glu_dw_kernel<TT, KM>), grid, dim3(256), lds, S_, *rg, (const TT*)x, (TT*)y, channels, k_w, w_dw, bn_scale, bn_shift)
+  if (dtype == JATTS_F16) {
+    if (k_w <= 8) DW_GO(f16, 8); else if (k_w <= 32) DW_GO(f16, 32); else DW_GO(f16, 0);
+  } else if (dtype == JATTS_F32) {
+    if (k_w <= 8) DW_GO(float, 8); else if (k_w <= 32) DW_GO(float, 32); else DW_GO(float, 0);
+  }
+#undef DW_GO
   else return jatts_set_error_msg(JATTS_ERR_ARG, "glu_dwconv: unknown dtype");
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
