@@ -118,10 +118,10 @@ struct StageRegs {
   V8 v[NIN][MAXU];
 };
 
-template <typename T, int MAXU, int NIN>
+template <typename T, int MAXU, int NIN, int UPR = 8>
 __device__ __forceinline__ void stage_issue(StageRegs<T, MAXU, NIN>& sr, int rows, int pos0, int L, int64_t seq_row0,
                                             const T* const* x, int n_in, int ldx, int c0) {
-  constexpr int UPR = 8;  // 64-channel chunk = 8 units of 8 elements per row
+  // UPR = 8-element units per row of the chunk (8 for a 64-channel chunk)
   const int total = rows * UPR;
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
@@ -141,10 +141,9 @@ __device__ __forceinline__ void stage_issue(StageRegs<T, MAXU, NIN>& sr, int row
   }
 }
 
-template <typename T, int MAXU, int NIN>
+template <typename T, int MAXU, int NIN, int UPR = 8>
 __device__ __forceinline__ void stage_commit(StageRegs<T, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in,
                                              float in_scale, int pre_act, float slope) {
-  constexpr int UPR = 8;
   const int total = rows * UPR;
   const bool plain = n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE;
 #pragma unroll
@@ -461,8 +460,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x
   }
 }
 
-template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
-__global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d, int f32_tile) {
+template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC, int KCHT = KCH>
+__global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kernel(jatts_conv_desc d, int f32_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32;
   const int b = blockIdx.y;
@@ -473,7 +472,7 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d, 
   const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave / WT, wt = wave % WT;
-  const int pitch = KCH * (int)sizeof(T) + 16;
+  const int pitch = KCHT * (int)sizeof(T) + 16;
   const int rows = BT + (d.k_w - 1) * d.dil;
   const int KC16 = d.c_in >> 4;
   const int n_pad = (d.n_out + 31) & ~31;
@@ -487,32 +486,33 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d, 
 
   // staged 8-element units per thread in the async pipeline (halo <= 32 rows; larger halos take
   // the synchronous single-buffer path)
-  constexpr int MAXU = ((BT + 32) * 8 + WN * WT * 64 - 1) / (WN * WT * 64);
-  constexpr int RD = KCH / 16;  // ring depth 4: k_w * (KCH/16) is always a multiple of it
+  constexpr int UPRC = KCHT / 8;
+  constexpr int MAXU = ((BT + 32) * UPRC + WN * WT * 64 - 1) / (WN * WT * 64);
+  constexpr int RD = KCHT / 16;  // ring depth: k_w * (KCHT/16) is always a multiple of it
   WRing<T, NF, RD> ring;
-  const int n_chunks = d.c_in / KCH;
-  ring.init((const T*)d.w, KC16, NFR, nf0, d.k_w, KCH / 16, n_chunks, lane);
+  const int n_chunks = d.c_in / KCHT;
+  ring.init((const T*)d.w, KC16, NFR, nf0, d.k_w, KCHT / 16, n_chunks, lane);
   if constexpr (ASYNC) {
     const size_t buf_bytes = (size_t)rows * pitch;
     StageRegs<T, MAXU, NIN> sr;
-    stage_issue<T, MAXU, NIN>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0);
-    stage_commit<T, MAXU, NIN>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
+    stage_issue<T, MAXU, NIN, UPRC>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0);
+    stage_commit<T, MAXU, NIN, UPRC>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     __syncthreads();
     for (int ci = 0; ci < n_chunks; ++ci) {
       const bool more = ci + 1 < n_chunks;
-      if (more) stage_issue<T, MAXU, NIN>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCH);
-      conv_stage<T, NF, NT, RD>(acc, ring, KCH / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0,
+      if (more) stage_issue<T, MAXU, NIN, UPRC>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT);
+      conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0,
                                 lane);
-      if (more) stage_commit<T, MAXU, NIN>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in,
+      if (more) stage_commit<T, MAXU, NIN, UPRC>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in,
                                            d.in_scale, d.pre_act, d.pre_slope);
       __syncthreads();
     }
   } else {
     for (int ci = 0; ci < n_chunks; ++ci) {
-      stage_rows<T>(smem, pitch, rows, KCH, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, ci * KCH, d.in_scale,
+      stage_rows<T>(smem, pitch, rows, KCHT, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, ci * KCHT, d.in_scale,
                     d.pre_act, d.pre_slope);
       __syncthreads();
-      conv_stage<T, NF, NT, RD>(acc, ring, KCH / 16, d.k_w, d.dil, smem, pitch, col0, lane);
+      conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem, pitch, col0, lane);
       __syncthreads();
     }
   }
@@ -553,13 +553,13 @@ __global__ __launch_bounds__(WN* WT * 64) void conv1d_kernel(jatts_conv_desc d, 
   }
 }
 
-template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC>
+template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC, int KCHT = KCH>
 int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + BT - 1) / BT), (unsigned)d.rg.n_seq, (unsigned)((d.n_out + BN - 1) / BN));
   const size_t rows = (size_t)BT + (size_t)(d.k_w - 1) * d.dil;
-  size_t lds = (ASYNC ? 2 : 1) * rows * (KCH * sizeof(T) + 16);
+  size_t lds = (ASYNC ? 2 : 1) * rows * (KCHT * sizeof(T) + 16);
   // output tile of the coalesced epilogues (f16 kernels): T-typed always, f32 (row-major f32 outputs, e.g. the
   // in-place residual-stream updates) when the conv is long enough that the bigger LDS footprint does not matter
   int f32_tile = 0;
@@ -571,7 +571,7 @@ int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
     }
   }
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: halo too large for LDS");
-  auto kern = conv1d_kernel<T, NF, NT, WN, WT, NIN, ASYNC>;
+  auto kern = conv1d_kernel<T, NF, NT, WN, WT, NIN, ASYNC, KCHT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
@@ -585,6 +585,13 @@ template <typename T, int NF, int NT, int WN, int WT>
 int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
   const bool small_halo = (d.k_w - 1) * d.dil <= 32;
   const bool multi_chunk = d.c_in > KCH;  // a single chunk has nothing to overlap with
+  if constexpr (sizeof(T) == 2 && NF == 2 && NT == 2 && WN == 2) {
+    // 128-channel chunks for deep-K convs: half as many stage -> barrier -> MFMA round trips per workgroup (a k=1
+    // projection with K=384 is otherwise 6 latency-bound chunk iterations around 2 us of MFMA work)
+    static const int kch = [] { const char* e = getenv("JATTS_CONV_KCH"); return e ? atoi(e) : 2; }();  // 0: never, 1: k=1 only, 2: all (default)
+    if (small_halo && d.n_in == 1 && d.c_in % 128 == 0 && d.c_in >= 256 && (kch == 2 || (kch == 1 && d.k_w == 1)))
+      return launch_conv_k<T, NF, NT, WN, WT, 1, true, 128>(d, s);
+  }
   if (small_halo && multi_chunk && d.n_in == 1) return launch_conv_k<T, NF, NT, WN, WT, 1, true>(d, s);
   if constexpr (sizeof(T) == 2) {
     if (small_halo && multi_chunk) return launch_conv_k<T, NF, NT, WN, WT, 3, true>(d, s);
