@@ -100,6 +100,8 @@ typedef struct jatts_conv_desc {
   int32_t ldy;
   int32_t y_is_f32;    /* 1: y is f32 regardless of dtype */
   int32_t y_transposed;/* 1: y[n*ldy + row] (used for V^T) */
+  const int32_t* y_seq_col0; /* transposed output only, or NULL: sequence b writes column y_seq_col0[b] + t
+                              * instead of its packed row (V^T with 8-aligned sequence starts, see vt_col0) */
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);
@@ -172,7 +174,7 @@ typedef struct jatts_relattn_desc {
   int32_t d_k;
   const void* q;  int32_t ldq;   /* [rows][ldq], head h at column h*d_k */
   const void* k;  int32_t ldk;
-  const void* vt; int32_t ldvt;  /* V^T: [(h*d_k + d)][ldvt], column = global row */
+  const void* vt; int32_t ldvt;  /* V^T: [(h*d_k + d)][ldvt]; column = vt_col0[b] + t, or the packed row if vt_col0 is NULL */
   const void* g;  int32_t ldg;   /* g[row][h][m], row stride n_heads*ldg; NULL = no rel-pos */
   const float* ku;               /* [rows][n_heads] or NULL */
   float scale;
@@ -183,6 +185,11 @@ typedef struct jatts_relattn_desc {
    * whose column m encodes relative position rel_center - m, rel_center = cap - 1. */
   int32_t rel_mode;
   int32_t rel_center;
+  /* Per-sequence first column of V^T (n_seq entries) or NULL.  With every entry a multiple of 8, ldvt % 8 == 0,
+   * a 32-byte aligned vt and >= 8 readable columns of slack after each sequence, the kernel stages V^T with aligned
+   * 16-byte loads; key tiles always start at the sequence's first key, so a sequence's result does not depend on
+   * where it sits in the packed batch. */
+  const int32_t* vt_col0;
 } jatts_relattn_desc;
 
 int jatts_relpos_attention(const jatts_relattn_desc* d, void* stream);

@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("w", C.c_void_p), ("c_in", C.c_int32), ("n_out", C.c_int32), ("k_w", C.c_int32),
         ("dil", C.c_int32), ("pad", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
         ("alpha", C.c_float), ("resid", C.c_void_p), ("ldr", C.c_int32), ("y", C.c_void_p),
-        ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32),
+        ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32), ("y_seq_col0", C.c_void_p),
     ]
 
 
@@ -46,7 +46,7 @@ class RelAttnDesc(C.Structure):
         ("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32),
         ("vt", C.c_void_p), ("ldvt", C.c_int32), ("g", C.c_void_p), ("ldg", C.c_int32),
         ("ku", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int32),
-        ("rel_mode", C.c_int32), ("rel_center", C.c_int32),
+        ("rel_mode", C.c_int32), ("rel_center", C.c_int32), ("vt_col0", C.c_void_p),
     ]
 
 

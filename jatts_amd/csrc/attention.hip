@@ -137,12 +137,14 @@ __global__ __launch_bounds__(256, (DK <= 192 && sizeof(T) == 2) ? 2 : 1) void re
   const int qi_c = qi < Tn ? qi : Tn - 1;      // clamped for loads
   const T* qg = (const T*)d.q + (int64_t)(row0 + qi_c) * d.ldq + h * DK;
   const T* kg = (const T*)d.k + (int64_t)row0 * d.ldk + h * DK;
-  const T* vtg = (const T*)d.vt + (int64_t)(h * DK) * d.ldvt + row0;
+  const int vcol0 = d.vt_col0 ? d.vt_col0[b] : row0;
+  const T* vtg = (const T*)d.vt + (int64_t)(h * DK) * d.ldvt + vcol0;
   const T* gg = d.g ? (const T*)d.g : nullptr;
   const int H = d.n_heads;
-  // Key tiles start where the packed V^T columns are 16-byte aligned: (row0 + j0) % 8 == 0, keys < 0 are masked.
-  const bool vt_vec = (d.ldvt & 7) == 0 && (reinterpret_cast<uintptr_t>(d.vt) & 31) == 0;
-  const int j_start = vt_vec ? -(row0 & 7) : 0;
+  // Key tiles always start at the sequence's first key (results do not depend on the position in the packed batch).
+  // V^T is staged with aligned 16-byte loads when the sequence's first column is (vt_col0, RaggedBatch.vt_layout).
+  const bool vt_vec = (d.ldvt & 7) == 0 && (vcol0 & 7) == 0 && (reinterpret_cast<uintptr_t>(d.vt) & 31) == 0;
+  constexpr int j_start = 0;
 
   Vec qf[NKS];
 #pragma unroll

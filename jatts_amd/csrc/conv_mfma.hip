@@ -367,6 +367,7 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
     const int pos = t0 + col0 + t * 32 + (lane & 31);
     if (pos >= L) continue;
     const int64_t row = seq_row0 + pos;
+    const int64_t trow = d.y_seq_col0 ? (int64_t)d.y_seq_col0[blockIdx.y] * d.rg.len_mul + pos : row;  // transposed output column
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -394,7 +395,7 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
             float s = v[e];
             if (!full) s = act_c<ACT>(acc[f][t][4 * q + e] + (d.bias ? d.bias[n] : 0.f)) * d.alpha;
             if (d.resid && !(full && vec_r)) s += d.resid[row * d.ldr + n];
-            const int64_t o = d.y_transposed ? (int64_t)n * d.ldy + row : row * d.ldy + n;
+            const int64_t o = d.y_transposed ? (int64_t)n * d.ldy + trow : row * d.ldy + n;
             if (d.y_is_f32) ((float*)d.y)[o] = s; else ((T*)d.y)[o] = from_f32<T>(s);
           }
         }

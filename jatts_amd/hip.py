@@ -93,6 +93,17 @@ class RaggedBatch:
     def struct(self, len_mul=1):
         return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul)
 
+    def vt_layout(self):
+        """(col0 int32 device tensor, ld): V^T column layout with every sequence starting on a multiple of 8 columns
+        and 8 columns of slack at the end (jatts_relattn_desc.vt_col0)."""
+        if not hasattr(self, "_vt"):
+            col, c = [], 0
+            for v in self.lens:
+                col.append(c)
+                c += round_up(v, 8)
+            self._vt = (torch.tensor(col or [0], dtype=torch.int32, device=self.device), c + 8)
+        return self._vt
+
 
 def round_up(v, m):
     return (v + m - 1) // m * m
@@ -131,7 +142,8 @@ def convtranspose_as_conv(w, stride, padding):
 
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
-           in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0):
+           in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
+           y_seq_col0=None):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
@@ -153,7 +165,9 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     odt = torch.float32 if out_f32 else tdt
     if out is None:
         if transposed:
-            out = torch.empty(n_out, rows if out_ld is None else out_ld, dtype=odt, device=x0.device)
+            # zeros: the slack columns of an aligned V^T layout are read (and masked) by the attention kernel
+            out = (torch.zeros if y_seq_col0 is not None else torch.empty)(
+                n_out, rows if out_ld is None else out_ld, dtype=odt, device=x0.device)
         else:
             out = torch.empty(rows if out_rows is None else out_rows, out_ld or n_out, dtype=odt, device=x0.device)
     if out.dtype != odt:
@@ -176,6 +190,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
         d.resid, d.ldr = _ptr(resid, resid_col0), resid.shape[-1]
     d.y, d.ldy = _ptr(out, out_col0), ldy
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
+    d.y_seq_col0 = _ptr(y_seq_col0) if transposed else None
     with _Timed("conv1d", (c_in, n_out, k_w, rows)):
         _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")
     return out
@@ -215,14 +230,8 @@ def hifigan_output(rb, len_mul, xs, in_scale, slope, c_in, k_w, w, bias, dtype):
     return y
 
 
-def vt_ld(total_rows):
-    """Leading dimension for a packed V^T buffer (channels x rows) that lets jatts_relpos_attention stage it
-    with aligned 16-byte loads: a multiple of 8 with 8 columns of slack past the last row."""
-    return round_up(total_rows, 8) + 8
-
-
 def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d_k, dtype,
-                     q_col0=0, k_col0=0, rel_mode=1, rel_center=0):
+                     q_col0=0, k_col0=0, rel_mode=1, rel_center=0, vt_col0=None):
     lib = _abi.load()
     out = torch.empty(rb.total, n_heads * d_k, dtype=torch_dtype(dtype), device=q.device)
     d = _abi.RelAttnDesc()
@@ -236,6 +245,7 @@ def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d
     d.scale = scale
     d.out, d.ldo = out.data_ptr(), n_heads * d_k
     d.rel_mode, d.rel_center = rel_mode, rel_center
+    d.vt_col0 = _ptr(vt_col0)
     with _Timed("relattn", (n_heads, d_k, rb.total)):
         _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
     return out

@@ -159,9 +159,9 @@ class ConformerRunner:
         A, H, dk = self.A, self.H, self.dk
         xn = hip.layernorm(x, L["norm_mha"][0], L["norm_mha"][1], self.dtype, LN_EPS)
         qk = hip.conv1d(rb, xn, L["qk"].w, A, 2 * A, 1, dtype=self.dtype, bias=L["qk"].b)       # (R, 2A)
-        ldvt = hip.vt_ld(rb.total)
+        vcol, ldvt = rb.vt_layout()
         vt = hip.conv1d(rb, xn, L["v"].w, A, A, 1, dtype=self.dtype, bias=L["v"].b, transposed=True,
-                        out_ld=ldvt)                                                             # (A, ldvt)
+                        out_ld=ldvt, y_seq_col0=vcol)                                            # (A, ldvt)
         g = ku = None
         ldg = 0
         rel_mode, rel_center = 1, 0
@@ -177,7 +177,7 @@ class ConformerRunner:
                 hip.conv1d(rb, qk, heads[h], hip.round_up(dk, 64), n_pos, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
                            x_col0=h * dk, out=g, out_ld=H * ldg, out_col0=h * ldg)
         ctx = hip.relpos_attention(rb, qk, 2 * A, qk, 2 * A, vt, ldvt, g, ldg, ku, 1.0 / math.sqrt(dk),
-                                   H, dk, self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center)
+                                   H, dk, self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center, vt_col0=vcol)
         hip.conv1d(rb, ctx, L["o"].w, A, A, 1, dtype=self.dtype, bias=L["o"].b, resid=x, out=x, out_f32=True)
 
     def _convmod(self, rb, x, L):

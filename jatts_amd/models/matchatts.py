@@ -98,10 +98,10 @@ class _TBlock:
         C, I = x.shape[1], self.inner
         n = hip.layernorm(x, self.n1[0], self.n1[1], dt, GN_EPS)
         qk = hip.conv1d(rb, n, self.qk.w, self.qk.c_in, 2 * I, 1, dtype=dt)
-        ldvt = hip.vt_ld(rb.total)
-        vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt)
+        vcol, ldvt = rb.vt_layout()
+        vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt, y_seq_col0=vcol)
         a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, ldvt, None, 0, None, self.dh ** -0.5, self.heads,
-                                 self.dh, dt, q_col0=0, k_col0=I, rel_mode=0)
+                                 self.dh, dt, q_col0=0, k_col0=I, rel_mode=0, vt_col0=vcol)
         hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)
         n = hip.layernorm(x, self.n3[0], self.n3[1], dt, GN_EPS)
         u = hip.conv1d(rb, n, self.ff1.w, self.ff1.c_in, self.ff1.n_out, 1, dtype=dt, bias=self.ff1.b)

@@ -194,7 +194,7 @@ def test_hifigan_resunit_len_mul(cuda, lib):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-@pytest.mark.parametrize("pad_vt", [False, True])   # True: hip.vt_ld layout -> aligned 16-byte V^T staging, tiles start at j < 0
+@pytest.mark.parametrize("pad_vt", [False, True])   # True: RaggedBatch.vt_layout -> aligned 16-byte V^T staging
 @pytest.mark.parametrize("H,dk,lens,rel", [(2, 32, [24, 9, 33], True), (2, 192, [130, 64], True),
                                           (2, 96, [65], True), (4, 64, [100, 1, 17], False),
                                           (2, 64, [3, 70, 5, 129], True)])
@@ -225,12 +225,16 @@ def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
     dt = _dt(prec)
     tdt = hip.torch_dtype(dt)
     rb = _ragged(lens, cuda)
-    ldvt = hip.vt_ld(R) if pad_vt else R
+    vcol, ldvt = rb.vt_layout() if pad_vt else (None, R)
     vt = torch.full((A, ldvt), float("nan"), dtype=tdt, device=cuda)   # slack columns must never be used
-    vt[:, :R] = v.t().to(cuda).to(tdt)
+    o = 0
+    for b, T in enumerate(lens):
+        c0 = int(vcol[b]) if pad_vt else o
+        vt[:, c0:c0 + T] = v[o:o + T].t().to(cuda).to(tdt)
+        o += T
     out = hip.relpos_attention(rb, q.to(cuda).to(tdt), A, k.to(cuda).to(tdt), A, vt, ldvt,
                                gm.reshape(R, H * ldg).to(cuda).to(tdt) if rel else None, ldg,
-                               ku.to(cuda), scale, H, dk, dt)
+                               ku.to(cuda), scale, H, dk, dt, vt_col0=vcol)
     e = relerr(out.float(), ref)
     assert e <= (5e-5 if prec == "fp32" else 3e-3), f"attention {H}x{dk} {prec}: rel err {e:.3e}"
 
