@@ -101,6 +101,27 @@ FS2_JSUT = dict(  # egs/jsut/tts1/conf/fastspeech2.v1.yaml:26-77 (model_params)
     stop_gradient_from_energy_predictor=False,
 )
 
+MATCHA_MAS_JSUT = dict(  # egs/jsut/tts2/conf/matcha_tts.mas.v1.yaml:22-63 (model_params; BASELINE config 3)
+    odim=80, adim=384, aheads=2, elayers=4, eunits=1536, positionwise_layer_type="conv1d",
+    positionwise_conv_kernel_size=3, duration_predictor_layers=2, duration_predictor_chans=256,
+    duration_predictor_kernel_size=3, use_masking=True, encoder_normalize_before=True, reduction_factor=1,
+    encoder_type="conformer", conformer_pos_enc_layer_type="rel_pos", conformer_self_attn_layer_type="rel_selfattn",
+    conformer_activation_type="swish", use_macaron_style_in_conformer=True, use_cnn_in_conformer=True,
+    conformer_enc_kernel_size=7, conformer_dec_kernel_size=31, init_type="xavier_uniform",
+    transformer_enc_dropout_rate=0.2, transformer_enc_positional_dropout_rate=0.2, transformer_enc_attn_dropout_rate=0.2,
+    decoder_channels=[512, 512], decoder_dropout=0.05, decoder_attention_head_dim=256, decoder_n_blocks=1,
+    decoder_num_mid_blocks=2, decoder_num_heads=2, decoder_act_fn="snakebeta",
+)
+
+VITS_JSUT = dict(  # egs/jsut/tts2/conf/vits.v1.bs32.yaml:22-44 (model_params; BASELINE config 5 adds spk_embed_dim=192)
+    odim=80, adim=384, aheads=2, dlayers=4, dunits=1536, decoder_positionwise_layer_type="conv1d",
+    decoder_positionwise_conv_kernel_size=3, duration_predictor_layers=2, duration_predictor_chans=256,
+    duration_predictor_kernel_size=3, use_masking=True, decoder_normalize_before=True, reduction_factor=1,
+    use_macaron_style_in_conformer=True, use_cnn_in_conformer=True, conformer_dec_kernel_size=31,
+    init_type="xavier_uniform", transformer_dec_dropout_rate=0.2, transformer_dec_positional_dropout_rate=0.2,
+    transformer_dec_attn_dropout_rate=0.2,
+)
+
 FS2_SMALL = dict(  # reduced-width config for fast CPU golden vectors (same code paths)
     odim=80, adim=64, aheads=2, elayers=2, eunits=128, dlayers=2, dunits=128,
     positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3,
