@@ -248,10 +248,12 @@ int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, const void* 
 /* GroupNorm over (channels/groups x time) of each utterance + Mish (+ per-utterance vector), the body of
  * Matcha's Block1D / ResnetBlock1D (modules/matchatts/decoder.py:66-97):
  *   y[t][c] = mish( (x[t][c] - mean_g) * rstd_g * gamma[c] + beta[c] ) + addvec[seq][c]
- * x: [rows][C] (in_dtype); y: [rows][C] (out_dtype); addvec: f32 [n_seq][C] or NULL. */
+ * x: [rows][C] (in_dtype); y: [rows][C] (out_dtype); addvec: f32 [n_seq][C] or NULL.
+ * workspace: caller-owned f32 scratch of n_seq * groups * ceil(max_len / 64) * 3 floats (chunk statistics of the
+ * time-split two-launch form) or NULL (single-launch form, one workgroup per (utterance, group)). */
 int jatts_groupnorm_mish(const jatts_ragged* rg, const void* x, int32_t in_dtype, void* y, int32_t out_dtype,
                          int32_t channels, int32_t groups, const float* gamma, const float* beta, float eps,
-                         const float* addvec, void* stream);
+                         const float* addvec, float* workspace, void* stream);
 
 /* SnakeBeta (modules/matchatts/transformer.py:84-102): y = x + inv_beta[c] * sin(x * alpha[c])^2 with
  * alpha = exp(log_alpha), inv_beta = 1 / (exp(log_beta) + 1e-9) precomputed by the host. */

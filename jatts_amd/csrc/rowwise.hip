@@ -297,9 +297,138 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(jatts_ragged rg, co
   }
 }
 
+// Time-split GroupNorm: (groups x n_seq x chunks) workgroups instead of (groups x n_seq), two launches.
+//   pass 1: each workgroup holds its GN_TCH-row chunk of one (utterance, group) in registers and writes the chunk's
+//           (count, mean, M2) -- two-pass inside the chunk;
+//   pass 2: every workgroup merges the chunk statistics of its (utterance, group) with Chan's parallel formula (a few
+//           dozen values, done redundantly), then normalises + Mish + per-utterance vector from the registers it
+//           re-loads with 16-byte accesses.
+// The single-workgroup kernel above streams 196 KB three times with 2-byte loads from 512 workgroups (~10x the HBM time).
+constexpr int GN_TCH = 64;  // rows per chunk
+constexpr int GN_MAXU = 4;  // 8-element units per thread: chunk rows * (C/groups) <= 256 * 4 * 8 elements
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(jatts_ragged rg, const T* x, int C, int groups, float* ws, int n_chunks) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, b = blockIdx.y, ch = blockIdx.z;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  float* out = ws + (((int64_t)b * groups + g) * n_chunks + ch) * 3;
+  const int r0 = ch * GN_TCH;
+  if (r0 >= L) {
+    if (threadIdx.x == 0) { out[0] = 0.f; out[1] = 0.f; out[2] = 0.f; }
+    return;
+  }
+  const int rows = min(GN_TCH, L - r0);
+  const int gc = C / groups, upr = gc >> 3, total = rows * upr;
+  const T* xb = x + (int64_t)(row0 + r0) * C + g * gc;
+  float v[GN_MAXU][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < GN_MAXU; ++j) {
+    const int u = threadIdx.x + j * 256;
+    if (u < total) {
+      const int r = u / upr, cu = u - r * upr;
+      load8f<T>(xb + (int64_t)r * C + cu * 8, v[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[j][e];
+    }
+  }
+  const float n = (float)(rows * gc);
+  const float mean = block_sum_256(s, red) / n;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < GN_MAXU; ++j) {
+    const int u = threadIdx.x + j * 256;
+    if (u < total) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mean; q += dlt * dlt; }
+    }
+  }
+  const float m2 = block_sum_256(q, red);
+  if (threadIdx.x == 0) { out[0] = n; out[1] = mean; out[2] = m2; }
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(jatts_ragged rg, const T* x, TO* y, int C, int groups, const float* gamma,
+                                                       const float* beta, float eps, const float* addvec, const float* ws,
+                                                       int n_chunks) {
+  const int g = blockIdx.x, b = blockIdx.y, ch = blockIdx.z;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int r0 = ch * GN_TCH;
+  if (r0 >= L) return;
+  const float* st = ws + ((int64_t)b * groups + g) * n_chunks * 3;
+  float na = 0.f, ma = 0.f, m2a = 0.f;   // Chan et al.: merge (n, mean, M2) pairs
+  for (int i = 0; i < n_chunks; ++i) {
+    const float nb = st[3 * i], mb = st[3 * i + 1], m2b = st[3 * i + 2];
+    if (nb > 0.f) {
+      const float nn = na + nb, dlt = mb - ma;
+      ma += dlt * (nb / nn);
+      m2a += m2b + dlt * dlt * (na * nb / nn);
+      na = nn;
+    }
+  }
+  const float mean = ma, rstd = rsqrtf(m2a / na + eps);
+  const int rows = min(GN_TCH, L - r0);
+  const int gc = C / groups, upr = gc >> 3, total = rows * upr;
+  const T* xb = x + (int64_t)(row0 + r0) * C + g * gc;
+  float v[GN_MAXU][8];
+#pragma unroll
+  for (int j = 0; j < GN_MAXU; ++j) {
+    const int u = threadIdx.x + j * 256;
+    if (u < total) {
+      const int r = u / upr, cu = u - r * upr;
+      load8f<T>(xb + (int64_t)r * C + cu * 8, v[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < GN_MAXU; ++j) {
+    const int u = threadIdx.x + j * 256;
+    if (u >= total) continue;
+    const int r = u / upr, cu = u - r * upr;
+    const int c = g * gc + cu * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (v[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+      t = t * tanhf(t > 20.f ? t : log1pf(expf(t)));
+      if (addvec) t += addvec[(int64_t)b * C + c + e];
+      o[e] = t;
+    }
+    TO* dst = y + (int64_t)(row0 + r0 + r) * C + c;
+    if (sizeof(TO) == 2) *reinterpret_cast<f16x8*>(dst) = f16x8{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
+    else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>((float*)dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
 template <typename T>
 __global__ void snakebeta_kernel(const T* x, T* y, int64_t rows, int C, const float* alpha, const float* inv_beta) {
   const int64_t total = rows * C;
+  if ((C & 7) == 0) {   // 8 channels per thread, 16-byte accesses
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < total; i += (int64_t)gridDim.x * blockDim.x * 8) {
+      const int c = (int)(i % C);
+      float v[8];
+      load8f<T>(x + i, v);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(alpha + c), a1 = *reinterpret_cast<const f32x4*>(alpha + c + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(inv_beta + c), b1 = *reinterpret_cast<const f32x4*>(inv_beta + c + 4);
+      T o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sn = sinf(v[e] * (e < 4 ? a0[e & 3] : a1[e & 3]));
+        o[e] = from_f32<T>(v[e] + (e < 4 ? b0[e & 3] : b1[e & 3]) * sn * sn);
+      }
+      if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(y + i) = f16x8{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
+      else {
+        *reinterpret_cast<f32x4*>(y + i) = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        *reinterpret_cast<f32x4*>(y + i + 4) = f32x4{(float)o[4], (float)o[5], (float)o[6], (float)o[7]};
+      }
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const float v = to_f32(x[i]);
@@ -680,10 +809,28 @@ extern "C" int jatts_gated_tanh_sigmoid(const jatts_ragged* rg, int32_t dtype, c
 
 extern "C" int jatts_groupnorm_mish(const jatts_ragged* rg, const void* x, int32_t in_dtype, void* y, int32_t out_dtype,
                                     int32_t channels, int32_t groups, const float* gamma, const float* beta, float eps,
-                                    const float* addvec, void* stream) {
+                                    const float* addvec, float* workspace, void* stream) {
   if (!rg || !x || !y || !gamma || !beta) return jatts_set_error_msg(JATTS_ERR_ARG, "groupnorm_mish: null pointer");
   if (groups < 1 || channels % groups) return jatts_set_error_msg(JATTS_ERR_ARG, "groupnorm_mish: channels % groups != 0");
   if (rg->max_len <= 0) return JATTS_OK;
+  const int gc = channels / groups;
+  if (workspace && (gc & 7) == 0 && GN_TCH * gc <= 256 * GN_MAXU * 8) {   // time-split two-launch form
+    const int n_chunks = (rg->max_len + GN_TCH - 1) / GN_TCH;
+    dim3 grid3((unsigned)groups, (unsigned)rg->n_seq, (unsigned)n_chunks), blk3(256);
+#define GN2_GO(TI, TO)                                                                                                   \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((gn_partial_kernel<TI>), grid3, blk3, 0, S_, *rg, (const TI*)x, channels, groups, workspace, n_chunks); \
+    hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid3, blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
+  } while (0)
+    if (in_dtype == JATTS_F32 && out_dtype == JATTS_F32) GN2_GO(float, float);
+    else if (in_dtype == JATTS_F32 && out_dtype == JATTS_F16) GN2_GO(float, f16);
+    else if (in_dtype == JATTS_F16 && out_dtype == JATTS_F16) GN2_GO(f16, f16);
+    else if (in_dtype == JATTS_F16 && out_dtype == JATTS_F32) GN2_GO(f16, float);
+    else return jatts_set_error_msg(JATTS_ERR_ARG, "groupnorm_mish: unknown dtype");
+#undef GN2_GO
+    JATTS_CHECK_LAUNCH();
+    return JATTS_OK;
+  }
   dim3 grid((unsigned)groups, (unsigned)rg->n_seq), blk(256);
 #define GN_GO(TI, TO) \
   hipLaunchKernelGGL((groupnorm_mish_kernel<TI, TO>), grid, blk, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec)

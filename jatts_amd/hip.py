@@ -326,12 +326,15 @@ def gated_tanh_sigmoid(rb, x, gseq, channels, dtype):
     return y
 
 
-def groupnorm_mish(rb, x, channels, groups, gamma, beta, out_dtype, eps=1e-5, addvec=None):
+def groupnorm_mish(rb, x, channels, groups, gamma, beta, out_dtype, eps=1e-5, addvec=None, time_split=True):
     lib = _abi.load()
     y = torch.empty(rb.total, channels, dtype=torch_dtype(out_dtype), device=x.device)
     rg = rb.struct()
+    ws = None
+    if time_split:  # chunk statistics of the two-launch form (include/jatts_hip.h)
+        ws = torch.empty(rb.n_seq * groups * ((rb.max_len + 63) // 64) * 3, dtype=torch.float32, device=x.device)
     _abi.check(lib.jatts_groupnorm_mish(C.byref(rg), _dev(x).data_ptr(), code_of(x), y.data_ptr(), out_dtype, channels,
-                                        groups, gamma.data_ptr(), beta.data_ptr(), eps, _ptr(addvec), _stream()),
+                                        groups, gamma.data_ptr(), beta.data_ptr(), eps, _ptr(addvec), _ptr(ws), _stream()),
                "jatts_groupnorm_mish")
     return y
 

@@ -483,3 +483,43 @@ def test_gaussian_upsample(cuda, lib):
         o += n
     out = hip.gaussian_upsample(_ragged(lens, cuda), d.to(cuda), _ragged(olens, cuda), hs.to(cuda))
     assert maxdiff(out, torch.cat(outs)) <= 1e-5
+
+
+@pytest.mark.parametrize("time_split", [False, True])
+@pytest.mark.parametrize("in_prec,out_prec", [("fp32", "fp32"), ("fp32", "fp16"), ("fp16", "fp32"), ("fp16", "fp16")])
+def test_groupnorm_mish(cuda, lib, time_split, in_prec, out_prec):
+    """Block1D / ResnetBlock1D body (modules/matchatts/decoder.py:66-97): GroupNorm(8) over (C/8 x T) of each utterance,
+    Mish, + per-utterance vector.  Both launch forms (one workgroup per group; time-split with merged chunk statistics)."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(31)
+    lens, C, G = [130, 1, 64, 257, 65], 64, 8
+    R = sum(lens)
+    x = _round(torch.randn(R, C, generator=g) * 2.0 + 0.3, in_prec)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    add = torch.randn(len(lens), C, generator=g)
+    outs, o = [], 0
+    for b, T in enumerate(lens):
+        xb = x[o:o + T].double().t().unsqueeze(0)                     # (1, C, T)
+        yb = torch.nn.functional.group_norm(xb, G, gamma.double(), beta.double(), 1e-5)
+        yb = torch.nn.functional.mish(yb) + add[b].double().view(1, C, 1)
+        outs.append(yb[0].t())
+        o += T
+    ref = torch.cat(outs)
+    rb = _ragged(lens, cuda)
+    y = hip.groupnorm_mish(rb, x.to(cuda).to(hip.torch_dtype(_dt(in_prec))), C, G, gamma.to(cuda), beta.to(cuda), _dt(out_prec),
+                           addvec=add.to(cuda), time_split=time_split)
+    tol = 2e-5 if out_prec == "fp32" else 2e-3
+    assert relerr(y.float(), ref) <= tol, relerr(y.float(), ref)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_snakebeta(cuda, lib, prec):
+    """SnakeBeta (modules/matchatts/transformer.py:84-102): x + sin(alpha x)^2 / beta."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(32)
+    R, C = 203, 48
+    x = _round(torch.randn(R, C, generator=g) * 3, prec)
+    alpha, inv_beta = torch.rand(C, generator=g) * 2 + 0.1, torch.rand(C, generator=g) + 0.2
+    ref = x.double() + inv_beta.double() * torch.sin(x.double() * alpha.double()) ** 2
+    y = hip.snakebeta(x.to(cuda).to(hip.torch_dtype(_dt(prec))), alpha.to(cuda), inv_beta.to(cuda))
+    assert relerr(y.float(), ref) <= (2e-6 if prec == "fp32" else 1e-3)
