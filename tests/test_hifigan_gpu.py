@@ -19,7 +19,11 @@ def _small(params, channels=128):
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp16", 2e-2)])
-@pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K, 512), _small(HIFIGAN_V1_24K, 512)], ids=["22k", "24k"])
+@pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K, 512), _small(HIFIGAN_V1_24K, 512),
+                                    # two ResBlocks, other kernels / dilations (MRF mean over 2, fused-mean with one partner)
+                                    dict(_small(HIFIGAN_V1_22K, 256), upsample_scales=(4, 4, 4), upsample_kernel_sizes=(8, 8, 8),
+                                         resblock_kernel_sizes=(3, 5), resblock_dilations=((1, 2), (2, 6, 3)))],
+                         ids=["22k", "24k", "odd-config"])
 def test_generator_matches_oracle(cuda, lib, prec, tol, params):
     from jatts_amd import hip
     from jatts_amd.vocoder import HiFiGANGenerator
@@ -63,3 +67,10 @@ def test_vocoder_decode_contract_and_normalisation(cuda, lib, golden_dir):
     assert maxdiff(voc.normalized(c), z["c_norm"]) <= 1e-5      # vocoder.py:56-61, pinned on the reference
     y, sr = voc.decode(c)
     assert sr == 24000 and y.dim() == 1 and y.numel() == c.shape[0] * 300 and y.is_cuda
+
+
+def test_unsupported_channel_counts_raise(lib):
+    """channels / 2**n_upsamples < 32 (HiFi-GAN V2/V3 widths) is outside the MFMA tiling: refuse loudly, never fall back."""
+    from jatts_amd.vocoder import HiFiGANGenerator
+    with pytest.raises(NotImplementedError):
+        HiFiGANGenerator(**_small(HIFIGAN_V1_22K, 256))
