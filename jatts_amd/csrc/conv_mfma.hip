@@ -920,12 +920,17 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
       case 641: return launch_resunit<f16, 64, 256, 1, 2>(*d, s);
       case 643: return launch_resunit<f16, 64, 256, 1, 4, 4>(*d, s);
       case 644: return launch_resunit<f16, 64, 512, 1, 4, 4>(*d, s);
-      case 1280: case 1283: return launch_resunit<f16, 128, 256, 2, 4, 4>(*d, s);
+      case 1280:
+        // 2 x (256 + 2*p1) rows x 272 B must fit in 160 KiB for 2 workgroups/CU: k=11, d=5 misses by 5 rows -> 3-fragment tile
+        if ((256 + (d->k_w - 1) * d->dil) * 272 * 2 > 160 * 1024) return launch_resunit<f16, 128, 192, 2, 3, 4>(*d, s);
+        return launch_resunit<f16, 128, 256, 2, 4, 4>(*d, s);
+      case 1283: return launch_resunit<f16, 128, 256, 2, 4, 4>(*d, s);
       case 1281: return launch_resunit<f16, 128, 128, 2, 2, 8>(*d, s);
       case 1284: return launch_resunit<f16, 128, 128, 2, 4, 4>(*d, s);
       case 2560: case 2563: return launch_resunit<f16, 256, 128, 4, 4, 4>(*d, s);
       case 2561: return launch_resunit<f16, 256, 64, 4, 2, 8>(*d, s);
       case 2564: return launch_resunit<f16, 256, 128, 4, 2, 4>(*d, s);
+      case 1285: return launch_resunit<f16, 128, 192, 2, 3, 4>(*d, s);
       case 5120: return launch_resunit<f16, 512, 32, 4, 1>(*d, s);
     }
   } else if (d->dtype == JATTS_F32) {
