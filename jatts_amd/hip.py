@@ -165,9 +165,9 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     odt = torch.float32 if out_f32 else tdt
     if out is None:
         if transposed:
-            # zeros: the slack columns of an aligned V^T layout are read (and masked) by the attention kernel
-            out = (torch.zeros if y_seq_col0 is not None else torch.empty)(
-                n_out, rows if out_ld is None else out_ld, dtype=odt, device=x0.device)
+            # slack columns of an aligned V^T layout stay uninitialised: the attention kernel masks every element
+            # outside [0, T) after loading it (tests fill them with NaN)
+            out = torch.empty(n_out, rows if out_ld is None else out_ld, dtype=odt, device=x0.device)
         else:
             out = torch.empty(rows if out_rows is None else out_rows, out_ld or n_out, dtype=odt, device=x0.device)
     if out.dtype != odt:
