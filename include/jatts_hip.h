@@ -298,6 +298,26 @@ int jatts_gaussian_upsample(const jatts_ragged* rg_in, const int64_t* d, const i
                             int32_t max_out_len, const float* hs, int32_t dim, float delta,
                             float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Alignment learning (training-side neighbours of the stage-4 path, Matcha-MAS / VITS).
+ * ------------------------------------------------------------------------------- */
+/* AlignmentModule.forward after its convolutions (modules/alignments.py:50-59):
+ *   log_p[f][i] = log_softmax_i( -|| feats[f] - text[i] ||_2 )  over the utterance's own tokens;
+ * columns >= T_text of a row are -inf (the reference's masked_fill of padded tokens).
+ * feats: f32 [frame rows][adim] (f_conv3 output), text: f32 [token rows][adim] (t_conv2 output),
+ * cu_text: int32 [n_seq + 1] token offsets, log_p: f32 [frame rows][ld], ld >= max_text_len <= 512. */
+int jatts_alignment_logp(const jatts_ragged* rg_feats, const int32_t* cu_text, int32_t max_text_len, const float* feats,
+                         const float* text, int32_t adim, float* log_p, int32_t ld, void* stream);
+
+/* Monotonic alignment search + duration extraction for the whole batch (modules/alignments.py:63-93
+ * _monotonic_alignment_search, :281-310 viterbi_decode; the reference runs a numba loop per utterance on the host):
+ *   path[f]  = token index of frame f (int64, per utterance),   dur[i] = number of frames of token i (np.bincount),
+ *   score[b] = sum_f log_p[f][path[f]]  (bin_loss = -mean over frames, averaged over the batch by the caller).
+ * Q is float64 as in the reference; row 0 is a float64 running sum of the float32 inputs (see oracle/mas_oracle.py).
+ * Limits: T_text <= 1024 and T_feats * ceil(T_text / 64) * 8 bytes of decision bits must fit LDS. score may be NULL. */
+int jatts_mas_viterbi(const jatts_ragged* rg_feats, const int32_t* cu_text, const float* log_p, int32_t ld,
+                      int32_t max_text_len, int64_t* path, int64_t* dur, double* score, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

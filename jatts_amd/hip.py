@@ -416,3 +416,29 @@ def gaussian_upsample(rb_in, d, rb_out, hs, delta=0.1):
                                            rb_out.max_len, hs.data_ptr(), dim, delta, out.data_ptr(),
                                            _stream()), "jatts_gaussian_upsample")
     return out
+
+
+def alignment_logp(rb_f, rb_t, feats, text, adim):
+    """jatts_alignment_logp: f32 (frame rows, ld) log-probabilities, ld = round_up(max text length, 8)."""
+    lib = _abi.load()
+    ld = round_up(max(rb_t.max_len, 1), 8)
+    out = torch.empty(rb_f.total, ld, dtype=torch.float32, device=feats.device)
+    rg = rb_f.struct()
+    _abi.check(lib.jatts_alignment_logp(C.byref(rg), rb_t.cu.data_ptr(), rb_t.max_len, _dev(feats).data_ptr(),
+                                        _dev(text).data_ptr(), adim, out.data_ptr(), ld, _stream()), "jatts_alignment_logp")
+    return out
+
+
+def mas_viterbi(rb_f, rb_t, log_p):
+    """jatts_mas_viterbi -> (path int64 (frame rows,), dur int64 (token rows,), score f64 (n_seq,))."""
+    lib = _abi.load()
+    dev = log_p.device
+    path = torch.empty(rb_f.total, dtype=torch.int64, device=dev)
+    dur = torch.empty(rb_t.total, dtype=torch.int64, device=dev)
+    score = torch.empty(rb_f.n_seq, dtype=torch.float64, device=dev)
+    rg = rb_f.struct()
+    if log_p.dtype != torch.float32 or not log_p.is_contiguous():
+        raise ValueError("mas_viterbi: log_p must be contiguous float32")
+    _abi.check(lib.jatts_mas_viterbi(C.byref(rg), rb_t.cu.data_ptr(), _dev(log_p).data_ptr(), log_p.shape[1], rb_t.max_len,
+                                     path.data_ptr(), dur.data_ptr(), score.data_ptr(), _stream()), "jatts_mas_viterbi")
+    return path, dur, score

@@ -141,3 +141,27 @@ def test_masks_golden():
         lens = z[f"m{n}_lens"].tolist()
         assert np.array_equal(make_pad_mask(lens).numpy(), z[f"m{n}_pad"])
         assert np.array_equal(make_non_pad_mask(lens).numpy(), z[f"m{n}_nonpad"])
+
+
+def test_mas_oracle_matches_reference(golden_dir):
+    """the numpy restatement of AlignmentModule / _monotonic_alignment_search / viterbi_decode against the
+    reference's own outputs (tests/golden/mas_kat.npz, make_golden_mas.py).  Bit-exact paths and durations."""
+    import json
+
+    from jatts_amd.synthetic import synth_state_dict
+    from oracle.mas_oracle import alignment_log_p, monotonic_alignment_search, viterbi_decode
+    z = np.load(golden_dir + "/mas_kat.npz")
+    for n in range(int(z["n_mas"])):
+        lp, ref = z[f"mas{n}_logp"], z[f"mas{n}_path"]
+        assert np.array_equal(monotonic_alignment_search(lp, literal=True), ref), n
+        assert np.array_equal(monotonic_alignment_search(lp), ref), n   # float64 running sum of row 0: same paths
+        assert (np.diff(ref) >= 0).all() and (np.diff(ref) <= 1).all() and ref[-1] == lp.shape[1] - 1
+    sd = synth_state_dict({k: tuple(s) for k, s in json.loads(str(z["keys"]))}, 7)
+    tl, fl = z["text_lengths"], z["feats_lengths"]
+    ref = torch.tensor(z["log_p_attn"])
+    for b in range(len(tl)):   # per utterance, unpadded: the parity target (make_golden_mas.py)
+        lp = alignment_log_p(sd, torch.tensor(z["text"][b:b + 1, : tl[b]]), torch.tensor(z["feats"][b:b + 1, : fl[b]]))[0]
+        assert float((lp - ref[b, : fl[b], : tl[b]]).abs().max()) <= 1e-6
+    ds, bin_loss, _ = viterbi_decode(ref, tl, fl, literal=True)
+    assert np.array_equal(ds.numpy(), z["ds"])
+    assert abs(float(bin_loss) - float(z["bin_loss"])) <= 1e-6
