@@ -298,6 +298,10 @@ int jatts_gaussian_upsample(const jatts_ragged* rg_in, const int64_t* d, const i
                             int32_t max_out_len, const float* hs, int32_t dim, float delta,
                             float* out, void* stream);
 
+/* Stage-4 output: float waveform -> little-endian 16-bit PCM, the conversion libsndfile applies for
+ * sf.write(path, y, fs, "PCM_16") (jatts/bin/tts_decode.py:250-255): y[i] = lrintf(clamp(x[i], -1, 1) * 32767.f). */
+int jatts_pcm16(const float* x, int64_t n, int16_t* y, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Alignment learning (training-side neighbours of the stage-4 path, Matcha-MAS / VITS).
  * ------------------------------------------------------------------------------- */

@@ -58,14 +58,71 @@ def read_stats(path, feat):
         return {"mean": f[f"{feat}_mean"][()].astype(np.float32), "scale": f[f"{feat}_scale"][()].astype(np.float32)}
 
 
+def to_pcm16(y):
+    """float [-1, 1] -> int16 exactly as libsndfile's PCM_16 writer converts float input (float multiply by 32767,
+    lrintf), the host twin of jatts_pcm16."""
+    y = np.clip(np.asarray(y, dtype=np.float32), np.float32(-1.0), np.float32(1.0))
+    return np.rint(y * np.float32(32767.0)).astype("<i2")
+
+
 def write_wav_pcm16(path, y, sr):
-    """float [-1, 1] -> 16-bit PCM, as soundfile's 'PCM_16' does (lrint(x * 32767))."""
-    pcm = np.rint(np.clip(np.asarray(y, dtype=np.float64), -1.0, 1.0) * 32767.0).astype("<i2")
+    """Write mono 16-bit PCM; ``y`` is float in [-1, 1] or already int16 PCM (from jatts_pcm16)."""
+    pcm = np.asarray(y)
+    if pcm.dtype != np.dtype("<i2"):
+        pcm = to_pcm16(pcm)
     with wave.open(path, "wb") as w:
         w.setnchannels(1)
         w.setsampwidth(2)
         w.setframerate(int(sr))
         w.writeframes(pcm.tobytes())
+
+
+class OutputPipeline:
+    """the stage-4 output side overlapped with synthesis.  Per batch: jatts_pcm16 on the compute stream,
+    an asynchronous device->host copy of the int16 samples (half the bytes of the float waveform) into one of two pinned
+    buffers on a side stream, and the wav files written by a worker thread while the GPU already runs the next batch.
+    The reference converts and writes utterance by utterance inside the synthesis loop (tts_decode.py:240-255)."""
+
+    def __init__(self, device, sr, n_buffers=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device, self.sr = device, int(sr)
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.slots = [dict(buf=None, fut=None) for _ in range(n_buffers)]
+        self.k = 0
+        self.pool = ThreadPoolExecutor(max_workers=1)
+
+    def submit(self, y, jobs):
+        """y: packed float waveform on the GPU; jobs: list of (path, first sample, n samples)."""
+        from jatts_amd import hip
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        if slot["fut"] is not None:
+            slot["fut"].result()                      # this buffer's previous batch is on disk
+        pcm = hip.pcm16(y)
+        if slot["buf"] is None or slot["buf"].numel() < pcm.numel():
+            slot["buf"] = torch.empty(max(pcm.numel(), 1), dtype=torch.int16).pin_memory()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ready)
+            slot["buf"][: pcm.numel()].copy_(pcm, non_blocking=True)
+            pcm.record_stream(self.copy_stream)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        host = slot["buf"]
+
+        def write():
+            done.synchronize()
+            a = host.numpy()
+            for path, o, n in jobs:
+                write_wav_pcm16(path, a[o:o + n], self.sr)
+        slot["fut"] = self.pool.submit(write)
+
+    def close(self):
+        for s in self.slots:
+            if s["fut"] is not None:
+                s["fut"].result()
+        self.pool.shutdown()
 
 
 def read_items(csv_path, token_column, converter):
@@ -140,6 +197,7 @@ def main(argv=None):
 
     order = sorted(range(len(items)), key=lambda i: -len(items[i]["token_indices"]))  # similar lengths together
     n_frames, t0 = 0, time.time()
+    out_pipe = OutputPipeline(device, vocoder.config["sampling_rate"])
     for s in range(0, len(order), args.batch_size):
         batch = [items[i] for i in order[s:s + args.batch_size]]
         texts = [torch.from_numpy(it["token_indices"]).to(device) for it in batch]
@@ -152,13 +210,16 @@ def main(argv=None):
         else:
             r = model.inference_batch(texts, **kw)
         y = vocoder.decode_batch(r["feats_rb"], r["feat_gen"])
-        y_host = y.cpu().numpy()                                            # one device->host copy per batch
+        jobs, o = [], 0
+        for it, nf in zip(batch, r["olens"]):
+            sid = it.get("sample_id", it.get("id", str(o)))
+            jobs.append((os.path.join(args.outdir, "wav", f"{sid}.wav"), o * hop, nf * hop))
+            o += nf
+        out_pipe.submit(y, jobs)                                            # PCM conversion, async D2H, wav writer thread
         mel_host = r["feat_gen"].cpu().numpy() if args.plot else None
         o = 0
         for it, nf in zip(batch, r["olens"]):
             sid = it.get("sample_id", it.get("id", str(o)))
-            write_wav_pcm16(os.path.join(args.outdir, "wav", f"{sid}.wav"), y_host[o * hop:(o + nf) * hop],
-                            vocoder.config["sampling_rate"])
             if args.plot:
                 import matplotlib
                 matplotlib.use("Agg")
@@ -170,6 +231,7 @@ def main(argv=None):
                 plt.close()
             o += nf
         n_frames += sum(r["olens"])
+    out_pipe.close()
     dt = time.time() - t0
     logging.info("inference speed = %.1f frames / sec. (RTF = %.5f)" % (
         n_frames / max(dt, 1e-9), dt / max(n_frames * hop / vocoder.config["sampling_rate"], 1e-9)))

@@ -699,6 +699,23 @@ __global__ __launch_bounds__(256) void hifigan_output_vec_kernel(jatts_ragged rg
   y[row0 + t0 + t] = tanhf(acc);
 }
 
+// float [-1, 1] -> 16-bit PCM exactly as libsndfile's PCM_16 writer does for float input (sf.write(..., "PCM_16"),
+// tts_decode.py:250-255): lrintf(x * 32767.f) in float arithmetic; values are clamped to [-1, 1] first (tanh output).
+__global__ void pcm16_kernel(const float* x, int16_t* y, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n && (reinterpret_cast<uintptr_t>(x + i) & 15) == 0 && (reinterpret_cast<uintptr_t>(y + i) & 7) == 0) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+      short o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (short)rintf(fminf(fmaxf(v[e], -1.f), 1.f) * 32767.f);
+      *reinterpret_cast<uint2*>(y + i) = uint2{(unsigned)(unsigned short)o[0] | ((unsigned)(unsigned short)o[1] << 16),
+                                               (unsigned)(unsigned short)o[2] | ((unsigned)(unsigned short)o[3] << 16)};
+    } else {
+      for (int64_t k2 = i; k2 < n && k2 < i + 4; ++k2) y[k2] = (int16_t)rintf(fminf(fmaxf(x[k2], -1.f), 1.f) * 32767.f);
+    }
+  }
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
@@ -960,6 +977,15 @@ extern "C" int jatts_hifigan_output(const jatts_ragged* rg, int32_t dtype, const
   else if (dtype == JATTS_F32)
     hipLaunchKernelGGL(hifigan_output_kernel<float>, grid, dim3(256), lds, S_, *rg, (const float*)x[0], (const float*)x1, (const float*)x2, n_in, in_scale, slope, c_in, k_w, w, bias, y);
   else return jatts_set_error_msg(JATTS_ERR_ARG, "hifigan_output: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_pcm16(const float* x, int64_t n, int16_t* y, void* stream) {
+  if (!x || !y) return jatts_set_error_msg(JATTS_ERR_ARG, "pcm16: null pointer");
+  if (n <= 0) return JATTS_OK;
+  const int64_t blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)(blocks < 8192 ? (blocks < 1 ? 1 : blocks) : 8192)), dim3(256), 0, S_, x, y, n);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -442,3 +442,15 @@ def mas_viterbi(rb_f, rb_t, log_p):
     _abi.check(lib.jatts_mas_viterbi(C.byref(rg), rb_t.cu.data_ptr(), _dev(log_p).data_ptr(), log_p.shape[1], rb_t.max_len,
                                      path.data_ptr(), dur.data_ptr(), score.data_ptr(), _stream()), "jatts_mas_viterbi")
     return path, dur, score
+
+
+def pcm16(y, out=None):
+    """jatts_pcm16: f32 waveform (n,) on the GPU -> int16 PCM (n,) on the GPU."""
+    lib = _abi.load()
+    y = _dev(y)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise ValueError("pcm16: contiguous float32 expected")
+    if out is None:
+        out = torch.empty(y.numel(), dtype=torch.int16, device=y.device)
+    _abi.check(lib.jatts_pcm16(y.data_ptr(), y.numel(), out.data_ptr(), _stream()), "jatts_pcm16")
+    return out
