@@ -96,3 +96,19 @@ def test_zero_length_sequences_are_skipped(cuda, lib):
     a1 = hip.relpos_attention(rb, x, C, x, C, vt, R, None, 0, None, 0.125, H, dk, hip.F16, rel_mode=0)
     a2 = hip.relpos_attention(rb2, x, C, x, C, vt, R, None, 0, None, 0.125, H, dk, hip.F16, rel_mode=0)
     assert torch.equal(a1, a2) and torch.isfinite(a1).all()
+
+
+def test_two_stream_pipeline_is_bit_identical(cuda, stack):
+    """jatts_amd.pipeline.Stage4Pipeline (text2mel of batch k+1 overlapping the vocoder of batch k) == sequential loop."""
+    from jatts_amd.pipeline import Stage4Pipeline
+    from jatts_amd.synthetic import synth_texts
+    m, voc = stack
+    batches = [[t.to(cuda) for t in synth_texts(16, 64 + 16 * i, 45, seed=10 + i)] for i in range(4)]
+    want = []
+    for b in batches:
+        r = m.inference_batch(b)
+        want.append(voc.decode_batch(r["feats_rb"], r["feat_gen"]).clone())
+    torch.cuda.synchronize()
+    got = [y.clone() for _, y in Stage4Pipeline(m, voc).run(batches)]
+    torch.cuda.synchronize()
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
