@@ -55,7 +55,7 @@ class _Resnet:
         self.gn2 = (f32(sd[p + "block2.block.1.weight"]), f32(sd[p + "block2.block.1.bias"]))
         self.mlp = PackedConv(sd[p + "mlp.1.weight"], sd[p + "mlp.1.bias"], dt, dev)
 
-    def run(self, rb, rbs, xs, tmish, dt):
+    def run(self, rb, rbs, xs, tmish, dt, tv_cache=None):
         """xs: list of operand-dtype tensors (rows, ld_i) matching in_sizes; tmish: (n_seq, Ct) = mish(time emb).
         Returns f32 (rows, c_out)."""
         C = self.c_out
@@ -63,7 +63,12 @@ class _Resnet:
         for x, cv in zip(xs, self.conv1):
             h = hip.conv1d(rb, x, cv.w, cv.c_in, C, 3, dtype=dt, bias=cv.b, resid=h, out=h, out_f32=True,
                            ldx=x.shape[1])
-        tv = hip.conv1d(rbs, tmish, self.mlp.w, self.mlp.c_in, C, 1, dtype=dt, bias=self.mlp.b, out_f32=True)
+        # the time vector depends only on (Euler step, n_timesteps, batch size): cached across batches by the caller
+        tv = tv_cache.get(id(self)) if tv_cache is not None else None
+        if tv is None:
+            tv = hip.conv1d(rbs, tmish, self.mlp.w, self.mlp.c_in, C, 1, dtype=dt, bias=self.mlp.b, out_f32=True)
+            if tv_cache is not None:
+                tv_cache[id(self)] = tv
         h = hip.groupnorm_mish(rb, h, C, 8, self.gn1[0], self.gn1[1], dt, GN_EPS, addvec=tv)
         h = hip.conv1d(rb, h, self.conv2.w, self.conv2.c_in, C, 3, dtype=dt, bias=self.conv2.b)
         out = hip.groupnorm_mish(rb, h, C, 8, self.gn2[0], self.gn2[1], hip.F32, GN_EPS)
@@ -288,17 +293,24 @@ class _MatchaBase(torch.nn.Module):
         return P
 
     # one U-Net evaluation; x_t / mu_t: operand dtype (R, ld) with odim valid columns; x32: f32 state (R, odim)
-    def _estimator_step(self, P, rb, rb2, rbs, x32, mu_t, temb_rows, dt_step):
+    def _estimator_step(self, P, rb, rb2, rbs, x32, mu_t, temb_rows, dt_step, tkey=None):
         dt = P["dtype"]
         od = self.odim
         ld_in = P["d0"][0].conv1[0].c_in
         x_t = hip.affine_cast(x32, dt, ldy=ld_in)
-        t1 = hip.conv1d(rbs, temb_rows, P["t1"].w, P["t1"].c_in, P["t1"].n_out, 1, dtype=dt, bias=P["t1"].b, act=ACT_SWISH)
-        tm = hip.conv1d(rbs, t1, P["t2"].w, P["t2"].c_in, P["t2"].n_out, 1, dtype=dt, bias=P["t2"].b, act=ACT_MISH)
+        # time MLP + the per-ResNet time projections: functions of the Euler step only (t is a scalar shared by the
+        # batch, flow_matching.py:77-93) -> computed once per (n_timesteps, step, batch size) and reused
+        tcache = P.setdefault("tcache", {}).setdefault(tkey, {}) if tkey is not None else None
+        tm = tcache.get("tm") if tcache is not None else None
+        if tm is None:
+            t1 = hip.conv1d(rbs, temb_rows, P["t1"].w, P["t1"].c_in, P["t1"].n_out, 1, dtype=dt, bias=P["t1"].b, act=ACT_SWISH)
+            tm = hip.conv1d(rbs, t1, P["t2"].w, P["t2"].c_in, P["t2"].n_out, 1, dtype=dt, bias=P["t2"].b, act=ACT_MISH)
+            if tcache is not None:
+                tcache["tm"] = tm
 
         def stage(blk, rbx, xs):
             res, tbs = blk
-            h = res.run(rbx, rbs, xs, tm, dt)
+            h = res.run(rbx, rbs, xs, tm, dt, tv_cache=tcache)
             for t in tbs:
                 t.run(rbx, h, dt)
             return h
@@ -388,7 +400,8 @@ class _MatchaBase(torch.nn.Module):
             emb = 1000.0 * t * freq
             temb = torch.zeros(B, c_t)
             temb[:, :2 * half] = torch.cat((emb.sin(), emb.cos()))
-            self._estimator_step(P, rbo, rb2, rbs, x, mu_t, temb.to(dev).to(hip.torch_dtype(dt)), float(dt_s))
+            self._estimator_step(P, rbo, rb2, rbs, x, mu_t, temb.to(dev).to(hip.torch_dtype(dt)), float(dt_s),
+                                 tkey=(int(n_timesteps), step, B))
             t = t + dt_s
             if step < n_timesteps:
                 dt_s = t_span[step + 1] - t
