@@ -113,7 +113,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, DK>& tr, char* ks, 
 }
 
 template <typename T, int DK>
-__global__ __launch_bounds__(256, (DK <= 192 && sizeof(T) == 2) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
+__global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<T>::vec8 Vec;
   // K tile pitch: the score MFMAs read 16 key rows x 4 channel groups per ds_read_b128; with the pitch = 2 (mod 4)
@@ -159,12 +159,17 @@ __global__ __launch_bounds__(256, (DK <= 192 && sizeof(T) == 2) ? 2 : 1) void re
   const T* g_q = gg ? gg + ((int64_t)(row0 + qi_c) * H + h) * d.ldg : nullptr;
   const T* g_q1 = gg ? gg + ((int64_t)(row0 + (qi_c + 1 < Tn ? qi_c + 1 : qi_c)) * H + h) * d.ldg : nullptr;
 
+  // d_k <= 192: the next tile is prefetched into registers during the current tile's MFMAs.  d_k = 256 does not
+  // have the registers for that at 2 waves/SIMD: it loads and stores the tile back to back (still 16-byte batched)
+  // and relies on the second resident workgroup to cover the round trip.
+  constexpr bool PREFETCH = DK <= 192 || sizeof(T) != 2;
   TileRegs<T, DK> tr;
-  tile_load<T, DK>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
+  if (PREFETCH) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
   for (int j0 = j_start; j0 < Tn; j0 += KB) {
+    if (!PREFETCH) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec);
     tile_store<T, DK>(tr, ks, vs, kus, KP, VP);
     __syncthreads();
-    if (j0 + KB < Tn) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0 + KB, Tn, vt_vec);
+    if (PREFETCH && j0 + KB < Tn) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0 + KB, Tn, vt_vec);
 
     // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
     float bd[4][4];
