@@ -125,6 +125,18 @@ class OutputPipeline:
         self.pool.shutdown()
 
 
+_SPKEMB_CACHE = {}
+
+
+def load_spkemb(path):
+    """Per-file cache of precomputed speaker embeddings (JVS decodes 100 speakers x many utterances; the
+    reference re-runs the SpeechBrain extractor per utterance, tts_decode.py:209-212)."""
+    v = _SPKEMB_CACHE.get(path)
+    if v is None:
+        v = _SPKEMB_CACHE[path] = np.load(path).astype(np.float32)
+    return v
+
+
 def read_items(csv_path, token_column, converter):
     items = []
     with open(csv_path, newline="") as f:
@@ -205,7 +217,7 @@ def main(argv=None):
             if "spkemb_path" not in batch[0]:
                 raise NotImplementedError("speaker embeddings must be precomputed (csv column spkemb_path -> .npy); "
                                           "the SpeechBrain extractor is outside the hot path")
-            spk = torch.from_numpy(np.stack([np.load(it["spkemb_path"]) for it in batch])).float().to(device)
+            spk = torch.from_numpy(np.stack([load_spkemb(it["spkemb_path"]) for it in batch])).float().to(device)
             r = model.inference_batch(texts, spembs=spk, **kw)
         else:
             r = model.inference_batch(texts, **kw)
