@@ -688,7 +688,7 @@ __device__ __forceinline__ void stage_unit(char* lds, int pitch, int rows, int u
 static unsigned long long* g_trace = nullptr;  // profiling hook, see jatts_debug_trace
 static unsigned g_trace_cap = 0;
 template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8>
-__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN * 32)) * NT * 16 <= 128) ? 2 : 1) void resunit_kernel(jatts_resunit_desc d, unsigned long long* trace, unsigned trace_cap) {
+__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN * 32)) * NT * 16 <= 128) ? 2 : 1) void resunit_kernel(jatts_resunit_desc d, unsigned long long* trace, unsigned trace_cap, unsigned bias_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
   constexpr int NF = C / (WN * 32);
@@ -731,6 +731,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
   // staging / epilogues overlap another's MFMA phase.
   char* xs = smem;
   char* hs = smem;
+  // b1 | b2 live in LDS behind the tile: read per fragment in the epilogues as ds_read_b128 (~100 clk) instead of
+  // 8 dependent global loads each (the epilogue-1 body measured 11 k of a 59 k-clk workgroup lifetime at C=128, k=3,
+  // almost all of it load latency: tools/trace_unit.py)
+  float* bs = reinterpret_cast<float*>(smem + bias_off);
+  for (int u = threadIdx.x; u < 2 * C; u += blockDim.x) bs[u] = u < C ? d.b1[u] : d.b2[u - C];
 
   const T* xin[3] = {(const T*)d.x, nullptr, nullptr};
   if (JATTS_ABLATE != 2 && JATTS_ABLATE != 7 && JATTS_ABLATE != 12)
@@ -742,13 +747,28 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
   __syncthreads();
   JATTS_STAMP(2);
 
+  // the accumulators start at the bias (C layout: register 4q+e of fragment f <-> channel 32(nf0+f) + 8q + 4g + e), which
+  // takes 128 adds and the bias reads out of each epilogue's dependent chain
   f32x16 acc[NF][NT];
-  zero_acc<NF, NT>(acc);
+  auto bias_acc = [&](const float* bv) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bv + (nf0 + f) * 32 + 8 * q + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = bb[e];
+      }
+  };
+  bias_acc(bs);
   if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
 
   JATTS_STAMP(3);
   // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
   __syncthreads();  // every wave is done reading x: the tile may now be overwritten by h
+  JATTS_STAMP(10);
   // rows of h past the computed columns are only read by discarded output columns
   for (int u = threadIdx.x; u < (K - 1) * (C / 8); u += blockDim.x) {
     const int r = WGCOLS + u / (C / 8), cu = u % (C / 8);
@@ -757,22 +777,22 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
     for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
     Vec8IO<T>::sts(hs + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T), z);
   }
+  JATTS_STAMP(11);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = col0 + t * 32 + (lane & 31);
     const int pos = t0 - p2 + col;
-    const bool inside = pos >= 0 && pos < L;
+    const float keep = (pos >= 0 && pos < L) ? 1.f : 0.f;   // h is 0 outside the sequence (conv2's zero padding)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(d.b1 + n0);
         T o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = inside ? lrelu(acc[f][t][4 * q + e] + bb[e], d.slope) : 0.f;
-          o[e] = from_f32<T>(v);
+          const float a = acc[f][t][4 * q + e] * keep;
+          o[e] = from_f32<T>(fmaxf(a, a * d.slope));           // LeakyReLU for 0 < slope < 1: max(a, slope * a)
         }
         char* p = hs + (size_t)col * pitch + (size_t)n0 * sizeof(T);
         if (sizeof(T) == 2) {
@@ -783,10 +803,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
         }
       }
   }
+  JATTS_STAMP(12);
   __syncthreads();
   JATTS_STAMP(4);
 
-  zero_acc<NF, NT>(acc);
+  bias_acc(bs + C);
   if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
 
   JATTS_STAMP(5);
@@ -808,17 +829,16 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(d.b2 + n0);
         char* p = ys + (size_t)col * pitch + (size_t)n0 * sizeof(T);
         if (sizeof(T) == 2) {
           f16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)(acc[f][t][4 * q + e] + bb[e]);
+          for (int e = 0; e < 4; ++e) o[e] = (f16)acc[f][t][4 * q + e];
           *reinterpret_cast<f16x4*>(p) = o;
         } else {
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e] + bb[e];
+          for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e];
           *reinterpret_cast<f32x4*>(p) = o;
         }
       }
@@ -846,6 +866,8 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   const size_t pitch = C * sizeof(T) + 16;
   const size_t rows_x = WGCOLS + 2 * p1, rows_h = WGCOLS + K - 1;
   size_t lds = (rows_x > rows_h ? rows_x : rows_h) * pitch;  // h overlays x
+  const unsigned bias_off = (unsigned)lds;
+  lds += 2 * C * sizeof(float);                               // b1 | b2
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: tile exceeds 160 KiB LDS");
   static const int pad_lds = [] { const char* e = getenv("JATTS_RESUNIT_PADLDS"); return e ? atoi(e) : 0; }();
   if (pad_lds && lds < (size_t)pad_lds) lds = pad_lds;  // experiment knob: force fewer workgroups per CU
@@ -856,7 +878,7 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, g_trace, g_trace_cap);
+  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, g_trace, g_trace_cap, bias_off);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -902,6 +924,7 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
     return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: null pointer");
   if (d->x == d->y) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: y must not alias x");
   if (d->k_w < 1 || !(d->k_w & 1) || d->dil < 1) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: odd k_w and dil>=1 required");
+  if (!(d->slope >= 0.f && d->slope <= 1.f)) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: LeakyReLU slope must be in [0, 1]");
   if (d->rg.max_len <= 0) return JATTS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) {
@@ -922,7 +945,7 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
       case 644: return launch_resunit<f16, 64, 512, 1, 4, 4>(*d, s);
       case 1280:
         // 2 x (256 + 2*p1) rows x 272 B must fit in 160 KiB for 2 workgroups/CU: k=11, d=5 misses by 5 rows -> 3-fragment tile
-        if ((256 + (d->k_w - 1) * d->dil) * 272 * 2 > 160 * 1024) return launch_resunit<f16, 128, 192, 2, 3, 4>(*d, s);
+        if (((256 + (d->k_w - 1) * d->dil) * 272 + 1024) * 2 > 160 * 1024) return launch_resunit<f16, 128, 192, 2, 3, 4>(*d, s);
         return launch_resunit<f16, 128, 256, 2, 4, 4>(*d, s);
       case 1283: return launch_resunit<f16, 128, 256, 2, 4, 4>(*d, s);
       case 1281: return launch_resunit<f16, 128, 128, 2, 2, 8>(*d, s);

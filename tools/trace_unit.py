@@ -48,6 +48,7 @@ def main():
     t = buf.cpu().numpy().reshape(a.n, 16)
     t = t[t[:, 7] > 0]
     rt = t[:, 8:10].astype(np.float64)
+    t16 = t
     t = t[:, :8]
     hw = t[:, 0]
     xcc, hwid = hw >> 32, hw & 0xFFFFFFFF
@@ -59,6 +60,10 @@ def main():
     print(f"  workgroup lifetime: median {np.median(tot):9.0f} clk  mean {tot.mean():9.0f}")
     for i, nme in enumerate(PH):
         print(f"  {nme:14s} median {np.median(d[:, i]):9.0f} clk  mean {d[:, i].mean():9.0f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)")
+    ex = t16[:, 10:13].astype(np.float64)
+    if (ex > 0).all():
+        print(f"  inside 'h -> LDS': barrier wait {np.mean(ex[:, 0] - st[:, 2]):8.0f}  zero-fill {np.mean(ex[:, 1] - ex[:, 0]):8.0f}  "
+              f"bias+lrelu+LDS writes {np.mean(ex[:, 2] - ex[:, 1]):8.0f}  closing barrier {np.mean(st[:, 3] - ex[:, 2]):8.0f} clk (mean)")
     ghz = (tot / ((rt[:, 1] - rt[:, 0]) * 10.0)).mean()   # s_memrealtime ticks are 10 ns
     print(f"  s_memtime runs at {ghz:.3f} ticks/ns (vs the 100 MHz s_memrealtime)")
     # concurrency per CU: how many traced workgroups overlap in time on one CU
