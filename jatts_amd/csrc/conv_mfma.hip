@@ -649,6 +649,21 @@ __device__ __forceinline__ void unit_store_pass(const jatts_resunit_desc& d, con
   }
 }
 
+__device__ __forceinline__ void lrelu8(f16x8& v, float slope) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 x2 = {v[2 * i], v[2 * i + 1]};
+    const f16x2 y2 = {(f16)((float)x2[0] * slope), (f16)((float)x2[1] * slope)};   // rounded to f16 once, as the select form
+    const f16x2 m = __builtin_elementwise_max(x2, y2);                             // v_pk_max_f16
+    v[2 * i] = m[0];
+    v[2 * i + 1] = m[1];
+  }
+}
+__device__ __forceinline__ void lrelu8(f32x8& v, float slope) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+}
+
 // Unit-kernel staging: the WHOLE x tile (one input, LeakyReLU) in one batch of UB 16-byte loads per thread, all in
 // flight before the first is consumed.  The accumulators are not live yet, so the registers are free; the generic
 // 8-per-batch form paid 3 serial HBM round trips per tile (stage x = 29 % of a k=3 workgroup's lifetime, tools/trace_unit.py).
@@ -676,8 +691,10 @@ __device__ __forceinline__ void stage_unit(char* lds, int pitch, int rows, int u
       if (u >= total) continue;
       const int r = u / upr, cu = u - r * upr;
       if (pre_lrelu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[j][e] = from_f32<T>(lrelu(to_f32(v[j][e]), slope));
+        // LeakyReLU(x) = max(x, T(float(x) * slope)) for 0 <= slope <= 1: the product is rounded to T once (same value
+        // as the select form), the max runs in T -- for f16 that is one v_fma_mix per element + packed max instead of
+        // cvt, cmp, cndmask, mul, cvt
+        lrelu8(v[j], slope);
       }
       Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T), v[j]);
     }
