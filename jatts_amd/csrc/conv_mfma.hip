@@ -375,14 +375,11 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
         const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
         if (n0 >= d.n_out) continue;
         const bool full = n0 + 3 < d.n_out;
-        f32x4 bq = {0.f, 0.f, 0.f, 0.f}, rq = {0.f, 0.f, 0.f, 0.f};
-        if (full) {
-          if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n0);
-          if (vec_r) rq = *reinterpret_cast<const f32x4*>(d.resid + row * d.ldr + n0);
-        }
+        f32x4 rq = {0.f, 0.f, 0.f, 0.f};   // (the bias is already in the accumulators: conv1d_kernel's init)
+        if (full && vec_r) rq = *reinterpret_cast<const f32x4*>(d.resid + row * d.ldr + n0);
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[f][t][4 * q + e] + bq[e]) * d.alpha + rq[e];
+        for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[f][t][4 * q + e]) * d.alpha + rq[e];
         if (full && vec_y && (vec_r || !d.resid)) {
           const int64_t o = row * d.ldy + n0;
           if (d.y_is_f32 || sizeof(T) == 4) *reinterpret_cast<f32x4*>((float*)d.y + o) = v;
@@ -393,7 +390,7 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
             const int n = n0 + e;
             if (n >= d.n_out) break;
             float s = v[e];
-            if (!full) s = act_c<ACT>(acc[f][t][4 * q + e] + (d.bias ? d.bias[n] : 0.f)) * d.alpha;
+            if (!full) s = act_c<ACT>(acc[f][t][4 * q + e]) * d.alpha;
             if (d.resid && !(full && vec_r)) s += d.resid[row * d.ldr + n];
             const int64_t o = d.y_transposed ? (int64_t)n * d.ldy + trow : row * d.ldy + n;
             if (d.y_is_f32) ((float*)d.y)[o] = s; else ((T*)d.y)[o] = from_f32<T>(s);
@@ -426,11 +423,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x
       for (int q = 0; q < 4; ++q) {
         const int nl = (nf_local0 + f) * 32 + 8 * q + 4 * g;   // channel inside the workgroup's BN slab
         if (n_base + nl >= d.n_out) continue;                   // n_out % 8 == 0: quads are all-or-nothing
-        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-        if (d.bias) bq = *reinterpret_cast<const f32x4*>(d.bias + n_base + nl);
-        f32x4 o;
+        f32x4 o;   // the bias is already in the accumulators
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = act_c<ACT>(acc[f][t][4 * q + e] + bq[e]) * d.alpha;
+        for (int e = 0; e < 4; ++e) o[e] = act_c<ACT>(acc[f][t][4 * q + e]) * d.alpha;
         char* p = smem + (size_t)col * opitch + (size_t)nl * sizeof(TO);
         if (sizeof(TO) == 2) *reinterpret_cast<f16x4*>(p) = f16x4{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
         else *reinterpret_cast<f32x4*>(p) = o;
@@ -484,6 +479,26 @@ __global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kerne
   const T* xin[3] = {(const T*)d.x[0], (const T*)d.x[1], (const T*)d.x[2]};
   f32x16 acc[NF][NT];
   zero_acc<NF, NT>(acc);
+  if (d.bias) {   // accumulators start at the bias: its loads overlap the first staging round trip instead of the epilogue
+    const int gq = lane >> 5;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = (nf0 + f) * 32 + 8 * q + 4 * gq;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + 3 < d.n_out) bq = *reinterpret_cast<const f32x4*>(d.bias + n0);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + e < d.n_out) bq[e] = d.bias[n0 + e];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = bq[e];
+      }
+  }
 
   // staged 8-element units per thread in the async pipeline (halo <= 32 rows; larger halos take
   // the synchronous single-buffer path)
