@@ -118,14 +118,14 @@ struct StageRegs {
   V8 v[NIN][MAXU];
 };
 
-template <typename T, int MAXU, int NIN, int UPR = 8>
+template <typename T, int MAXU, int NIN, int UPR = 8, int NTHR = 256>
 __device__ __forceinline__ void stage_issue(StageRegs<T, MAXU, NIN>& sr, int rows, int pos0, int L, int64_t seq_row0,
                                             const T* const* x, int n_in, int ldx, int c0) {
   // UPR = 8-element units per row of the chunk (8 for a 64-channel chunk)
   const int total = rows * UPR;
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
-    const int u = threadIdx.x + j * blockDim.x;
+    const int u = threadIdx.x + j * NTHR;   // NTHR = blockDim.x at compile time: the index math folds
     const int r = u / UPR, cu = u % UPR;
     const int pos = pos0 + r;
     const bool ok = u < total && pos >= 0 && pos < L;
@@ -141,14 +141,14 @@ __device__ __forceinline__ void stage_issue(StageRegs<T, MAXU, NIN>& sr, int row
   }
 }
 
-template <typename T, int MAXU, int NIN, int UPR = 8>
+template <typename T, int MAXU, int NIN, int UPR = 8, int NTHR = 256>
 __device__ __forceinline__ void stage_commit(StageRegs<T, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in,
                                              float in_scale, int pre_act, float slope) {
   const int total = rows * UPR;
   const bool plain = n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE;
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
-    const int u = threadIdx.x + j * blockDim.x;
+    const int u = threadIdx.x + j * NTHR;
     if (u >= total) continue;
     const int r = u / UPR, cu = u % UPR;
     typename Elem<T>::vec8 o = sr.v[0][j];
@@ -511,15 +511,15 @@ __global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kerne
   if constexpr (ASYNC) {
     const size_t buf_bytes = (size_t)rows * pitch;
     StageRegs<T, MAXU, NIN> sr;
-    stage_issue<T, MAXU, NIN, UPRC>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0);
-    stage_commit<T, MAXU, NIN, UPRC>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
+    stage_issue<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0);
+    stage_commit<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     __syncthreads();
     for (int ci = 0; ci < n_chunks; ++ci) {
       const bool more = ci + 1 < n_chunks;
-      if (more) stage_issue<T, MAXU, NIN, UPRC>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT);
+      if (more) stage_issue<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT);
       conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0,
                                 lane);
-      if (more) stage_commit<T, MAXU, NIN, UPRC>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in,
+      if (more) stage_commit<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in,
                                            d.in_scale, d.pre_act, d.pre_slope);
       __syncthreads();
     }
@@ -617,18 +617,18 @@ int launch_conv(const jatts_conv_desc& d, hipStream_t s) {
 
 // Unit-kernel output pass: y = (acc + b2 tile in LDS) + x [+ MRF partners] with row-contiguous 16-byte accesses;
 // all global reads of a batch are issued before any is consumed (one round trip per batch, not per unit).
-template <typename T, int C, int UB, bool ADD>
+template <typename T, int C, int UB, bool ADD, int NTHR>
 __device__ __forceinline__ void unit_store_pass(const jatts_resunit_desc& d, const char* ys, int pitch, int vrows,
                                                 const T* xg, T* yg, int64_t g0) {
   typedef typename Elem<T>::vec8 V8;
   constexpr int UPR = C / 8;
   const int total = vrows * UPR;
   const bool has_add1 = ADD && d.add1 != nullptr;
-  for (int u0 = threadIdx.x; u0 < total; u0 += UB * blockDim.x) {
+  for (int u0 = threadIdx.x; u0 < total; u0 += UB * NTHR) {
     V8 xr[UB], a0[ADD ? UB : 1], a1[ADD ? UB : 1];
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
-      const int u = u0 + i * blockDim.x;
+      const int u = u0 + i * NTHR;
       if (u < total) {
         if (JATTS_ABLATE != 3) xr[i] = Vec8IO<T>::ldg(xg + g0 + (int64_t)u * 8);
         if (ADD) {
@@ -639,7 +639,7 @@ __device__ __forceinline__ void unit_store_pass(const jatts_resunit_desc& d, con
     }
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
-      const int u = u0 + i * blockDim.x;
+      const int u = u0 + i * NTHR;
       if (u >= total) continue;
       const int r = u / UPR, cu = u - r * UPR;
       V8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
@@ -682,16 +682,18 @@ __device__ __forceinline__ void lrelu8(f32x8& v, float slope) {
 // Unit-kernel staging: the WHOLE x tile (one input, LeakyReLU) in one batch of UB 16-byte loads per thread, all in
 // flight before the first is consumed.  The accumulators are not live yet, so the registers are free; the generic
 // 8-per-batch form paid 3 serial HBM round trips per tile (stage x = 29 % of a k=3 workgroup's lifetime, tools/trace_unit.py).
-template <typename T, int UB>
+template <typename T, int UB, int NTHR>
 __device__ __forceinline__ void stage_unit(char* lds, int pitch, int rows, int upr, int pos0, int L, int64_t seq_row0,
                                            const T* x, int ldx, bool pre_lrelu, float slope) {
   typedef typename Elem<T>::vec8 V8;
   const int total = rows * upr;
-  for (int base = threadIdx.x; base < total; base += blockDim.x * UB) {
+  // NTHR (= blockDim.x) and upr are compile-time: unit j of a thread is (row0 + j * NTHR / upr, same column), so the
+  // per-unit index arithmetic folds to one add -- every VALU op of this phase is paid ~3x under a co-resident MFMA wave
+  for (int base = threadIdx.x; base < total; base += NTHR * UB) {
     V8 v[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
-      const int u = base + j * blockDim.x;
+      const int u = base + j * NTHR;
       const int r = u / upr, cu = u - r * upr;
       const int pos = pos0 + r;
       if (u < total && pos >= 0 && pos < L) v[j] = Vec8IO<T>::ldg(x + (seq_row0 + pos) * (int64_t)ldx + cu * 8);
@@ -702,7 +704,7 @@ __device__ __forceinline__ void stage_unit(char* lds, int pitch, int rows, int u
     }
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
-      const int u = base + j * blockDim.x;
+      const int u = base + j * NTHR;
       if (u >= total) continue;
       const int r = u / upr, cu = u - r * upr;
       if (pre_lrelu) {
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
   {
     constexpr int NTHR = WN * WT * 64;
     constexpr int UBX = ((WGCOLS + 64) * (C / 8) + NTHR - 1) / NTHR;   // covers halos up to 32 rows a side in one batch
-    stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24))>(xs, pitch, rx, C / 8, t0 - p2 - p1, L, seq_row0, xin[0], C, JATTS_ABLATE != 1, d.slope);
+    stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24)), NTHR>(xs, pitch, rx, C / 8, t0 - p2 - p1, L, seq_row0, xin[0], C, JATTS_ABLATE != 1, d.slope);
   }
   __syncthreads();
   JATTS_STAMP(2);
@@ -881,8 +883,8 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, (C <= 256 && (C / (WN
     const int vrows = min(tt_out, L - t0);
     const int64_t g0 = (seq_row0 + t0) * (int64_t)C;  // the valid rows are contiguous in y: unit u <-> 8 elements at g0 + 8u
     constexpr bool keep_small = C <= 64;   // small-channel kernels live on occupancy (6 workgroups/CU): keep the batch short
-    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true>(d, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
-    else unit_store_pass<T, C, keep_small ? 4 : 8, false>(d, ys, pitch, vrows, xg, yg, g0);
+    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true, WN * WT * 64>(d, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
+    else unit_store_pass<T, C, keep_small ? 4 : 8, false, WN * WT * 64>(d, ys, pitch, vrows, xg, yg, g0);
   }
   JATTS_STAMP(7);
   if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();
