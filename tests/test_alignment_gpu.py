@@ -89,3 +89,26 @@ def test_alignment_module_and_viterbi_decode(cuda, lib, golden_dir):
     assert abs(float(bin_loss) - float(z["bin_loss"])) <= 1e-5
     ds2, _ = viterbi_decode(lp, torch.tensor(tl), torch.tensor(fl))   # end to end on the HIP log-probabilities
     assert np.array_equal(ds2.cpu().numpy(), z["ds"])
+
+
+def test_mas_limits_fail_loudly_and_empty_sequences_are_handled(cuda, lib):
+    from jatts_amd import hip
+    from jatts_amd._abi import JattsHipError
+    rng = np.random.default_rng(1)
+    # an utterance with no frames in the middle of the batch: durations 0, score 0, neighbours unaffected
+    fl, tl = [40, 0, 25], [7, 3, 5]
+    mats = [_logsoftmax(rng, f, t) for f, t in zip(fl, tl)]
+    rb_f, rb_t = hip.RaggedBatch(fl, cuda), hip.RaggedBatch(tl, cuda)
+    lp = torch.zeros(sum(fl), 8)
+    o = 0
+    for m in mats:
+        lp[o:o + m.shape[0], : m.shape[1]] = torch.tensor(m)
+        o += m.shape[0]
+    path, dur, score = hip.mas_viterbi(rb_f, rb_t, lp.to(cuda))
+    assert dur.cpu().tolist()[7:10] == [0, 0, 0] and float(score[1]) == 0.0
+    assert int(dur[:7].sum()) == 40 and int(dur[10:].sum()) == 25
+    # more than 1024 tokens, or decision bits beyond LDS: refused, not silently wrong
+    with pytest.raises(JattsHipError):
+        hip.mas_viterbi(hip.RaggedBatch([8], cuda), hip.RaggedBatch([1025], cuda), torch.zeros(8, 1032, device=cuda))
+    with pytest.raises(JattsHipError):
+        hip.mas_viterbi(hip.RaggedBatch([4000], cuda), hip.RaggedBatch([1000], cuda), torch.zeros(4000, 1000, device=cuda))
