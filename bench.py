@@ -96,12 +96,12 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:   # one process per GPU, RCCL over xGMI (backend "nccl" on ROCm); rendezvous from the torchrun env
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from jatts_amd import hip
     from jatts_amd.models import FastSpeech2
