@@ -42,8 +42,8 @@ class HiFiGANGenerator(torch.nn.Module):
         self.upsample_kernel_sizes = tuple(int(k) for k in upsample_kernel_sizes)
         self.resblock_kernel_sizes = tuple(int(k) for k in resblock_kernel_sizes)
         self.resblock_dilations = tuple(tuple(int(d) for d in ds) for ds in resblock_dilations)
-        if channels % (32 << len(self.upsample_scales)):
-            raise NotImplementedError("channels / 2**n_upsamples must be a multiple of 32 (MFMA tile)")
+        if channels % (1 << len(self.upsample_scales)) or channels > 512:
+            raise NotImplementedError("channels must be divisible by 2**n_upsamples and <= 512")
         self.hop = 1
         for s in self.upsample_scales:
             self.hop *= s
@@ -108,28 +108,58 @@ class HiFiGANGenerator(torch.nn.Module):
         sd = self.state_dict()
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
         P = {"key": key, "dtype": dt, "dev": dev}
-        P["in"] = PackedConv(sd["input_conv.weight"], sd["input_conv.bias"], dt, dev)
         nb = len(self.resblock_kernel_sizes)
         P["ups"], P["blocks"] = [], []
         supported = {hip.F16: (32, 64, 128, 256, 512), hip.F32: (32, 64, 128, 256)}[dt]
         P["unit_channels"] = supported
+
+        # Stage widths the fused unit has no tile for (HiFi-GAN V2/V3: 16, 8 ... channels) are zero-padded to the next
+        # supported width at load time: padded channels carry weight 0 and bias 0 everywhere (conv -> 0, LeakyReLU(0) = 0,
+        # residual + 0, zero input weights downstream), so the result is exact.
+        def cp(c):
+            for v in supported:
+                if c <= v:
+                    return v
+            raise NotImplementedError(f"{c} channels exceed the widest fused-unit tile for this precision")
+
+        def padw(w, n, c):   # (n0, c0, k) -> (n, c, k)
+            w = w.detach().float()
+            o = torch.zeros(n, c, w.shape[2], dtype=torch.float32)
+            o[: w.shape[0], : w.shape[1]] = w
+            return o
+
+        def padb(b, n):
+            o = torch.zeros(n, dtype=torch.float32)
+            o[: b.numel()] = b.detach().float()
+            return o
+
+        c_prev = hip.round_up(self.channels, 64)   # input conv feeds the generic conv: 64-channel chunks
+        P["in"] = PackedConv(padw(sd["input_conv.weight"], c_prev, sd["input_conv.weight"].shape[1]),
+                             padb(sd["input_conv.bias"], c_prev), dt, dev)
         for i, (s, uk) in enumerate(zip(self.upsample_scales, self.upsample_kernel_sizes)):
-            w = sd[f"upsamples.{i}.1.weight"].detach().float()
-            wc, pad = hip.convtranspose_as_conv(w, s, s // 2 + s % 2)
-            pc = PackedConv(wc, sd[f"upsamples.{i}.1.bias"].detach().float().repeat(s), dt, dev)
-            P["ups"].append((pc, pad, s, w.shape[1]))
+            w = sd[f"upsamples.{i}.1.weight"].detach().float()            # ConvTranspose1d: (c_in, c_out, k)
+            c_out = cp(w.shape[1])
+            if i + 1 < len(self.upsample_scales):
+                c_out = max(c_out, 64)   # this stage feeds the next polyphase conv (jatts_conv1d: 64-channel chunks)
+            wp = torch.zeros(c_prev, c_out, w.shape[2], dtype=torch.float32)
+            wp[: w.shape[0], : w.shape[1]] = w
+            wc, pad = hip.convtranspose_as_conv(wp, s, s // 2 + s % 2)
+            pc = PackedConv(wc, padb(sd[f"upsamples.{i}.1.bias"], c_out).repeat(s), dt, dev)
+            P["ups"].append((pc, pad, s, c_out))
             stage = []
             for j, rk in enumerate(self.resblock_kernel_sizes):
                 units = []
                 for di, d in enumerate(self.resblock_dilations[j]):
                     q = f"blocks.{i * nb + j}."
-                    cm = 32 if w.shape[1] in supported else 64  # fused unit takes c_in == channels
-                    c1 = PackedConv(sd[q + f"convs1.{di}.1.weight"], sd[q + f"convs1.{di}.1.bias"], dt, dev, c_mult=cm)
-                    c2 = PackedConv(sd[q + f"convs2.{di}.1.weight"], sd[q + f"convs2.{di}.1.bias"], dt, dev, c_mult=cm)
+                    c1 = PackedConv(padw(sd[q + f"convs1.{di}.1.weight"], c_out, c_out), padb(sd[q + f"convs1.{di}.1.bias"], c_out),
+                                    dt, dev, c_mult=32)   # fused unit takes c_in == channels
+                    c2 = PackedConv(padw(sd[q + f"convs2.{di}.1.weight"], c_out, c_out), padb(sd[q + f"convs2.{di}.1.bias"], c_out),
+                                    dt, dev, c_mult=32)
                     units.append((c1, c2, rk, d))
                 stage.append(units)
             P["blocks"].append(stage)
-        wo = sd["output_conv.1.weight"].detach().float()  # (1, C, k) -> [k][C]
+            c_prev = c_out
+        wo = padw(sd["output_conv.1.weight"], 1, c_prev)                  # (1, C, k) -> [k][C]
         P["out_w"] = f32(wo[0].t())
         P["out_b"] = float(sd["output_conv.1.bias"].detach().float()[0])
         self._prep = P

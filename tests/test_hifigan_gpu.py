@@ -20,10 +20,12 @@ def _small(params, channels=128):
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp16", 2e-2)])
 @pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K, 512), _small(HIFIGAN_V1_24K, 512),
+                                    # narrow generators (HiFi-GAN V3 / V2 widths): 16- and 8-channel stages are zero-padded to 32
+                                    _small(HIFIGAN_V1_22K, 256), _small(HIFIGAN_V1_22K, 128),
                                     # two ResBlocks, other kernels / dilations (MRF mean over 2, fused-mean with one partner)
                                     dict(_small(HIFIGAN_V1_22K, 256), upsample_scales=(4, 4, 4), upsample_kernel_sizes=(8, 8, 8),
                                          resblock_kernel_sizes=(3, 5), resblock_dilations=((1, 2), (2, 6, 3)))],
-                         ids=["22k", "24k", "odd-config"])
+                         ids=["22k", "24k", "v3-width-256", "v2-width-128", "odd-config"])
 def test_generator_matches_oracle(cuda, lib, prec, tol, params):
     from jatts_amd import hip
     from jatts_amd.vocoder import HiFiGANGenerator
@@ -70,7 +72,7 @@ def test_vocoder_decode_contract_and_normalisation(cuda, lib, golden_dir):
 
 
 def test_unsupported_channel_counts_raise(lib):
-    """channels / 2**n_upsamples < 32 (HiFi-GAN V2/V3 widths) is outside the MFMA tiling: refuse loudly, never fall back."""
+    """Widths beyond the widest fused-unit tile are refused loudly, never routed to a fallback."""
     from jatts_amd.vocoder import HiFiGANGenerator
     with pytest.raises(NotImplementedError):
-        HiFiGANGenerator(**_small(HIFIGAN_V1_22K, 256))
+        HiFiGANGenerator(**_small(HIFIGAN_V1_22K, 1024))
