@@ -48,17 +48,19 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
+    dt = hip.F16 if a.dtype == "f16" else hip.F32
     if a.all:
         tot = 0.0
         for C in (256, 128, 64, 32):
             for k in (3, 7, 11):
                 for d in (1, 3, 5):
-                    tot += run(C, k, d, rates[C], a.iters)
+                    tot += run(C, k, d, rates[C], a.iters, dtype=dt)
         print(f"sum over the 36 units of one generator pass: {tot:.2f} ms")
     else:
-        run(a.C, a.k, a.dil, rates[a.C], a.iters, B=a.batch)
+        run(a.C, a.k, a.dil, rates[a.C], a.iters, B=a.batch, dtype=dt)
 
 
 if __name__ == "__main__":

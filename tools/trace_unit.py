@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--k", type=int, default=11)
     ap.add_argument("--dil", type=int, default=1)
     ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}
     dev = torch.device("cuda:0")
@@ -30,11 +31,12 @@ def main():
     rb = hip.RaggedBatch([T] * B, dev)
     rows = B * T * rate
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = (torch.randn(rows, a.C, generator=g) * 0.5).to(dev).half()
+    dt = hip.F16 if a.dtype == "f16" else hip.F32
+    x = (torch.randn(rows, a.C, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
     y = torch.empty_like(x)
-    w = [hip.pack_conv_weight((torch.randn(a.C, a.C, a.k, generator=g) / (a.C * a.k) ** 0.5).to(dev), hip.F16, 32) for _ in range(2)]
+    w = [hip.pack_conv_weight((torch.randn(a.C, a.C, a.k, generator=g) / (a.C * a.k) ** 0.5).to(dev), dt, 32) for _ in range(2)]
     b = torch.zeros(a.C, device=dev)
-    run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, hip.F16)
+    run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, dt)
     run()
     torch.cuda.synchronize()
     lib = _abi.load()
