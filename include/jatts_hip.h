@@ -281,12 +281,14 @@ int jatts_add_seq_vector(const jatts_ragged* rg, float* hs, int32_t dim, const f
  * Length regulator (modules/length_regulator.py:70-97), bit-exact integer path.
  * Step 1: d_eff = (alpha == 1) ? d : (int64) rint((float)d * alpha)   [half-to-even],
  *         cum[row] = inclusive prefix sum of d_eff inside each sequence, olens[b] = total.
- *         force_ones != 0 sets every d_eff to 1 (the whole-batch-zero rule, :85-94; the
- *         host decides after reading olens).
+ *         zero_rule (the all-zero rule, :85-94): 0 = none; 1 = every d_eff of every sequence is 1; 2 = per sequence,
+ *         as the reference's B=1 inference() behaves: a sequence whose d_eff sum to 0 gets every entry 1, and
+ *         olens must then hold 2*n_seq entries, olens[n_seq + b] = 1 where the rule fired (the host logs the
+ *         reference's warning), else 0.
  * Step 2: out[cu_out[b] + f][:] = x[cu_rows[b] + idx][:], idx = #{t : cum[t] <= f};
  *         frame_index (optional) receives idx as int64.
  * ------------------------------------------------------------------------------- */
-int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, int32_t force_ones,
+int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, int32_t zero_rule,
                        int64_t* d_eff, int64_t* cum, int64_t* olens, void* stream);
 int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, const int32_t* cu_out,
                     int32_t max_out_len, const float* x, int32_t dim, float* out,

@@ -471,7 +471,7 @@ __global__ void flip_kernel(const float* x, float* y, int64_t rows, int C) {
 // -------------------------------------------------------------------- length regulator
 // One 256-thread block per sequence: alpha rounding + inclusive scan (int64, exact).
 __global__ __launch_bounds__(256) void lr_durations_kernel(jatts_ragged rg, const int64_t* d, float alpha,
-                                                           int force_ones, int64_t* d_eff, int64_t* cum,
+                                                           int zero_rule, int64_t* d_eff, int64_t* cum,
                                                            int64_t* olens) {
   __shared__ int64_t part[256];
   const int b = blockIdx.x;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void lr_durations_kernel(jatts_ragged rg, cons
   int64_t s = 0;
   for (int t = lo; t < hi; ++t) {
     int64_t v = d[row0 + t];
-    if (force_ones) v = 1;
+    if (zero_rule == 1) v = 1;
     else if (alpha != 1.0f) v = (int64_t)rintf((float)v * alpha);  // torch.round(ds.float()*alpha).long()
     d_eff[row0 + t] = v;
     s += v;
@@ -495,12 +495,19 @@ __global__ __launch_bounds__(256) void lr_durations_kernel(jatts_ragged rg, cons
     part[threadIdx.x] += add;
     __syncthreads();
   }
-  int64_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  // zero_rule 2: a sequence whose durations sum to 0 gets every entry = 1 -- what the reference's B=1 inference() does with
+  // it (length_regulator.py:86-94: `ds[ds.sum(dim=1).eq(0)] = 1` once the batch, i.e. that utterance, sums to 0)
+  const bool fallback = zero_rule == 2 && part[255] == 0 && L > 0;
+  int64_t run = fallback ? lo : (threadIdx.x ? part[threadIdx.x - 1] : 0);
   for (int t = lo; t < hi; ++t) {
+    if (fallback) d_eff[row0 + t] = 1;
     run += d_eff[row0 + t];
     cum[row0 + t] = run;
   }
-  if (threadIdx.x == 255) olens[b] = part[255];
+  if (threadIdx.x == 255) {
+    olens[b] = fallback ? L : part[255];
+    if (zero_rule == 2) olens[gridDim.x + b] = fallback ? 1 : 0;
+  }
 }
 
 // One wave per output frame: idx = #{t : cum[t] <= f} (upper bound), then copy the row.
@@ -919,11 +926,12 @@ extern "C" int jatts_add_seq_vector(const jatts_ragged* rg, float* hs, int32_t d
   return JATTS_OK;
 }
 
-extern "C" int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, int32_t force_ones,
+extern "C" int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, int32_t zero_rule,
                                   int64_t* d_eff, int64_t* cum, int64_t* olens, void* stream) {
   if (!rg || !d || !d_eff || !cum || !olens) return jatts_set_error_msg(JATTS_ERR_ARG, "lr_durations: null pointer");
+  if (zero_rule < 0 || zero_rule > 2) return jatts_set_error_msg(JATTS_ERR_ARG, "lr_durations: zero_rule must be 0, 1 or 2");
   if (rg->n_seq <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(lr_durations_kernel, dim3((unsigned)rg->n_seq), dim3(256), 0, S_, *rg, d, alpha, force_ones, d_eff, cum, olens);
+  hipLaunchKernelGGL(lr_durations_kernel, dim3((unsigned)rg->n_seq), dim3(256), 0, S_, *rg, d, alpha, zero_rule, d_eff, cum, olens);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -12,34 +12,62 @@ import torch.distributed as dist
 from .hostlogic import shard_utterances  # noqa: F401  (re-exported)
 
 
-def gather_audio(wave, lens, group=None):
-    """All-gather variable-length audio.
+def gather_audio(wave, lens, max_utts=None, group=None, pcm16=None):
+    """All-gather-v of variable-length audio: flat buffer + offsets, no padding to the longest rank.
 
-    wave: (sum(lens),) float tensor of this rank's packed waveforms; lens: list[int] samples per
-    local utterance.  Returns (list over ranks of packed tensors, list over ranks of lens).
-    Two collectives: lengths (tiny) then ONE flat padded payload.
+    wave: (sum(lens),) packed waveforms of this rank (f32 in [-1, 1], or int16 PCM already); lens: samples per local
+    utterance.  Float audio on the GPU is first converted to int16 PCM by the jatts_pcm16 kernel -- the format
+    tts_decode.py:250-255 stores anyway (sf.write(..., "PCM_16")) and half the bytes on xGMI.  ``pcm16=False`` keeps
+    the input dtype.  ``max_utts``: an upper bound on utterances per rank known to every rank (the batch size); when
+    omitted it is agreed on with one extra tiny all-reduce.
+    Returns (list over ranks of packed tensors -- views of one flat buffer --, list over ranks of lens).
+
+    Two collectives: (1) one fixed-size header all-gather [n_utts, n_samples, lens...]; (2) the payload as ONE
+    grouped all-gather-v (RCCL: torch's uneven all_gather = a coalesced group of broadcasts straight into the flat
+    buffer; gloo, used by the CPU tests: the same broadcasts issued one by one).
     """
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     dev = wave.device
-    n_local = torch.tensor([len(lens), int(wave.numel())], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    max_utts = max(int(c[0]) for c in counts)
-    max_samples = max(int(c[1]) for c in counts)
-    lens_t = torch.zeros(max_utts, dtype=torch.int64, device=dev)
-    lens_t[: len(lens)] = torch.tensor(lens, dtype=torch.int64, device=dev)
-    all_lens = torch.empty(world * max_utts, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_lens, lens_t, group=group)
-    payload = wave if wave.numel() == max_samples else torch.cat(
-        [wave, wave.new_zeros(max_samples - wave.numel())])
-    out = torch.empty(world * max_samples, dtype=wave.dtype, device=dev)
-    dist.all_gather_into_tensor(out, payload.contiguous(), group=group)
-    waves, lens_out = [], []
-    for r in range(world):
-        n_u, n_s = int(counts[r][0]), int(counts[r][1])
-        waves.append(out[r * max_samples: r * max_samples + n_s])
-        lens_out.append(all_lens[r * max_utts: r * max_utts + n_u].tolist())
-    return waves, lens_out
+    if pcm16 is None:
+        pcm16 = wave.is_cuda and wave.is_floating_point()
+    if pcm16 and wave.is_floating_point():
+        from . import hip
+        wave = hip.pcm16(wave.float().contiguous())
+    wave = wave.contiguous()
+    if max_utts is None:
+        m = torch.tensor([len(lens)], dtype=torch.int64, device=dev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        max_utts = int(m)
+    if len(lens) > max_utts:
+        raise ValueError("gather_audio: more local utterances than max_utts")
+    head = torch.zeros(max_utts + 2, dtype=torch.int64)
+    head[0], head[1] = len(lens), int(wave.numel())
+    if lens:
+        head[2:2 + len(lens)] = torch.tensor(lens, dtype=torch.int64)
+    heads = torch.empty(world * (max_utts + 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads, head.to(dev), group=group)
+    heads = heads.view(world, max_utts + 2).cpu()
+    n_utts, n_samp = heads[:, 0].tolist(), heads[:, 1].tolist()
+    offs = [0]
+    for n in n_samp:
+        offs.append(offs[-1] + n)
+    flat = torch.empty(offs[-1], dtype=wave.dtype, device=dev)
+    parts = [flat[offs[r]:offs[r + 1]] for r in range(world)]
+    esz = wave.element_size()
+    as_bytes = (lambda t: t.view(torch.uint8)) if esz != 1 and wave.dtype == torch.int16 else (lambda t: t)  # RCCL has no int16 type
+    if offs[-1] > 0:
+        backend = dist.get_backend(group)
+        if backend == "nccl" and all(n > 0 for n in n_samp):
+            dist.all_gather([as_bytes(p) for p in parts], as_bytes(wave), group=group)
+        else:
+            parts[rank].copy_(wave)
+            works = [dist.broadcast(as_bytes(parts[r]), src=dist.get_global_rank(group, r) if group is not None else r,
+                                    group=group, async_op=True) for r in range(world) if n_samp[r] > 0]
+            for w in works:
+                w.wait()
+    lens_out = [heads[r, 2:2 + n_utts[r]].tolist() for r in range(world)]
+    return parts, lens_out
 
 
 def unshard(waves, lens_per_rank, parts):

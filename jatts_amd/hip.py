@@ -383,16 +383,30 @@ def add_seq_vector(rb, hs, vec):
     return hs
 
 
-def lr_durations(rb, d, alpha=1.0, force_ones=False):
+def lr_durations(rb, d, alpha=1.0, zero_rule=2):
+    """-> (d_eff, cum, olens int64 (n_seq,), fallback int64 (n_seq,) or None).  zero_rule 2 (default): an utterance whose
+    durations sum to 0 gets all ones, as the reference's B=1 inference() does; ``fallback`` marks those utterances."""
     lib = _abi.load()
     d_eff = torch.empty_like(d)
     cum = torch.empty_like(d)
-    olens = torch.empty(rb.n_seq, dtype=torch.int64, device=d.device)
+    buf = torch.empty(2 * rb.n_seq, dtype=torch.int64, device=d.device)
     rg = rb.struct()
-    _abi.check(lib.jatts_lr_durations(C.byref(rg), _dev(d).data_ptr(), float(alpha), int(force_ones),
-                                      d_eff.data_ptr(), cum.data_ptr(), olens.data_ptr(), _stream()),
+    _abi.check(lib.jatts_lr_durations(C.byref(rg), _dev(d).data_ptr(), float(alpha), int(zero_rule),
+                                      d_eff.data_ptr(), cum.data_ptr(), buf.data_ptr(), _stream()),
                "jatts_lr_durations")
-    return d_eff, cum, olens
+    return d_eff, cum, buf[:rb.n_seq], (buf[rb.n_seq:] if zero_rule == 2 else None)
+
+
+def lr_sizes(rb, d, alpha=1.0):
+    """lr_durations + the one host sync of the path: -> (d_eff, cum, olens list).  Logs the reference's warning
+    (length_regulator.py:87-90) for utterances that took the all-zero fallback."""
+    d_eff, cum, olens, fb = lr_durations(rb, d, alpha)
+    host = torch.cat([olens, fb]).tolist()
+    olens_h, fb_h = host[:rb.n_seq], host[rb.n_seq:]
+    if any(fb_h):
+        import logging
+        logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
+    return d_eff, cum, olens_h
 
 
 def lr_gather(rb_in, cum, rb_out, x, want_index=False):

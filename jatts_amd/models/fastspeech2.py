@@ -166,7 +166,8 @@ class FastSpeech2(torch.nn.Module):
         P["emb"] = f32(sd["encoder.embed.0.weight"])
         P["enc"] = ConformerRunner(sd, "encoder.", self.aheads, dt, dev)
         P["dec"] = ConformerRunner(sd, "decoder.", self.aheads, dt, dev)
-        P["dur"] = _Predictor(sd, "duration_predictor.", dt, dev)
+        P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32: durations are integers, a
+        # rounding-boundary flip under f16 would change the utterance length (the trunk is 0.3 % of the FLOPs)
         P["pitch"] = _Predictor(sd, "pitch_predictor.", dt, dev)
         P["energy"] = _Predictor(sd, "energy_predictor.", dt, dev)
         for nm in ("pitch_embed", "energy_embed"):
@@ -234,7 +235,8 @@ class FastSpeech2(torch.nn.Module):
         hs_t = hip.affine_cast(hs, dt)
         p_outs = hip.predictor_head(P["pitch"].trunk(rb, hs_t), P["pitch"].w, P["pitch"].b)
         e_outs = hip.predictor_head(P["energy"].trunk(rb, hs_t), P["energy"].w, P["energy"].b)
-        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs_t), P["dur"].w, P["dur"].b, want_duration=True)
+        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
+                                          want_duration=True)
         hip.variance_embed_add(rb, hs, p_outs, P["pitch_embed"][0], P["pitch_embed"][1],
                                e_outs, P["energy_embed"][0], P["energy_embed"][1])
         if taps is not None:
@@ -245,14 +247,7 @@ class FastSpeech2(torch.nn.Module):
             if d_used.numel() != rb.total:
                 raise ValueError("durations do not match texts")
         # length regulator (length_regulator.py:70-97): the one host sync of the path — output sizes
-        d_eff, cum, olens = hip.lr_durations(rb, d_used, alpha)
-        olens_h = olens.tolist()
-        if sum(olens_h) == 0:
-            logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
-            d_eff, cum, olens = hip.lr_durations(rb, d_used, alpha, force_ones=True)
-            olens_h = olens.tolist()
-        if min(olens_h) <= 0:
-            raise RuntimeError("an utterance has zero output frames (all durations 0)")
+        d_eff, cum, olens_h = hip.lr_sizes(rb, d_used, alpha)   # an all-zero utterance gets all ones, as the reference's B=1 call
         rbo = hip.RaggedBatch(olens_h, dev)
         if taps is not None:
             ys, fidx = hip.lr_gather(rb, cum, rbo, hs, want_index=True)

@@ -258,7 +258,7 @@ class _MatchaBase(torch.nn.Module):
         P = {"key": key, "dtype": dt, "dev": dev}
         P["emb"] = f32(sd["encoder.embed.0.weight"])
         P["enc"] = ConformerRunner(sd, "encoder.", self.aheads, dt, dev)  # legacy rel-pos (matchatts_mas.py:196-218)
-        P["dur"] = _Predictor(sd, "duration_predictor.", dt, dev)
+        P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
         P["eproj"] = PackedConv(sd["encoder_proj.weight"], sd["encoder_proj.bias"], dt, dev)
         if self.spk_embed_dim is not None:
             P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
@@ -360,17 +360,12 @@ class _MatchaBase(torch.nn.Module):
             pj = P["proj"]
             sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
             hip.add_seq_vector(rb, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
-        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hip.affine_cast(hs, dt)), P["dur"].w, P["dur"].b,
+        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
                                           want_duration=True)
         d_used = d_pred
         if durations is not None:
             d_used = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
-        d_eff, cum, olens_t = hip.lr_durations(rb, d_used)
-        olens = olens_t.tolist()                                   # host sync: output sizes
-        if sum(olens) == 0:
-            logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
-            d_eff, cum, olens_t = hip.lr_durations(rb, d_used, force_ones=True)
-            olens = olens_t.tolist()
+        d_eff, cum, olens = hip.lr_sizes(rb, d_used)                # host sync: output sizes (all-zero utterances -> all ones)
         olens = [n - n % 2 for n in olens]                         # matchatts_mas.py:521-526: even lengths
         if min(olens) <= 0:
             raise RuntimeError("an utterance has fewer than 2 output frames")

@@ -167,7 +167,7 @@ class VITS(torch.nn.Module):
         P["dec"] = ConformerRunner(sd, "decoder.", self.aheads, dt, dev, rel_style="new")
         P["te_proj"] = PackedConv(sd["text_encoder.proj.weight"], sd["text_encoder.proj.bias"], dt, dev)
         P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
-        P["dur"] = _Predictor(sd, "duration_predictor.", dt, dev)
+        P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
         flows = []
         for i in range(self.flow_flows):
             q = f"flow.flows.{2 * i}."
@@ -214,16 +214,12 @@ class VITS(torch.nn.Module):
         vec = hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b,
                          out_f32=True)
         hip.add_seq_vector(rb, hs, vec)
-        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hip.affine_cast(hs, dt)), P["dur"].w, P["dur"].b,
+        logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
                                           want_duration=True)
         d_used = d_pred
         if durations is not None:
             d_used = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
-        olens = hip.lr_durations(rb, d_used)[2].tolist()                   # per-utterance frame counts (host sync)
-        if sum(olens) == 0:
-            logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
-            d_used = torch.ones_like(d_used)
-            olens = list(lens)
+        d_used, _, olens = hip.lr_sizes(rb, d_used)                        # per-utterance frame counts (host sync)
         if min(olens) <= 0:
             raise RuntimeError("an utterance has zero output frames (all durations 0)")
         rbo = hip.RaggedBatch(olens, dev)

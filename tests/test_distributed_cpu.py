@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: the N>1 exchange step (lengths + one audio all-gather) and the
-shard/unshard bookkeeping.  The synthesis itself needs no collective."""
+"""CPU, world_size 2 and 4 over gloo: the N>1 exchange step (header all-gather + one int16 PCM all-gather-v) and the
+shard/unshard bookkeeping, with ragged shards and ranks that own no utterance.  The synthesis itself needs no
+collective."""
 import os
 import socket
 
@@ -16,31 +17,34 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _pcm(i, n):
+    return ((torch.arange(n, dtype=torch.int32) * 7 + 1000 * i) % 30000 - 15000).to(torch.int16)
+
+
+def _worker(rank, world, port, q, lens_all, max_utts):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from jatts_amd.distributed import gather_audio, shard_utterances, unshard
 
-    lens_all = [700, 30, 512, 64, 5]           # samples per utterance (global order)
     parts = shard_utterances(lens_all, world)
     mine = parts[rank]
-    # "synthesise": utterance i is a ramp tagged with its id
-    waves = [torch.arange(lens_all[i], dtype=torch.float32) + 1000.0 * i for i in mine]
-    packed = torch.cat(waves) if waves else torch.zeros(0)
-    got, lens = gather_audio(packed, [lens_all[i] for i in mine])
+    # "synthesise": utterance i is an int16 PCM ramp tagged with its id (the GPU path converts f32 -> PCM with jatts_pcm16)
+    waves = [_pcm(i, lens_all[i]) for i in mine]
+    packed = torch.cat(waves) if waves else torch.zeros(0, dtype=torch.int16)
+    got, lens = gather_audio(packed, [lens_all[i] for i in mine], max_utts=max_utts)
     full = unshard(got, lens, parts)
-    ok = all(torch.equal(full[i], torch.arange(lens_all[i], dtype=torch.float32) + 1000.0 * i)
-             for i in range(len(lens_all)))
+    ok = all(torch.equal(full[i], _pcm(i, lens_all[i])) for i in range(len(lens_all)))
+    ok = ok and got[0].dtype == torch.int16 and sum(g.numel() for g in got) == sum(lens_all)   # flat, unpadded
     q.put((rank, ok, [len(p) for p in parts]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_audio_world2():
+def _run(world, lens_all, max_utts):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, lens_all, max_utts)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -48,4 +52,18 @@ def test_gather_audio_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
-    assert res[0][2] == [3, 2]
+    return sorted(res)[0][2]
+
+
+def test_gather_audio_world2():
+    assert _run(2, [700, 30, 512, 64, 5], 3) == [3, 2]
+
+
+def test_gather_audio_world4_ragged_with_empty_ranks():
+    """3 utterances on 4 ranks: one rank owns nothing; max_utts agreed on by the extra all-reduce (None)."""
+    assert sorted(_run(4, [4000, 17, 901], None)) == [0, 1, 1, 1]
+
+
+def test_gather_audio_world4_many():
+    counts = _run(4, [100 + 37 * i for i in range(11)], 3)
+    assert sum(counts) == 11 and max(counts) == 3

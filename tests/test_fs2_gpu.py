@@ -96,3 +96,40 @@ def test_no_cpu_fallback(lib):
     m = FastSpeech2(idim=20, **FS2_SMALL)
     with pytest.raises(JattsHipError):
         m.inference(torch.tensor([1, 2, 3]))
+
+
+@pytest.mark.parametrize("name,cfg,idim", [("fs2_small.npz", FS2_SMALL, 20), ("fs2_jsut.npz", FS2_JSUT, 45)])
+def test_fs2_fp16_predicted_durations_match_reference(cuda, lib, name, cfg, idim):
+    """Fast mode must not change utterance lengths: the duration trunk always runs in f32, so the integer durations
+    predicted under precision='fp16' equal the reference's (no teacher forcing here)."""
+    z, keys = load_golden(name)
+    m = _model(cfg, idim, keys, 0, cuda, "fp16")
+    u = 0
+    while f"u{u}_text" in z.files:
+        alpha = float(z[f"u{u}_alpha"]) if f"u{u}_alpha" in z.files else 1.0
+        r = m.inference_batch([torch.tensor(z[f"u{u}_text"]).to(cuda)], alpha=alpha)
+        assert torch.equal(r["duration"].cpu(), torch.tensor(z[f"u{u}_duration"])), f"{name} u{u}"
+        assert r["feat_gen"].shape == z[f"u{u}_feat_gen"].shape
+        u += 1
+
+
+def test_all_zero_utterance_inside_a_batch(cuda, lib, caplog):
+    """length_regulator.py:86-94 through the reference's B=1 inference(): an utterance whose durations are all 0 gets every
+    duration = 1 (with the reference's warning) -- also when it sits in a batch with normal utterances, which keep theirs."""
+    z, keys = load_golden("fs2_small.npz")
+    m = _model(FS2_SMALL, 20, keys, 0, cuda, "fp32")
+    texts = [torch.tensor(z[f"u{u}_text"]).to(cuda) for u in range(3)]
+    durs = [torch.tensor(z[f"u{u}_duration"]) for u in range(3)]
+    durs[1] = torch.zeros_like(durs[1])
+    with caplog.at_level("WARNING"):
+        r = m.inference_batch(texts, durations=durs)
+    assert any("all 0 sequences" in rec.message for rec in caplog.records)
+    assert r["olens"][1] == len(texts[1]) and r["olens"][0] == int(durs[0].sum()) and r["olens"][2] == int(durs[2].sum())
+    alone = m.inference_batch([texts[1]], durations=[torch.ones_like(durs[1])])
+    o = r["olens"][0]
+    assert maxdiff(r["feat_gen"][o:o + r["olens"][1]], alone["feat_gen"]) <= 1e-4
+    normal = m.inference_batch([texts[0]], durations=[durs[0]])
+    assert maxdiff(r["feat_gen"][:o], normal["feat_gen"]) <= 1e-4
+    # the whole batch all-zero: every utterance takes the fallback, none raises
+    r0 = m.inference_batch(texts, durations=[torch.zeros_like(d) for d in durs])
+    assert r0["olens"] == [len(t) for t in texts]

@@ -355,7 +355,7 @@ def test_length_regulator_bit_exact(cuda, lib, alpha):
     d[128] = 2  # the length-1 utterance must produce frames
     x = torch.randn(sum(lens), dim, generator=g)
     rb = _ragged(lens, cuda)
-    d_eff, cum, olens = hip.lr_durations(rb, d.to(cuda), alpha)
+    d_eff, cum, olens, _ = hip.lr_durations(rb, d.to(cuda), alpha, zero_rule=0)
     o = 0
     want_olens = []
     for n in lens:
@@ -384,9 +384,9 @@ def test_length_regulator_golden_kats(cuda, lib, golden_dir):
         B, T = ds.shape
         rb = _ragged([T] * B, cuda)
         d = torch.tensor(ds).reshape(-1).to(cuda)
-        d_eff, cum, olens = hip.lr_durations(rb, d, alpha)
-        if sum(olens.tolist()) == 0:  # whole-batch-zero rule, length_regulator.py:85-94 (host decides)
-            d_eff, cum, olens = hip.lr_durations(rb, d, alpha, force_ones=True)
+        d_eff, cum, olens, _ = hip.lr_durations(rb, d, alpha, zero_rule=0)
+        if sum(olens.tolist()) == 0:  # the reference's BATCHED call applies the rule only when the whole batch sums to 0 (:85-94)
+            d_eff, cum, olens, _ = hip.lr_durations(rb, d, alpha, zero_rule=1)
         ol = olens.tolist()
         assert max(ol) == ref.shape[1], (n, ol, ref.shape)
         x = torch.tensor(xs).reshape(B * T, -1).to(cuda)
