@@ -20,7 +20,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .fs2_oracle import Sub, conformer_stack, duration_from_log, duration_predictor_log
+from .fs2_oracle import Sub, conformer_stack, duration_from_log, duration_predictor_log, length_regulate
 from .vits_oracle import gaussian_upsample
 
 
@@ -113,8 +113,9 @@ def estimator(sd, prefix, x, mu, t, heads):
 
 
 def matcha_inference(sd, text, enc_heads, dec_heads, noise, n_timesteps=10, temperature=0.667, durations=None,
-                     spembs=None, taps=None):
-    """MatchaTTS_MAS.inference (matchatts_mas.py:552-642) for feats=None, with injected noise (T', odim)."""
+                     spembs=None, taps=None, hard_lr=False):
+    """MatchaTTS_MAS.inference (matchatts_mas.py:552-642) for feats=None, with injected noise (T', odim).
+    hard_lr=True: the tts1 `MatchaTTS` class instead (matchatts.py:423-427,482-558: LengthRegulator on the predicted durations)."""
     emb = sd["encoder.embed.0.weight"][text]
     hs = conformer_stack(emb, Sub(sd, "encoder."), enc_heads)
     if spembs is not None and "projection.weight" in sd:
@@ -122,7 +123,7 @@ def matcha_inference(sd, text, enc_heads, dec_heads, noise, n_timesteps=10, temp
     logd = duration_predictor_log(hs, Sub(sd, "duration_predictor."))
     d_pred = duration_from_log(logd)
     d_used = d_pred if durations is None else durations
-    up = gaussian_upsample(hs, d_used)
+    up = length_regulate(hs, d_used)[0] if hard_lr else gaussian_upsample(hs, d_used)
     mu = F.linear(up, sd["encoder_proj.weight"], sd["encoder_proj.bias"])
     T = mu.shape[0] - mu.shape[0] % 2           # matchatts_mas.py:521-526: even length
     mu = mu[:T]

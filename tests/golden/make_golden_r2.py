@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Round-2 golden vectors, again captured by importing the REAL reference from /root/reference (build container
+only; the fixtures are data: ids, durations, injected noise, outputs -- weights are rebuilt from seeds):
+
+  matcha_jsut.npz        full-width BASELINE config 3 model (MATCHA_MAS_JSUT: U-Net 512/512, attention head dim 256),
+                         10 Euler steps, temperature 0.667, one short utterance          [diffusers attention = SDPA stand-in]
+  vits_jsut.npz          full-width BASELINE config 5 model (VITS_JSUT + 192-d speaker embedding), two short utterances
+  matcha_tts1_small.npz  the tts1 `MatchaTTS` class (hard LengthRegulator), small config, 4 Euler steps
+  fs2_forward_small.npz  FastSpeech2.forward() -- the training-time, teacher-forced, PADDED batched pass
+                         (fastspeech2.py:473-564): before_outs / after_outs / d_outs / p_outs / e_outs for a ragged batch
+
+    python tests/golden/make_golden_r2.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G  # noqa: E402
+
+from jatts_amd.synthetic import (FS2_SMALL, MATCHA_MAS_JSUT, VITS_JSUT, matcha_golden_tweaks,  # noqa: E402
+                                 synth_state_dict)
+
+np_ = G.np_
+
+
+def with_noise(seed, fn):
+    """Run fn() with torch.randn_like replaced by a seeded generator; returns (result, the noise drawn)."""
+    holder = {}
+    real = torch.randn_like
+
+    def fake(t, *a, **k):
+        holder["noise"] = torch.randn(t.shape, generator=torch.Generator().manual_seed(seed))
+        return holder["noise"]
+
+    torch.randn_like = fake
+    try:
+        with torch.no_grad():
+            r = fn()
+    finally:
+        torch.randn_like = real
+    return r, holder["noise"]
+
+
+def matcha_full(Matcha):
+    model = Matcha(idim=45, **MATCHA_MAS_JSUT).eval()
+    ref_sd = model.state_dict()
+    sd = matcha_golden_tweaks(synth_state_dict(ref_sd, 0))
+    model.load_state_dict(sd)
+    text = torch.randint(1, 45, (18,), generator=torch.Generator().manual_seed(21))
+    r, noise = with_noise(500, lambda: model.inference(text, n_timesteps=10, temperature=0.667))
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "n_timesteps": np.int64(10),
+           "temperature": np.float32(0.667), "u0_text": np_(text), "u0_noise": np_(noise[0].t()),
+           "u0_feat_gen": np_(r["feat_gen"]), "u0_duration": np_(r["duration"])}
+    print("matcha_jsut: frames", r["feat_gen"].shape[0], "absmax", float(r["feat_gen"].abs().max()))
+    return out, model
+
+
+def vits_full(VITS):
+    model = VITS(idim=45, spk_embed_dim=192, **VITS_JSUT).eval()
+    ref_sd = model.state_dict()
+    model.load_state_dict(synth_state_dict(ref_sd, 0))
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()])}
+    g = torch.Generator().manual_seed(22)
+    for u, n in enumerate((12, 31)):
+        text = torch.randint(1, 45, (n,), generator=g)
+        spemb = torch.randn(192, generator=torch.Generator().manual_seed(600 + u))
+        r, noise = with_noise(700 + u, lambda: model.inference(text, spembs=spemb))
+        out.update({f"u{u}_text": np_(text), f"u{u}_spemb": np_(spemb), f"u{u}_noise": np_(noise[0].t()),
+                    f"u{u}_feat_gen": np_(r["feat_gen"]), f"u{u}_duration": np_(r["duration"])})
+        print(f"vits_jsut u{u}: frames", r["feat_gen"].shape[0], "absmax", float(r["feat_gen"].abs().max()))
+    return out, model
+
+
+MATCHA_TTS1_SMALL = dict(G.MATCHA_SMALL)
+
+
+def matcha_tts1():
+    for m in [k for k in sys.modules if k == "jatts.models.matchatts"]:
+        del sys.modules[m]
+    from jatts.models.matchatts import MatchaTTS
+
+    model = MatchaTTS(idim=20, **MATCHA_TTS1_SMALL).eval()
+    ref_sd = model.state_dict()
+    sd = matcha_golden_tweaks(synth_state_dict(ref_sd, 4))
+    model.load_state_dict(sd)
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "config": json.dumps(MATCHA_TTS1_SMALL),
+           "n_timesteps": np.int64(4), "temperature": np.float32(0.667)}
+    g = torch.Generator().manual_seed(23)
+    for u, n in enumerate((13, 22)):
+        text = torch.randint(1, 20, (n,), generator=g)
+        r, noise = with_noise(800 + u, lambda: model.inference(text, n_timesteps=4, temperature=0.667))
+        out.update({f"u{u}_text": np_(text), f"u{u}_noise": np_(noise[0].t()), f"u{u}_feat_gen": np_(r["feat_gen"]),
+                    f"u{u}_duration": np_(r["duration"])})
+        print(f"matcha_tts1 u{u}: frames", r["feat_gen"].shape[0], "sum(d)", int(r["duration"].sum()),
+              "absmax", float(r["feat_gen"].abs().max()))
+    return out
+
+
+def fs2_forward(FastSpeech2):
+    """forward(): padded ragged batch, ground-truth durations / pitch / energy (fastspeech2.py:473-564)."""
+    model = FastSpeech2(idim=20, **FS2_SMALL).eval()
+    ref_sd = model.state_dict()
+    model.load_state_dict(synth_state_dict(ref_sd, 0))
+    g = torch.Generator().manual_seed(31)
+    ilens = torch.tensor([17, 9, 23])
+    B, Tm = len(ilens), int(ilens.max())
+    text = torch.zeros(B, Tm, dtype=torch.long)
+    ds = torch.zeros(B, Tm, dtype=torch.long)
+    ps, es = torch.zeros(B, Tm, 1), torch.zeros(B, Tm, 1)
+    for b, n in enumerate(ilens.tolist()):
+        text[b, :n] = torch.randint(1, 20, (n,), generator=g)
+        ds[b, :n] = torch.randint(0, 5, (n,), generator=g)
+        ps[b, :n] = torch.randn(n, 1, generator=g)
+        es[b, :n] = torch.randn(n, 1, generator=g)
+    olens = ds.sum(1)
+    feats = torch.randn(B, int(olens.max()), 80, generator=g)
+    with torch.no_grad():
+        r = model(text, ilens, feats, olens, ds, ilens, ps, ilens, es, ilens)
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "text": np_(text), "text_lengths": np_(ilens),
+           "feats": np_(feats), "feats_lengths": np_(olens), "durations": np_(ds), "pitch": np_(ps), "energy": np_(es)}
+    for k in ("before_outs", "after_outs", "d_outs", "p_outs", "e_outs", "ys", "olens"):
+        out["ref_" + k] = np_(r[k])
+    print("fs2_forward: olens", olens.tolist(), {k: tuple(r[k].shape) for k in ("before_outs", "d_outs", "p_outs")})
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    FastSpeech2 = G.import_reference()
+    np.savez_compressed(os.path.join(HERE, "fs2_forward_small.npz"), **fs2_forward(FastSpeech2))
+    VITS = G.import_reference_vits()
+    from oracle.vits_oracle import vits_inference
+    vz, vmodel = vits_full(VITS)
+    np.savez_compressed(os.path.join(HERE, "vits_jsut.npz"), **vz)
+    vsd = vmodel.state_dict()
+    for u in range(2):
+        o = vits_inference(vsd, torch.tensor(vz[f"u{u}_text"]), 2, 2, torch.tensor(vz[f"u{u}_spemb"]), torch.tensor(vz[f"u{u}_noise"]))
+        print(f"vits_jsut u{u}: oracle-vs-ref mel max|d| =", float((o["feat_gen"] - torch.tensor(vz[f"u{u}_feat_gen"])).abs().max()),
+              "dur equal:", bool((o["duration"].numpy() == vz[f"u{u}_duration"]).all()))
+    del vmodel, vsd
+    Matcha = G.import_reference_matcha()
+    from oracle.matcha_oracle import matcha_inference
+    mz, mmodel = matcha_full(Matcha)
+    np.savez_compressed(os.path.join(HERE, "matcha_jsut.npz"), **mz)
+    o = matcha_inference(mmodel.state_dict(), torch.tensor(mz["u0_text"]), 2, 2, torch.tensor(mz["u0_noise"]), n_timesteps=10,
+                         temperature=0.667)
+    print("matcha_jsut: oracle-vs-ref mel max|d| =", float((o["feat_gen"] - torch.tensor(mz["u0_feat_gen"])).abs().max()),
+          "dur equal:", bool((o["duration"].numpy() == mz["u0_duration"]).all()))
+    del mmodel
+    np.savez_compressed(os.path.join(HERE, "matcha_tts1_small.npz"), **matcha_tts1())
+    for f in ("fs2_forward_small.npz", "vits_jsut.npz", "matcha_jsut.npz", "matcha_tts1_small.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

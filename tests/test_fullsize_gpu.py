@@ -9,6 +9,8 @@ through size-independent properties -- the oracle cannot run this size in second
 import pytest
 import torch
 
+from helpers import maxdiff
+
 pytestmark = pytest.mark.gpu
 
 
@@ -112,3 +114,116 @@ def test_two_stream_pipeline_is_bit_identical(cuda, stack):
     got = [y.clone() for _, y in Stage4Pipeline(m, voc).run(batches)]
     torch.cuda.synchronize()
     assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+# ------------------------------------------------------------------ f16 fast mode against the f32 path at BASELINE sizes
+def _split(y, lens):
+    out, o = [], 0
+    for n in lens:
+        out.append(y[o:o + n])
+        o += n
+    return out
+
+
+def test_config2_f16_against_f32_full_size(cuda, stack):
+    """configs[1] at its own size (64 x 768 frames -> 12.6 M samples): the f16 fast mode against the f32 (reference
+    arithmetic) path on the same batch.  Tolerances: mel max abs 3e-2 (values up to ~6), waveform max abs 5e-3 and
+    rms 1e-3 on [-1, 1] (measured: 5e-3 / 1e-3 / 1.5e-4)."""
+    from jatts_amd.synthetic import synth_texts
+    m, voc = stack
+    texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
+    res = {}
+    try:
+        for p in ("fp32", "fp16"):
+            m.set_precision(p)
+            voc.set_precision(p)
+            r = m.inference_batch(texts)
+            res[p] = (r["feat_gen"].float().clone(), voc.decode_batch(r["feats_rb"], r["feat_gen"]).float().clone(), r["olens"])
+    finally:
+        m.set_precision("fp16")
+        voc.set_precision("fp16")
+    assert res["fp32"][2] == res["fp16"][2] == [768] * 64
+    dm = (res["fp16"][0] - res["fp32"][0]).abs()
+    dw = res["fp16"][1] - res["fp32"][1]
+    assert float(dm.max()) <= 3e-2, float(dm.max())
+    assert float(dw.abs().max()) <= 5e-3 and float(dw.pow(2).mean().sqrt()) <= 1e-3, (float(dw.abs().max()), float(dw.pow(2).mean().sqrt()))
+
+
+def _vocoder(cuda, prec):
+    from jatts_amd.synthetic import HIFIGAN_V1_22K, synth_hifigan_state
+    from jatts_amd.vocoder import Vocoder
+    ones, zeros = [1.0] * 80, [0.0] * 80
+    voc = Vocoder(synth_hifigan_state(HIFIGAN_V1_22K, 0),
+                  {"sampling_rate": 22050, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_22K},
+                  {"mean": zeros, "scale": ones}, cuda, trg_stats={"mean": zeros, "scale": ones})
+    return voc.set_precision(prec)
+
+
+def test_config3_matcha_full_size(cuda, lib):
+    """BASELINE configs[2]: MatchaTTS_MAS (U-Net 512/512, head dim 256), 64 utterances x 128 phonemes, 10 Euler steps.
+    Properties in f32 (determinism, every utterance equal to the same utterance synthesised alone) and the f16 fast mode
+    against f32 on the same batch (mel max abs <= 0.1 after 10 U-Net evaluations; measured 4.4e-3)."""
+    from jatts_amd.models import MatchaTTS_MAS
+    from jatts_amd.synthetic import MATCHA_MAS_JSUT, synth_state_dict, synth_texts
+    m = MatchaTTS_MAS(idim=45, **MATCHA_MAS_JSUT)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    m = m.to(cuda).set_precision("fp32")
+    texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
+    g = torch.Generator().manual_seed(5)
+    texts = [t[: int(torch.randint(64, 129, (1,), generator=g))] for t in texts]          # ragged
+    dur = [torch.full((len(t),), 6, dtype=torch.int64, device=cuda) for t in texts]
+    noise = [torch.randn(6 * len(t), 80, generator=g).to(cuda) for t in texts]
+    run = lambda idx: m.inference_batch([texts[i] for i in idx], n_timesteps=10, temperature=0.667,  # noqa: E731
+                                        durations=[dur[i] for i in idx], noise=[noise[i] for i in idx])
+    r = run(range(64))
+    assert r["olens"] == [6 * len(t) for t in texts]
+    mel = r["feat_gen"].clone()
+    assert torch.isfinite(mel).all()
+    assert torch.equal(run(range(64))["feat_gen"], mel), "not deterministic"
+    parts = _split(mel, r["olens"])
+    for i in (0, 29, 63):
+        alone = run([i])["feat_gen"]
+        assert maxdiff(alone, parts[i]) <= 1e-4, f"utterance {i} depends on its batch neighbours: {maxdiff(alone, parts[i]):.3e}"
+    voc = _vocoder(cuda, "fp32")
+    y32 = voc.decode_batch(r["feats_rb"], mel).clone()
+    assert y32.numel() == sum(r["olens"]) * 256 and float(y32.abs().max()) <= 1.0
+    m.set_precision("fp16")
+    r16 = run(range(64))
+    assert r16["olens"] == r["olens"]
+    e = float((r16["feat_gen"].float() - mel).abs().max())
+    assert e <= 0.1, e
+    y16 = _vocoder(cuda, "fp16").decode_batch(r16["feats_rb"], r16["feat_gen"])
+    assert float((y16 - y32).abs().max()) <= 2e-2
+
+
+def test_config5_vits_full_size(cuda, lib):
+    """BASELINE configs[4] per-GPU share: mel-VITS with 192-d speaker embeddings, 32 utterances x 128 phonemes."""
+    from jatts_amd.models import VITS
+    from jatts_amd.synthetic import VITS_JSUT, synth_state_dict, synth_texts
+    m = VITS(idim=45, spk_embed_dim=192, **VITS_JSUT)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    m = m.to(cuda).set_precision("fp32")
+    g = torch.Generator().manual_seed(7)
+    texts = [t.to(cuda) for t in synth_texts(32, 128, 45, seed=3)]
+    texts = [t[: int(torch.randint(64, 129, (1,), generator=g))] for t in texts]
+    spk = torch.randn(32, 192, generator=g).to(cuda)
+    dur = [torch.full((len(t),), 6, dtype=torch.int64, device=cuda) for t in texts]
+    noise = [torch.randn(6 * len(t), 384, generator=g).to(cuda) for t in texts]
+    run = lambda idx: m.inference_batch([texts[i] for i in idx], spk[list(idx)], noise_scale=0.667,  # noqa: E731
+                                        durations=[dur[i] for i in idx], noise=[noise[i] for i in idx])
+    r = run(range(32))
+    assert r["olens"] == [6 * len(t) for t in texts]
+    mel = r["feat_gen"].clone()
+    assert torch.isfinite(mel).all()
+    assert torch.equal(run(range(32))["feat_gen"], mel), "not deterministic"
+    parts = _split(mel, r["olens"])
+    for i in (0, 13, 31):
+        alone = run([i])["feat_gen"]
+        assert maxdiff(alone, parts[i]) <= 1e-4, f"utterance {i} depends on its batch neighbours: {maxdiff(alone, parts[i]):.3e}"
+    y32 = _vocoder(cuda, "fp32").decode_batch(r["feats_rb"], mel).clone()
+    m.set_precision("fp16")
+    r16 = run(range(32))
+    e = float((r16["feat_gen"].float() - mel).abs().max())
+    assert e <= 5e-2, e
+    y16 = _vocoder(cuda, "fp16").decode_batch(r16["feats_rb"], r16["feat_gen"])
+    assert float((y16 - y32).abs().max()) <= 1e-2

@@ -62,3 +62,51 @@ def test_matcha_oracle_agrees_at_10_steps(cuda, lib):
     r = m.inference_batch([text.to(cuda)], n_timesteps=10, temperature=0.667, noise=[noise])
     assert torch.equal(r["duration"].cpu(), ref["duration"])
     assert maxdiff(r["feat_gen"], ref["feat_gen"]) <= 1e-2
+
+
+@pytest.mark.parametrize("prec,atol,rtol", [("fp32", 5e-3, 1e-3), ("fp16", 0.15, 3e-2)])
+def test_matcha_full_width_matches_reference_golden(cuda, lib, prec, atol, rtol):
+    """BASELINE config 3's own model (MATCHA_MAS_JSUT: U-Net channels 512/512, attention head dim 256 -- the
+    relattn_kernel<d_k=256> path), 10 Euler steps, temperature 0.667, against the reference run (matcha_jsut.npz)."""
+    from jatts_amd.models import MatchaTTS_MAS
+    from jatts_amd.synthetic import MATCHA_MAS_JSUT
+    z, keys = load_golden("matcha_jsut.npz")
+    m = MatchaTTS_MAS(idim=45, **MATCHA_MAS_JSUT)
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 0)))
+    m = m.to(cuda).set_precision(prec)
+    text, noise, dur = torch.tensor(z["u0_text"]).to(cuda), torch.tensor(z["u0_noise"]), torch.tensor(z["u0_duration"])
+    r = m.inference_batch([text], n_timesteps=int(z["n_timesteps"]), temperature=float(z["temperature"]), noise=[noise])
+    assert torch.equal(r["duration"].cpu(), dur), "predicted durations differ from the reference (both precisions: f32 trunk)"
+    ref = z["u0_feat_gen"]
+    assert r["feat_gen"].shape == ref.shape
+    e = maxdiff(r["feat_gen"], ref)
+    assert e <= atol, f"{prec}: max|d| = {e:.3e}"
+    assert relerr(r["feat_gen"], ref) <= rtol
+
+
+@pytest.mark.parametrize("prec,atol,rtol", [("fp32", 5e-3, 1e-3), ("fp16", 0.15, 3e-2)])
+def test_matcha_tts1_matches_reference_golden(cuda, lib, prec, atol, rtol):
+    """The tts1 `MatchaTTS` class (reference models/matchatts.py: hard LengthRegulator instead of Gaussian upsampling)."""
+    from jatts_amd.models import MatchaTTS
+    z, keys = load_golden("matcha_tts1_small.npz")
+    m = MatchaTTS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 4)))
+    m = m.to(cuda).set_precision(prec)
+    nt, temp = int(z["n_timesteps"]), float(z["temperature"])
+    texts = [torch.tensor(z[f"u{u}_text"]).to(cuda) for u in range(2)]
+    noises = [torch.tensor(z[f"u{u}_noise"]) for u in range(2)]
+    for u in range(2):
+        out = m.inference(texts[u], n_timesteps=nt, temperature=temp, noise=noises[u])
+        assert set(out) == {"feat_gen", "duration"}
+        assert torch.equal(out["duration"].cpu(), torch.tensor(z[f"u{u}_duration"]))
+        ref = z[f"u{u}_feat_gen"]
+        assert out["feat_gen"].shape == ref.shape
+        e = maxdiff(out["feat_gen"], ref)
+        assert e <= atol, f"u{u} {prec}: max|d| = {e:.3e}"
+        assert relerr(out["feat_gen"], ref) <= rtol
+    rb = m.inference_batch(texts, n_timesteps=nt, temperature=temp, noise=noises)
+    o = 0
+    for u in range(2):
+        n = rb["olens"][u]
+        assert maxdiff(rb["feat_gen"][o:o + n], z[f"u{u}_feat_gen"]) <= atol
+        o += n

@@ -76,6 +76,28 @@ def test_matcha_oracle_matches_reference():
         assert maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-5
 
 
+def test_oracles_match_reference_at_full_width():
+    """Round-2 fixtures (make_golden_r2.py): the BASELINE config-3 / config-5 models at their own width (U-Net 512/512 with
+    attention head dim 256; VITS with a 192-d speaker embedding) and the tts1 MatchaTTS class, oracle vs the reference run."""
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    from oracle.matcha_oracle import matcha_inference
+    from oracle.vits_oracle import vits_inference
+    z, keys = load_golden("matcha_jsut.npz")
+    o = matcha_inference(matcha_golden_tweaks(golden_state(keys, 0)), torch.tensor(z["u0_text"]), 2, 2, torch.tensor(z["u0_noise"]),
+                         n_timesteps=int(z["n_timesteps"]), temperature=float(z["temperature"]))
+    assert np.array_equal(o["duration"].numpy(), z["u0_duration"]) and maxdiff(o["feat_gen"], z["u0_feat_gen"]) <= 1e-4
+    z, keys = load_golden("vits_jsut.npz")
+    sd = golden_state(keys, 0)
+    for u in range(2):
+        o = vits_inference(sd, torch.tensor(z[f"u{u}_text"]), 2, 2, torch.tensor(z[f"u{u}_spemb"]), torch.tensor(z[f"u{u}_noise"]))
+        assert np.array_equal(o["duration"].numpy(), z[f"u{u}_duration"]) and maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-4
+    z, keys = load_golden("matcha_tts1_small.npz")
+    sd = matcha_golden_tweaks(golden_state(keys, 4))
+    for u in range(2):
+        o = matcha_inference(sd, torch.tensor(z[f"u{u}_text"]), 2, 2, torch.tensor(z[f"u{u}_noise"]), n_timesteps=4, hard_lr=True)
+        assert np.array_equal(o["duration"].numpy(), z[f"u{u}_duration"]) and maxdiff(o["feat_gen"], z[f"u{u}_feat_gen"]) <= 1e-4
+
+
 def test_rel_shift_closed_form_equals_view_trick():
     g = torch.Generator().manual_seed(0)
     for T in (1, 2, 3, 7, 16):

@@ -53,3 +53,22 @@ def test_vits_state_dict_schema(golden_dir):
     sd = VITS(idim=20, **json.loads(str(z["config"]))).state_dict()
     assert [k for k, _ in keys] == list(sd.keys())
     assert all(tuple(s) == tuple(sd[k].shape) for k, s in keys)
+
+
+@pytest.mark.parametrize("prec,atol,rtol", [("fp32", 3e-3, 5e-4), ("fp16", 8e-2, 2e-2)])
+def test_vits_full_width_192d_matches_reference_golden(cuda, lib, prec, atol, rtol):
+    """BASELINE config 5's own model (VITS_JSUT + 192-d speaker embedding) against the reference run (vits_jsut.npz)."""
+    from jatts_amd.models import VITS
+    from jatts_amd.synthetic import VITS_JSUT
+    z, keys = load_golden("vits_jsut.npz")
+    m = VITS(idim=45, spk_embed_dim=192, **VITS_JSUT)
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda).set_precision(prec)
+    for u in range(2):
+        r = m.inference_batch([torch.tensor(z[f"u{u}_text"]).to(cuda)], torch.tensor(z[f"u{u}_spemb"]).unsqueeze(0),
+                              noise=[torch.tensor(z[f"u{u}_noise"])])
+        assert torch.equal(r["duration"].cpu(), torch.tensor(z[f"u{u}_duration"])), "predicted durations differ (f32 trunk in both modes)"
+        ref = z[f"u{u}_feat_gen"]
+        assert r["feat_gen"].shape == ref.shape
+        assert maxdiff(r["feat_gen"], ref) <= atol, f"u{u} {prec}: max|d| = {maxdiff(r['feat_gen'], ref):.3e}"
+        assert relerr(r["feat_gen"], ref) <= rtol
