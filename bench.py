@@ -290,15 +290,18 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
         fam.setdefault((tag, meta), []).append(ms)
     units = []
     for (tag, meta), v in fam.items():
-        if tag != "resunit":
+        if tag not in ("resunit", "resblock"):
             continue
         C, k, d, rows = meta
+        nu = len(d) if tag == "resblock" else 1     # a fused ResBlock launch = nu dilation units; x in + y out ONCE
         avg = sum(v) / len(v)
-        flops, byts = 4.0 * C * C * k * rows, 2.0 * rows * C * esz
+        flops, byts = 4.0 * C * C * k * rows * nu, 2.0 * rows * C * esz
         peak_tf = MFMA_F16_PEAK_TF if esz == 2 else MFMA_F32_PEAK_TF
         ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         u = dict(C=C, k=k, dil=d, rows=rows, launches=len(v), avg_ms=avg, total_ms=sum(v),
-                 tflops=flops / avg / 1e9, gbs=byts / avg / 1e6, ai=flops / byts)
+                 tflops=flops / avg / 1e9, gbs=byts / avg / 1e6, ai=flops / byts, units_per_launch=nu)
+        if nu > 1:   # what the same arithmetic costs as nu separate unit launches (SURVEY 8d's per-unit bytes)
+            u["unit_equivalent_gbs"] = nu * byts / avg / 1e6
         u["bound"] = "mfma" if u["ai"] >= ridge else "hbm"
         u["frac"] = u["tflops"] / peak_tf if u["bound"] == "mfma" else u["gbs"] / HBM_PEAK_GBS
         units.append(u)
@@ -309,7 +312,7 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     dom = by_c[dom_c]
     dom_ms = sum(u["total_ms"] for u in dom)
     n_launch = sum(u["launches"] for u in dom)
-    dom_flops = sum(4.0 * u["C"] ** 2 * u["k"] * u["rows"] * u["launches"] for u in dom)
+    dom_flops = sum(4.0 * u["C"] ** 2 * u["k"] * u["rows"] * u["launches"] * u["units_per_launch"] for u in dom)
     dom_bytes = sum(2.0 * u["rows"] * u["C"] * esz * u["launches"] for u in dom)
     ai = dom_flops / dom_bytes
     peak_tf = MFMA_F16_PEAK_TF if esz == 2 else MFMA_F32_PEAK_TF
@@ -328,7 +331,7 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     roof["share_of_step"] = dom_ms / (dt * 1e3)
     other = {}
     for (tag, meta), v in fam.items():
-        if tag != "resunit":
+        if tag not in ("resunit", "resblock"):
             other[tag] = other.get(tag, 0.0) + sum(v)
     return dict(
         roofline=roof,

@@ -142,6 +142,37 @@ typedef struct jatts_resunit_desc {
 
 int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * HiFi-GAN ResBlock, all dilation units fused in one launch (f16 operands only):
+ *   for u in 0..n_units-1:  x <- x + conv_k,1( lrelu( conv_k,dil[u]( lrelu(x) ) + b1[u] ) ) + b2[u]
+ * parallel_wavegan.layers.HiFiGANResidualBlock.forward [third party; call site jatts/vocoder/vocoder.py:64].
+ * x is read once and y written once per ResBlock (the per-unit launches move 3x the bytes); the residual stream stays
+ * in registers between units, rounded to f16 once per unit (where the per-unit launches round it on its way to HBM).
+ * channels in {32, 64, 128}, k_w in {3, 7} (wider receptive fields waste too much of the tile on halo), n_units <= 3;
+ * returns JATTS_ERR_UNSUPPORTED otherwise -- callers then issue jatts_hifigan_resunit per unit.
+ * add0 / add1 / out_scale: the MRF mean fused into the output pass, as in jatts_resunit_desc.
+ * ------------------------------------------------------------------------------- */
+typedef struct jatts_resblock_desc {
+  jatts_ragged rg;
+  int32_t dtype;     /* JATTS_F16 */
+  int32_t channels;
+  int32_t k_w;
+  int32_t n_units;
+  int32_t dil[3];
+  float slope;
+  const void* x;
+  void* y;           /* must not alias x */
+  const void* w1[3];
+  const float* b1[3];
+  const void* w2[3];
+  const float* b2[3];
+  const void* add0;
+  const void* add1;
+  float out_scale;
+} jatts_resblock_desc;
+
+int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream);
+
 /* Profiling hook (not part of the reference interface): while `buf` is non-NULL, thread 0 of the first n_workgroups
  * workgroups of every jatts_hifigan_resunit launch writes 16 uint64 to buf[16*wg ..]: {XCC_ID<<32 | HW_ID, s_memtime
  * at start, x staged, conv1 done, h written, conv2 done, y assembled, y stored, then s_memrealtime (100 MHz) at start

@@ -40,6 +40,15 @@ class ResUnitDesc(C.Structure):
     ]
 
 
+class ResBlockDesc(C.Structure):
+    _fields_ = [
+        ("rg", Ragged), ("dtype", C.c_int32), ("channels", C.c_int32), ("k_w", C.c_int32), ("n_units", C.c_int32),
+        ("dil", C.c_int32 * 3), ("slope", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
+        ("w1", C.c_void_p * 3), ("b1", C.c_void_p * 3), ("w2", C.c_void_p * 3), ("b2", C.c_void_p * 3),
+        ("add0", C.c_void_p), ("add1", C.c_void_p), ("out_scale", C.c_float),
+    ]
+
+
 class RelAttnDesc(C.Structure):
     _fields_ = [
         ("rg", Ragged), ("dtype", C.c_int32), ("n_heads", C.c_int32), ("d_k", C.c_int32),
@@ -58,6 +67,7 @@ PROTOTYPES = {
     "jatts_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "jatts_conv_weight_index": (C.c_int64, [C.c_int32] * 5),
     "jatts_hifigan_resunit": (C.c_int, [C.POINTER(ResUnitDesc), C.c_void_p]),
+    "jatts_hifigan_resblock": (C.c_int, [C.POINTER(ResBlockDesc), C.c_void_p]),
     "jatts_debug_trace": (C.c_int, [C.c_void_p, C.c_int64]),
     "jatts_pcm16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "jatts_alignment_logp": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,

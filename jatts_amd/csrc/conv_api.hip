@@ -12,6 +12,7 @@ int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s);
 int jatts_resunit_f16_narrow(const jatts_resunit_desc& d, hipStream_t s);  // C = 32, 64
 int jatts_resunit_f16_wide(const jatts_resunit_desc& d, hipStream_t s);    // C = 128, 256, 512
 int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
+int jatts_resblock_f16(const jatts_resblock_desc& d, hipStream_t s);
 
 extern "C" int jatts_debug_trace(void* buf, int64_t n_workgroups) {
   jatts_g_trace = (unsigned long long*)buf;
@@ -50,4 +51,19 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
   if (d->dtype == JATTS_F16) return d->channels <= 64 ? jatts_resunit_f16_narrow(*d, s) : jatts_resunit_f16_wide(*d, s);
   if (d->dtype == JATTS_F32) return jatts_resunit_f32(*d, s);
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels/dtype (use jatts_conv1d)");
+}
+
+extern "C" int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream) {
+  if (!d || !d->x || !d->y || !d->rg.cu_rows) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: null pointer");
+  if (d->n_units < 1 || d->n_units > 3) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: 1..3 units");
+  for (int u = 0; u < d->n_units; ++u) {
+    if (!d->w1[u] || !d->w2[u] || !d->b1[u] || !d->b2[u]) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: null weights");
+    if (d->dil[u] < 1) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: dil >= 1 required");
+  }
+  if (d->x == d->y) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: y must not alias x");
+  if (d->k_w < 1 || !(d->k_w & 1)) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: odd k_w required");
+  if (!(d->slope >= 0.f && d->slope <= 1.f)) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: LeakyReLU slope must be in [0, 1]");
+  if (d->dtype != JATTS_F16) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resblock: f16 operands only (use jatts_hifigan_resunit)");
+  if (d->rg.max_len <= 0) return JATTS_OK;
+  return jatts_resblock_f16(*d, (hipStream_t)stream);
 }

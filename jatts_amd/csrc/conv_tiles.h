@@ -262,6 +262,56 @@ __device__ __forceinline__ void conv_full(f32x16 (&acc)[NF][NT], const T* __rest
   }
 }
 
+// Weight stream across the convs of one fused kernel: the ring outlives a conv, so the first group of the NEXT conv
+// is fetched during the last group of the current one and its L2 round trip hides under the epilogue between them
+// (with 32-64 channels a conv is only ~0.8-3 k cycles of MFMA: an exposed ~600-cycle ring fill per conv is a large tax).
+template <typename T, int NF, int KCG>
+struct WStream {
+  typename Elem<T>::vec8 ring[KCG][NF];
+  WFrags<T, NF> wf;
+  __device__ __forceinline__ void prefetch(const T* w, int NFR, int nf0, int lane) {
+    wf.init(NFR, nf0);
+    ring_fill<T, NF, KCG>(ring, wf, w + (size_t)lane * 8);
+  }
+};
+
+// conv_full on a pre-filled stream; w_next (or nullptr) = packed weights of the conv that follows.
+template <typename T, int NF, int NT, int KC16, int KCG>
+__device__ __forceinline__ void conv_full_ws(f32x16 (&acc)[NF][NT], WStream<T, NF, KCG>& ws, const T* __restrict__ w,
+                                             const T* __restrict__ w_next, int k_w, int dil, const char* act, int pitch,
+                                             int col0, int lane) {
+  typedef typename Elem<T>::vec8 V8;
+  constexpr int GPT = KC16 / KCG;
+  static_assert(GPT * KCG == KC16, "group size must divide the steps per tap");
+  const T* wl = w + (size_t)lane * 8;
+  const size_t gstride = (size_t)KCG * ws.wf.stride;  // elements per group
+  const int n_groups = k_w * GPT;
+  const T* tail = w_next ? w_next + (size_t)lane * 8 : wl + (size_t)(n_groups - 1) * gstride;   // no successor: harmless re-read
+  const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * (lane >> 5)) * sizeof(T);
+  V8 bb[2][NT];
+  fetch_b<T, NT>(bb[0], bbase, pitch);
+  __builtin_amdgcn_sched_barrier(0);
+  int g = 0;
+  for (int tap = 0; tap < k_w; ++tap) {
+    const char* btap = bbase + (size_t)(tap * dil) * pitch;
+    const char* btap_next = bbase + (size_t)(min(tap + 1, k_w - 1) * dil) * pitch;
+#pragma unroll
+    for (int h = 0; h < GPT; ++h, ++g) {
+      const T* nb = g + 1 < n_groups ? wl + (size_t)(g + 1) * gstride : tail;
+      const char* bcur = btap + (size_t)(h * KCG) * 16 * sizeof(T);
+      const char* bnext = h + 1 < GPT ? btap + (size_t)((h + 1) * KCG) * 16 * sizeof(T) : btap_next;
+      conv_group<T, NF, NT, KCG>(acc, ws.ring, bb, ws.wf, nb, bcur, bnext, pitch);
+    }
+  }
+}
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads -- weight
+// fragments prefetched for the next conv stay in flight across it (__syncthreads() drains vmcnt too).  Global stores
+// issued before it are not ordered by it: use __syncthreads() where another wave reads them.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Weight-fragment register ring for the generic conv (chunked activations).  Fragments are consumed
 // in the order  for chunk: for tap: for kk  and the producer runs D iterations ahead of the consumer
 // ACROSS chunk boundaries, so the loads for the next chunk are in flight while the activation tile

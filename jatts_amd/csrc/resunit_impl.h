@@ -10,23 +10,23 @@ namespace {
 
 // Unit-kernel output pass: y = (acc + b2 tile in LDS) + x [+ MRF partners] with row-contiguous 16-byte accesses;
 // all global reads of a batch are issued before any is consumed (one round trip per batch, not per unit).
-template <typename T, int C, int UB, bool ADD, int NTHR>
-__device__ __forceinline__ void unit_store_pass(const jatts_resunit_desc& d, const char* ys, int pitch, int vrows,
-                                                const T* xg, T* yg, int64_t g0) {
+template <typename T, int C, int UB, bool ADD, int NTHR, bool RESID = true>
+__device__ __forceinline__ void unit_store_pass(const void* add0, const void* add1, float out_scale, const char* ys, int pitch,
+                                                int vrows, const T* xg, T* yg, int64_t g0) {
   typedef typename Elem<T>::vec8 V8;
   constexpr int UPR = C / 8;
   const int total = vrows * UPR;
-  const bool has_add1 = ADD && d.add1 != nullptr;
+  const bool has_add1 = ADD && add1 != nullptr;
   for (int u0 = threadIdx.x; u0 < total; u0 += UB * NTHR) {
     V8 xr[UB], a0[ADD ? UB : 1], a1[ADD ? UB : 1];
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
       const int u = u0 + i * NTHR;
       if (u < total) {
-        if (JATTS_ABLATE != 3) xr[i] = Vec8IO<T>::ldg(xg + g0 + (int64_t)u * 8);
+        if (RESID && JATTS_ABLATE != 3) xr[i] = Vec8IO<T>::ldg(xg + g0 + (int64_t)u * 8);
         if (ADD) {
-          a0[i] = Vec8IO<T>::ldg((const T*)d.add0 + g0 + (int64_t)u * 8);
-          if (has_add1) a1[i] = Vec8IO<T>::ldg((const T*)d.add1 + g0 + (int64_t)u * 8);
+          a0[i] = Vec8IO<T>::ldg((const T*)add0 + g0 + (int64_t)u * 8);
+          if (has_add1) a1[i] = Vec8IO<T>::ldg((const T*)add1 + g0 + (int64_t)u * 8);
         }
       }
     }
@@ -36,14 +36,14 @@ __device__ __forceinline__ void unit_store_pass(const jatts_resunit_desc& d, con
       if (u >= total) continue;
       const int r = u / UPR, cu = u - r * UPR;
       V8 v = Vec8IO<T>::lds(ys + (size_t)r * pitch + (size_t)cu * 8 * sizeof(T));
-      if (JATTS_ABLATE != 3) {
+      if (RESID && JATTS_ABLATE != 3) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(xr[i][e]));  // residual
       }
       if (ADD) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[i][e]) + (has_add1 ? to_f32(a1[i][e]) : 0.f)) * d.out_scale);
+          v[e] = from_f32<T>((to_f32(v[e]) + to_f32(a0[i][e]) + (has_add1 ? to_f32(a1[i][e]) : 0.f)) * out_scale);
       }
       T* dst = yg + g0 + (int64_t)u * 8;
       if ((JATTS_ABLATE != 4 && JATTS_ABLATE != 12) || to_f32(v[0]) == 12345.678f) {
@@ -163,6 +163,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
   float* bs = reinterpret_cast<float*>(smem + bias_off);
   for (int u = threadIdx.x; u < 2 * C; u += blockDim.x) bs[u] = u < C ? d.b1[u] : d.b2[u - C];
 
+  // f16: one weight stream for both convs -- conv1's first group is fetched under the x staging, conv2's under epilogue 1.
+  // f32 (64-cycle MFMAs, two-deep ring): the fill is already hidden and the longer register lifetime measured 2 % slower.
+  constexpr bool STREAM = sizeof(T) == 2;
+  WStream<T, NF, KCG> ws;
+  if constexpr (STREAM) ws.prefetch((const T*)d.w1, NFR, nf0, lane);
   const T* xin[3] = {(const T*)d.x, nullptr, nullptr};
   if (JATTS_ABLATE != 2 && JATTS_ABLATE != 7 && JATTS_ABLATE != 12)
   {
@@ -189,11 +194,15 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
       }
   };
   bias_acc(bs);
-  if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
+  if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) {
+    if constexpr (STREAM) conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w1, (const T*)d.w2, K, dil, xs, pitch, col0, lane);
+    else conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w1, NFR, nf0, K, dil, xs, pitch, col0, lane);
+  }
 
   JATTS_STAMP(3);
   // epilogue 1: h = lrelu(acc + b1), forced to 0 outside the sequence (conv2's zero padding)
-  __syncthreads();  // every wave is done reading x: the tile may now be overwritten by h
+  if constexpr (STREAM) lds_barrier();  // every wave is done reading x: the tile may now be overwritten by h (conv2's first weights stay in flight)
+  else __syncthreads();
   JATTS_STAMP(10);
   // rows of h past the computed columns are only read by discarded output columns
   for (int u = threadIdx.x; u < (K - 1) * (C / 8); u += blockDim.x) {
@@ -230,11 +239,15 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
       }
   }
   JATTS_STAMP(12);
-  __syncthreads();
+  if constexpr (STREAM) lds_barrier();
+  else __syncthreads();
   JATTS_STAMP(4);
 
   bias_acc(bs + C);
-  if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
+  if (JATTS_ABLATE < 6 || JATTS_ABLATE > 9) {
+    if constexpr (STREAM) conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w2, nullptr, K, 1, hs, pitch, col0, lane);
+    else conv_full<T, NF, NT, KC16, KCG>(acc, (const T*)d.w2, NFR, nf0, K, 1, hs, pitch, col0, lane);
+  }
 
   JATTS_STAMP(5);
   // epilogue 2: y = x + acc + b2 for the tt_out valid columns.  acc + b2 is assembled in LDS (the h region
@@ -275,8 +288,8 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
     const int vrows = min(tt_out, L - t0);
     const int64_t g0 = (seq_row0 + t0) * (int64_t)C;  // the valid rows are contiguous in y: unit u <-> 8 elements at g0 + 8u
     constexpr bool keep_small = C <= 64;   // small-channel kernels live on occupancy (6 workgroups/CU): keep the batch short
-    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true, WN * WT * 64>(d, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
-    else unit_store_pass<T, C, keep_small ? 4 : 8, false, WN * WT * 64>(d, ys, pitch, vrows, xg, yg, g0);
+    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true, WN * WT * 64>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
+    else unit_store_pass<T, C, keep_small ? 4 : 8, false, WN * WT * 64>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
   }
   JATTS_STAMP(7);
   if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();

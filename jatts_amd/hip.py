@@ -218,6 +218,30 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
     return y
 
 
+def hifigan_resblock(rb, len_mul, x, y, units, channels, k_w, slope, dtype, add=None, out_scale=1.0):
+    """jatts_hifigan_resblock: ``units`` = [(w1, b1, w2, b2, dil), ...] (<= 3), all dilation units of one ResBlock in one launch."""
+    lib = _abi.load()
+    d = _abi.ResBlockDesc()
+    d.rg = rb.struct(len_mul)
+    d.dtype, d.channels, d.k_w, d.n_units, d.slope = dtype, channels, k_w, len(units), slope
+    rows = rb.total * len_mul
+    if x.numel() != rows * channels or y.numel() != rows * channels or x.dtype != torch_dtype(dtype):
+        raise ValueError("hifigan_resblock: bad buffer size/dtype")
+    d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
+    for i, (w1, b1, w2, b2, dil) in enumerate(units):
+        d.w1[i], d.b1[i], d.w2[i], d.b2[i], d.dil[i] = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), dil
+    if add:
+        for a in add:
+            if a.numel() != rows * channels or a.dtype != x.dtype:
+                raise ValueError("hifigan_resblock: bad mix buffer")
+        d.add0 = add[0].data_ptr()
+        d.add1 = add[1].data_ptr() if len(add) > 1 else None
+    d.out_scale = out_scale
+    with _Timed("resblock", (channels, k_w, tuple(u[4] for u in units), rows)):
+        _abi.check(lib.jatts_hifigan_resblock(C.byref(d), _stream()), "jatts_hifigan_resblock")
+    return y
+
+
 def hifigan_output(rb, len_mul, xs, in_scale, slope, c_in, k_w, w, bias, dtype):
     lib = _abi.load()
     rows = rb.total * len_mul

@@ -165,6 +165,10 @@ class HiFiGANGenerator(torch.nn.Module):
         self._prep = P
         return P
 
+    # (channels, kernel size) of the ResBlocks issued as ONE fused launch (jatts_hifigan_resblock): the shapes where it
+    # measured faster than three unit launches (profiles/r02_notes.md); JATTS_HIFIGAN_FUSE=0 switches it off
+    fused_blocks = frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE", "1") == "0" else frozenset({(32, 3), (32, 7), (64, 3)})
+
     # tuning knob (profiles/r01_notes.md): run the independent ResBlock chains of a stage on separate HIP streams
     concurrent = os.environ.get("JATTS_HIFIGAN_STREAMS", "0") == "1"
 
@@ -212,6 +216,14 @@ class HiFiGANGenerator(torch.nn.Module):
             for j, units in enumerate(blocks):
                 cur = up
                 st = side[j] if j < len(side) else None
+                # HBM-bound shapes: the whole ResBlock in one launch (x read once, y written once; residual in registers)
+                if dt == hip.F16 and (c_out, units[0][2]) in self.fused_blocks and len(units) <= 3 and st is None:
+                    lastb = fuse_mean and j == len(blocks) - 1
+                    hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(c1.w, c1.b, c2.w, c2.b, d) for c1, c2, _, d in units],
+                                         c_out, units[0][2], self.slope, dt, add=outs if lastb else None,
+                                         out_scale=1.0 / len(blocks) if lastb else 1.0)
+                    outs.append(bufs[j][0])
+                    continue
                 if st is not None:
                     st.wait_event(fork)
                 with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():

@@ -156,6 +156,60 @@ def test_hifigan_resunit(cuda, lib, prec, C, k, d, lens):
     assert e <= TOL[prec], f"resunit C={C} k={k} d={d} {prec}: rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("C,k,dils,lens,mrf", [
+    (32, 3, (1, 3, 5), [1300, 3, 250, 40], False), (32, 7, (1, 3, 5), [900, 31], False), (64, 3, (1, 3, 5), [513, 700], False),
+    (64, 7, (1, 3, 5), [600, 64], False), (128, 3, (1, 3, 5), [300, 40], False), (64, 3, (1, 3), [260], False),
+    (32, 3, (1, 3, 5), [700, 90], True), (32, 7, (2,), [500], False),
+])
+def test_hifigan_resblock_fused(cuda, lib, C, k, dils, lens, mrf):
+    """jatts_hifigan_resblock (all dilation units of a ResBlock in one launch, residual stream in registers) against
+    (a) the fp64 chain of units with the stream rounded to f16 between units, as the per-unit launches store it, and
+    (b) the per-unit launches themselves."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + len(dils))
+    R = sum(lens)
+    x = _round(torch.randn(R, C, generator=g), "fp16")
+    ws = [(_round(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), "fp16"), torch.randn(C, generator=g) * 0.1,
+           _round(torch.randn(C, C, k, generator=g) * 0.5 / math.sqrt(C * k), "fp16"), torch.randn(C, generator=g) * 0.1) for _ in dils]
+    adds = [_round(torch.randn(R, C, generator=g), "fp16") for _ in range(2)] if mrf else None
+    ref = x
+    for (w1, b1, w2, b2), d in zip(ws, dils):
+        ref = _ref_unit(ref, w1, b1, w2, b2, lens, k, d, 0.1, True).half().float()
+    ref = ref.double()
+    if mrf:
+        ref = (ref + adds[0].double() + adds[1].double()) / 3.0
+    rb = _ragged(lens, cuda)
+    xd = x.to(cuda).half()
+    packed = [(hip.pack_conv_weight(w1.to(cuda), hip.F16, 32), b1.to(cuda), hip.pack_conv_weight(w2.to(cuda), hip.F16, 32), b2.to(cuda), d)
+              for (w1, b1, w2, b2), d in zip(ws, dils)]
+    y = torch.full_like(xd, float("nan"))
+    addd = [a.to(cuda).half() for a in adds] if mrf else None
+    hip.hifigan_resblock(rb, 1, xd, y, packed, C, k, 0.1, hip.F16, add=addd, out_scale=1.0 / 3.0 if mrf else 1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all(), "unwritten / non-finite outputs"
+    e = relerr(y.float(), ref)
+    assert e <= TOL["fp16"], f"resblock C={C} k={k} dils={dils}: rel err {e:.3e}"
+    cur, bufs = xd, [torch.empty_like(xd), torch.empty_like(xd)]
+    for i, (w1, b1, w2, b2, d) in enumerate(packed):
+        lastu = i == len(packed) - 1
+        hip.hifigan_resunit(rb, 1, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, hip.F16,
+                            add=addd if (mrf and lastu) else None, out_scale=1.0 / 3.0 if (mrf and lastu) else 1.0)
+        cur = bufs[i & 1]
+    assert relerr(y.float(), cur.float().double()) <= 2e-3   # same arithmetic up to one f16 rounding of the stream per unit
+
+
+def test_hifigan_resblock_refuses_wide_receptive_fields(cuda, lib):
+    from jatts_amd import hip
+    from jatts_amd._abi import JattsHipError
+    C, k = 32, 15
+    rb = _ragged([400], cuda)
+    x = torch.zeros(400, C, device=cuda, dtype=torch.float16)
+    w = hip.pack_conv_weight(torch.zeros(C, C, k, device=cuda), hip.F16, 32)
+    b = torch.zeros(C, device=cuda)
+    with pytest.raises(JattsHipError):
+        hip.hifigan_resblock(rb, 1, x, torch.empty_like(x), [(w, b, w, b, d) for d in (1, 3, 5)], C, k, 0.1, hip.F16)
+
+
 def test_hifigan_resunit_fused_mrf_mean(cuda, lib):
     """y = (unit(x) + add0 + add1) / 3 written by the unit's coalesced output pass."""
     from jatts_amd import hip

@@ -40,6 +40,48 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     return ms
 
 
+def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5)):
+    """Fused ResBlock launch against the three per-unit launches (f16)."""
+    dev = torch.device("cuda:0")
+    rb = hip.RaggedBatch([T] * B, dev)
+    rows = B * T * rate
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).half()
+    bufs = [torch.empty_like(x), torch.empty_like(x)]
+    units = []
+    for d in dils:
+        w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), hip.F16, 32)
+        w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) * 0.3 / (C * k) ** 0.5).to(dev), hip.F16, 32)
+        units.append((w1, torch.zeros(C, device=dev), w2, torch.zeros(C, device=dev), d))
+
+    def fused():
+        hip.hifigan_resblock(rb, rate, x, bufs[0], units, C, k, 0.1, hip.F16)
+
+    def unfused():
+        cur = x
+        for i, (w1, b1, w2, b2, d) in enumerate(units):
+            hip.hifigan_resunit(rb, rate, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, hip.F16)
+            cur = bufs[i & 1]
+
+    res = []
+    for fn in (fused, unfused):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b) / iters)
+    flops = 4.0 * C * C * k * rows * len(dils)
+    byts = 2.0 * rows * C * 2
+    print(f"ResBlock C={C:4d} k={k:2d} rows={rows:9d}: fused {res[0]:7.3f} ms ({flops / res[0] / 1e9:7.1f} TFLOP/s, {byts / res[0] / 1e6:7.1f} GB/s "
+          f"of x-in + y-out)   3 unit launches {res[1]:7.3f} ms   speed-up {res[1] / res[0]:.2f}x")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--C", type=int, default=128)
@@ -49,9 +91,15 @@ def main():
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--resblock", action="store_true", help="fused ResBlock launches vs per-unit launches (f16)")
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
     dt = hip.F16 if a.dtype == "f16" else hip.F32
+    if a.resblock:
+        for C in (32, 64, 128):
+            for k in (3, 7):
+                run_block(C, k, rates[C], a.iters)
+        return
     if a.all:
         tot = 0.0
         for C in (256, 128, 64, 32):
