@@ -221,6 +221,10 @@ typedef struct jatts_relattn_desc {
    * 16-byte loads; key tiles always start at the sequence's first key, so a sequence's result does not depend on
    * where it sits in the packed batch. */
   const int32_t* vt_col0;
+  /* Per-sequence number of valid keys (n_seq entries) or NULL = all.  Keys >= kv_len[b] are excluded from the softmax
+   * (the key padding mask of the reference's batched forward(), attention.py:80-88); queries, the rel-shift geometry
+   * and V^T keep the full (padded) sequence length. */
+  const int32_t* kv_len;
 } jatts_relattn_desc;
 
 int jatts_relpos_attention(const jatts_relattn_desc* d, void* stream);
@@ -324,6 +328,13 @@ int jatts_lr_durations(const jatts_ragged* rg, const int64_t* d, float alpha, in
 int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, const int32_t* cu_out,
                     int32_t max_out_len, const float* x, int32_t dim, float* out,
                     int64_t* frame_index, void* stream);
+/* Output sequences may be longer than sum(d_eff): frames past the end are zero (pad_list, length_regulator.py:16-43;
+ * the padded batches of forward()), frame_index -1. */
+
+/* Zero the rows t >= valid_len[b] of every sequence of a packed f32 matrix x[rows][ld] (first `dim` columns):
+ * the `xs * x_masks` / masked_fill steps of the reference's batched forward() (variance_predictor.py:81-83,
+ * duration_predictor.py:93-96). */
+int jatts_zero_pad_rows(const jatts_ragged* rg, float* x, int32_t ld, int32_t dim, const int32_t* valid_len, void* stream);
 
 /* Gaussian upsampling (modules/length_regulator.py:111-154), one unmasked sequence each:
  * out[f] = softmax_t( -delta (f - c_t)^2 ) @ hs,  c_t = cumsum(d)_t - d_t/2 (float math). */

@@ -55,7 +55,7 @@ class RelAttnDesc(C.Structure):
         ("q", C.c_void_p), ("ldq", C.c_int32), ("k", C.c_void_p), ("ldk", C.c_int32),
         ("vt", C.c_void_p), ("ldvt", C.c_int32), ("g", C.c_void_p), ("ldg", C.c_int32),
         ("ku", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int32),
-        ("rel_mode", C.c_int32), ("rel_center", C.c_int32), ("vt_col0", C.c_void_p),
+        ("rel_mode", C.c_int32), ("rel_center", C.c_int32), ("vt_col0", C.c_void_p), ("kv_len", C.c_void_p),
     ]
 
 
@@ -109,6 +109,7 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_lr_gather": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_zero_pad_rows": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "jatts_gaussian_upsample": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
 }

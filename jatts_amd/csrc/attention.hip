@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
   const int Tn = d.rg.cu_rows[b + 1] - row0;
   const int i0 = blockIdx.x * QB;
   if (i0 >= Tn) return;
+  // keys >= Tk are masked out of the softmax (a PADDED batch, the reference's training-time forward(): Tn is then the padded
+  // length, which the rel-shift geometry keeps using, and Tk the utterance's own length; attention.py:80-88)
+  const int Tk = d.kv_len ? min(max(d.kv_len[b], 1), Tn) : Tn;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qc = lane & 15, g = lane >> 4;
   const int qi = i0 + wave * 16 + qc;          // this lane's query (may be >= Tn: never stored)
@@ -165,11 +168,11 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
   constexpr bool PREFETCH = DK <= 192 || sizeof(T) != 2;
   TileRegs<T, DK> tr;
   if (PREFETCH) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
-  for (int j0 = j_start; j0 < Tn; j0 += KB) {
+  for (int j0 = j_start; j0 < Tk; j0 += KB) {
     if (!PREFETCH) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec);
     tile_store<T, DK>(tr, ks, vs, kus, KP, VP);
     __syncthreads();
-    if (PREFETCH && j0 + KB < Tn) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0 + KB, Tn, vt_vec);
+    if (PREFETCH && j0 + KB < Tk) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0 + KB, Tn, vt_vec);
 
     // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
     float bd[4][4];
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * f + 4 * g + r;
-        float s = (j >= 0 && j < Tn) ? (st[f][r] + kq[r] + bd[f][r]) * d.scale : -INFINITY;
+        float s = (j >= 0 && j < Tk) ? (st[f][r] + kq[r] + bd[f][r]) * d.scale : -INFINITY;
         st[f][r] = s;
         mx = fmaxf(mx, s);
       }

@@ -530,8 +530,21 @@ __global__ __launch_bounds__(256) void lr_gather_kernel(jatts_ragged rg, const i
     }
     const float* src = x + (int64_t)(row0 + lo) * dim;
     float* dst = out + (int64_t)(o0 + f) * dim;
-    for (int c = lane; c < dim; c += 64) dst[c] = src[c];
-    if (frame_index && lane == 0) frame_index[o0 + f] = lo;
+    const bool past = lo >= Lin;   // frame beyond sum(d): pad_list's zero padding (padded batches of forward())
+    for (int c = lane; c < dim; c += 64) dst[c] = past ? 0.f : src[c];
+    if (frame_index && lane == 0) frame_index[o0 + f] = past ? -1 : lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(jatts_ragged rg, float* x, int ld, int dim, const int32_t* valid_len) {
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int v = max(valid_len[b], 0);
+  const int64_t n = (int64_t)(L - v) * dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / dim;
+    x[(row0 + v + r) * (int64_t)ld + (i - r * dim)] = 0.f;
   }
 }
 
@@ -942,6 +955,15 @@ extern "C" int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, co
   if (!rg_in || !cum || !cu_out || !x || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "lr_gather: null pointer");
   if (max_out_len <= 0) return JATTS_OK;
   hipLaunchKernelGGL(lr_gather_kernel, dim3((unsigned)((max_out_len + 15) / 16), (unsigned)rg_in->n_seq), dim3(256), 0, S_, *rg_in, cum, cu_out, x, dim, out, frame_index);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_zero_pad_rows(const jatts_ragged* rg, float* x, int32_t ld, int32_t dim, const int32_t* valid_len, void* stream) {
+  if (!rg || !x || !valid_len) return jatts_set_error_msg(JATTS_ERR_ARG, "zero_pad_rows: null pointer");
+  if (rg->n_seq <= 0 || rg->max_len <= 0 || dim <= 0) return JATTS_OK;
+  const int64_t per = (int64_t)rg->max_len * dim;
+  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3((unsigned)((per + 1023) / 1024 < 64 ? (per + 1023) / 1024 : 64), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, ld, dim, valid_len);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -255,7 +255,7 @@ def hifigan_output(rb, len_mul, xs, in_scale, slope, c_in, k_w, w, bias, dtype):
 
 
 def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d_k, dtype,
-                     q_col0=0, k_col0=0, rel_mode=1, rel_center=0, vt_col0=None):
+                     q_col0=0, k_col0=0, rel_mode=1, rel_center=0, vt_col0=None, kv_len=None):
     lib = _abi.load()
     out = torch.empty(rb.total, n_heads * d_k, dtype=torch_dtype(dtype), device=q.device)
     d = _abi.RelAttnDesc()
@@ -270,6 +270,7 @@ def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d
     d.out, d.ldo = out.data_ptr(), n_heads * d_k
     d.rel_mode, d.rel_center = rel_mode, rel_center
     d.vt_col0 = _ptr(vt_col0)
+    d.kv_len = _ptr(kv_len)
     with _Timed("relattn", (n_heads, d_k, rb.total)):
         _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
     return out
@@ -431,6 +432,16 @@ def lr_sizes(rb, d, alpha=1.0):
         import logging
         logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
     return d_eff, cum, olens_h
+
+
+def zero_pad_rows(rb, x, valid_len):
+    """x: f32 (rb.total, dim) or (rb.total,); zero the rows t >= valid_len[b] of every sequence, in place."""
+    lib = _abi.load()
+    dim = x.shape[1] if x.dim() == 2 else 1
+    rg = rb.struct()
+    _abi.check(lib.jatts_zero_pad_rows(C.byref(rg), _dev(x).data_ptr(), dim, dim, valid_len.data_ptr(), _stream()),
+               "jatts_zero_pad_rows")
+    return x
 
 
 def lr_gather(rb_in, cum, rb_out, x, want_index=False):

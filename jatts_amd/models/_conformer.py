@@ -155,7 +155,7 @@ class ConformerRunner:
         hip.conv1d(rb, h, w2.w, w2.c_in, w2.n_out, w2.k, dtype=self.dtype, bias=w2.b, act=ACT_NONE,
                    alpha=scale, resid=x, out=x, out_f32=True)
 
-    def _mha(self, rb, x, L, pos):
+    def _mha(self, rb, x, L, pos, kv_len=None):
         A, H, dk = self.A, self.H, self.dk
         xn = hip.layernorm(x, L["norm_mha"][0], L["norm_mha"][1], self.dtype, LN_EPS)
         qk = hip.conv1d(rb, xn, L["qk"].w, A, 2 * A, 1, dtype=self.dtype, bias=L["qk"].b)       # (R, 2A)
@@ -177,7 +177,8 @@ class ConformerRunner:
                 hip.conv1d(rb, qk, heads[h], hip.round_up(dk, 64), n_pos, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
                            x_col0=h * dk, out=g, out_ld=H * ldg, out_col0=h * ldg)
         ctx = hip.relpos_attention(rb, qk, 2 * A, qk, 2 * A, vt, ldvt, g, ldg, ku, 1.0 / math.sqrt(dk),
-                                   H, dk, self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center, vt_col0=vcol)
+                                   H, dk, self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center, vt_col0=vcol,
+                                   kv_len=kv_len)
         hip.conv1d(rb, ctx, L["o"].w, A, A, 1, dtype=self.dtype, bias=L["o"].b, resid=x, out=x, out_f32=True)
 
     def _convmod(self, rb, x, L):
@@ -187,16 +188,18 @@ class ConformerRunner:
         dw = hip.glu_dwconv_bn_swish(rb, pw, A, L["dw_k"], L["dw_w"], L["dw_s"], L["dw_t"], self.dtype)
         hip.conv1d(rb, dw, L["pw2"].w, A, A, 1, dtype=self.dtype, bias=L["pw2"].b, resid=x, out=x, out_f32=True)
 
-    def run(self, rb, x, final_dtype=None, taps=None):
+    def run(self, rb, x, final_dtype=None, taps=None, kv_len=None):
         """x: f32 (rows, A) = input-layer output BEFORE the x*sqrt(A) scaling is applied by the caller.
-        Returns after_norm output as f32 (or ``final_dtype``).  x is updated in place."""
+        Returns after_norm output as f32 (or ``final_dtype``).  x is updated in place.
+        kv_len (int32 device tensor, n_seq): key padding mask of a PADDED batch (the reference's batched forward():
+        encoder.py:233-289 with masks) -- only the attention sees it, exactly as in the reference."""
         pos = self._pos(rb.max_len) if any(L["rel"] for L in self.layers) else None  # (cap, per_layer)
         for i, L in enumerate(self.layers):
             macaron = "feed_forward_macaron" in L
             ff_scale = 0.5 if macaron else 1.0
             if macaron:
                 self._ffn(rb, x, L["norm_ff_macaron"], L["feed_forward_macaron"], ff_scale)
-            self._mha(rb, x, L, (pos[0], pos[1][i]) if pos else None)
+            self._mha(rb, x, L, (pos[0], pos[1][i]) if pos else None, kv_len)
             if "pw1" in L:
                 self._convmod(rb, x, L)
             self._ffn(rb, x, L["norm_ff"], L["feed_forward"], ff_scale)

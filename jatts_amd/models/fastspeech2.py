@@ -291,8 +291,85 @@ class FastSpeech2(torch.nn.Module):
         return dict(feat_gen=r["feat_gen"], duration=r["duration"], pitch=r["pitch"].unsqueeze(-1),
                     energy=r["energy"].unsqueeze(-1))
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "jatts_amd.FastSpeech2.forward (training-time teacher-forced pass, fastspeech2.py:473-564) is outside "
-            "the stage-4 hot path; use inference()/inference_batch()."
-        )
+    @torch.no_grad()
+    def forward(
+        self, text: torch.Tensor, text_lengths: torch.Tensor, feats: torch.Tensor, feats_lengths: torch.Tensor,
+        durations: torch.Tensor, durations_lengths: torch.Tensor, pitch: torch.Tensor, pitch_lengths: torch.Tensor,
+        energy: torch.Tensor, energy_lengths: torch.Tensor, spembs: Optional[torch.Tensor] = None,
+        sids: Optional[torch.Tensor] = None, lids: Optional[torch.Tensor] = None, joint_training: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        """The reference's training-time call (fastspeech2.py:473-564 -> _forward(is_inference=False) :566-653), forward
+        only: teacher-forced durations / pitch / energy on a PADDED batch.  Same arguments, same return dict
+        {before_outs, after_outs, d_outs, p_outs, e_outs, ys, olens}.
+
+        Unlike inference_batch (ragged, every utterance as the reference's B=1 call), this reproduces the reference's
+        batched arithmetic: every sequence is computed at the padded length, only the attention sees the key mask
+        (encoder.py:233-289), so padding rows flow through the convolutions exactly as they do there; the predictors'
+        outputs are multiplied by the non-pad mask (variance_predictor.py:81-83), the length regulator zero-pads to the
+        longest output (length_regulator.py:96-97), and outputs at padded frames are returned as computed."""
+        P = self._prepare()
+        dt, dev = P["dtype"], P["dev"]
+        A = self.adim
+        ilens = [int(v) for v in text_lengths.tolist()]
+        olens = feats_lengths
+        B, Tm = len(ilens), max(ilens)
+        xs = text[:, :Tm].to(dev)                                    # "for data-parallel" truncations (:520-524)
+        ys = feats[:, : int(feats_lengths.max())]
+        ds = durations[:, : int(durations_lengths.max())].to(dev)
+        ps = pitch[:, : int(pitch_lengths.max())].to(dev).float()
+        es = energy[:, : int(energy_lengths.max())].to(dev).float()
+        if ds.shape[1] != Tm or ps.shape[1] != Tm or es.shape[1] != Tm:
+            raise ValueError("durations / pitch / energy must be padded to the text length")
+        rb = hip.RaggedBatch([Tm] * B, dev)                          # padded geometry: every sequence Tm rows
+        kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+        ids = xs.reshape(-1).to(torch.int64).contiguous()
+        x = hip.embed_scale(ids, P["emb"], math.sqrt(A))
+        hs = P["enc"].run(rb, x, kv_len=kv)                          # f32 (B*Tm, A)
+        if self.spks is not None:
+            hip.add_seq_vector(rb, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
+        if self.spk_embed_dim is not None:
+            rbs = hip.RaggedBatch([1] * B, dev)
+            c_in = P["proj"].c_in
+            sp_t = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=c_in)
+            hip.add_seq_vector(rb, hs, hip.conv1d(rbs, sp_t, P["proj"].w, c_in, A, 1, dtype=dt, bias=P["proj"].b, out_f32=True))
+        hs_t = hip.affine_cast(hs, dt)
+        p_outs = hip.zero_pad_rows(rb, hip.predictor_head(P["pitch"].trunk(rb, hs_t), P["pitch"].w, P["pitch"].b), kv)
+        e_outs = hip.zero_pad_rows(rb, hip.predictor_head(P["energy"].trunk(rb, hs_t), P["energy"].w, P["energy"].b), kv)
+        d_outs = hip.zero_pad_rows(rb, hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b), kv)   # log domain
+        # ground-truth pitch / energy embeddings (:618-622), then the length regulator on the ground-truth durations
+        hip.variance_embed_add(rb, hs, ps.reshape(-1).contiguous(), P["pitch_embed"][0], P["pitch_embed"][1],
+                               es.reshape(-1).contiguous(), P["energy_embed"][0], P["energy_embed"][1])
+        d_used = ds.reshape(-1).to(torch.int64).contiguous()
+        d_eff, cum, ol, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=0)
+        ol_h = ol.tolist()
+        if sum(ol_h) == 0:   # the batched call applies the all-zero rule only when the whole batch sums to 0 (:85-94)
+            logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
+            d_eff, cum, ol, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=1)
+            ol_h = ol.tolist()
+        To = max(ol_h)
+        rbo = hip.RaggedBatch([To] * B, dev)
+        yl = hip.lr_gather(rb, cum, rbo, hs)                         # zero rows past each utterance's frames (pad_list)
+        if "sqrtA" not in P:
+            P["sqrtA"] = torch.full((A,), math.sqrt(A), dtype=torch.float32, device=dev)
+        yl = hip.affine_cast(yl, hip.F32, scale=P["sqrtA"])
+        kvo = olens.to(device=dev, dtype=torch.int32).contiguous()  # h_masks = _source_mask(olens) (:636-637)
+        zs_t = P["dec"].run(rbo, yl, final_dtype=dt, kv_len=kvo)
+        fo = P["feat_out"]
+        before = hip.conv1d(rbo, zs_t, fo.w, fo.c_in, fo.n_out, 1, dtype=dt, bias=fo.b, out_f32=True)
+        after = None
+        if P["postnet"]:
+            h = hip.affine_cast(before, dt, ldy=P["postnet"][0].c_in)
+            n = len(P["postnet"])
+            for i, pc in enumerate(P["postnet"]):
+                if i == n - 1:
+                    after = hip.conv1d(rbo, h, pc.w, pc.c_in, pc.n_out, pc.k, dtype=dt, bias=pc.b, act=ACT_NONE,
+                                       resid=before, out_f32=True)
+                else:
+                    h = hip.conv1d(rbo, h, pc.w, pc.c_in, pc.n_out, pc.k, dtype=dt, bias=pc.b, act=ACT_TANH)
+        od = self.odim
+        return {
+            "before_outs": before.view(B, To, od),
+            "after_outs": None if after is None else after.view(B, To, od),
+            "d_outs": d_outs.view(B, Tm), "p_outs": p_outs.view(B, Tm, 1), "e_outs": e_outs.view(B, Tm, 1),
+            "ys": ys, "olens": olens,
+        }

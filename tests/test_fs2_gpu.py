@@ -133,3 +133,28 @@ def test_all_zero_utterance_inside_a_batch(cuda, lib, caplog):
     # the whole batch all-zero: every utterance takes the fallback, none raises
     r0 = m.inference_batch(texts, durations=[torch.zeros_like(d) for d in durs])
     assert r0["olens"] == [len(t) for t in texts]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_fs2_forward_matches_reference_golden(cuda, lib, prec):
+    """forward(): the reference's training-time, teacher-forced, PADDED batched pass (fastspeech2.py:473-564), captured from the
+    real reference (tests/golden/fs2_forward_small.npz, make_golden_r2.py): same argument list, same return dict, compared
+    everywhere -- including the padded positions, whose values depend on padding flowing through the convolutions."""
+    z, keys = load_golden("fs2_forward_small.npz")
+    m = _model(FS2_SMALL, 20, keys, 0, cuda, prec)
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    r = m(t("text"), il, t("feats"), ol, t("durations"), il, t("pitch"), il, t("energy"), il)
+    assert set(r) == {"before_outs", "after_outs", "d_outs", "p_outs", "e_outs", "ys", "olens"}
+    assert torch.equal(r["olens"], ol) and torch.equal(r["ys"], t("ref_ys"))
+    tol = ABS[prec]
+    for k in ("d_outs", "p_outs", "e_outs"):
+        assert r[k].shape == z["ref_" + k].shape
+        assert maxdiff(r[k], z["ref_" + k]) <= (tol if prec == "fp32" else 3e-2), (k, maxdiff(r[k], z["ref_" + k]))
+        for b, n in enumerate(il.tolist()):
+            assert not r[k][b, n:].any()                      # masked by the non-pad mask
+    for k in ("before_outs", "after_outs"):
+        assert r[k].shape == z["ref_" + k].shape
+        for b, n in enumerate(ol.tolist()):                   # valid frames: tight; padded frames: the same leakage arithmetic
+            assert maxdiff(r[k][b, :n], z["ref_" + k][b, :n]) <= tol, (k, b, maxdiff(r[k][b, :n], z["ref_" + k][b, :n]))
+        assert maxdiff(r[k], z["ref_" + k]) <= 5 * tol, (k, maxdiff(r[k], z["ref_" + k]))
