@@ -158,7 +158,8 @@ def get_parser():
     p.add_argument("--config", default=None, type=str)
     p.add_argument("--verbose", type=int, default=1)
     p.add_argument("--batch-size", type=int, default=64, help="utterances per ragged batch (extension)")
-    p.add_argument("--precision", default="fp16", choices=["fp16", "fp32"], help="MFMA operand precision (extension)")
+    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32"],
+                   help="fp32 = the reference's arithmetic (default); fp16 = fast mode: f16 MFMA operands, f32 accumulate (extension)")
     p.add_argument("--plot", action="store_true", help="also write <outdir>/outs/<id>.png like the reference")
     return p
 

@@ -130,7 +130,7 @@ class FastSpeech2(torch.nn.Module):
         if postnet_layers > 0:
             S.postnet_spec(spec, "postnet.", odim, postnet_layers, postnet_chans, postnet_filts, use_batch_norm)
         S.build_from_spec(self, spec)
-        self.precision = "fp16"
+        self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
 

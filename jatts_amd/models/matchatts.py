@@ -225,7 +225,7 @@ class _MatchaBase(torch.nn.Module):
         S._norm(spec, e + "final_block.block.1", up[-1])
         S._conv(spec, e + "final_proj", odim, up[-1], 1)
         S.build_from_spec(self, spec)
-        self.precision = "fp16"
+        self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
 

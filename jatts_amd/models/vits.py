@@ -129,7 +129,7 @@ class VITS(torch.nn.Module):
                          conformer_dec_kernel_size, attn_type="rel_selfattn", normalize_before=decoder_normalize_before)
         S._lin(spec, "feat_out", odim, adim)
         S.build_from_spec(self, spec)
-        self.precision = "fp16"
+        self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
 

@@ -61,7 +61,7 @@ class HiFiGANGenerator(torch.nn.Module):
                     S._conv(spec, f"blocks.{i * nb + j}.convs2.{d}.1", c, c, rk)
         S._conv(spec, "output_conv.1", out_channels, c, kernel_size)
         S.build_from_spec(self, spec)
-        self.precision = "fp16"
+        self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
 

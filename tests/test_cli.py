@@ -43,16 +43,14 @@ def test_pcm16_kernel_equals_host_conversion(cuda, lib):
         assert np.array_equal(got, to_pcm16(y[off:].numpy()))
 
 
-@pytest.mark.gpu
-def test_stage4_cli_end_to_end(cuda, lib, tmp_path):
-    from jatts_amd.bin import tts_decode
+def _make_expdir(d, csv_name="dev.csv"):
+    """A synthetic exp/<expname> directory in the reference's layout (config.yml, tokens.txt, stats, checkpoint, vocoder)."""
     from jatts_amd.models import FastSpeech2
     from jatts_amd.synthetic import FS2_SMALL, HIFIGAN_V1_24K, synth_hifigan_state, synth_state_dict
-    d = tmp_path
     tokens = ["<blank>", "<unk>"] + [f"p{i}" for i in range(17)] + ["<sos/eos>"]
     (d / "tokens.txt").write_text("\n".join(tokens) + "\n")
     g = torch.Generator().manual_seed(0)
-    with open(d / "dev.csv", "w", newline="") as f:
+    with open(d / csv_name, "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=["sample_id", "phonemes"])
         w.writeheader()
         for i, n in enumerate((7, 15, 11)):
@@ -60,19 +58,107 @@ def test_stage4_cli_end_to_end(cuda, lib, tmp_path):
     m = FastSpeech2(idim=20, **FS2_SMALL)
     torch.save({"model": synth_state_dict(m.state_dict(), 0)}, d / "checkpoint-1steps.pkl")
     vparams = dict(HIFIGAN_V1_24K, channels=512)
-    torch.save({"model": {"generator": synth_hifigan_state(vparams, 0)}}, d / "voc.pkl")
-    with open(d / "voc.yml", "w") as f:
+    v = d / "hfg"     # the recipes keep the vocoder under downloads/hfg, not next to the TTS checkpoints
+    os.makedirs(v, exist_ok=True)
+    torch.save({"model": {"generator": synth_hifigan_state(vparams, 0)}}, v / "voc.pkl")
+    with open(v / "voc.yml", "w") as f:
         yaml.safe_dump({"sampling_rate": 24000, "generator_type": "HiFiGANGenerator",
                         "generator_params": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vparams.items()}}, f)
     np.savez(d / "stats.npz", mel_mean=np.zeros(80, np.float32), mel_scale=np.ones(80, np.float32))
-    np.savez(d / "vstats.npz", mean=np.zeros(80, np.float32), scale=np.ones(80, np.float32))
+    np.savez(v / "vstats.npz", mean=np.zeros(80, np.float32), scale=np.ones(80, np.float32))
     with open(d / "config.yml", "w") as f:
         yaml.safe_dump({"model_type": "FastSpeech2", "model_params": dict(FS2_SMALL, idim=20), "out_feat_type": "mel",
-                        "feat_list": ["mel"], "vocoder": {"checkpoint": str(d / "voc.pkl"), "config": str(d / "voc.yml"),
-                                                          "stats": str(d / "vstats.npz")}}, f)
+                        "feat_list": ["mel"], "vocoder": {"checkpoint": str(v / "voc.pkl"), "config": str(v / "voc.yml"),
+                                                          "stats": str(v / "vstats.npz")}}, f)
+
+
+@pytest.mark.gpu
+def test_stage4_cli_end_to_end(cuda, lib, tmp_path):
+    from jatts_amd.bin import tts_decode
+    d = tmp_path
+    _make_expdir(d)
     tts_decode.main(["--csv", str(d / "dev.csv"), "--stats", str(d / "stats.npz"), "--token-list", str(d / "tokens.txt"),
                      "--token-column", "phonemes", "--checkpoint", str(d / "checkpoint-1steps.pkl"),
                      "--outdir", str(d / "out"), "--verbose", "0", "--batch-size", "2"])
     for i in range(3):
         with wave.open(str(d / "out" / "wav" / f"utt{i}.wav")) as w:
+            assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
+
+
+def test_recipe_option_parser(tmp_path):
+    """egs/common/parse_options.sh: `--name value` / `--name=value` set declared variables (dashes or underscores), unknown
+    options are refused -- the interface the reference recipes get from their utils/parse_options.sh."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "t.sh"
+    script.write_text(f"stage=4\nstop_stage=4\ncheckpoint=\"\"\nn_gpus=1\n. {root}/egs/common/parse_options.sh\n"
+                      "echo \"$stage|$stop_stage|$checkpoint|$n_gpus|$#\"\n")
+    run = lambda *a: subprocess.run(["bash", str(script), *a], capture_output=True, text=True)  # noqa: E731
+    assert run("--stage", "2", "--stop-stage=7", "--checkpoint", "a b.pkl", "--n_gpus", "8").stdout.strip() == "2|7|a b.pkl|8|0"
+    assert run().stdout.strip() == "4|4||1|0"
+    bad = run("--nope", "1")
+    assert bad.returncode != 0 and "unknown option" in bad.stderr
+
+
+def test_h5stats_converter_with_stub_h5py(tmp_path, monkeypatch):
+    """tools/h5stats_to_npz.py copies every dataset of the reference's stats.h5 (compute_statistics.py:94-103) under its own key;
+    h5py is absent here, so a recording stub stands in for it (the converter is meant for the machine that trained the model)."""
+    import importlib.util
+    import sys
+    import types
+    data = {"mel_mean": np.arange(80, dtype=np.float64), "mel_scale": np.ones(80), "pitch_mean": np.zeros(1)}
+    h5 = types.ModuleType("h5py")
+
+    class Dataset:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, k):
+            return self.a
+
+    class File:
+        def __init__(self, path, mode):
+            assert mode == "r"
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def visititems(self, fn):
+            for k, v in data.items():
+                fn(k, Dataset(v))
+
+    h5.Dataset, h5.File = Dataset, File
+    monkeypatch.setitem(sys.modules, "h5py", h5)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("h5conv", os.path.join(root, "tools", "h5stats_to_npz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dst, keys = mod.convert(str(tmp_path / "stats.h5"))
+    assert dst.endswith("stats.npz") and keys == sorted(data)
+    from jatts_amd.bin.tts_decode import read_stats
+    st = read_stats(dst, "mel")
+    assert st["mean"].dtype == np.float32 and np.array_equal(st["mean"], np.arange(80, dtype=np.float32))
+
+
+@pytest.mark.gpu
+def test_recipe_run_sh_stage4(cuda, lib, tmp_path):
+    """egs/jsut/tts1/run.sh --stage 4: the reference recipe's variables and directory layout, decoding on the HIP path."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "recipe"
+    exp = work / "exp" / "train_phn_none_unit"
+    os.makedirs(exp)
+    os.makedirs(work / "data")
+    _make_expdir(exp, "test.csv")
+    os.replace(exp / "test.csv", work / "data" / "test.csv")
+    r = subprocess.run(["bash", os.path.join(root, "egs", "jsut", "tts1", "run.sh"), "--stage", "4", "--stop_stage", "4", "--tag", "unit",
+                        "--verbose", "0", "--decode_batch_size", "2"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = exp / "results" / "checkpoint-1steps" / "test"
+    assert (out / "decode.log").exists()
+    for i in range(3):
+        with wave.open(str(out / "wav" / f"utt{i}.wav")) as w:
             assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
