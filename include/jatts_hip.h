@@ -236,9 +236,11 @@ int jatts_rowdot(int32_t dtype, const void* x, int32_t ldx, int64_t rows, int32_
 /* ---------------------------------------------------------------------------------
  * Row-wise kernels (HBM bound).
  * ------------------------------------------------------------------------------- */
-/* Embedding lookup * scale (encoder.py:133-137 + positional_encoding.py:232): f32 out. */
+/* Embedding lookup * scale (encoder.py:133-137 + positional_encoding.py:232): f32 out.  vocab > 0: ids outside [0, vocab)
+ * give a zero row and are counted into *n_bad (device int64, caller-zeroed, may be NULL) -- torch.nn.Embedding raises
+ * IndexError for them; the host raises it at its next synchronisation point instead of paying one here. */
 int jatts_embed_scale(const int64_t* ids, int64_t rows, const float* table, int32_t dim,
-                      float scale, float* out, void* stream);
+                      float scale, float* out, int64_t vocab, int64_t* n_bad, void* stream);
 
 /* LayerNorm over the last dim (modules/transformer/layer_norm.py:12-42, eps 1e-12):
  * x (in_dtype) -> y (out_dtype); gamma/beta f32. */

@@ -81,7 +81,7 @@ PROTOTYPES = {
     "jatts_rowdot": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_embed_scale": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
-                                    C.c_void_p]),
+                                    C.c_int64, C.c_void_p, C.c_void_p]),
     "jatts_layernorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "jatts_affine_cast": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,

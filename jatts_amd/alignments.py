@@ -24,17 +24,26 @@ class AlignmentModule(torch.nn.Module):
         self._prep = None
 
     def _prepare(self):
+        names = ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")
+        ver = tuple(p._version for n in names for p in (getattr(self, n).weight, getattr(self, n).bias))
+        if self._prep is not None and self._prep.get("_ver") != ver:   # in-place parameter updates (an optimiser step) too
+            self._prep = None
         if self._prep is None:
             dev = self.t_conv1.weight.device
             if dev.type != "cuda":
                 raise hip._abi.JattsHipError("jatts_amd.AlignmentModule runs on the GPU only (no CPU fallback)")
             self._prep = {n: PackedConv(getattr(self, n).weight.detach(), getattr(self, n).bias.detach(), hip.F32, dev)
-                          for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
+                          for n in names}
+            self._prep["_ver"] = ver
         return self._prep
 
     def _apply(self, fn, *a, **k):
         self._prep = None
         return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
 
     @torch.no_grad()
     def forward_ragged(self, rb_t, text, rb_f, feats):

@@ -21,11 +21,14 @@ __device__ __forceinline__ void load8f(const T* p, float (&o)[8]) {
 
 // ------------------------------------------------------------------------- embedding
 __global__ void embed_scale_kernel(const int64_t* ids, int64_t rows, const float* table, int dim,
-                                   float scale, float* out) {
+                                   float scale, float* out, int64_t vocab, int64_t* n_bad) {
   const int64_t row = blockIdx.x;
-  const float* src = table + ids[row] * (int64_t)dim;
+  const int64_t id = ids[row];
+  const bool bad = vocab > 0 && (id < 0 || id >= vocab);   // torch.nn.Embedding raises IndexError: counted here, raised by the host
+  if (bad && threadIdx.x == 0 && n_bad) atomicAdd(reinterpret_cast<unsigned long long*>(n_bad), 1ull);
+  const float* src = table + (bad ? 0 : id) * (int64_t)dim;
   float* dst = out + row * (int64_t)dim;
-  for (int c = threadIdx.x; c < dim; c += blockDim.x) dst[c] = src[c] * scale;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) dst[c] = bad ? 0.f : src[c] * scale;
 }
 
 // ------------------------------------------------------------------------- layernorm
@@ -741,10 +744,10 @@ __global__ void pcm16_kernel(const float* x, int16_t* y, int64_t n) {
 #define S_ ((hipStream_t)stream)
 
 extern "C" int jatts_embed_scale(const int64_t* ids, int64_t rows, const float* table, int32_t dim,
-                                 float scale, float* out, void* stream) {
+                                 float scale, float* out, int64_t vocab, int64_t* n_bad, void* stream) {
   if (!ids || !table || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "embed_scale: null pointer");
   if (rows <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(embed_scale_kernel, dim3((unsigned)rows), dim3(128), 0, S_, ids, rows, table, dim, scale, out);
+  hipLaunchKernelGGL(embed_scale_kernel, dim3((unsigned)rows), dim3(128), 0, S_, ids, rows, table, dim, scale, out, vocab, n_bad);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -284,11 +284,14 @@ def rowdot(x, ldx, rows, n_heads, d_k, vec, col0=0):
     return out
 
 
-def embed_scale(ids, table, scale):
+def embed_scale(ids, table, scale, n_bad=None):
+    """n_bad: optional int64 (1,) device counter (zeroed by the caller) of ids outside the table -- read at the caller's next
+    host synchronisation (lr_sizes(..., check=n_bad)) instead of a dedicated ids.max()/min() round trip per batch."""
     lib = _abi.load()
     out = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=ids.device)
     _abi.check(lib.jatts_embed_scale(_dev(ids).data_ptr(), ids.numel(), table.data_ptr(), table.shape[1],
-                                     float(scale), out.data_ptr(), _stream()), "jatts_embed_scale")
+                                     float(scale), out.data_ptr(), table.shape[0] if n_bad is not None else 0,
+                                     _ptr(n_bad), _stream()), "jatts_embed_scale")
     return out
 
 
@@ -422,12 +425,15 @@ def lr_durations(rb, d, alpha=1.0, zero_rule=2):
     return d_eff, cum, buf[:rb.n_seq], (buf[rb.n_seq:] if zero_rule == 2 else None)
 
 
-def lr_sizes(rb, d, alpha=1.0):
+def lr_sizes(rb, d, alpha=1.0, check=None):
     """lr_durations + the one host sync of the path: -> (d_eff, cum, olens list).  Logs the reference's warning
-    (length_regulator.py:87-90) for utterances that took the all-zero fallback."""
+    (length_regulator.py:87-90) for utterances that took the all-zero fallback.  ``check``: the embed_scale bad-id
+    counter, read in the same transfer; non-zero raises IndexError like torch.nn.Embedding."""
     d_eff, cum, olens, fb = lr_durations(rb, d, alpha)
-    host = torch.cat([olens, fb]).tolist()
-    olens_h, fb_h = host[:rb.n_seq], host[rb.n_seq:]
+    host = torch.cat([olens, fb] + ([check.view(-1)] if check is not None else [])).tolist()
+    if check is not None and host[2 * rb.n_seq]:
+        raise IndexError("token id out of range")
+    olens_h, fb_h = host[:rb.n_seq], host[rb.n_seq:2 * rb.n_seq]
     if any(fb_h):
         import logging
         logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")

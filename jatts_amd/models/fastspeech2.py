@@ -212,10 +212,10 @@ class FastSpeech2(torch.nn.Module):
             raise ValueError("empty text")
         rb = hip.RaggedBatch(lens, dev)
         ids = torch.cat([t.reshape(-1) for t in texts]).to(device=dev, dtype=torch.int64)
-        if int(ids.max()) >= self.idim or int(ids.min()) < 0:
-            raise IndexError("token id out of range")  # torch.nn.Embedding raises likewise
-        # encoder.embed: Embedding -> LegacyRelPositionalEncoding (x * sqrt(adim))  encoder.py:133-137
-        x = hip.embed_scale(ids, P["emb"], math.sqrt(A))
+        # encoder.embed: Embedding -> LegacyRelPositionalEncoding (x * sqrt(adim))  encoder.py:133-137.  Out-of-range ids are
+        # counted by the kernel and raised (IndexError, as torch.nn.Embedding) at the length-regulator host sync below
+        n_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        x = hip.embed_scale(ids, P["emb"], math.sqrt(A), n_bad)
         hs = P["enc"].run(rb, x, taps=taps)                                  # f32 (R, A)
         if taps is not None:
             taps["encoder_out"] = hs.clone()
@@ -247,7 +247,7 @@ class FastSpeech2(torch.nn.Module):
             if d_used.numel() != rb.total:
                 raise ValueError("durations do not match texts")
         # length regulator (length_regulator.py:70-97): the one host sync of the path — output sizes
-        d_eff, cum, olens_h = hip.lr_sizes(rb, d_used, alpha)   # an all-zero utterance gets all ones, as the reference's B=1 call
+        d_eff, cum, olens_h = hip.lr_sizes(rb, d_used, alpha, check=n_bad)   # an all-zero utterance gets all ones, as the reference's B=1 call
         rbo = hip.RaggedBatch(olens_h, dev)
         if taps is not None:
             ys, fidx = hip.lr_gather(rb, cum, rbo, hs, want_index=True)

@@ -350,9 +350,8 @@ class _MatchaBase(torch.nn.Module):
         lens = [int(t.numel()) for t in texts]
         rb = hip.RaggedBatch(lens, dev)
         ids = torch.cat([t.reshape(-1) for t in texts]).to(device=dev, dtype=torch.int64)
-        if int(ids.max()) >= self.idim or int(ids.min()) < 0:
-            raise IndexError("token id out of range")
-        hs = P["enc"].run(rb, hip.embed_scale(ids, P["emb"], math.sqrt(A)))
+        n_bad = torch.zeros(1, dtype=torch.int64, device=dev)   # out-of-range ids: counted by the kernel, raised at the LR host sync
+        hs = P["enc"].run(rb, hip.embed_scale(ids, P["emb"], math.sqrt(A), n_bad))
         rbs = hip.RaggedBatch([1] * B, dev)
         if self.spks is not None:
             hip.add_seq_vector(rb, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
@@ -365,7 +364,7 @@ class _MatchaBase(torch.nn.Module):
         d_used = d_pred
         if durations is not None:
             d_used = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
-        d_eff, cum, olens = hip.lr_sizes(rb, d_used)                # host sync: output sizes (all-zero utterances -> all ones)
+        d_eff, cum, olens = hip.lr_sizes(rb, d_used, check=n_bad)                # host sync: output sizes (all-zero utterances -> all ones)
         olens = [n - n % 2 for n in olens]                         # matchatts_mas.py:521-526: even lengths
         if min(olens) <= 0:
             raise RuntimeError("an utterance has fewer than 2 output frames")

@@ -197,10 +197,9 @@ class VITS(torch.nn.Module):
         lens = [int(t.numel()) for t in texts]
         rb = hip.RaggedBatch(lens, dev)
         ids = torch.cat([t.reshape(-1) for t in texts]).to(device=dev, dtype=torch.int64)
-        if int(ids.max()) >= self.idim or int(ids.min()) < 0:
-            raise IndexError("token id out of range")
+        n_bad = torch.zeros(1, dtype=torch.int64, device=dev)   # out-of-range ids: counted by the kernel, raised at the LR host sync
         # TextEncoder: emb * sqrt(A) (text_encoder.py:123), then RelPositionalEncoding scales by sqrt(A) again
-        x = hip.embed_scale(ids, P["emb"], float(A))
+        x = hip.embed_scale(ids, P["emb"], float(A), n_bad)
         hs = P["tenc"].run(rb, x)                                          # f32 (R, A)
         if taps is not None:
             taps["text_encoder_out"] = hs.clone()
@@ -219,7 +218,7 @@ class VITS(torch.nn.Module):
         d_used = d_pred
         if durations is not None:
             d_used = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
-        d_used, _, olens = hip.lr_sizes(rb, d_used)                        # per-utterance frame counts (host sync)
+        d_used, _, olens = hip.lr_sizes(rb, d_used, check=n_bad)                        # per-utterance frame counts (host sync)
         if min(olens) <= 0:
             raise RuntimeError("an utterance has zero output frames (all durations 0)")
         rbo = hip.RaggedBatch(olens, dev)

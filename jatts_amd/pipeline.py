@@ -49,6 +49,9 @@ class Stage4Pipeline:
                     ready.record(self.s_mel)
             caller.wait_event(done)
             y.record_stream(caller)
+            for t in out[0].values():   # every tensor of the result was allocated on s_mel and is read on the caller's stream
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(caller)
             yield out
             if nxt is None:
                 return

@@ -44,6 +44,11 @@ class HiFiGANGenerator(torch.nn.Module):
         self.resblock_dilations = tuple(tuple(int(d) for d in ds) for ds in resblock_dilations)
         if channels % (1 << len(self.upsample_scales)) or channels > 512:
             raise NotImplementedError("channels must be divisible by 2**n_upsamples and <= 512")
+        for s_, uk in zip(self.upsample_scales, self.upsample_kernel_sizes):
+            if uk != 2 * s_:   # the polyphase upsampling emits exactly L*s samples: ConvTranspose1d(padding=s//2+s%2, output_padding=s%2) only for k = 2s
+                raise NotImplementedError(f"upsample_kernel_size {uk} != 2 * scale {s_}: only the k = 2s geometry of the HiFi-GAN recipes is supported")
+        if not 1 <= len(self.resblock_kernel_sizes) <= 3:
+            raise NotImplementedError("1..3 ResBlocks per stage (the MRF mix kernels take up to 3 inputs)")
         self.hop = 1
         for s in self.upsample_scales:
             self.hop *= s
@@ -229,21 +234,14 @@ class HiFiGANGenerator(torch.nn.Module):
                 with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
                     for di, (c1, c2, rk, d) in enumerate(units):
                         nxt = bufs[j][di & 1]
-                        if c_out in supported:
-                            last = fuse_mean and j == len(blocks) - 1 and di == len(units) - 1
-                            if last:
-                                for ev in done:
-                                    torch.cuda.current_stream().wait_event(ev)
-                            # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
-                            hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt,
-                                                add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0)
-                        else:  # generic two-launch fallback for unusual channel counts
-                            h = hip.conv1d(rb, cur, c1.w, c_out, c_out, rk, dtype=dt, bias=c1.b, dil=d,
-                                           pre_lrelu=self.slope, len_mul=rate)
-                            r32 = cur.float()
-                            y32 = hip.conv1d(rb, h, c2.w, c_out, c_out, rk, dtype=dt, bias=c2.b,
-                                             pre_lrelu=self.slope, len_mul=rate, resid=r32, out_f32=True)
-                            nxt = hip.affine_cast(y32, dt)
+                        # (c_out is always a fused-unit width: _prepare zero-pads narrower stages and refuses wider ones)
+                        last = fuse_mean and j == len(blocks) - 1 and di == len(units) - 1
+                        if last:
+                            for ev in done:
+                                torch.cuda.current_stream().wait_event(ev)
+                        # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
+                        hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt,
+                                            add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0)
                         cur = nxt
                     if st is not None:
                         ev = torch.cuda.Event()

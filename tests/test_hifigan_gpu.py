@@ -76,3 +76,27 @@ def test_unsupported_channel_counts_raise(lib):
     from jatts_amd.vocoder import HiFiGANGenerator
     with pytest.raises(NotImplementedError):
         HiFiGANGenerator(**_small(HIFIGAN_V1_22K, 1024))
+
+
+def test_unsupported_generator_geometries_raise(lib):
+    """a ConvTranspose kernel != 2 * stride (the polyphase upsampling would give wrong lengths) and more than
+    three ResBlocks per stage (the MRF mix takes three inputs) are rejected in the constructor."""
+    from jatts_amd.vocoder import HiFiGANGenerator
+    with pytest.raises(NotImplementedError):
+        HiFiGANGenerator(**dict(HIFIGAN_V1_22K, upsample_kernel_sizes=(16, 16, 4, 5)))
+    with pytest.raises(NotImplementedError):
+        HiFiGANGenerator(**dict(HIFIGAN_V1_22K, resblock_kernel_sizes=(3, 5, 7, 11), resblock_dilations=((1, 3, 5),) * 4))
+
+
+def test_out_of_range_token_ids_raise_index_error(cuda, lib):
+    """torch.nn.Embedding raises IndexError for ids outside the table; here the embed kernel counts them and the host raises at
+    its one synchronisation point (no per-batch ids.max()/min() round trip)."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.synthetic import FS2_SMALL, synth_state_dict
+    m = FastSpeech2(idim=20, **FS2_SMALL)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    m = m.to(cuda)
+    m.inference(torch.tensor([1, 5, 19]).to(cuda))
+    for bad in ([1, 20, 3], [2, -1]):
+        with pytest.raises(IndexError):
+            m.inference(torch.tensor(bad).to(cuda))
