@@ -111,7 +111,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x
 }
 
 template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC, int KCHT = KCH>
-__global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kernel(jatts_conv_desc d, int f32_tile) {
+// two workgroups per CU (<= 256 registers) for the single-input pipelines: one workgroup's LDS commits, barriers and epilogue
+// then run under the other's MFMAs (the f32 kernel at 268 registers had the CU to itself and sat at ~55 % MFMA utilisation)
+__global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN == 1 && ASYNC && WT * NT * 32 <= 128)) ? 2 : 1) void conv1d_kernel(jatts_conv_desc d, int f32_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32;
   const int b = blockIdx.y;
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kerne
   // the synchronous single-buffer path)
   constexpr int UPRC = KCHT / 8;
   constexpr int MAXU = ((BT + 32) * UPRC + WN * WT * 64 - 1) / (WN * WT * 64);
-  constexpr int RD = KCHT / 16;  // ring depth: k_w * (KCHT/16) is always a multiple of it
+  // ring depth: k_w * (KCHT/16) is always a multiple of it.  f32: a step is 32 x 64-cycle MFMAs, two steps of look-ahead
+  // cover any L2 round trip and free 32 registers
+  constexpr int RD = sizeof(T) == 4 ? 2 : KCHT / 16;
   WRing<T, NF, RD> ring;
   const int n_chunks = d.c_in / KCHT;
   ring.init((const T*)d.w, KC16, NFR, nf0, d.k_w, KCHT / 16, n_chunks, lane);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kerne
   // epilogue, specialised per activation by ONE uniform branch: a runtime switch inside the 64-element
   // unrolled body inlined tanh/mish 128 times, the unroller gave up and the accumulators went to scratch
   // (1.8x slower conv, profiles/r01_notes.md).
-  if constexpr (sizeof(T) == 2) {
+  {
     // the loop's last barrier has retired every read of the activation buffers: reuse them as the output tile
     constexpr int BN = WN * NF * 32;
     const int n_base = blockIdx.z * BN;
@@ -203,11 +207,15 @@ __global__ __launch_bounds__(WN* WT * 64, KCHT == 128 ? 2 : 1) void conv1d_kerne
     case JATTS_ACT_MISH: conv_epilogue_lds<T, TO, JATTS_ACT_MISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;  \
     default: conv_epilogue_lds<T, TO, JATTS_ACT_NONE, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;              \
   }
-    if (rowmajor && !d.y_is_f32 && !d.resid && (d.ldy & 7) == 0) {
-      JATTS_EPI(T)
-      return;
+    if constexpr (sizeof(T) == 2) {
+      if (rowmajor && !d.y_is_f32 && !d.resid && (d.ldy & 7) == 0) {
+        JATTS_EPI(T)
+        return;
+      }
     }
-    if (rowmajor && d.y_is_f32 && f32_tile && (d.ldy & 3) == 0 &&
+    // f32 rows (f16 kernels writing the f32 residual streams, and every row-major output of the f32 kernels): in fragment
+    // order a lane's 16-byte store lands 32 rows from its neighbour's, so each output row gets 32-byte pieces
+    if (rowmajor && (d.y_is_f32 || sizeof(T) == 4) && f32_tile && (d.ldy & 3) == 0 &&
         (!d.resid || ((d.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(d.resid) & 15) == 0))) {
       JATTS_EPI(float)
       return;
@@ -233,6 +241,12 @@ int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
   // output tile of the coalesced epilogues (f16 kernels): T-typed always, f32 (row-major f32 outputs, e.g. the
   // in-place residual-stream updates) when the conv is long enough that the bigger LDS footprint does not matter
   int f32_tile = 0;
+  if (sizeof(T) == 4) {   // f32 kernels: coalesced f32 output tile whenever it fits beside nothing else (the staging buffers are dead by then)
+    if (!d.y_transposed && (size_t)BT * (BN * 4 + 16) <= 160 * 1024) {
+      f32_tile = 1;
+      if (lds < (size_t)BT * (BN * 4 + 16)) lds = (size_t)BT * (BN * 4 + 16);
+    }
+  }
   if (sizeof(T) == 2) {
     if (lds < (size_t)BT * (BN * sizeof(T) + 16)) lds = (size_t)BT * (BN * sizeof(T) + 16);
     if (d.y_is_f32 && !d.y_transposed) {

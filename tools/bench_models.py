@@ -31,13 +31,16 @@ def timed(fn, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--model", default="both", choices=["both", "matcha", "vits"])
+    ap.add_argument("--no-vocoder", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     ones, zeros = [1.0] * 80, [0.0] * 80
     voc = Vocoder(synth_hifigan_state(HIFIGAN_V1_24K, 0),
                   {"sampling_rate": 24000, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_24K},
                   {"mean": zeros, "scale": ones}, dev, trg_stats={"mean": zeros, "scale": ones})
-    voc.set_precision("fp16")
+    voc.set_precision(a.precision)
     hop = voc.model.hop
 
     def report(name, dt, r, y, n_utts):
@@ -46,29 +49,37 @@ def main():
                           "ms_per_batch": dt * 1e3, "samples_per_s": frames * hop / dt, "rtf": dt / (frames * hop / 24000.0),
                           "finite": bool(torch.isfinite(y).all())}))
 
+    if a.model in ("both", "matcha"):
+        run_matcha_cfg(a, dev, voc, report)
+    if a.model in ("both", "vits"):
+        run_vits_cfg(a, dev, voc, report)
+
+
+def run_matcha_cfg(a, dev, voc, report):
     m = MatchaTTS_MAS(idim=45, **MATCHA_MAS_JSUT)
     m.load_state_dict(synth_state_dict(m.state_dict(), 0))
-    m = m.to(dev).set_precision("fp16")
+    m = m.to(dev).set_precision(a.precision)
     texts = [t.to(dev) for t in synth_texts(64, 128, 45, seed=1)]
     dur = [torch.full((128,), 6, dtype=torch.int64, device=dev) for _ in texts]   # durations pinned to 6 frames / phoneme
 
     def run_matcha():
         r = m.inference_batch(texts, n_timesteps=10, temperature=0.667, durations=dur)
-        return r, voc.decode_batch(r["feats_rb"], r["feat_gen"])
+        return r, (r["feat_gen"] if a.no_vocoder else voc.decode_batch(r["feats_rb"], r["feat_gen"]))
     dt, (r, y) = timed(run_matcha, a.steps)
     report("3: MatchaTTS_MAS(10 Euler steps)+HiFi-GAN 24k, 64x128 phonemes x 6 frames", dt, r, y, 64)
-    del m
 
+
+def run_vits_cfg(a, dev, voc, report):
     v = VITS(idim=45, spk_embed_dim=192, **VITS_JSUT)
     v.load_state_dict(synth_state_dict(v.state_dict(), 0))
-    v = v.to(dev).set_precision("fp16")
+    v = v.to(dev).set_precision(a.precision)
     texts = [t.to(dev) for t in synth_texts(32, 128, 45, seed=3)]
     spk = torch.randn(32, 192, generator=torch.Generator().manual_seed(3)).to(dev)
     dur = [torch.full((128,), 6, dtype=torch.int64, device=dev) for _ in texts]
 
     def run_vits():
         r = v.inference_batch(texts, spk, noise_scale=0.667, durations=dur)
-        return r, voc.decode_batch(r["feats_rb"], r["feat_gen"])
+        return r, (r["feat_gen"] if a.no_vocoder else voc.decode_batch(r["feats_rb"], r["feat_gen"]))
     dt, (r, y) = timed(run_vits, a.steps)
     report("5: mel-VITS(spk 192)+HiFi-GAN 24k, 32x128 phonemes x 6 frames", dt, r, y, 32)
 
