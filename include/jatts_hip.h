@@ -38,6 +38,9 @@ extern "C" {
 #define JATTS_ACT_SWISH 3
 #define JATTS_ACT_MISH 4
 
+#define JATTS_PAD_ZERO 0
+#define JATTS_PAD_REFLECT 1
+
 #define JATTS_PRE_NONE 0
 #define JATTS_PRE_LRELU 1
 
@@ -102,6 +105,8 @@ typedef struct jatts_conv_desc {
   int32_t y_transposed;/* 1: y[n*ldy + row] (used for V^T) */
   const int32_t* y_seq_col0; /* transposed output only, or NULL: sequence b writes column y_seq_col0[b] + t
                               * instead of its packed row (V^T with 8-aligned sequence starts, see vt_col0) */
+  int32_t pad_mode;    /* JATTS_PAD_ZERO (rows outside the sequence read as zero) or JATTS_PAD_REFLECT (torch
+                        * padding_mode="reflect", the SpeechBrain Conv1d default used by ECAPA-TDNN; halo < length) */
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);
@@ -254,6 +259,10 @@ int jatts_layernorm(const void* x, int32_t in_dtype, int32_t ldx, void* y, int32
 int jatts_affine_cast(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
                       int64_t rows, int32_t dim, const float* scale, const float* shift,
                       void* stream);
+/* The same map into a column slice: exactly `dim` columns per row are written (row stride ldy), nothing is zero-filled. */
+int jatts_affine_slice(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                      int64_t rows, int32_t dim, const float* scale, const float* shift,
+                      void* stream);
 
 /* Conformer conv-module core (modules/conformer/convolution.py:67-75):
  *   h = GLU(x[:, :C], x[:, C:]) ; y = swish( dwconv_k(h) * bn_scale + bn_shift )
@@ -313,6 +322,35 @@ int jatts_flip_channels(const float* x, float* y, int64_t rows, int32_t channels
 /* hs[row][:] += vec[seq(row)][:]  (speaker embedding add, fastspeech2.py:591-597,751-753) */
 int jatts_add_seq_vector(const jatts_ragged* rg, float* hs, int32_t dim, const float* vec,
                          void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Speaker-embedding front end: what jatts/modules/feature_extract/spkemb_speechbrain.py:14-28 gets from
+ * SpeechBrain's EncoderClassifier.encode_batch (third party, not vendored: log-mel filterbank -> sentence mean
+ * normalisation -> ECAPA-TDNN; called per utterance at jatts/bin/tts_decode.py:209-212).  The contractions (DFT, mel
+ * projection, TDNN / Res2Net / SE / pooling convs) are jatts_conv1d launches (pad_mode = JATTS_PAD_REFLECT where
+ * SpeechBrain's Conv1d pads); these are the row-wise pieces.  All f32 unless noted.
+ * ------------------------------------------------------------------------------- */
+/* Windowed frames of packed waveforms: frames[row(b,t)][n] = window[n] * x_b[reflect(t*hop + n - n_fft/2)] (torch.stft
+ * center=True); rg_frames counts frames per utterance, cu_samples (n_seq+1) delimits the waveforms; columns n_fft..ldo-1 = 0. */
+int jatts_frame_signal(const jatts_ragged* rg_frames, const int32_t* cu_samples, const float* x, const float* window,
+                       int32_t n_fft, int32_t hop, float* out, int32_t ldo, void* stream);
+/* out[row][k] = x[row][k]^2 + x[row][n_bins + k]^2 (k < n_bins), zero up to ldo. */
+int jatts_power_spectrum(const float* x, int32_t ldx, int32_t n_bins, int64_t rows, float* out, int32_t ldo, void* stream);
+/* Per utterance: dB = 10 log10(max(p, amin)), clamped from below at max(dB) - top_db, minus its mean over time per channel. */
+int jatts_fbank_post(const jatts_ragged* rg, const float* p, int32_t ldp, int32_t n_mels, float amin, float top_db,
+                     float* out, int32_t ldo, void* stream);
+/* Per (utterance, channel) statistics over time with weights softmax_t(logits) (logits == NULL: uniform):
+ * mean[b*ldm + c], std[b*ldm + c] = sqrt(max(weighted variance, eps)) (std may be NULL).  SE squeeze + attentive statistics pooling. */
+int jatts_seq_mean_std(const jatts_ragged* rg, const float* x, int32_t ldx, int32_t dim, const float* logits, int32_t ldl,
+                       float* mean, float* stdv, int32_t ldm, float eps, void* stream);
+/* y = post_act( scale[c] * pre_act(x + seq_vec[b][c]) + shift[c] ); pre_act: JATTS_ACT_NONE / _RELU, post_act: _NONE / _TANH;
+ * seq_vec / scale / shift may be NULL; y in out_dtype with columns dim..ldy-1 zeroed (TDNNBlock: conv -> ReLU -> BatchNorm). */
+int jatts_seq_affine_act(const jatts_ragged* rg, const float* x, int32_t ldx, int32_t dim, const float* seq_vec, int32_t pre_act,
+                         const float* scale, const float* shift, int32_t post_act, void* y, int32_t out_dtype, int32_t ldy,
+                         void* stream);
+/* y[row*ldy + c] = x * sigmoid(s[b][c]) + resid (x, resid: [rows][dim]; resid may be NULL): SE gate + residual connection. */
+int jatts_se_scale_add(const jatts_ragged* rg, const float* x, int32_t dim, const float* s, const float* resid, float* y, int32_t ldy,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Length regulator (modules/length_regulator.py:70-97), bit-exact integer path.

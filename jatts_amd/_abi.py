@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjat
 F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH = 0, 1, 2, 3, 4
 PRE_NONE, PRE_LRELU = 0, 1
+PAD_ZERO, PAD_REFLECT = 0, 1
 
 
 class Ragged(C.Structure):
@@ -28,6 +29,7 @@ class ConvDesc(C.Structure):
         ("dil", C.c_int32), ("pad", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
         ("alpha", C.c_float), ("resid", C.c_void_p), ("ldr", C.c_int32), ("y", C.c_void_p),
         ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32), ("y_seq_col0", C.c_void_p),
+        ("pad_mode", C.c_int32),
     ]
 
 
@@ -86,6 +88,8 @@ PROTOTYPES = {
                                   C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "jatts_affine_cast": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_affine_slice": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_glu_dwconv_bn_swish": (C.c_int, [C.POINTER(Ragged), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_predictor_head": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
@@ -109,6 +113,17 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_lr_gather": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_frame_signal": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_int32, C.c_void_p]),
+    "jatts_power_spectrum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "jatts_fbank_post": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p,
+                                   C.c_int32, C.c_void_p]),
+    "jatts_seq_mean_std": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
+    "jatts_seq_affine_act": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "jatts_se_scale_add": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p]),
     "jatts_zero_pad_rows": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "jatts_gaussian_upsample": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),

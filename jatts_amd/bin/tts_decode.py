@@ -211,14 +211,22 @@ def main(argv=None):
     order = sorted(range(len(items)), key=lambda i: -len(items[i]["token_indices"]))  # similar lengths together
     n_frames, t0 = 0, time.time()
     out_pipe = OutputPipeline(device, vocoder.config["sampling_rate"])
+    spk_extractor = None
     for s in range(0, len(order), args.batch_size):
         batch = [items[i] for i in order[s:s + args.batch_size]]
         texts = [torch.from_numpy(it["token_indices"]).to(device) for it in batch]
         if uses_spk:
-            if "spkemb_path" not in batch[0]:
-                raise NotImplementedError("speaker embeddings must be precomputed (csv column spkemb_path -> .npy); "
-                                          "the SpeechBrain extractor is outside the hot path")
-            spk = torch.from_numpy(np.stack([load_spkemb(it["spkemb_path"]) for it in batch])).float().to(device)
+            if "spkemb_path" in batch[0]:          # precomputed embeddings (.npy), cached per file
+                spk = torch.from_numpy(np.stack([load_spkemb(it["spkemb_path"]) for it in batch])).float().to(device)
+            else:                                  # the reference's path: extract from ref_wav_path (tts_decode.py:209-212)
+                if spk_extractor is None:
+                    from jatts_amd.spkemb import SpkEmbExtractor
+                    ckpt = config.get("spkemb_checkpoint") or os.environ.get("JATTS_SPKEMB_CHECKPOINT")
+                    if not ckpt:
+                        raise RuntimeError("feat_list has 'spkemb' and the csv has no spkemb_path column: set spkemb_checkpoint (config) or "
+                                           "JATTS_SPKEMB_CHECKPOINT to SpeechBrain's ECAPA embedding_model.ckpt")
+                    spk_extractor = SpkEmbExtractor(device, checkpoint=ckpt)
+                spk = torch.from_numpy(spk_extractor.forward_many([it["ref_wav_path"] for it in batch])).float().to(device)
             r = model.inference_batch(texts, spembs=spk, **kw)
         else:
             r = model.inference_batch(texts, **kw)

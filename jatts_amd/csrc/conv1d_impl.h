@@ -133,6 +133,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   const int col0 = wt * NT * 32;
 
   const T* xin[3] = {(const T*)d.x[0], (const T*)d.x[1], (const T*)d.x[2]};
+  const bool reflect = d.pad_mode == JATTS_PAD_REFLECT;
   f32x16 acc[NF][NT];
   zero_acc<NF, NT>(acc);
   if (d.bias) {   // accumulators start at the bias: its loads overlap the first staging round trip instead of the epilogue
@@ -169,12 +170,12 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   if constexpr (ASYNC) {
     const size_t buf_bytes = (size_t)rows * pitch;
     StageRegs<T, MAXU, NIN> sr;
-    stage_issue<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0);
+    stage_issue<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0, reflect);
     stage_commit<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     __syncthreads();
     for (int ci = 0; ci < n_chunks; ++ci) {
       const bool more = ci + 1 < n_chunks;
-      if (more) stage_issue<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT);
+      if (more) stage_issue<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
       conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0,
                                 lane);
       if (more) stage_commit<T, MAXU, NIN, UPRC, WN * WT * 64>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in,
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   } else {
     for (int ci = 0; ci < n_chunks; ++ci) {
       stage_rows<T>(smem, pitch, rows, KCHT, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, ci * KCHT, d.in_scale,
-                    d.pre_act, d.pre_slope);
+                    d.pre_act, d.pre_slope, reflect);
       __syncthreads();
       conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem, pitch, col0, lane);
       __syncthreads();

@@ -50,10 +50,17 @@ template <> struct Vec8IO<float> {
 // Loads are issued in batches of UB per thread BEFORE any of them is consumed: a one-load-
 // per-iteration loop serialises a full L2/HBM round trip per 16 bytes (measured: the staging
 // phases were as long as the MFMA phases).
+// Reflect padding (torch padding_mode="reflect": no edge repeat): position p of a length-L sequence, |overshoot| < L.
+__device__ __forceinline__ int reflect_pos(int p, int L) {
+  if (p < 0) p = -p;
+  if (p >= L) p = 2 * (L - 1) - p;
+  return p;
+}
+
 template <typename T, int UB = 8>
 __device__ __forceinline__ void stage_rows(char* lds, int pitch, int rows, int nch, int pos0, int L,
                                            int64_t seq_row0, const T* const* x, int n_in, int ldx,
-                                           int c0, float in_scale, int pre_act, float slope) {
+                                           int c0, float in_scale, int pre_act, float slope, bool reflect = false) {
   typedef typename Elem<T>::vec8 V8;
   const int upr = nch >> 3;  // 8-element units per row
   const int total = rows * upr;
@@ -67,7 +74,8 @@ __device__ __forceinline__ void stage_rows(char* lds, int pitch, int rows, int n
     for (int j = 0; j < UB; ++j) {
       const int u = base + j * blockDim.x;
       const int r = u / upr, cu = u - r * upr;
-      const int pos = pos0 + r;
+      int pos = pos0 + r;
+      if (reflect) pos = reflect_pos(pos, L);
       ok[j] = u < total && pos >= 0 && pos < L;
       dst[j] = u < total ? r * pitch + cu * 8 * (int)sizeof(T) : -1;
       off[j] = (seq_row0 + pos) * (int64_t)ldx + c0 + cu * 8;
@@ -121,14 +129,15 @@ struct StageRegs {
 
 template <typename T, int MAXU, int NIN, int UPR = 8, int NTHR = 256>
 __device__ __forceinline__ void stage_issue(StageRegs<T, MAXU, NIN>& sr, int rows, int pos0, int L, int64_t seq_row0,
-                                            const T* const* x, int n_in, int ldx, int c0) {
+                                            const T* const* x, int n_in, int ldx, int c0, bool reflect = false) {
   // UPR = 8-element units per row of the chunk (8 for a 64-channel chunk)
   const int total = rows * UPR;
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
     const int u = threadIdx.x + j * NTHR;   // NTHR = blockDim.x at compile time: the index math folds
     const int r = u / UPR, cu = u % UPR;
-    const int pos = pos0 + r;
+    int pos = pos0 + r;
+    if (reflect) pos = reflect_pos(pos, L);
     const bool ok = u < total && pos >= 0 && pos < L;
     const int64_t off = (seq_row0 + pos) * (int64_t)ldx + c0 + cu * 8;
 #pragma unroll

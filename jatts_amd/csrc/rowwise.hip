@@ -70,21 +70,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, int ldx, TO
 }
 
 // ----------------------------------------------------------------------- affine + cast
+// W = columns written per row: ldy (zero-padded rows) or dim (a column slice of a wider matrix: jatts_affine_slice)
 template <typename TO>
 __global__ void affine_cast_kernel(const float* x, int ldx, TO* y, int ldy, int64_t rows, int dim,
-                                   const float* scale, const float* shift) {
-  const int64_t total = rows * (int64_t)ldy;
+                                   const float* scale, const float* shift, int W) {
+  const int64_t total = rows * (int64_t)W;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / ldy;
-    const int c = (int)(i - r * ldy);
+    const int64_t r = i / W;
+    const int c = (int)(i - r * W);
     float v = 0.f;
     if (c < dim) {
       v = x[r * ldx + c];
       if (scale) v = v * scale[c];
       if (shift) v = v + shift[c];
     }
-    y[i] = from_f32<TO>(v);
+    y[r * ldy + c] = from_f32<TO>(v);
   }
 }
 
@@ -771,20 +772,31 @@ extern "C" int jatts_layernorm(const void* x, int32_t in_dtype, int32_t ldx, voi
   return JATTS_OK;
 }
 
-extern "C" int jatts_affine_cast(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
-                                 int64_t rows, int32_t dim, const float* scale, const float* shift,
-                                 void* stream) {
+static int affine_launch(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy, int64_t rows, int32_t dim,
+                         const float* scale, const float* shift, int W, void* stream) {
   if (!x || !y) return jatts_set_error_msg(JATTS_ERR_ARG, "affine_cast: null pointer");
-  if (rows <= 0) return JATTS_OK;
-  const int64_t total = rows * (int64_t)ldy;
+  if (rows <= 0 || W <= 0) return JATTS_OK;
+  const int64_t total = rows * (int64_t)W;
   dim3 grid((unsigned)min((int64_t)4096, (total + 255) / 256));
   if (out_dtype == JATTS_F16)
-    hipLaunchKernelGGL(affine_cast_kernel<f16>, grid, dim3(256), 0, S_, x, ldx, (f16*)y, ldy, rows, dim, scale, shift);
+    hipLaunchKernelGGL(affine_cast_kernel<f16>, grid, dim3(256), 0, S_, x, ldx, (f16*)y, ldy, rows, dim, scale, shift, W);
   else if (out_dtype == JATTS_F32)
-    hipLaunchKernelGGL(affine_cast_kernel<float>, grid, dim3(256), 0, S_, x, ldx, (float*)y, ldy, rows, dim, scale, shift);
+    hipLaunchKernelGGL(affine_cast_kernel<float>, grid, dim3(256), 0, S_, x, ldx, (float*)y, ldy, rows, dim, scale, shift, W);
   else return jatts_set_error_msg(JATTS_ERR_ARG, "affine_cast: unknown dtype");
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
+}
+
+extern "C" int jatts_affine_cast(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                                 int64_t rows, int32_t dim, const float* scale, const float* shift,
+                                 void* stream) {
+  return affine_launch(x, ldx, y, out_dtype, ldy, rows, dim, scale, shift, ldy, stream);
+}
+
+extern "C" int jatts_affine_slice(const float* x, int32_t ldx, void* y, int32_t out_dtype, int32_t ldy,
+                                  int64_t rows, int32_t dim, const float* scale, const float* shift,
+                                  void* stream) {
+  return affine_launch(x, ldx, y, out_dtype, ldy, rows, dim, scale, shift, dim, stream);
 }
 
 extern "C" int jatts_glu_dwconv_bn_swish(const jatts_ragged* rg, int32_t dtype, const void* x, void* y,

@@ -143,7 +143,7 @@ def convtranspose_as_conv(w, stride, padding):
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
            in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
-           y_seq_col0=None):
+           y_seq_col0=None, reflect=False):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
@@ -155,7 +155,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
         if x.dtype != tdt or not x.is_contiguous():
             raise ValueError(f"conv1d: inputs must be contiguous {tdt}")
     ldx = ldx if ldx is not None else x0.shape[-1]
-    if x0.numel() < rows * ldx or x_col0 + c_in > ldx:
+    if x0.numel() < rows * ldx or max(x_col0 if isinstance(x_col0, (list, tuple)) else [x_col0]) + c_in > ldx:
         raise ValueError("conv1d: input too small for the ragged geometry")
     if pad is None:
         pad = (k_w - 1) // 2 * dil
@@ -176,8 +176,10 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     d = _abi.ConvDesc()
     d.rg = rb.struct(len_mul)
     d.dtype, d.n_in = dtype, len(xs)
+    cols = x_col0 if isinstance(x_col0, (list, tuple)) else [x_col0] * len(xs)   # per-input first column (views into wider rows)
     for i, x in enumerate(xs):
-        d.x[i] = _ptr(x, x_col0)
+        d.x[i] = _ptr(x, cols[i])
+    d.pad_mode = _abi.PAD_REFLECT if reflect else _abi.PAD_ZERO
     d.ldx, d.in_scale = ldx, in_scale
     d.pre_act = _abi.PRE_LRELU if pre_lrelu is not None else _abi.PRE_NONE
     d.pre_slope = pre_lrelu or 0.0
@@ -305,13 +307,24 @@ def layernorm(x, gamma, beta, out_dtype, eps=1e-12, out=None):
     return out
 
 
-def affine_cast(x, out_dtype, scale=None, shift=None, ldy=None):
+def affine_cast(x, out_dtype, scale=None, shift=None, ldy=None, x_col0=0, dim=None, out=None, out_col0=0):
+    """y = x * scale + shift -> out_dtype.  ``x_col0`` / ``dim`` select a column slice of x; ``out`` / ``out_col0`` write into
+    a column slice of an existing matrix (row stride out.shape[1]) instead of a fresh (rows, ldy) one."""
     lib = _abi.load()
-    rows, dim = x.shape
-    ldy = ldy or dim
-    out = torch.empty(rows, ldy, dtype=torch_dtype(out_dtype), device=x.device)
-    _abi.check(lib.jatts_affine_cast(_dev(x).data_ptr(), dim, out.data_ptr(), out_dtype, ldy, rows, dim,
-                                     _ptr(scale), _ptr(shift), _stream()), "jatts_affine_cast")
+    rows, ldx = x.shape
+    dim = dim if dim is not None else ldx - x_col0
+    fresh = out is None
+    if fresh:
+        ldy = ldy or dim
+        out = torch.empty(rows, ldy, dtype=torch_dtype(out_dtype), device=x.device)
+        dim_w = dim
+    else:
+        ldy, dim_w = out.shape[1], dim
+        if out.dtype != torch_dtype(out_dtype) or out.shape[0] != rows or out_col0 + dim > ldy:
+            raise ValueError("affine_cast: bad output slice")
+    fn = lib.jatts_affine_cast if fresh else lib.jatts_affine_slice   # a slice writes exactly dim columns, no zero fill
+    _abi.check(fn(_ptr(_dev(x), x_col0), ldx, _ptr(out, out_col0), out_dtype, ldy, rows, dim_w,
+                  _ptr(scale), _ptr(shift), _stream()), "jatts_affine_cast")
     return out
 
 
@@ -509,3 +522,62 @@ def pcm16(y, out=None):
         out = torch.empty(y.numel(), dtype=torch.int16, device=y.device)
     _abi.check(lib.jatts_pcm16(y.data_ptr(), y.numel(), out.data_ptr(), _stream()), "jatts_pcm16")
     return out
+
+
+# ---- speaker-embedding front end (csrc/spkemb.hip)
+def frame_signal(rb_frames, cu_samples, x, window, n_fft, hop, ldo):
+    lib = _abi.load()
+    out = torch.empty(rb_frames.total, ldo, dtype=torch.float32, device=x.device)
+    rg = rb_frames.struct()
+    _abi.check(lib.jatts_frame_signal(C.byref(rg), cu_samples.data_ptr(), _dev(x).data_ptr(), window.data_ptr(), n_fft, hop,
+                                      out.data_ptr(), ldo, _stream()), "jatts_frame_signal")
+    return out
+
+
+def power_spectrum(x, n_bins, ldo):
+    lib = _abi.load()
+    out = torch.empty(x.shape[0], ldo, dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_power_spectrum(_dev(x).data_ptr(), x.shape[1], n_bins, x.shape[0], out.data_ptr(), ldo, _stream()),
+               "jatts_power_spectrum")
+    return out
+
+
+def fbank_post(rb, p, n_mels, ldo, amin=1e-10, top_db=80.0):
+    lib = _abi.load()
+    out = torch.empty(rb.total, ldo, dtype=torch.float32, device=p.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_fbank_post(C.byref(rg), _dev(p).data_ptr(), p.shape[1], n_mels, amin, top_db, out.data_ptr(), ldo,
+                                    _stream()), "jatts_fbank_post")
+    return out
+
+
+def seq_mean_std(rb, x, dim, logits=None, want_std=True, eps=1e-12):
+    """-> (n_seq, 2*dim) f32 [mean | std] (or (n_seq, dim) means when want_std is False)."""
+    lib = _abi.load()
+    ld = 2 * dim if want_std else dim
+    out = torch.empty(rb.n_seq, ld, dtype=torch.float32, device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_seq_mean_std(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dim, _ptr(logits),
+                                      logits.shape[1] if logits is not None else 0, out.data_ptr(),
+                                      _ptr(out, dim) if want_std else None, ld, eps, _stream()), "jatts_seq_mean_std")
+    return out
+
+
+def seq_affine_act(rb, x, dim, out_dtype, seq_vec=None, pre_act=ACT_NONE, scale=None, shift=None, post_act=ACT_NONE, ldy=None):
+    lib = _abi.load()
+    ldy = ldy or dim
+    y = torch.empty(rb.total, ldy, dtype=torch_dtype(out_dtype), device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_seq_affine_act(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dim, _ptr(seq_vec), pre_act, _ptr(scale),
+                                        _ptr(shift), post_act, y.data_ptr(), out_dtype, ldy, _stream()), "jatts_seq_affine_act")
+    return y
+
+
+def se_scale_add(rb, x, s, resid=None, out=None, out_col0=0):
+    """y = x * sigmoid(s[b]) + resid; ``out`` / ``out_col0``: write into a column slice of a wider matrix."""
+    lib = _abi.load()
+    y = torch.empty_like(x) if out is None else out
+    rg = rb.struct()
+    _abi.check(lib.jatts_se_scale_add(C.byref(rg), _dev(x).data_ptr(), x.shape[1], s.data_ptr(), _ptr(resid), _ptr(y, out_col0),
+                                      y.shape[1], _stream()), "jatts_se_scale_add")
+    return y

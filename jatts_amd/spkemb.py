@@ -1,0 +1,254 @@
+"""Speaker-embedding front end on the MI355X path -- drop-in for
+``jatts.modules.feature_extract.spkemb_speechbrain.SpeechBrainSpkEmbExtractor`` (reference :14-28): same constructor
+(``device``), same ``forward(wav_path) -> np.ndarray (192,)``.  The reference calls it once per utterance inside the
+stage-4 loop (jatts/bin/tts_decode.py:209-212); multi-speaker decoding (JVS, BASELINE config 5) is bottlenecked by it
+once synthesis takes milliseconds, so results are cached per reference wav and whole batches go through
+``encode_batch``.
+
+What SpeechBrain's ``EncoderClassifier.encode_batch`` computes (third party, not vendored in the reference; restated
+from the public recipe, see oracle/ecapa_oracle.py -- parity unpinned): log-mel filterbank features (STFT as an f32
+MFMA contraction with the DFT matrix, mel projection, dB, top-dB floor), sentence mean normalisation, ECAPA-TDNN.
+Every contraction is a ``jatts_conv1d`` launch in f32 (SpeechBrain's "same" reflect padding = ``pad_mode``
+JATTS_PAD_REFLECT); pooling / squeeze-excitation / normalisation pieces are the kernels of csrc/spkemb.hip.
+No CPU fallback: CPU tensors or a missing libjatts_hip.so raise.
+"""
+import math
+import wave
+
+import numpy as np
+import torch
+
+from . import hip
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH
+from .models import _schema as S
+from .models._conformer import BN_EPS, PackedConv
+
+F32 = hip.F32
+
+
+def _tdnn(spec, name, cin, cout, k):
+    S._conv(spec, name + ".conv.conv", cout, cin, k)
+    S._bn(spec, name + ".norm.norm", cout)
+
+
+class ECAPA_TDNN(torch.nn.Module):
+    """Parameter tree with SpeechBrain's state_dict keys (speechbrain.lobes.models.ECAPA_TDNN.ECAPA_TDNN [recalled]), so
+    ``load_state_dict(torch.load("embedding_model.ckpt"))`` works; arithmetic in HIP kernels, always f32."""
+
+    def __init__(self, input_size=80, lin_neurons=192, channels=(1024, 1024, 1024, 1024, 3072), kernel_sizes=(5, 3, 3, 3, 1),
+                 dilations=(1, 2, 3, 4, 1), attention_channels=128, res2net_scale=8, se_channels=128, global_context=True):
+        super().__init__()
+        if not global_context:
+            raise NotImplementedError("global_context=False is not supported")
+        if len(channels) != 5 or len(set(channels[:4])) != 1 or channels[0] % (64 * res2net_scale):
+            raise NotImplementedError("three SE-Res2Net blocks of equal width (a multiple of 64 * res2net_scale) are supported")
+        self.input_size, self.lin_neurons, self.channels = input_size, lin_neurons, tuple(channels)
+        self.kernel_sizes, self.dilations = tuple(kernel_sizes), tuple(dilations)
+        self.scale, self.att = res2net_scale, attention_channels
+        C = channels[0]
+        spec = S.new_spec()
+        _tdnn(spec, "blocks.0", input_size, C, kernel_sizes[0])
+        for i in (1, 2, 3):
+            p = f"blocks.{i}."
+            _tdnn(spec, p + "tdnn1", C, C, 1)
+            for j in range(res2net_scale - 1):
+                _tdnn(spec, p + f"res2net_block.blocks.{j}", C // res2net_scale, C // res2net_scale, kernel_sizes[i])
+            _tdnn(spec, p + "tdnn2", C, C, 1)
+            S._conv(spec, p + "se_block.conv1.conv", se_channels, C, 1)
+            S._conv(spec, p + "se_block.conv2.conv", C, se_channels, 1)
+        M = channels[4]
+        _tdnn(spec, "mfa", 3 * C, M, kernel_sizes[4])
+        _tdnn(spec, "asp.tdnn", 3 * M, attention_channels, 1)
+        S._conv(spec, "asp.conv.conv", M, attention_channels, 1)
+        S._bn(spec, "asp_bn.norm", 2 * M)
+        S._conv(spec, "fc.conv", lin_neurons, 2 * M, 1)
+        S.build_from_spec(self, spec)
+        self._prep = None
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def _prepare(self):
+        dev = self.fc.conv.weight.device
+        if dev.type != "cuda":
+            raise hip._abi.JattsHipError("jatts_amd ECAPA_TDNN runs on the GPU only (no CPU fallback)")
+        if self._prep is not None and self._prep["dev"] == dev:
+            return self._prep
+        hip._abi.load()
+        sd = self.state_dict()
+
+        def bn(p):
+            s = sd[p + "weight"].float() / torch.sqrt(sd[p + "running_var"].float() + BN_EPS)
+            t = sd[p + "bias"].float() - sd[p + "running_mean"].float() * s
+            return s.to(dev).contiguous(), t.to(dev).contiguous()
+
+        def tdnn(p, w=None):
+            return (PackedConv(sd[p + "conv.conv.weight"] if w is None else w, sd[p + "conv.conv.bias"], F32, dev),) + bn(p + "norm.norm.")
+
+        P = {"dev": dev, "b0": tdnn("blocks.0.")}
+        for i in (1, 2, 3):
+            p = f"blocks.{i}."
+            P[i] = dict(t1=tdnn(p + "tdnn1."), r2=[tdnn(p + f"res2net_block.blocks.{j}.") for j in range(self.scale - 1)],
+                        t2=tdnn(p + "tdnn2."),
+                        se1=PackedConv(sd[p + "se_block.conv1.conv.weight"], sd[p + "se_block.conv1.conv.bias"], F32, dev),
+                        se2=PackedConv(sd[p + "se_block.conv2.conv.weight"], sd[p + "se_block.conv2.conv.bias"], F32, dev))
+        P["mfa"] = tdnn("mfa.")
+        M = self.channels[4]
+        wa = sd["asp.tdnn.conv.conv.weight"]                      # (att, 3M, 1): [x | mean | std] input channels
+        P["asp_x"] = PackedConv(wa[:, :M], sd["asp.tdnn.conv.conv.bias"], F32, dev)
+        P["asp_g"] = PackedConv(wa[:, M:], None, F32, dev)        # global-context half: one row per utterance
+        P["asp_bn"] = bn("asp.tdnn.norm.norm.")
+        P["asp_conv"] = PackedConv(sd["asp.conv.conv.weight"], sd["asp.conv.conv.bias"], F32, dev)
+        P["pool_bn"] = bn("asp_bn.norm.")
+        P["fc"] = PackedConv(sd["fc.conv.weight"], sd["fc.conv.bias"], F32, dev)
+        self._prep = P
+        return P
+
+    def _tdnn(self, rb, x, t, dil=1, x_col0=0, ldx=None, xs=None, out=None, out_col0=0, ldy=None):
+        """TDNNBlock: conv ("same", reflect) -> ReLU -> BatchNorm(eval), f32 in / out."""
+        pc, s, sh = t
+        h = hip.conv1d(rb, xs if xs is not None else x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=F32, dil=dil, bias=pc.b, act=ACT_RELU,
+                       reflect=pc.k > 1, x_col0=x_col0, ldx=ldx)
+        return hip.affine_cast(h, F32, scale=s, shift=sh, ldy=ldy, out=out, out_col0=out_col0)
+
+    @torch.no_grad()
+    def embed_batch(self, rb, feats):
+        """rb: RaggedBatch over frames; feats f32 (rows, >= input_size; zero-padded to a multiple of 64) -> (n_seq, lin_neurons)."""
+        P = self._prepare()
+        C, M, G = self.channels[0], self.channels[4], self.channels[0] // self.scale
+        if min(rb.lens) <= max(d * (k - 1) // 2 for d, k in zip(self.dilations, self.kernel_sizes)):
+            raise ValueError("utterance shorter than the reflect padding of the TDNN layers")
+        rbs = hip.RaggedBatch([1] * rb.n_seq, rb.device)
+        x = self._tdnn(rb, feats, P["b0"], self.dilations[0])                                   # (rows, C)
+        cat = torch.empty(rb.total, 3 * C, dtype=torch.float32, device=feats.device)
+        for i in (1, 2, 3):
+            B = P[i]
+            h = self._tdnn(rb, x, B["t1"])
+            y = torch.empty(rb.total, C, dtype=torch.float32, device=feats.device)              # Res2Net output, chunk by chunk
+            hip.affine_cast(h, F32, dim=G, out=y)                                                # chunk 0 passes through
+            for j in range(1, self.scale):
+                if j == 1:
+                    self._tdnn(rb, h, B["r2"][0], self.dilations[i], x_col0=G, ldx=C, out=y, out_col0=G)
+                else:   # conv(x_j + y_{j-1}): two summed inputs, both column views of C-wide rows
+                    self._tdnn(rb, None, B["r2"][j - 1], self.dilations[i], xs=[h, y], x_col0=[j * G, (j - 1) * G], ldx=C,
+                               out=y, out_col0=j * G)
+            h = self._tdnn(rb, y, B["t2"])
+            s = hip.seq_mean_std(rb, h, C, want_std=False)                                       # squeeze: mean over time
+            s = hip.conv1d(rbs, s, B["se1"].w, B["se1"].c_in, B["se1"].n_out, 1, dtype=F32, bias=B["se1"].b, act=ACT_RELU)
+            s = hip.conv1d(rbs, s, B["se2"].w, B["se2"].c_in, B["se2"].n_out, 1, dtype=F32, bias=B["se2"].b)
+            hip.se_scale_add(rb, h, s, resid=x, out=cat, out_col0=(i - 1) * C)                   # gate + residual -> concat slot
+            x = torch.empty(rb.total, C, dtype=torch.float32, device=feats.device)
+            hip.affine_cast(cat, F32, x_col0=(i - 1) * C, dim=C, out=x)                          # next block's input (contiguous)
+        m = self._tdnn(rb, cat, P["mfa"], self.dilations[4])                                     # (rows, M)
+        # attentive statistics pooling with global context: W [x; mean; std] = W_x x + (W_g [mean; std]) per utterance
+        g = hip.seq_mean_std(rb, m, M)                                                           # (B, 2M)
+        gv = hip.conv1d(rbs, g, P["asp_g"].w, P["asp_g"].c_in, self.att, 1, dtype=F32)
+        a = hip.conv1d(rb, m, P["asp_x"].w, P["asp_x"].c_in, self.att, 1, dtype=F32, bias=P["asp_x"].b)
+        a = hip.seq_affine_act(rb, a, self.att, F32, seq_vec=gv, pre_act=ACT_RELU, scale=P["asp_bn"][0], shift=P["asp_bn"][1],
+                               post_act=ACT_TANH, ldy=P["asp_conv"].c_in)
+        logits = hip.conv1d(rb, a, P["asp_conv"].w, P["asp_conv"].c_in, M, 1, dtype=F32, bias=P["asp_conv"].b)
+        pooled = hip.seq_mean_std(rb, m, M, logits=logits)                                       # (B, 2M) attention-weighted
+        pooled = hip.affine_cast(pooled, F32, scale=P["pool_bn"][0], shift=P["pool_bn"][1])
+        return hip.conv1d(rbs, pooled, P["fc"].w, P["fc"].c_in, self.lin_neurons, 1, dtype=F32, bias=P["fc"].b)
+
+
+class FbankFrontEnd:
+    """SpeechBrain Fbank(n_mels=80) + InputNormalization(sentence, mean only) [recalled]: 16 kHz, 25 ms Hamming window = n_fft 400,
+    10 ms hop, centre reflect padding, power spectrum, triangular mel filters 0..8 kHz, 10 log10 with amin 1e-10 and top_db 80."""
+
+    def __init__(self, device, n_mels=80, n_fft=400, hop=160, sample_rate=16000, f_min=0.0, f_max=8000.0):
+        self.n_mels, self.n_fft, self.hop = n_mels, n_fft, hop
+        self.nb = n_fft // 2 + 1
+        self.nbp = hip.round_up(self.nb, 8)                        # re / im blocks padded to 8 columns
+        self.ldf = hip.round_up(n_fft, 64)
+        self.window = torch.hamming_window(n_fft).to(device)
+        n = torch.arange(n_fft, dtype=torch.float64)
+        k = torch.arange(self.nb, dtype=torch.float64)
+        ang = 2.0 * math.pi * k.unsqueeze(1) * n.unsqueeze(0) / n_fft
+        w = torch.zeros(2 * self.nbp, n_fft, dtype=torch.float64)
+        w[: self.nb] = torch.cos(ang)
+        w[self.nbp: self.nbp + self.nb] = -torch.sin(ang)
+        self.dft = PackedConv(w.float(), None, F32, device)       # (2 nbp, n_fft) -> c_in padded to ldf
+        self.ldp = hip.round_up(self.nbp, 64)
+        self.mel = PackedConv(self.mel_matrix(n_mels, n_fft, sample_rate, f_min, f_max).t().contiguous(), None, F32, device)
+        self.ldo = hip.round_up(n_mels, 64)
+
+    @staticmethod
+    def mel_matrix(n_mels, n_fft, sample_rate, f_min, f_max):
+        """(n_fft // 2 + 1, n_mels) triangular filters the way SpeechBrain's Filterbank lays them out."""
+        mel = torch.linspace(2595.0 * math.log10(1.0 + f_min / 700.0), 2595.0 * math.log10(1.0 + f_max / 700.0), n_mels + 2)
+        hz = 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+        band = (hz[1:] - hz[:-1])[:-1]
+        freqs = torch.linspace(0, sample_rate // 2, n_fft // 2 + 1)
+        slope = (freqs.unsqueeze(0) - hz[1:-1].unsqueeze(1)) / band.unsqueeze(1)
+        return torch.clamp(torch.minimum(slope + 1.0, 1.0 - slope), min=0.0).t().contiguous()
+
+    @torch.no_grad()
+    def __call__(self, waves):
+        """waves: list of 1-D float tensors -> (RaggedBatch over frames, feats f32 (rows, ldo))."""
+        dev = self.window.device
+        ns = [int(w.numel()) for w in waves]
+        if min(ns) <= self.n_fft // 2:
+            raise ValueError("waveform shorter than the STFT's reflect padding")
+        x = torch.cat([w.reshape(-1).float() for w in waves]).to(dev).contiguous()
+        cu = [0]
+        for n in ns:
+            cu.append(cu[-1] + n)
+        rb = hip.RaggedBatch([1 + n // self.hop for n in ns], dev)
+        frames = hip.frame_signal(rb, torch.tensor(cu, dtype=torch.int32, device=dev), x, self.window, self.n_fft, self.hop, self.ldf)
+        spec = hip.conv1d(rb, frames, self.dft.w, self.dft.c_in, 2 * self.nbp, 1, dtype=F32)            # [re | im]
+        power = hip.power_spectrum(spec, self.nbp, self.ldp)
+        mel = hip.conv1d(rb, power, self.mel.w, self.mel.c_in, self.n_mels, 1, dtype=F32)
+        return rb, hip.fbank_post(rb, mel, self.n_mels, self.ldo)
+
+
+def load_wav(path):
+    """torchaudio.load's contract for 16-bit PCM: float32 in [-1, 1) (int16 / 32768), channels averaged away never (the
+    reference passes the file as is, multi-channel files become a batch there; mono is what the recipes hold)."""
+    with wave.open(path, "rb") as w:
+        if w.getsampwidth() != 2:
+            raise NotImplementedError("16-bit PCM wav expected")
+        a = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+        if w.getnchannels() > 1:
+            a = a.reshape(-1, w.getnchannels())[:, 0]
+        return torch.from_numpy(a.copy()), w.getframerate()
+
+
+class SpkEmbExtractor:
+    """``SpeechBrainSpkEmbExtractor`` contract: ``forward(wav_path) -> np.ndarray (lin_neurons,)``; like the reference the file is
+    used at its own sampling rate (encode_batch does not resample).  ``checkpoint``: SpeechBrain's embedding_model.ckpt state
+    dict (path or dict); results are cached per path."""
+
+    def __init__(self, device="cuda", checkpoint=None, **ecapa_kwargs):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise hip._abi.JattsHipError("jatts_amd.SpkEmbExtractor runs on the GPU only (no CPU fallback)")
+        self.model = ECAPA_TDNN(**ecapa_kwargs)
+        if checkpoint is not None:
+            self.model.load_state_dict(torch.load(checkpoint, map_location="cpu") if not isinstance(checkpoint, dict) else checkpoint)
+        self.model = self.model.to(self.device)
+        self.front = FbankFrontEnd(self.device, n_mels=self.model.input_size)
+        self._cache = {}
+
+    @torch.no_grad()
+    def encode_batch(self, waves):
+        """list of 1-D float waveforms -> (B, lin_neurons) f32 on the GPU."""
+        rb, feats = self.front(waves)
+        return self.model.embed_batch(rb, feats)
+
+    def forward_many(self, wav_paths):
+        todo = [p for p in dict.fromkeys(wav_paths) if p not in self._cache]
+        if todo:
+            emb = self.encode_batch([load_wav(p)[0] for p in todo]).cpu().numpy()
+            for p, e in zip(todo, emb):
+                self._cache[p] = e
+        return np.stack([self._cache[p] for p in wav_paths])
+
+    def forward(self, wav_path):
+        return self.forward_many([wav_path])[0].reshape(-1)

@@ -26,7 +26,8 @@ def test_ctypes_structs_match_header_field_order():
     hdr = open(os.path.join(ROOT, "include", "jatts_hip.h")).read()
     from jatts_amd import _abi
     for cname, cls in (("jatts_ragged", _abi.Ragged), ("jatts_conv_desc", _abi.ConvDesc),
-                       ("jatts_resunit_desc", _abi.ResUnitDesc), ("jatts_relattn_desc", _abi.RelAttnDesc)):
+                       ("jatts_resunit_desc", _abi.ResUnitDesc), ("jatts_relattn_desc", _abi.RelAttnDesc),
+                       ("jatts_resblock_desc", _abi.ResBlockDesc)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = re.findall(r"([a-z_0-9]+)(?:\[\d+\])?\s*;", body)
