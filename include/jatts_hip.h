@@ -371,10 +371,18 @@ int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, const int32_t
 /* Output sequences may be longer than sum(d_eff): frames past the end are zero (pad_list, length_regulator.py:16-43;
  * the padded batches of forward()), frame_index -1. */
 
-/* Zero the rows t >= valid_len[b] of every sequence of a packed f32 matrix x[rows][ld] (first `dim` columns):
- * the `xs * x_masks` / masked_fill steps of the reference's batched forward() (variance_predictor.py:81-83,
- * duration_predictor.py:93-96). */
-int jatts_zero_pad_rows(const jatts_ragged* rg, float* x, int32_t ld, int32_t dim, const int32_t* valid_len, void* stream);
+/* Zero the rows t >= valid_len[b] of every sequence of a packed matrix x[rows][ld] (first `dim` columns; f32 or f16):
+ * the `xs * x_masks` / `x * mask` steps of the reference's batched forward() passes (variance_predictor.py:81-83,
+ * duration_predictor.py:93-96, matchatts/decoder.py:75-77,93-96). */
+int jatts_zero_pad_rows(const jatts_ragged* rg, void* x, int32_t dtype, int32_t ld, int32_t dim, const int32_t* valid_len,
+                        void* stream);
+/* Conditional-flow-matching training pair (matchatts/flow_matching.py:115-121): per sequence b with time t[b],
+ * y = (1 - (1 - sigma_min) t) z + t x1, u = x1 - (1 - sigma_min) z; all [rows][dim] f32. */
+int jatts_cfm_mix(const jatts_ragged* rg, const float* x1, const float* z, const float* t, float sigma_min, int32_t dim,
+                  float* y, float* u, void* stream);
+/* *out = scale * sum_i (a_i - b_i)^2 (double accumulation, fixed order): F.mse_loss(..., reduction="sum") / normaliser
+ * (flow_matching.py:123-125).  workspace: 256 doubles. */
+int jatts_sq_err_sum(const float* a, const float* b, int64_t n, float scale, float* out, double* workspace, void* stream);
 
 /* Gaussian upsampling (modules/length_regulator.py:111-154), one unmasked sequence each:
  * out[f] = softmax_t( -delta (f - c_t)^2 ) @ hs,  c_t = cumsum(d)_t - d_t/2 (float math). */

@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256) void lr_gather_kernel(jatts_ragged rg, const i
   }
 }
 
-__global__ __launch_bounds__(256) void zero_pad_rows_kernel(jatts_ragged rg, float* x, int ld, int dim, const int32_t* valid_len) {
+template <typename T>
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(jatts_ragged rg, T* x, int ld, int dim, const int32_t* valid_len) {
   const int b = blockIdx.y;
   const int row0 = rg.cu_rows[b];
   const int L = rg.cu_rows[b + 1] - row0;
@@ -548,8 +549,44 @@ __global__ __launch_bounds__(256) void zero_pad_rows_kernel(jatts_ragged rg, flo
   const int64_t n = (int64_t)(L - v) * dim;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / dim;
-    x[(row0 + v + r) * (int64_t)ld + (i - r * dim)] = 0.f;
+    x[(row0 + v + r) * (int64_t)ld + (i - r * dim)] = from_f32<T>(0.f);
   }
+}
+
+// Conditional flow matching training pair (flow_matching.py:118-121): y = (1 - (1 - sigma) t_b) z + t_b x1, u = x1 - (1 - sigma) z
+__global__ __launch_bounds__(256) void cfm_mix_kernel(jatts_ragged rg, const float* x1, const float* z, const float* t, float sigma,
+                                                      int dim, float* y, float* u) {
+  const int b = blockIdx.y;
+  const int row0 = rg.cu_rows[b], L = rg.cu_rows[b + 1] - row0;
+  const float tb = t[b];
+  const int64_t n = (int64_t)L * dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = (int64_t)row0 * dim + i;
+    y[o] = (1.f - (1.f - sigma) * tb) * z[o] + tb * x1[o];
+    u[o] = x1[o] - (1.f - sigma) * z[o];
+  }
+}
+
+// sum_i (a_i - b_i)^2 in double, fixed summation order (one partial per block, then one block folds the partials)
+__global__ __launch_bounds__(256) void sq_err_partial_kernel(const float* a, const float* b, int64_t n, double* part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double dlt = (double)a[i] - (double)b[i];
+    s += dlt * dlt;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void fold_partials_kernel(const double* part, int n, float scale, float* out) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += part[i];
+  *out = (float)(s * (double)scale);
 }
 
 // ------------------------------------------------------------------ gaussian upsampling
@@ -974,11 +1011,34 @@ extern "C" int jatts_lr_gather(const jatts_ragged* rg_in, const int64_t* cum, co
   return JATTS_OK;
 }
 
-extern "C" int jatts_zero_pad_rows(const jatts_ragged* rg, float* x, int32_t ld, int32_t dim, const int32_t* valid_len, void* stream) {
+extern "C" int jatts_zero_pad_rows(const jatts_ragged* rg, void* x, int32_t dtype, int32_t ld, int32_t dim, const int32_t* valid_len,
+                                   void* stream) {
   if (!rg || !x || !valid_len) return jatts_set_error_msg(JATTS_ERR_ARG, "zero_pad_rows: null pointer");
   if (rg->n_seq <= 0 || rg->max_len <= 0 || dim <= 0) return JATTS_OK;
-  const int64_t per = (int64_t)rg->max_len * dim;
-  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3((unsigned)((per + 1023) / 1024 < 64 ? (per + 1023) / 1024 : 64), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, ld, dim, valid_len);
+  const int64_t per = (int64_t)rg->max_len * rg->len_mul * dim;
+  dim3 grid((unsigned)((per + 1023) / 1024 < 64 ? (per + 1023) / 1024 : 64), (unsigned)rg->n_seq);
+  if (dtype == JATTS_F32) hipLaunchKernelGGL(zero_pad_rows_kernel<float>, grid, dim3(256), 0, S_, *rg, (float*)x, ld, dim, valid_len);
+  else if (dtype == JATTS_F16) hipLaunchKernelGGL(zero_pad_rows_kernel<f16>, grid, dim3(256), 0, S_, *rg, (f16*)x, ld, dim, valid_len);
+  else return jatts_set_error_msg(JATTS_ERR_ARG, "zero_pad_rows: unknown dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_cfm_mix(const jatts_ragged* rg, const float* x1, const float* z, const float* t, float sigma_min, int32_t dim,
+                             float* y, float* u, void* stream) {
+  if (!rg || !x1 || !z || !t || !y || !u) return jatts_set_error_msg(JATTS_ERR_ARG, "cfm_mix: null pointer");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  const int64_t per = ((int64_t)rg->max_len * dim + 255) / 256;
+  hipLaunchKernelGGL(cfm_mix_kernel, dim3((unsigned)(per < 256 ? per : 256), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x1, z, t, sigma_min, dim, y, u);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_sq_err_sum(const float* a, const float* b, int64_t n, float scale, float* out, double* workspace, void* stream) {
+  if (!a || !b || !out || !workspace) return jatts_set_error_msg(JATTS_ERR_ARG, "sq_err_sum: null pointer");
+  const int blocks = (int)((n + 4095) / 4096 < 256 ? (n + 4095) / 4096 : 256);
+  hipLaunchKernelGGL(sq_err_partial_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, S_, a, b, n, workspace);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(1), 0, S_, workspace, blocks < 1 ? 1 : blocks, scale, out);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -453,14 +453,33 @@ def lr_sizes(rb, d, alpha=1.0, check=None):
     return d_eff, cum, olens_h
 
 
-def zero_pad_rows(rb, x, valid_len):
-    """x: f32 (rb.total, dim) or (rb.total,); zero the rows t >= valid_len[b] of every sequence, in place."""
+def zero_pad_rows(rb, x, valid_len, len_mul=1):
+    """x: f32 / f16 (rb.total, dim) or (rb.total,); zero the rows t >= valid_len[b] of every sequence, in place."""
     lib = _abi.load()
     dim = x.shape[1] if x.dim() == 2 else 1
-    rg = rb.struct()
-    _abi.check(lib.jatts_zero_pad_rows(C.byref(rg), _dev(x).data_ptr(), dim, dim, valid_len.data_ptr(), _stream()),
+    rg = rb.struct(len_mul)
+    _abi.check(lib.jatts_zero_pad_rows(C.byref(rg), _dev(x).data_ptr(), code_of(x), dim, dim, valid_len.data_ptr(), _stream()),
                "jatts_zero_pad_rows")
     return x
+
+
+def cfm_mix(rb, x1, z, t, sigma_min):
+    lib = _abi.load()
+    y, u = torch.empty_like(x1), torch.empty_like(x1)
+    rg = rb.struct()
+    _abi.check(lib.jatts_cfm_mix(C.byref(rg), _dev(x1).data_ptr(), z.data_ptr(), t.data_ptr(), float(sigma_min), x1.shape[1],
+                                 y.data_ptr(), u.data_ptr(), _stream()), "jatts_cfm_mix")
+    return y, u
+
+
+def sq_err_sum(a, b, scale=1.0):
+    """scale * sum((a - b)^2) -> f32 scalar tensor on the GPU (double accumulation, deterministic order)."""
+    lib = _abi.load()
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    ws = torch.empty(256, dtype=torch.float64, device=a.device)
+    _abi.check(lib.jatts_sq_err_sum(_dev(a).data_ptr(), b.data_ptr(), a.numel(), float(scale), out.data_ptr(), ws.data_ptr(),
+                                    _stream()), "jatts_sq_err_sum")
+    return out
 
 
 def lr_gather(rb_in, cum, rb_out, x, want_index=False):

@@ -20,7 +20,7 @@ from typing import Optional, Sequence
 import torch
 
 from .. import hip
-from ..hip import ACT_MISH, ACT_NONE, ACT_SWISH
+from ..hip import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH
 from . import _schema as S
 from ._conformer import ConformerRunner, PackedConv
 from .fastspeech2 import _Predictor
@@ -55,9 +55,10 @@ class _Resnet:
         self.gn2 = (f32(sd[p + "block2.block.1.weight"]), f32(sd[p + "block2.block.1.bias"]))
         self.mlp = PackedConv(sd[p + "mlp.1.weight"], sd[p + "mlp.1.bias"], dt, dev)
 
-    def run(self, rb, rbs, xs, tmish, dt, tv_cache=None):
+    def run(self, rb, rbs, xs, tmish, dt, tv_cache=None, valid=None):
         """xs: list of operand-dtype tensors (rows, ld_i) matching in_sizes; tmish: (n_seq, Ct) = mish(time emb).
-        Returns f32 (rows, c_out)."""
+        Returns f32 (rows, c_out).  valid (int32 (n_seq,), padded batches only): the `x * mask` / `output * mask` steps of
+        Block1D / ResnetBlock1D (decoder.py:75-77,93-96) -- xs must already be masked by the caller."""
         C = self.c_out
         h = None
         for x, cv in zip(xs, self.conv1):
@@ -70,8 +71,12 @@ class _Resnet:
             if tv_cache is not None:
                 tv_cache[id(self)] = tv
         h = hip.groupnorm_mish(rb, h, C, 8, self.gn1[0], self.gn1[1], dt, GN_EPS, addvec=tv)
+        if valid is not None:
+            hip.zero_pad_rows(rb, h, valid)          # block1(x) * mask, + time vector, then block2's own x * mask
         h = hip.conv1d(rb, h, self.conv2.w, self.conv2.c_in, C, 3, dtype=dt, bias=self.conv2.b)
         out = hip.groupnorm_mish(rb, h, C, 8, self.gn2[0], self.gn2[1], hip.F32, GN_EPS)
+        if valid is not None:
+            hip.zero_pad_rows(rb, out, valid)        # block2 output * mask; res_conv(x * mask) below adds its bias at padded rows
         for x, cv in zip(xs, self.res):
             hip.conv1d(rb, x, cv.w, cv.c_in, C, 1, dtype=dt, bias=cv.b, resid=out, out=out, out_f32=True, ldx=x.shape[1])
         return out
@@ -98,14 +103,15 @@ class _TBlock:
         self.alpha = f32(torch.exp(sd[p + "ff.net.0.alpha"].detach().float()))
         self.inv_beta = f32(1.0 / (torch.exp(sd[p + "ff.net.0.beta"].detach().float()) + 1e-9))
 
-    def run(self, rb, x, dt):
-        """x: f32 (rows, C), updated in place."""
+    def run(self, rb, x, dt, key_bias=None):
+        """x: f32 (rows, C), updated in place.  key_bias f32 (rows, heads) or None: added to every score of that key AFTER the
+        1/sqrt(d) scaling -- diffusers adds `attention_mask` to the scores [recalled]; Matcha passes its 1/0 frame mask."""
         C, I = x.shape[1], self.inner
         n = hip.layernorm(x, self.n1[0], self.n1[1], dt, GN_EPS)
         qk = hip.conv1d(rb, n, self.qk.w, self.qk.c_in, 2 * I, 1, dtype=dt)
         vcol, ldvt = rb.vt_layout()
         vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt, y_seq_col0=vcol)
-        a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, ldvt, None, 0, None, self.dh ** -0.5, self.heads,
+        a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, ldvt, None, 0, key_bias, self.dh ** -0.5, self.heads,
                                  self.dh, dt, q_col0=0, k_col0=I, rel_mode=0, vt_col0=vcol)
         hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)
         n = hip.layernorm(x, self.n3[0], self.n3[1], dt, GN_EPS)
@@ -152,6 +158,7 @@ class _MatchaBase(torch.nn.Module):
         self.idim, self.odim, self.adim, self.aheads = idim, odim, adim, aheads
         self.dec_heads, self.dec_channels = decoder_num_heads, tuple(decoder_channels)
         self.n_blocks, self.n_mid = decoder_n_blocks, decoder_num_mid_blocks
+        self.sigma_min = 1e-4   # CFM default (flow_matching.py:31); the reference never overrides it
         self.spk_embed_dim = spk_embed_dim if (spk_embed_dim is not None and spk_embed_dim > 0) else None
         if self.spk_embed_dim is not None and spk_embed_integration_type != "add":
             raise NotImplementedError("spk_embed_integration_type='concat' is not supported")
@@ -293,11 +300,18 @@ class _MatchaBase(torch.nn.Module):
         return P
 
     # one U-Net evaluation; x_t / mu_t: operand dtype (R, ld) with odim valid columns; x32: f32 state (R, odim)
-    def _estimator_step(self, P, rb, rb2, rbs, x32, mu_t, temb_rows, dt_step, tkey=None):
+    def _estimator_step(self, P, rb, rb2, rbs, x32, mu_t, temb_rows, dt_step, tkey=None, valid=None):
+        """One U-Net evaluation.  Inference (valid None): ragged batch, x32 += dt_step * v(x32) in place.  Training forward
+        (valid = (int32 lengths at full rate, at half rate, key-bias rows at full rate, at half rate)): PADDED batch with the
+        reference's mask multiplications (decoder.py:413-487); returns v(x) * mask as f32 and leaves x32 alone."""
         dt = P["dtype"]
         od = self.odim
         ld_in = P["d0"][0].conv1[0].c_in
         x_t = hip.affine_cast(x32, dt, ldy=ld_in)
+        v1 = v2 = kb1 = kb2 = None
+        if valid is not None:
+            v1, v2, kb1, kb2 = valid
+            hip.zero_pad_rows(rb, x_t, v1)            # pack([x, mu]) * mask
         # time MLP + the per-ResNet time projections: functions of the Euler step only (t is a scalar shared by the
         # batch, flow_matching.py:77-93) -> computed once per (n_timesteps, step, batch size) and reused
         tcache = P.setdefault("tcache", {}).setdefault(tkey, {}) if tkey is not None else None
@@ -308,36 +322,41 @@ class _MatchaBase(torch.nn.Module):
             if tcache is not None:
                 tcache["tm"] = tm
 
-        def stage(blk, rbx, xs):
+        def stage(blk, rbx, xs, vl, kb):
             res, tbs = blk
-            h = res.run(rbx, rbs, xs, tm, dt, tv_cache=tcache)
+            h = res.run(rbx, rbs, xs, tm, dt, tv_cache=tcache, valid=vl)
             for t in tbs:
-                t.run(rbx, h, dt)
+                t.run(rbx, h, dt, key_bias=kb)
             return h
 
-        h0 = stage(P["d0"], rb, [x_t, mu_t])                     # (R, C0) f32; skip connection 0
-        h0_t = hip.affine_cast(h0, dt)
+        def masked(rbx, t, vl, len_mul=1):     # `x * mask` in front of a conv / a skip connection (no-op on ragged batches)
+            return t if vl is None else hip.zero_pad_rows(rbx, t, vl, len_mul)
+
+        h0 = stage(P["d0"], rb, [x_t, mu_t], v1, kb1)            # (R, C0) f32; skip connection 0
+        h0_t = masked(rb, hip.affine_cast(h0, dt), v1)
         C0 = h0.shape[1]
         dn = P["down"]
         h = hip.conv1d(rb2, h0_t.view(-1, 2 * C0), dn.w, dn.c_in, C0, 2, dtype=dt, bias=dn.b, pad=1)   # (R/2, C0)
-        h1 = stage(P["d1"], rb2, [h])                            # skip connection 1
-        h1_t = hip.affine_cast(h1, dt)
+        h1 = stage(P["d1"], rb2, [masked(rb2, h, v2)], v2, kb2)  # skip connection 1
+        h1_t = masked(rb2, hip.affine_cast(h1, dt), v2)
         c = P["d1c"]
         h = hip.conv1d(rb2, h1_t, c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
         for blk in P["mid"]:
-            h = hip.affine_cast(stage(blk, rb2, [h]), dt)
-        h = stage(P["u0"], rb2, [h, h1_t])
+            h = hip.affine_cast(stage(blk, rb2, [masked(rb2, h, v2)], v2, kb2), dt)
+        h = stage(P["u0"], rb2, [masked(rb2, h, v2), h1_t], v2, kb2)
         up, pad = P["up"]
         C1 = h.shape[1]
-        h = hip.conv1d(rb2, hip.affine_cast(h, dt), up.w, up.c_in, 2 * C1, up.k, dtype=dt, bias=up.b, pad=pad)
+        h = hip.conv1d(rb2, masked(rb2, hip.affine_cast(h, dt), v2), up.w, up.c_in, 2 * C1, up.k, dtype=dt, bias=up.b, pad=pad)
         h = h.view(-1, C1)                                        # (R, C1): polyphase rows are already interleaved
-        h = stage(P["u1"], rb, [h, h0_t])
+        h = stage(P["u1"], rb, [masked(rb, h, v1), h0_t], v1, kb1)
         c = P["u1c"]
-        h = hip.conv1d(rb, hip.affine_cast(h, dt), c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
+        h = hip.conv1d(rb, masked(rb, hip.affine_cast(h, dt), v1), c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
         fbc, g, b = P["fb"]
-        h = hip.conv1d(rb, h, fbc.w, fbc.c_in, fbc.n_out, 3, dtype=dt, bias=fbc.b)
-        h = hip.groupnorm_mish(rb, h, fbc.n_out, 8, g, b, dt, GN_EPS)
+        h = hip.conv1d(rb, masked(rb, h, v1), fbc.w, fbc.c_in, fbc.n_out, 3, dtype=dt, bias=fbc.b)
+        h = masked(rb, hip.groupnorm_mish(rb, h, fbc.n_out, 8, g, b, dt, GN_EPS), v1)
         fp = P["fp"]
+        if valid is not None:   # the vector field itself, masked (decoder.py:485-487)
+            return masked(rb, hip.conv1d(rb, h, fp.w, fp.c_in, od, 1, dtype=dt, bias=fp.b, out_f32=True), v1)
         # Euler update fused into the projection epilogue: x += dt * (W h + b)   (flow_matching.py:86-88)
         hip.conv1d(rb, h, fp.w, fp.c_in, od, 1, dtype=dt, bias=fp.b, alpha=dt_step, resid=x32, out=x32, out_f32=True)
 
@@ -414,8 +433,100 @@ class _MatchaBase(torch.nn.Module):
             out.update(log_p_attn=None, ds=None)
         return out
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("training pass (CFM loss) is outside the stage-4 hot path")
+    @torch.no_grad()
+    def forward(self, text, text_lengths, feats, feats_lengths, durations=None, durations_lengths=None, spembs=None, sids=None,
+                lids=None, joint_training=False, cfm_t=None, cfm_noise=None):
+        """The reference's training-time call, forward only (matchatts_mas.py:337-550 with is_inference=False): padded batch ->
+        alignment module + monotonic alignment search -> duration predictor -> masked Gaussian upsampling -> encoder_proj ->
+        conditional-flow-matching loss.  Same arguments and return dict {d_outs, ys, hs, olens_in, bin_loss, log_p_attn, ds,
+        cfm_loss}.  ``cfm_t`` (B,) / ``cfm_noise`` (B, T, odim): the two random draws of CFM.compute_loss
+        (flow_matching.py:115-117), injectable for parity; drawn with torch.rand / randn when omitted.
+        Padded-batch arithmetic as in the reference: key masks in the encoder attention, mask multiplications inside the
+        U-Net (GroupNorm statistics run over the padded length), the attention mask of the U-Net's transformer blocks added to
+        the scores."""
+        if not self._MAS:
+            raise NotImplementedError("MatchaTTS (tts1) forward(): external-duration training pass is not built; MatchaTTS_MAS.forward is")
+        P = self._prepare()
+        dt, dev, A, od = P["dtype"], P["dev"], self.adim, self.odim
+        ilens = [int(v) for v in text_lengths.tolist()]
+        olens = [int(v) for v in feats_lengths.tolist()]
+        B, Tm, To = len(ilens), max(ilens), max(olens)
+        xs = text[:, :Tm].to(dev)
+        ys = feats[:, :To].to(dev).float().contiguous()
+        rbt = hip.RaggedBatch([Tm] * B, dev)                       # padded text geometry
+        kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+        rbs = hip.RaggedBatch([1] * B, dev)
+        hs = P["enc"].run(rbt, hip.embed_scale(xs.reshape(-1).to(torch.int64).contiguous(), P["emb"], math.sqrt(A)), kv_len=kv)
+        if self.spks is not None:
+            hip.add_seq_vector(rbt, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
+        if self.spk_embed_dim is not None:
+            pj = P["proj"]
+            sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
+            hip.add_seq_vector(rbt, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
+        # ---- alignment module on the PADDED batch (its k=3 convolutions read across the padding, alignments.py:39-49), softmax
+        #      over the valid tokens (x_masks -> -inf), then the batched monotonic alignment search
+        al = P.get("align")
+        if al is None:
+            sd = self.state_dict()
+            al = P["align"] = {n: PackedConv(sd[f"alignment_module.{n}.weight"], sd[f"alignment_module.{n}.bias"], hip.F32, dev)
+                               for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
+
+        def aconv(rb, x, n, relu):
+            pc = al[n]
+            if x.shape[1] != pc.c_in:
+                x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
+            return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b, act=ACT_RELU if relu else hip.ACT_NONE)
+        rbf = hip.RaggedBatch([To] * B, dev)
+        tf = aconv(rbt, aconv(rbt, hs, "t_conv1", True), "t_conv2", False)
+        ff = aconv(rbf, aconv(rbf, aconv(rbf, ys.reshape(B * To, od), "f_conv1", True), "f_conv2", True), "f_conv3", False)
+        rbv = hip.RaggedBatch(ilens, dev)                          # valid tokens, packed (row selection: plumbing)
+        sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
+        lp = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, sel).contiguous(), A)      # (B*To, ld): every frame, padded or not
+        log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
+        lp3 = lp.view(B, To, -1)
+        for b in range(B):
+            log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
+        from ..alignments import viterbi_decode
+        ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
+        # ---- duration predictor (log domain, masked) and masked Gaussian upsampling
+        d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
+        d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()
+        rbo = hip.RaggedBatch(olens, dev)
+        up = hip.gaussian_upsample(rbv, d_int, rbo, hs.index_select(0, sel).contiguous())    # valid frames of every utterance
+        # h_masks zero the frame index of padded frames (length_regulator.py:139-141): they all equal frame 0 of their utterance
+        olens_in = [n - n % 2 for n in olens]
+        Te = max(olens_in)
+        cu = rbo.cu_host
+        rows = torch.tensor([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(Te)], dtype=torch.int64, device=dev)
+        ep = P["eproj"]
+        rbe = hip.RaggedBatch([Te] * B, dev)
+        mu = hip.conv1d(rbe, hip.affine_cast(up.index_select(0, rows).contiguous(), dt), ep.w, ep.c_in, od, 1, dtype=dt, bias=ep.b,
+                        out_f32=True)                              # hs of the return dict: (B, Te, odim)
+        ys_e = ys[:, :Te].contiguous()
+        # ---- CFM loss (flow_matching.py:99-127)
+        t = (torch.rand(B) if cfm_t is None else cfm_t.reshape(B).float().cpu())
+        z = (torch.randn(B, Te, od) if cfm_noise is None else cfm_noise[:, :Te].float()).to(dev).reshape(B * Te, od).contiguous()
+        y, u = hip.cfm_mix(rbe, ys_e.view(B * Te, od), z, t.to(dev).contiguous(), self.sigma_min)
+        v1 = torch.tensor(olens_in, dtype=torch.int32, device=dev)
+        v2 = torch.tensor([n // 2 for n in olens_in], dtype=torch.int32, device=dev)
+        heads, scale = self.dec_heads, P["d0"][1][0].dh ** -0.5 if P["d0"][1] else 1.0
+
+        def key_bias(T, vl):   # the (B, T) 1/0 frame mask as an additive score bias (after scaling): ku = mask / scale
+            m = (torch.arange(T, device=dev).unsqueeze(0) < vl.unsqueeze(1)).float().reshape(-1, 1) / scale
+            return m.expand(-1, heads).contiguous()
+        half = od
+        freq = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+        emb = 1000.0 * t.unsqueeze(1) * freq.unsqueeze(0)
+        temb = torch.zeros(B, P["t1"].c_in)
+        temb[:, :2 * half] = torch.cat((emb.sin(), emb.cos()), dim=-1)
+        mu_t = hip.zero_pad_rows(rbe, hip.affine_cast(mu, dt, ldy=P["d0"][0].conv1[1].c_in), v1)
+        rb2 = hip.RaggedBatch([Te // 2] * B, dev)
+        pred = self._estimator_step(P, rbe, rb2, rbs, y, mu_t, temb.to(dev).to(hip.torch_dtype(dt)), 0.0,
+                                    valid=(v1, v2, key_bias(Te, v1), key_bias(Te // 2, v2)))
+        # F.mse_loss(pred, u, reduction="sum") / (sum(mask) * n_feats): the sum runs over the padded frames too (pred is 0 there)
+        cfm_loss = hip.sq_err_sum(pred, u, 1.0 / (float(sum(olens_in)) * od))
+        return {"d_outs": d_outs, "ys": ys_e, "hs": mu.view(B, Te, od), "olens_in": torch.tensor(olens_in), "bin_loss": bin_loss,
+                "log_p_attn": log_p_attn, "ds": ds, "cfm_loss": cfm_loss}
 
 
 class MatchaTTS_MAS(_MatchaBase):

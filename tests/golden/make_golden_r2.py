@@ -129,6 +129,52 @@ def fs2_forward(FastSpeech2):
     return out
 
 
+def matcha_forward(Matcha):
+    """MatchaTTS_MAS.forward() (matchatts_mas.py:337-550, is_inference=False): alignment module + MAS + masked Gaussian
+    upsampling + CFM loss on a padded ragged batch, with the two random draws of CFM.compute_loss (t ~ U, z ~ N) injected.
+    The diffusers attention stand-in adds the (B, T) float mask to the scores, as diffusers does with `attention_mask`
+    [recalled: Attention.prepare_attention_mask -> additive bias] -- unpinned, like the rest of that class."""
+    import jatts.modules.matchatts.transformer as T
+
+    def attn_forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        B, L, _ = hidden_states.shape
+        sp = lambda t: t.view(B, L, self.heads, -1).transpose(1, 2)  # noqa: E731
+        q, k, v = sp(self.to_q(hidden_states)), sp(self.to_k(hidden_states)), sp(self.to_v(hidden_states))
+        sc = q @ k.transpose(-1, -2) * self.scale
+        if attention_mask is not None:
+            sc = sc + attention_mask.to(sc.dtype)[:, None, None, :]
+        return self.to_out[0]((torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, L, -1))
+
+    T.Attention.forward = attn_forward
+    model = Matcha(idim=20, **G.MATCHA_SMALL).eval()
+    ref_sd = model.state_dict()
+    sd = matcha_golden_tweaks(synth_state_dict(ref_sd, 3))
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(41)
+    ilens, olens = torch.tensor([14, 9, 17]), torch.tensor([53, 40, 62])
+    B, Tm, To = 3, int(ilens.max()), int(olens.max())
+    text = torch.zeros(B, Tm, dtype=torch.long)
+    feats = torch.zeros(B, To, 80)
+    for b in range(B):
+        text[b, : ilens[b]] = torch.randint(1, 20, (int(ilens[b]),), generator=g)
+        feats[b, : olens[b]] = torch.randn(int(olens[b]), 80, generator=g)
+    t_fix = torch.rand(B, 1, 1, generator=g)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: t_fix.clone()
+    try:
+        r, z = with_noise(900, lambda: model(text, ilens, feats, olens))
+    finally:
+        torch.rand = real_rand
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "config": json.dumps(G.MATCHA_SMALL),
+           "text": np_(text), "text_lengths": np_(ilens), "feats": np_(feats), "feats_lengths": np_(olens),
+           "t": np_(t_fix.reshape(-1)), "z": np_(z.permute(0, 2, 1))}                 # z as (B, T, odim)
+    for k in ("d_outs", "ys", "hs", "olens_in", "log_p_attn", "ds", "cfm_loss", "bin_loss"):
+        out["ref_" + k] = np_(torch.as_tensor(r[k]))
+    print("matcha_forward: cfm_loss", float(r["cfm_loss"]), "bin_loss", float(r["bin_loss"]), "olens_in", r["olens_in"].tolist(),
+          "ds sums", r["ds"].sum(1).tolist())
+    return out
+
+
 def main():
     torch.set_num_threads(8)
     FastSpeech2 = G.import_reference()
@@ -153,6 +199,9 @@ def main():
           "dur equal:", bool((o["duration"].numpy() == mz["u0_duration"]).all()))
     del mmodel
     np.savez_compressed(os.path.join(HERE, "matcha_tts1_small.npz"), **matcha_tts1())
+    np.savez_compressed(os.path.join(HERE, "matcha_forward_small.npz"), **matcha_forward(Matcha))
+    for f in ("matcha_forward_small.npz",):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
     for f in ("fs2_forward_small.npz", "vits_jsut.npz", "matcha_jsut.npz", "matcha_tts1_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

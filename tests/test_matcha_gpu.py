@@ -110,3 +110,31 @@ def test_matcha_tts1_matches_reference_golden(cuda, lib, prec, atol, rtol):
         n = rb["olens"][u]
         assert maxdiff(rb["feat_gen"][o:o + n], z[f"u{u}_feat_gen"]) <= atol
         o += n
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_matcha_mas_forward_matches_reference_golden(cuda, lib, prec):
+    """MatchaTTS_MAS.forward() -- the reference's training-time pass on a padded ragged batch (alignment module, monotonic
+    alignment search, masked Gaussian upsampling, CFM loss with the U-Net's mask multiplications), captured from the reference
+    with the two random draws of CFM.compute_loss injected (matcha_forward_small.npz).  Integer parts (MAS durations) exact."""
+    from jatts_amd.models import MatchaTTS_MAS
+    z, keys = load_golden("matcha_forward_small.npz")
+    m = MatchaTTS_MAS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 3)))
+    m = m.to(cuda).set_precision(prec)
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    r = m(t("text"), il, t("feats"), ol, cfm_t=t("t"), cfm_noise=t("z"))
+    assert set(r) == {"d_outs", "ys", "hs", "olens_in", "bin_loss", "log_p_attn", "ds", "cfm_loss"}
+    assert torch.equal(r["olens_in"], t("ref_olens_in")) and torch.equal(r["ys"].cpu(), t("ref_ys"))
+    assert torch.equal(r["ds"].cpu(), t("ref_ds")), "monotonic alignment search durations differ"
+    lp, ref = r["log_p_attn"].cpu(), t("ref_log_p_attn")
+    assert torch.equal(torch.isinf(lp), torch.isinf(ref))
+    fin = ~torch.isinf(ref)
+    tol = {"fp32": 2e-3, "fp16": 2e-3}[prec]     # the alignment module always runs in f32
+    assert float((lp[fin] - ref[fin]).abs().max()) <= tol
+    assert abs(float(r["bin_loss"]) - float(z["ref_bin_loss"])) <= 1e-3
+    assert maxdiff(r["d_outs"], z["ref_d_outs"]) <= (2e-3 if prec == "fp32" else 3e-2)
+    assert maxdiff(r["hs"], z["ref_hs"]) <= (3e-3 if prec == "fp32" else 5e-2)
+    rel = abs(float(r["cfm_loss"]) - float(z["ref_cfm_loss"])) / float(z["ref_cfm_loss"])
+    assert rel <= (1e-3 if prec == "fp32" else 2e-2), (float(r["cfm_loss"]), float(z["ref_cfm_loss"]))
