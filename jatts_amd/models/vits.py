@@ -171,15 +171,7 @@ class VITS(torch.nn.Module):
         flows = []
         for i in range(self.flow_flows):
             q = f"flow.flows.{2 * i}."
-            layers = []
-            for l in range(self.flow_layers):
-                c = q + f"encoder.conv_layers.{l}."
-                wo = _fold_wn(sd, c + "conv1x1_out")           # (2A, A, 1): [residual | skip] rows
-                bo = sd[c + "conv1x1_out.bias"].detach().float()
-                layers.append(dict(
-                    conv=PackedConv(_fold_wn(sd, c + "conv"), sd[c + "conv.bias"], dt, dev),
-                    glo=PackedConv(_fold_wn(sd, c + "conv1x1_glo"), None, dt, dev),
-                    res=PackedConv(wo[:A], bo[:A], dt, dev), skip=PackedConv(wo[A:], bo[A:], dt, dev)))
+            layers = self._wn_layers(sd, q + "encoder.", self.flow_layers, dt, dev)
             flows.append(dict(inp=PackedConv(sd[q + "input_conv.weight"], sd[q + "input_conv.bias"], dt, dev),
                               proj=PackedConv(sd[q + "proj.weight"], sd[q + "proj.bias"], dt, dev), layers=layers))
         P["flows"] = flows
@@ -187,6 +179,35 @@ class VITS(torch.nn.Module):
         P["sqrtA"] = torch.full((A,), math.sqrt(A), dtype=torch.float32, device=dev)
         self._prep = P
         return P
+
+    def _wavenet(self, P, rbo, rbs, h, layers, sp_t):
+        """WaveNet residual stack (wavenet.py:115-153, residual_block.py:112-167) on a ragged batch: h f32 (rows, A) is the
+        residual stream (updated in place), returns the skip sum f32.  The reference's `* x_mask` after every conv1x1_out is
+        the ragged layout itself (rows past an utterance's end do not exist)."""
+        dt, A = P["dtype"], self.adim
+        skips = torch.zeros_like(h)
+        for ly in layers:
+            g = hip.conv1d(rbs, sp_t, ly["glo"].w, ly["glo"].c_in, 2 * A, 1, dtype=dt, out_f32=True)  # (B, 2A)
+            cv = ly["conv"]
+            y = hip.conv1d(rbo, hip.affine_cast(h, dt), cv.w, cv.c_in, 2 * A, cv.k, dtype=dt, bias=cv.b)
+            gate = hip.gated_tanh_sigmoid(rbo, y, g, A, dt)
+            hip.conv1d(rbo, gate, ly["skip"].w, ly["skip"].c_in, A, 1, dtype=dt, bias=ly["skip"].b, resid=skips,
+                       out=skips, out_f32=True)
+            hip.conv1d(rbo, gate, ly["res"].w, ly["res"].c_in, A, 1, dtype=dt, bias=ly["res"].b, resid=h, out=h,
+                       out_f32=True)
+        return skips
+
+    def _wn_layers(self, sd, prefix, n_layers, dt, dev):
+        A, layers = self.adim, []
+        for l in range(n_layers):
+            c = prefix + f"conv_layers.{l}."
+            wo = _fold_wn(sd, c + "conv1x1_out")           # (2A, A, 1): [residual | skip] rows
+            bo = sd[c + "conv1x1_out.bias"].detach().float()
+            layers.append(dict(
+                conv=PackedConv(_fold_wn(sd, c + "conv"), sd[c + "conv.bias"], dt, dev),
+                glo=PackedConv(_fold_wn(sd, c + "conv1x1_glo"), None, dt, dev),
+                res=PackedConv(wo[:A], bo[:A], dt, dev), skip=PackedConv(wo[A:], bo[A:], dt, dev)))
+        return layers
 
     @torch.no_grad()
     def inference_batch(self, texts, spembs, noise=None, noise_scale: float = 0.667, durations=None, taps=None):
@@ -239,16 +260,7 @@ class VITS(torch.nn.Module):
             xa_t = hip.affine_cast(z, dt)                                  # coupling reads the first half only
             fi = fl["inp"]
             h = hip.conv1d(rbo, xa_t, fi.w, fi.c_in, A, 1, dtype=dt, bias=fi.b, out_f32=True, ldx=A)  # (Rf, A) f32
-            skips = torch.zeros_like(h)
-            for ly in fl["layers"]:
-                g = hip.conv1d(rbs, sp_t, ly["glo"].w, ly["glo"].c_in, 2 * A, 1, dtype=dt, out_f32=True)  # (B, 2A)
-                cv = ly["conv"]
-                y = hip.conv1d(rbo, hip.affine_cast(h, dt), cv.w, cv.c_in, 2 * A, cv.k, dtype=dt, bias=cv.b)
-                gate = hip.gated_tanh_sigmoid(rbo, y, g, A, dt)
-                hip.conv1d(rbo, gate, ly["skip"].w, ly["skip"].c_in, A, 1, dtype=dt, bias=ly["skip"].b, resid=skips,
-                           out=skips, out_f32=True)
-                hip.conv1d(rbo, gate, ly["res"].w, ly["res"].c_in, A, 1, dtype=dt, bias=ly["res"].b, resid=h, out=h,
-                           out_f32=True)
+            skips = self._wavenet(P, rbo, rbs, h, fl["layers"], sp_t)
             # m = proj(skips * sqrt(1/layers));  xb <- xb - m   (use_only_mean: logs = 0)
             sk_t = hip.affine_cast(skips, dt, scale=P.setdefault(
                 "skip_scale", torch.full((A,), math.sqrt(1.0 / len(fl["layers"])), device=dev)))
@@ -273,5 +285,110 @@ class VITS(torch.nn.Module):
                                  noise_scale=noise_scale)
         return dict(feat_gen=r["feat_gen"], duration=r["duration"], log_p_attn=None, ds=None)
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("jatts_amd.VITS.forward (training pass, vits.py:337-411) is outside the stage-4 hot path")
+    @torch.no_grad()
+    def forward(self, text, text_lengths, feats, feats_lengths, durations=None, durations_lengths=None, spembs=None, sids=None,
+                lids=None, joint_training=False, post_noise=None):
+        """The reference's training-time call, forward only (vits.py:342-579 with is_inference=False): padded batch -> text encoder,
+        posterior encoder (WaveNet) + sampling, forward flow, alignment module + monotonic alignment search, duration predictor,
+        masked Gaussian upsampling of the prior statistics, conformer decoder.  Same arguments and return dict {outs, d_outs, ys,
+        hs, olens_in, bin_loss, log_p_attn, ds, m_p, logs_p, z, y_mask, z_p, m_q, logs_q}, tensors in the reference's layouts.
+        ``post_noise`` (B, T_feats, adim): the posterior encoder's randn_like draw (posterior_encoder.py:128), injectable.
+        The conformers run on the PADDED batch (key masks only, convolutions read the padding, as in the reference); the
+        WaveNet parts run ragged -- there the reference masks after every layer, which is the ragged layout."""
+        if spembs is None:
+            raise ValueError("spembs is required (the reference crashes without it, vits.py:485)")
+        P = self._prepare()
+        dt, dev, A, od = P["dtype"], P["dev"], self.adim, self.odim
+        ilens = [int(v) for v in text_lengths.tolist()]
+        olens = [int(v) for v in feats_lengths.tolist()]
+        B, Tm, To = len(ilens), max(ilens), max(olens)
+        xs = text[:, :Tm].to(dev)
+        ys = feats[:, :To].to(dev).float().contiguous()
+        rbt, rbs = hip.RaggedBatch([Tm] * B, dev), hip.RaggedBatch([1] * B, dev)
+        kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+        # ---- text encoder on the padded batch (text_encoder.py:104-140)
+        hs = P["tenc"].run(rbt, hip.embed_scale(xs.reshape(-1).to(torch.int64).contiguous(), P["emb"], float(A)), kv_len=kv)
+        tp = P["te_proj"]
+        stats_p = hip.zero_pad_rows(rbt, hip.conv1d(rbt, hip.affine_cast(hs, dt), tp.w, tp.c_in, 2 * A, 1, dtype=dt, bias=tp.b,
+                                                    out_f32=True), kv)                 # proj(x) * x_mask: m_p | logs_p
+        spembs = spembs.to(dev).float().reshape(B, -1).contiguous()
+        pj = P["proj"]
+        hip.add_seq_vector(rbt, hs, hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt,
+                                               bias=pj.b, out_f32=True))
+        # ---- posterior encoder + forward flow on the valid frames (ragged)
+        post = P.get("post")
+        if post is None:
+            sd = self.state_dict()
+            post = P["post"] = dict(
+                inp=PackedConv(sd["posterior_encoder.input_conv.weight"], sd["posterior_encoder.input_conv.bias"], dt, dev),
+                layers=self._wn_layers(sd, "posterior_encoder.encoder.", sum(1 for k in sd if k.startswith("posterior_encoder.encoder.")
+                                                                             and k.endswith("conv.bias")), dt, dev),
+                proj=PackedConv(sd["posterior_encoder.proj.weight"], sd["posterior_encoder.proj.bias"], dt, dev))
+            P["align"] = {n: PackedConv(sd[f"alignment_module.{n}.weight"], sd[f"alignment_module.{n}.bias"], hip.F32, dev)
+                          for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
+        rbo = hip.RaggedBatch(olens, dev)
+        fsel = torch.cat([torch.arange(b * To, b * To + olens[b], device=dev) for b in range(B)])     # valid frame rows (plumbing)
+        yv = ys.reshape(B * To, od).index_select(0, fsel).contiguous()
+        sp_t = hip.affine_cast(spembs, dt, ldy=P["flows"][0]["layers"][0]["glo"].c_in)               # g = spembs, unnormalised
+        pi = post["inp"]
+        h = hip.conv1d(rbo, hip.affine_cast(yv, dt, ldy=pi.c_in), pi.w, pi.c_in, A, 1, dtype=dt, bias=pi.b, out_f32=True)
+        sk = self._wavenet(P, rbo, rbs, h, post["layers"], sp_t)
+        scale_q = torch.full((A,), math.sqrt(1.0 / len(post["layers"])), device=dev)
+        pp = post["proj"]
+        stats_q = hip.conv1d(rbo, hip.affine_cast(sk, dt, scale=scale_q), pp.w, pp.c_in, 2 * A, 1, dtype=dt, bias=pp.b, out_f32=True)
+        nz = (torch.randn(B, To, A) if post_noise is None else post_noise[:, :To].float()).to(dev).reshape(B * To, A)
+        z = hip.gaussian_sample(stats_q, nz.index_select(0, fsel).contiguous(), 1.0)                 # m_q + eps * exp(logs_q)
+        half = A // 2
+        zp = z.clone()
+        skip_scale = P.setdefault("skip_scale", torch.full((A,), math.sqrt(1.0 / self.flow_layers), device=dev))
+        for fl in P["flows"]:                                              # coupling (xb <- m + xb), then FlipFlow
+            fi = fl["inp"]
+            h = hip.conv1d(rbo, hip.affine_cast(zp, dt), fi.w, fi.c_in, A, 1, dtype=dt, bias=fi.b, out_f32=True, ldx=A)
+            sk = self._wavenet(P, rbo, rbs, h, fl["layers"], sp_t)
+            pr = fl["proj"]
+            hip.conv1d(rbo, hip.affine_cast(sk, dt, scale=skip_scale), pr.w, pr.c_in, half, 1, dtype=dt, bias=pr.b, alpha=1.0,
+                       resid=zp, resid_col0=half, out=zp, out_ld=A, out_col0=half, out_f32=True)
+            zp = hip.flip_channels(zp)
+        # ---- alignment module on the padded batch + monotonic alignment search (as MatchaTTS_MAS.forward)
+        al = P["align"]
+
+        def aconv(rb, x, n, relu):
+            pc = al[n]
+            if x.shape[1] != pc.c_in:
+                x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
+            return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b,
+                              act=hip.ACT_RELU if relu else hip.ACT_NONE)
+        rbf = hip.RaggedBatch([To] * B, dev)
+        tf = aconv(rbt, aconv(rbt, hs, "t_conv1", True), "t_conv2", False)
+        ff = aconv(rbf, aconv(rbf, aconv(rbf, ys.reshape(B * To, od), "f_conv1", True), "f_conv2", True), "f_conv3", False)
+        rbv = hip.RaggedBatch(ilens, dev)
+        tsel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
+        lp3 = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, tsel).contiguous(), A).view(B, To, -1)
+        log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
+        for b in range(B):
+            log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
+        from ..alignments import viterbi_decode
+        ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
+        d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
+        # ---- prior statistics upsampled with the MAS durations (padded frames take the value of frame 0, length_regulator.py:139-141)
+        d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()
+        up = hip.gaussian_upsample(rbv, d_int, rbo, stats_p.index_select(0, tsel).contiguous())      # (valid frames, 2A)
+        cu = rbo.cu_host
+        rows = torch.tensor([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(To)], dtype=torch.int64, device=dev)
+        up_pad = up.index_select(0, rows).view(B, To, 2 * A)
+        # ---- decoder on the padded batch (z is zero at padded frames; key mask = olens)
+        def pad_frames(v):     # ragged (valid frames, C) -> padded (B, To, C) with zeros
+            out = torch.zeros(B * To, v.shape[1], dtype=v.dtype, device=dev)
+            out[fsel] = v
+            return out.view(B, To, -1)
+        z_pad = pad_frames(z)
+        kvo = torch.tensor(olens, dtype=torch.int32, device=dev)
+        zs_t = P["dec"].run(rbf, hip.affine_cast(z_pad.view(B * To, A), hip.F32, scale=P["sqrtA"]), final_dtype=dt, kv_len=kvo)
+        fo = P["feat_out"]
+        outs = hip.conv1d(rbf, zs_t, fo.w, fo.c_in, fo.n_out, 1, dtype=dt, bias=fo.b, out_f32=True).view(B, To, od)
+        sq = pad_frames(stats_q)
+        y_mask = (torch.arange(To, device=dev).unsqueeze(0) < kvo.unsqueeze(1)).float().unsqueeze(1)
+        tr = lambda v: v.transpose(1, 2)   # noqa: E731  the reference keeps these channel-first
+        return {"m_q": tr(sq[..., :A]), "logs_q": tr(sq[..., A:]), "outs": outs, "d_outs": d_outs, "ys": ys,
+                "hs": tr(hs.view(B, Tm, A)), "olens_in": feats_lengths, "bin_loss": bin_loss, "log_p_attn": log_p_attn, "ds": ds,
+                "m_p": tr(up_pad[..., :A]), "logs_p": tr(up_pad[..., A:]), "z": tr(z_pad), "y_mask": y_mask, "z_p": tr(pad_frames(zp))}

@@ -8,6 +8,8 @@ only; the fixtures are data: ids, durations, injected noise, outputs -- weights 
   matcha_tts1_small.npz  the tts1 `MatchaTTS` class (hard LengthRegulator), small config, 4 Euler steps
   fs2_forward_small.npz  FastSpeech2.forward() -- the training-time, teacher-forced, PADDED batched pass
                          (fastspeech2.py:473-564): before_outs / after_outs / d_outs / p_outs / e_outs for a ragged batch
+  matcha_forward_small.npz, vits_forward_small.npz  MatchaTTS_MAS.forward() / VITS.forward() on padded ragged batches, random
+                         draws injected (CFM t and noise; posterior sampling noise)
 
     python tests/golden/make_golden_r2.py
 """
@@ -175,6 +177,33 @@ def matcha_forward(Matcha):
     return out
 
 
+def vits_forward(VITS):
+    """VITS.forward() (vits.py:342-579, is_inference=False): posterior encoder + forward flow + alignment module / MAS +
+    masked Gaussian upsampling + decoder on a padded ragged batch; the posterior sampling noise is injected."""
+    model = VITS(idim=20, **G.VITS_SMALL).eval()
+    ref_sd = model.state_dict()
+    model.load_state_dict(synth_state_dict(ref_sd, 2))
+    g = torch.Generator().manual_seed(51)
+    ilens, olens = torch.tensor([12, 16, 7]), torch.tensor([45, 58, 31])
+    B, Tm, To = 3, int(ilens.max()), int(olens.max())
+    text = torch.zeros(B, Tm, dtype=torch.long)
+    feats = torch.zeros(B, To, 80)
+    for b in range(B):
+        text[b, : ilens[b]] = torch.randint(1, 20, (int(ilens[b]),), generator=g)
+        feats[b, : olens[b]] = torch.randn(int(olens[b]), 80, generator=g)
+    spembs = torch.randn(B, 16, generator=g)
+    r, noise = with_noise(950, lambda: model(text, ilens, feats, olens, spembs=spembs))
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "config": json.dumps(G.VITS_SMALL),
+           "text": np_(text), "text_lengths": np_(ilens), "feats": np_(feats), "feats_lengths": np_(olens), "spembs": np_(spembs),
+           "noise": np_(noise.permute(0, 2, 1))}                                        # (B, T_feats, adim)
+    for k in ("outs", "d_outs", "ys", "hs", "olens_in", "bin_loss", "log_p_attn", "ds", "m_p", "logs_p", "z", "y_mask", "z_p",
+              "m_q", "logs_q"):
+        out["ref_" + k] = np_(torch.as_tensor(r[k]))
+    print("vits_forward:", {k: tuple(out["ref_" + k].shape) for k in ("outs", "hs", "m_p", "z", "z_p", "m_q", "y_mask", "d_outs")},
+          "bin_loss", float(r["bin_loss"]))
+    return out
+
+
 def main():
     torch.set_num_threads(8)
     FastSpeech2 = G.import_reference()
@@ -200,7 +229,8 @@ def main():
     del mmodel
     np.savez_compressed(os.path.join(HERE, "matcha_tts1_small.npz"), **matcha_tts1())
     np.savez_compressed(os.path.join(HERE, "matcha_forward_small.npz"), **matcha_forward(Matcha))
-    for f in ("matcha_forward_small.npz",):
+    np.savez_compressed(os.path.join(HERE, "vits_forward_small.npz"), **vits_forward(VITS))
+    for f in ("matcha_forward_small.npz", "vits_forward_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
     for f in ("fs2_forward_small.npz", "vits_jsut.npz", "matcha_jsut.npz", "matcha_tts1_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -72,3 +72,33 @@ def test_vits_full_width_192d_matches_reference_golden(cuda, lib, prec, atol, rt
         assert r["feat_gen"].shape == ref.shape
         assert maxdiff(r["feat_gen"], ref) <= atol, f"u{u} {prec}: max|d| = {maxdiff(r['feat_gen'], ref):.3e}"
         assert relerr(r["feat_gen"], ref) <= rtol
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_vits_forward_matches_reference_golden(cuda, lib, prec):
+    """VITS.forward() -- the reference's training-time pass on a padded ragged batch (posterior encoder, forward flow, alignment
+    module + MAS, masked Gaussian upsampling, decoder), captured from the reference with the posterior noise injected."""
+    from jatts_amd.models import VITS
+    z, keys = load_golden("vits_forward_small.npz")
+    m = VITS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(golden_state(keys, 2))
+    m = m.to(cuda).set_precision(prec)
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    r = m(t("text"), il, t("feats"), ol, spembs=t("spembs"), post_noise=t("noise"))
+    assert set(r) == {"outs", "d_outs", "ys", "hs", "olens_in", "bin_loss", "log_p_attn", "ds", "m_p", "logs_p", "z", "y_mask", "z_p",
+                      "m_q", "logs_q"}
+    assert torch.equal(r["ds"].cpu(), t("ref_ds")), "monotonic alignment search durations differ"
+    assert torch.equal(r["olens_in"], t("ref_olens_in")) and torch.equal(r["y_mask"].cpu(), t("ref_y_mask"))
+    lp, ref = r["log_p_attn"].cpu(), t("ref_log_p_attn")
+    assert torch.equal(torch.isinf(lp), torch.isinf(ref))
+    fin = ~torch.isinf(ref)
+    assert float((lp[fin] - ref[fin]).abs().max()) <= 2e-3
+    assert abs(float(r["bin_loss"]) - float(z["ref_bin_loss"])) <= 1e-3
+    tol = {"fp32": 3e-3, "fp16": 8e-2}[prec]
+    for k in ("hs", "m_p", "logs_p", "m_q", "logs_q", "z", "z_p", "d_outs"):
+        assert r[k].shape == z["ref_" + k].shape, k
+        assert maxdiff(r[k], z["ref_" + k]) <= tol, (k, maxdiff(r[k], z["ref_" + k]))
+    for b, n in enumerate(ol.tolist()):          # valid frames tight; padded frames carry the same padding leakage
+        assert maxdiff(r["outs"][b, :n], z["ref_outs"][b, :n]) <= tol, (b, maxdiff(r["outs"][b, :n], z["ref_outs"][b, :n]))
+    assert maxdiff(r["outs"], z["ref_outs"]) <= 5 * tol
