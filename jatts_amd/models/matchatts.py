@@ -444,8 +444,6 @@ class _MatchaBase(torch.nn.Module):
         Padded-batch arithmetic as in the reference: key masks in the encoder attention, mask multiplications inside the
         U-Net (GroupNorm statistics run over the padded length), the attention mask of the U-Net's transformer blocks added to
         the scores."""
-        if not self._MAS:
-            raise NotImplementedError("MatchaTTS (tts1) forward(): external-duration training pass is not built; MatchaTTS_MAS.forward is")
         P = self._prepare()
         dt, dev, A, od = P["dtype"], P["dev"], self.adim, self.odim
         ilens = [int(v) for v in text_lengths.tolist()]
@@ -463,44 +461,56 @@ class _MatchaBase(torch.nn.Module):
             pj = P["proj"]
             sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
             hip.add_seq_vector(rbt, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
-        # ---- alignment module on the PADDED batch (its k=3 convolutions read across the padding, alignments.py:39-49), softmax
-        #      over the valid tokens (x_masks -> -inf), then the batched monotonic alignment search
-        al = P.get("align")
-        if al is None:
-            sd = self.state_dict()
-            al = P["align"] = {n: PackedConv(sd[f"alignment_module.{n}.weight"], sd[f"alignment_module.{n}.bias"], hip.F32, dev)
-                               for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
-
-        def aconv(rb, x, n, relu):
-            pc = al[n]
-            if x.shape[1] != pc.c_in:
-                x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
-            return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b, act=ACT_RELU if relu else hip.ACT_NONE)
-        rbf = hip.RaggedBatch([To] * B, dev)
-        tf = aconv(rbt, aconv(rbt, hs, "t_conv1", True), "t_conv2", False)
-        ff = aconv(rbf, aconv(rbf, aconv(rbf, ys.reshape(B * To, od), "f_conv1", True), "f_conv2", True), "f_conv3", False)
-        rbv = hip.RaggedBatch(ilens, dev)                          # valid tokens, packed (row selection: plumbing)
-        sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
-        lp = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, sel).contiguous(), A)      # (B*To, ld): every frame, padded or not
-        log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
-        lp3 = lp.view(B, To, -1)
-        for b in range(B):
-            log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
-        from ..alignments import viterbi_decode
-        ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
-        # ---- duration predictor (log domain, masked) and masked Gaussian upsampling
-        d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
-        d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()
-        rbo = hip.RaggedBatch(olens, dev)
-        up = hip.gaussian_upsample(rbv, d_int, rbo, hs.index_select(0, sel).contiguous())    # valid frames of every utterance
-        # h_masks zero the frame index of padded frames (length_regulator.py:139-141): they all equal frame 0 of their utterance
         olens_in = [n - n % 2 for n in olens]
         Te = max(olens_in)
-        cu = rbo.cu_host
-        rows = torch.tensor([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(Te)], dtype=torch.int64, device=dev)
+        if self._MAS:
+            # ---- alignment module on the PADDED batch (its k=3 convolutions read across the padding, alignments.py:39-49), softmax
+            #      over the valid tokens (x_masks -> -inf), then the batched monotonic alignment search
+            al = P.get("align")
+            if al is None:
+                sd = self.state_dict()
+                al = P["align"] = {n: PackedConv(sd[f"alignment_module.{n}.weight"], sd[f"alignment_module.{n}.bias"], hip.F32, dev)
+                                   for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
+
+            def aconv(rb, x, n, relu):
+                pc = al[n]
+                if x.shape[1] != pc.c_in:
+                    x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
+                return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b, act=ACT_RELU if relu else hip.ACT_NONE)
+            rbf = hip.RaggedBatch([To] * B, dev)
+            tf = aconv(rbt, aconv(rbt, hs, "t_conv1", True), "t_conv2", False)
+            ff = aconv(rbf, aconv(rbf, aconv(rbf, ys.reshape(B * To, od), "f_conv1", True), "f_conv2", True), "f_conv3", False)
+            rbv = hip.RaggedBatch(ilens, dev)                          # valid tokens, packed (row selection: plumbing)
+            sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
+            lp = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, sel).contiguous(), A)      # (B*To, ld): every frame, padded or not
+            log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
+            lp3 = lp.view(B, To, -1)
+            for b in range(B):
+                log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
+            from ..alignments import viterbi_decode
+            ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
+            # ---- duration predictor (log domain, masked) and masked Gaussian upsampling
+            d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
+            d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()
+            rbo = hip.RaggedBatch(olens, dev)
+            up = hip.gaussian_upsample(rbv, d_int, rbo, hs.index_select(0, sel).contiguous())    # valid frames of every utterance
+            # h_masks zero the frame index of padded frames (length_regulator.py:139-141): they all equal frame 0 of their utterance
+            cu = rbo.cu_host
+            rows = torch.tensor([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(Te)], dtype=torch.int64, device=dev)
+            up_pad = up.index_select(0, rows).contiguous()
+        else:   # tts1: ground-truth durations, hard length regulator, zero padding (length_regulator.py:70-97)
+            if durations is None:
+                raise ValueError("MatchaTTS.forward needs durations")
+            d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
+            d_flat = durations[:, : int(durations_lengths.max())].to(dev).reshape(-1).to(torch.int64).contiguous()
+            if d_flat.numel() != B * Tm:
+                raise ValueError("durations must be padded to the text length")
+            _, cum, _, _ = hip.lr_durations(rbt, d_flat, 1.0, zero_rule=0)
+            up_pad = hip.lr_gather(rbt, cum, hip.RaggedBatch([Te] * B, dev), hs)
+            ds = log_p_attn = bin_loss = None
         ep = P["eproj"]
         rbe = hip.RaggedBatch([Te] * B, dev)
-        mu = hip.conv1d(rbe, hip.affine_cast(up.index_select(0, rows).contiguous(), dt), ep.w, ep.c_in, od, 1, dtype=dt, bias=ep.b,
+        mu = hip.conv1d(rbe, hip.affine_cast(up_pad, dt), ep.w, ep.c_in, od, 1, dtype=dt, bias=ep.b,
                         out_f32=True)                              # hs of the return dict: (B, Te, odim)
         ys_e = ys[:, :Te].contiguous()
         # ---- CFM loss (flow_matching.py:99-127)
@@ -525,8 +535,10 @@ class _MatchaBase(torch.nn.Module):
                                     valid=(v1, v2, key_bias(Te, v1), key_bias(Te // 2, v2)))
         # F.mse_loss(pred, u, reduction="sum") / (sum(mask) * n_feats): the sum runs over the padded frames too (pred is 0 there)
         cfm_loss = hip.sq_err_sum(pred, u, 1.0 / (float(sum(olens_in)) * od))
-        return {"d_outs": d_outs, "ys": ys_e, "hs": mu.view(B, Te, od), "olens_in": torch.tensor(olens_in), "bin_loss": bin_loss,
-                "log_p_attn": log_p_attn, "ds": ds, "cfm_loss": cfm_loss}
+        ret = {"d_outs": d_outs, "ys": ys_e, "hs": mu.view(B, Te, od), "olens_in": torch.tensor(olens_in), "cfm_loss": cfm_loss}
+        if self._MAS:
+            ret.update(bin_loss=bin_loss, log_p_attn=log_p_attn, ds=ds)
+        return ret
 
 
 class MatchaTTS_MAS(_MatchaBase):

@@ -131,11 +131,7 @@ def fs2_forward(FastSpeech2):
     return out
 
 
-def matcha_forward(Matcha):
-    """MatchaTTS_MAS.forward() (matchatts_mas.py:337-550, is_inference=False): alignment module + MAS + masked Gaussian
-    upsampling + CFM loss on a padded ragged batch, with the two random draws of CFM.compute_loss (t ~ U, z ~ N) injected.
-    The diffusers attention stand-in adds the (B, T) float mask to the scores, as diffusers does with `attention_mask`
-    [recalled: Attention.prepare_attention_mask -> additive bias] -- unpinned, like the rest of that class."""
+def install_additive_mask_attention():
     import jatts.modules.matchatts.transformer as T
 
     def attn_forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
@@ -148,6 +144,14 @@ def matcha_forward(Matcha):
         return self.to_out[0]((torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, L, -1))
 
     T.Attention.forward = attn_forward
+
+
+def matcha_forward(Matcha):
+    """MatchaTTS_MAS.forward() (matchatts_mas.py:337-550, is_inference=False): alignment module + MAS + masked Gaussian
+    upsampling + CFM loss on a padded ragged batch, with the two random draws of CFM.compute_loss (t ~ U, z ~ N) injected.
+    The diffusers attention stand-in adds the (B, T) float mask to the scores, as diffusers does with `attention_mask`
+    [recalled: Attention.prepare_attention_mask -> additive bias] -- unpinned, like the rest of that class."""
+    install_additive_mask_attention()
     model = Matcha(idim=20, **G.MATCHA_SMALL).eval()
     ref_sd = model.state_dict()
     sd = matcha_golden_tweaks(synth_state_dict(ref_sd, 3))
@@ -174,6 +178,42 @@ def matcha_forward(Matcha):
         out["ref_" + k] = np_(torch.as_tensor(r[k]))
     print("matcha_forward: cfm_loss", float(r["cfm_loss"]), "bin_loss", float(r["bin_loss"]), "olens_in", r["olens_in"].tolist(),
           "ds sums", r["ds"].sum(1).tolist())
+    return out
+
+
+def matcha_tts1_forward():
+    """tts1 MatchaTTS.forward() (matchatts.py:317-480): ground-truth durations + hard LengthRegulator + CFM loss."""
+    from jatts.models.matchatts import MatchaTTS
+
+    install_additive_mask_attention()
+    model = MatchaTTS(idim=20, **MATCHA_TTS1_SMALL).eval()
+    ref_sd = model.state_dict()
+    model.load_state_dict(matcha_golden_tweaks(synth_state_dict(ref_sd, 4)))
+    g = torch.Generator().manual_seed(61)
+    ilens = torch.tensor([11, 15, 8])
+    B, Tm = 3, int(ilens.max())
+    text = torch.zeros(B, Tm, dtype=torch.long)
+    ds = torch.zeros(B, Tm, dtype=torch.long)
+    for b in range(B):
+        text[b, : ilens[b]] = torch.randint(1, 20, (int(ilens[b]),), generator=g)
+        ds[b, : ilens[b]] = torch.randint(1, 6, (int(ilens[b]),), generator=g)
+    olens = ds.sum(1)
+    feats = torch.zeros(B, int(olens.max()), 80)
+    for b in range(B):
+        feats[b, : olens[b]] = torch.randn(int(olens[b]), 80, generator=g)
+    t_fix = torch.rand(B, 1, 1, generator=g)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: t_fix.clone()
+    try:
+        r, z = with_noise(960, lambda: model(text, ilens, feats, olens, ds, ilens))
+    finally:
+        torch.rand = real_rand
+    out = {"keys": json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]), "config": json.dumps(MATCHA_TTS1_SMALL),
+           "text": np_(text), "text_lengths": np_(ilens), "feats": np_(feats), "feats_lengths": np_(olens), "durations": np_(ds),
+           "t": np_(t_fix.reshape(-1)), "z": np_(z.permute(0, 2, 1))}
+    for k in ("d_outs", "ys", "hs", "olens_in", "cfm_loss"):
+        out["ref_" + k] = np_(torch.as_tensor(r[k]))
+    print("matcha_tts1_forward: cfm_loss", float(r["cfm_loss"]), "olens", olens.tolist(), "olens_in", r["olens_in"].tolist())
     return out
 
 
@@ -230,7 +270,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "matcha_tts1_small.npz"), **matcha_tts1())
     np.savez_compressed(os.path.join(HERE, "matcha_forward_small.npz"), **matcha_forward(Matcha))
     np.savez_compressed(os.path.join(HERE, "vits_forward_small.npz"), **vits_forward(VITS))
-    for f in ("matcha_forward_small.npz", "vits_forward_small.npz"):
+    np.savez_compressed(os.path.join(HERE, "matcha_tts1_forward_small.npz"), **matcha_tts1_forward())
+    for f in ("matcha_forward_small.npz", "vits_forward_small.npz", "matcha_tts1_forward_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
     for f in ("fs2_forward_small.npz", "vits_jsut.npz", "matcha_jsut.npz", "matcha_tts1_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))

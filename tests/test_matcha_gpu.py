@@ -138,3 +138,22 @@ def test_matcha_mas_forward_matches_reference_golden(cuda, lib, prec):
     assert maxdiff(r["hs"], z["ref_hs"]) <= (3e-3 if prec == "fp32" else 5e-2)
     rel = abs(float(r["cfm_loss"]) - float(z["ref_cfm_loss"])) / float(z["ref_cfm_loss"])
     assert rel <= (1e-3 if prec == "fp32" else 2e-2), (float(r["cfm_loss"]), float(z["ref_cfm_loss"]))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_matcha_tts1_forward_matches_reference_golden(cuda, lib, prec):
+    """tts1 MatchaTTS.forward(): ground-truth durations, hard LengthRegulator with zero padding, CFM loss (matchatts.py:317-480)."""
+    from jatts_amd.models import MatchaTTS
+    z, keys = load_golden("matcha_tts1_forward_small.npz")
+    m = MatchaTTS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 4)))
+    m = m.to(cuda).set_precision(prec)
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    r = m(t("text"), il, t("feats"), ol, t("durations"), il, cfm_t=t("t"), cfm_noise=t("z"))
+    assert set(r) == {"d_outs", "ys", "hs", "olens_in", "cfm_loss"}
+    assert torch.equal(r["olens_in"], t("ref_olens_in")) and torch.equal(r["ys"].cpu(), t("ref_ys"))
+    assert maxdiff(r["d_outs"], z["ref_d_outs"]) <= (2e-3 if prec == "fp32" else 3e-2)
+    assert maxdiff(r["hs"], z["ref_hs"]) <= (3e-3 if prec == "fp32" else 5e-2)
+    rel = abs(float(r["cfm_loss"]) - float(z["ref_cfm_loss"])) / float(z["ref_cfm_loss"])
+    assert rel <= (1e-3 if prec == "fp32" else 2e-2), (float(r["cfm_loss"]), float(z["ref_cfm_loss"]))
