@@ -58,7 +58,9 @@ def gather_audio(wave, lens, max_utts=None, group=None, pcm16=None):
     as_bytes = (lambda t: t.view(torch.uint8)) if esz != 1 and wave.dtype == torch.int16 else (lambda t: t)  # RCCL has no int16 type
     if offs[-1] > 0:
         backend = dist.get_backend(group)
-        if backend == "nccl" and all(n > 0 for n in n_samp):
+        if len(set(n_samp)) == 1:            # equal shards (the weak-scaling bench): the plain dense all-gather
+            dist.all_gather_into_tensor(as_bytes(flat), as_bytes(wave), group=group)
+        elif backend == "nccl" and all(n > 0 for n in n_samp):
             dist.all_gather([as_bytes(p) for p in parts], as_bytes(wave), group=group)
         else:
             parts[rank].copy_(wave)

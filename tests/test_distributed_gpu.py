@@ -1,0 +1,36 @@
+"""The RCCL side of the exchange step on the one GPU a test box has: a single-rank "nccl" process group exercises the same
+calls (header all_gather_into_tensor, uint8 payload collectives, jatts_pcm16 conversion) that N ranks issue; the multi-rank
+bookkeeping is covered on CPU (tests/test_distributed_cpu.py)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_audio_on_rccl_world1(cuda, lib):
+    import torch.distributed as dist
+    from jatts_amd.bin.tts_decode import to_pcm16
+    from jatts_amd.distributed import gather_audio
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(cuda)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        g = torch.Generator().manual_seed(0)
+        lens = [4096, 300, 77777]
+        y = torch.tanh(torch.randn(sum(lens), generator=g)).to(cuda)
+        got, lens_out = gather_audio(y, lens, max_utts=8)
+        assert lens_out == [lens] and got[0].dtype == torch.int16 and got[0].numel() == sum(lens)
+        assert torch.equal(got[0].cpu(), torch.from_numpy(to_pcm16(y.cpu().numpy())))      # jatts_pcm16 == the host conversion
+        got, lens_out = gather_audio(y, lens, pcm16=False)                                 # f32 payload, max_utts by all-reduce
+        assert torch.equal(got[0], y) and lens_out == [lens]
+    finally:
+        dist.destroy_process_group()
