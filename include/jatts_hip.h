@@ -178,6 +178,24 @@ typedef struct jatts_resblock_desc {
 
 int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Training side, first slice of SURVEY 8 f.4 (jatts/trainers/fastspeech2.py:24-100): the criterion sums on forward()'s
+ * outputs and the parameter gradients of jatts_conv1d.  dx of a conv is jatts_conv1d itself on W'[c][n][k-1-tap] with
+ * pad' = (k-1)*dil - pad.
+ * ------------------------------------------------------------------------------- */
+/* *out = scale * sum over sequences b, rows t < valid_len[b] (NULL: all rows), columns c < dim of |a - b'| (kind 0, L1Loss) or
+ * (a - b')^2 (kind 1, MSELoss); b' = log(b + log_offset) when log_offset >= 0 (DurationPredictorLoss, duration_predictor_loss.py:55),
+ * else b.  losses/l1l2_loss.py:43-63, variance_predictor_loss.py.  workspace: 4 * n_seq doubles. */
+int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
+                      const int32_t* valid_len, int32_t kind, float log_offset, double scale, float* out, double* workspace,
+                      void* stream);
+/* dw[n][c][tap] += sum_t dy[t][n] * x[t + tap*dil - pad][c] over all sequences (torch weight layout (n_out, c_in, k_w), f32;
+ * caller zeroes dw; accumulation order is not fixed: f32 atomics). */
+int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
+                       int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, void* stream);
+/* out[c] += sum over rows of x[row][c] (bias gradient; caller zeroes out). */
+int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* out, void* stream);
+
 /* Profiling hook (not part of the reference interface): while `buf` is non-NULL, thread 0 of the first n_workgroups
  * workgroups of every jatts_hifigan_resunit launch writes 16 uint64 to buf[16*wg ..]: {XCC_ID<<32 | HW_ID, s_memtime
  * at start, x staged, conv1 done, h written, conv2 done, y assembled, y stored, then s_memrealtime (100 MHz) at start

@@ -1,0 +1,138 @@
+// Training-side kernels (first slice): the loss sums of the FastSpeech2 criterion and the weight / bias
+// gradients of jatts_conv1d.  The data gradient of a conv is jatts_conv1d itself on flipped, transposed weights.
+// Reference: jatts/trainers/fastspeech2.py:24-100 (_train_step), jatts/losses/{l1l2_loss,duration_predictor_loss,
+// variance_predictor_loss}.py, torch.nn.Conv1d's autograd.
+#include "common.h"
+
+namespace {
+
+// sum over valid rows (t < valid_len[b]) and the first `dim` columns of |a - b'| (kind 0) or (a - b')^2 (kind 1);
+// b' = b, or log(b + log_offset) when log_offset >= 0 (DurationPredictorLoss: targets in the log domain)
+__global__ __launch_bounds__(256) void masked_loss_partial_kernel(jatts_ragged rg, const float* a, int lda, const float* b, int ldb,
+                                                                 int dim, const int32_t* valid_len, int kind, float log_offset,
+                                                                 double* part) {
+  __shared__ double red[256];
+  const int s = blockIdx.y;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  const int v = valid_len ? min(max(valid_len[s], 0), L) : L;
+  const int64_t n = (int64_t)v * dim;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / dim;
+    const int c = (int)(i - t * dim);
+    float y = b[(row0 + t) * ldb + c];
+    if (log_offset >= 0.f) y = logf(y + log_offset);
+    const float dlt = a[(row0 + t) * lda + c] - y;
+    acc += kind == 0 ? (double)fabsf(dlt) : (double)dlt * (double)dlt;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void fold_loss_kernel(const double* part, int n, double scale, float* out) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += part[i];
+  *out = (float)(s * scale);
+}
+
+// dW[n][c][tap] += sum over sequences, t of dy[t][n] * x[t + tap*dil - pad][c] (x outside its sequence = 0).
+// One workgroup = a 64(n) x 64(c) tile of one tap over a slice of the sequences; a thread owns 4 x 4 outputs; dy / x tiles of
+// 32 time steps go through LDS; partial sums are added with f32 atomics (f32 FMA at the f32-MFMA rate on gfx950).
+constexpr int WG_TT = 32;
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const float* x, int ldx, const float* dy, int ldy, int c_in,
+                                                         int n_out, int k_w, int dil, int pad, int seq_groups, float* dw) {
+  __shared__ float dys[WG_TT][64 + 4];
+  __shared__ float xs[WG_TT][64 + 4];
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tap = blockIdx.z % k_w, grp = blockIdx.z / k_w;
+  const int tn = threadIdx.x >> 4, tc = threadIdx.x & 15;   // 16 x 16 threads, 4 x 4 outputs each
+  float acc[4][4] = {};
+  for (int s = grp; s < rg.n_seq; s += seq_groups) {
+    const int row0 = rg.cu_rows[s] * rg.len_mul, L = (rg.cu_rows[s + 1] - rg.cu_rows[s]) * rg.len_mul;
+    for (int t0 = 0; t0 < L; t0 += WG_TT) {
+      for (int i = threadIdx.x; i < WG_TT * 64; i += 256) {
+        const int t = i >> 6, j = i & 63;
+        const int tt = t0 + t, p = tt + tap * dil - pad;
+        dys[t][j] = (tt < L && n0 + j < n_out) ? dy[(int64_t)(row0 + tt) * ldy + n0 + j] : 0.f;
+        xs[t][j] = (tt < L && p >= 0 && p < L && c0 + j < c_in) ? x[(int64_t)(row0 + p) * ldx + c0 + j] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int t = 0; t < WG_TT; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&dys[t][4 * tn]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&xs[t][4 * tc]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tn + i, c = c0 + 4 * tc + j;
+      if (n < n_out && c < c_in) atomicAdd(&dw[((int64_t)n * c_in + c) * k_w + tap], acc[i][j]);
+    }
+}
+
+// out[c] += sum over rows of x[row][c]
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, int64_t rows, int dim, float* out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < dim)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
+                                 const int32_t* valid_len, int32_t kind, float log_offset, double scale, float* out, double* workspace,
+                                 void* stream) {
+  if (!rg || !a || !b || !out || !workspace) return jatts_set_error_msg(JATTS_ERR_ARG, "masked_loss: null pointer");
+  if (kind != 0 && kind != 1) return jatts_set_error_msg(JATTS_ERR_ARG, "masked_loss: kind must be 0 (L1) or 1 (L2)");
+  if (rg->n_seq <= 0 || rg->n_seq > 4096) return jatts_set_error_msg(JATTS_ERR_ARG, "masked_loss: 1..4096 sequences");
+  const int bx = 4;
+  hipLaunchKernelGGL(masked_loss_partial_kernel, dim3(bx, (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, a, lda, b, ldb, dim, valid_len, kind,
+                     log_offset, workspace);
+  hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(1), 0, S_, workspace, bx * rg->n_seq, scale, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
+                                  int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, void* stream) {
+  if (!rg || !x || !dy || !dw) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: null pointer");
+  if (c_in < 1 || n_out < 1 || k_w < 1 || dil < 1) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: bad geometry");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  const int tiles = ((n_out + 63) / 64) * ((c_in + 63) / 64) * k_w;
+  int groups = (1024 + tiles - 1) / tiles;            // enough workgroups to fill the chip; each group strides over the sequences
+  if (groups > rg->n_seq) groups = rg->n_seq;
+  if (groups < 1) groups = 1;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)(k_w * groups)), dim3(256), 0, S_,
+                     *rg, x, ldx, dy, ldy, c_in, n_out, k_w, dil, pad, groups, dw);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* out, void* stream) {
+  if (!x || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "col_sum: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  const int64_t gy = (rows + 255) / 256;
+  hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, ld, rows, dim, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}

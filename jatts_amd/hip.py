@@ -600,3 +600,35 @@ def se_scale_add(rb, x, s, resid=None, out=None, out_col0=0):
     _abi.check(lib.jatts_se_scale_add(C.byref(rg), _dev(x).data_ptr(), x.shape[1], s.data_ptr(), _ptr(resid), _ptr(y, out_col0),
                                       y.shape[1], _stream()), "jatts_se_scale_add")
     return y
+
+
+# ---- training side (csrc/training.hip)
+def masked_loss(rb, a, b, valid_len, kind, scale, log_offset=-1.0):
+    """scale * sum over valid rows of |a - b| (kind 0) or (a - b)^2 (kind 1); b -> log(b + log_offset) when log_offset >= 0."""
+    lib = _abi.load()
+    a2 = a if a.dim() == 2 else a.reshape(-1, 1)
+    b2 = b if b.dim() == 2 else b.reshape(-1, 1)
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    ws = torch.empty(4 * rb.n_seq, dtype=torch.float64, device=a.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_masked_loss(C.byref(rg), _dev(a2).data_ptr(), a2.shape[1], b2.data_ptr(), b2.shape[1], a2.shape[1],
+                                     _ptr(valid_len), kind, float(log_offset), float(scale), out.data_ptr(), ws.data_ptr(), _stream()),
+               "jatts_masked_loss")
+    return out
+
+
+def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1):
+    lib = _abi.load()
+    dw = torch.zeros(n_out, c_in, k_w, dtype=torch.float32, device=x.device)
+    rg = rb.struct(len_mul)
+    _abi.check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
+                                      pad, dw.data_ptr(), _stream()), "jatts_conv1d_wgrad")
+    return dw
+
+
+def col_sum(x, dim=None):
+    lib = _abi.load()
+    dim = dim or x.shape[1]
+    out = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_col_sum(_dev(x).data_ptr(), x.shape[1], x.shape[0], dim, out.data_ptr(), _stream()), "jatts_col_sum")
+    return out

@@ -244,10 +244,29 @@ def vits_forward(VITS):
     return out
 
 
+
+def fs2_losses():
+    """The reference's FastSpeech2 criterion (jatts/losses: MelLoss/L1Loss, DurationPredictorLoss, PitchLoss, EnergyLoss, as
+    trainers/fastspeech2.py:62-84 calls them) on the forward() golden -> tests/golden/fs2_losses_small.npz."""
+    import importlib
+    l1 = importlib.import_module("jatts.losses.l1l2_loss")
+    dl = importlib.import_module("jatts.losses.duration_predictor_loss")
+    vl = importlib.import_module("jatts.losses.variance_predictor_loss")
+    z = np.load(os.path.join(HERE, "fs2_forward_small.npz"))
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    np.savez(os.path.join(HERE, "fs2_losses_small.npz"),
+             mel_loss=np.float32(l1.MelLoss()(t("ref_after_outs"), t("ref_before_outs"), t("ref_ys"), ol)),
+             duration_loss=np.float32(dl.DurationPredictorLoss()(t("ref_d_outs"), t("durations"), il)),
+             pitch_loss=np.float32(vl.PitchLoss()(t("ref_p_outs"), t("pitch"), il)),
+             energy_loss=np.float32(vl.EnergyLoss()(t("ref_e_outs"), t("energy"), il)))
+
+
 def main():
     torch.set_num_threads(8)
     FastSpeech2 = G.import_reference()
     np.savez_compressed(os.path.join(HERE, "fs2_forward_small.npz"), **fs2_forward(FastSpeech2))
+    fs2_losses()
     VITS = G.import_reference_vits()
     from oracle.vits_oracle import vits_inference
     vz, vmodel = vits_full(VITS)

@@ -67,3 +67,34 @@ def test_gather_audio_world4_ragged_with_empty_ranks():
 def test_gather_audio_world4_many():
     counts = _run(4, [100 + 37 * i for i in range(11)], 3)
     assert sum(counts) == 11 and max(counts) == 3
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jatts_amd.training import allreduce_gradients
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 7, 300000, 64)]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    n = allreduce_gradients(params, bucket_bytes=1 << 20)     # 1 MiB buckets -> the 1.2 MB tensor gets its own collective
+    want = [(sum(range(1, world + 1)) / world) * (i + 1) for i in range(len(params))]
+    ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(params, want))
+    q.put((rank, ok, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_world2():
+    """what DistributedDataParallel does for the reference (tts_train.py:355-363): bucketed, averaged all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and all(n == 3 for _, _, n in res), res

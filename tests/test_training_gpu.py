@@ -1,0 +1,104 @@
+"""SURVEY §8 f.4, first slice: the FastSpeech2 criterion on forward()'s outputs (pinned on the reference's loss classes), the
+backward of the conv op (against torch autograd in fp64 on the CPU) and one optimiser step through it."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden_state, load_golden, maxdiff, relerr
+from jatts_amd.synthetic import FS2_SMALL
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fastspeech2_losses_match_reference(cuda, lib):
+    """forward() + criterion = `_train_step` up to gen_loss (trainers/fastspeech2.py:44-84), against the reference's own
+    MelLoss / DurationPredictorLoss / PitchLoss / EnergyLoss evaluated on the reference's forward() (fs2_losses_small.npz)."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import fastspeech2_losses
+    z, keys = load_golden("fs2_forward_small.npz")
+    ref = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "fs2_losses_small.npz"))
+    m = FastSpeech2(idim=20, **FS2_SMALL)
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    r = m(t("text"), il, t("feats"), ol, t("durations"), il, t("pitch"), il, t("energy"), il)
+    got = fastspeech2_losses(r, t("durations"), t("pitch"), t("energy"), il)
+    for k in ("mel_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(got[k]) - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, float(got[k]), float(ref[k]))
+    assert abs(float(got["loss"]) - sum(float(ref[k]) for k in ref.files)) <= 1e-3
+
+
+@pytest.mark.parametrize("c_in,n_out,k,dil,lens", [(64, 96, 3, 1, [70, 5, 33]), (80, 64, 5, 2, [40, 41]), (128, 128, 1, 1, [129]),
+                                                   (48, 20, 7, 3, [64, 30])])
+def test_conv1d_backward_matches_autograd(cuda, lib, c_in, n_out, k, dil, lens):
+    from jatts_amd import hip
+    from jatts_amd.training import Conv1dFunction
+    g = torch.Generator().manual_seed(c_in + n_out + k)
+    R = sum(lens)
+    x = torch.randn(R, c_in, generator=g)
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k)
+    b = torch.randn(n_out, generator=g) * 0.1
+    gy = torch.randn(R, n_out, generator=g)
+    pad = (k - 1) // 2 * dil
+    # reference: torch autograd in fp64, one utterance at a time (zero padding at utterance boundaries)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    outs, o = [], 0
+    for n in lens:
+        outs.append(F.conv1d(xr[o:o + n].t().unsqueeze(0), wr, br, padding=pad, dilation=dil)[0].t())
+        o += n
+    yr = torch.cat(outs)
+    yr.backward(gy.double())
+    xd, wd, bd = x.to(cuda).requires_grad_(), w.to(cuda).requires_grad_(), b.to(cuda).requires_grad_()
+    rb = hip.RaggedBatch(lens, cuda)
+    y = Conv1dFunction.apply(xd, wd, bd, rb, dil, pad)
+    y.backward(gy.to(cuda))
+    assert relerr(y.detach(), yr.detach()) <= 2e-5
+    assert relerr(xd.grad, xr.grad) <= 2e-5, relerr(xd.grad, xr.grad)
+    assert relerr(wd.grad, wr.grad) <= 2e-5, relerr(wd.grad, wr.grad)
+    assert relerr(bd.grad, br.grad) <= 2e-5
+
+
+def test_one_optimiser_step_through_the_hip_conv(cuda, lib):
+    """A two-layer ragged conv net trained for a few Adam steps on the HIP forward / backward: the loss goes down and the
+    parameters follow the same trajectory as the torch reference model to f32 accuracy."""
+    from jatts_amd import hip
+    from jatts_amd.training import RaggedConv1d
+    torch.manual_seed(0)
+    lens = [50, 23, 64]
+    rb = hip.RaggedBatch(lens, cuda)
+    x = torch.randn(sum(lens), 64, device=cuda)
+    tgt = torch.randn(sum(lens), 32, device=cuda)
+    l1, l2 = RaggedConv1d(64, 128, 3).to(cuda), RaggedConv1d(128, 32, 5, dilation=2).to(cuda)
+    r1, r2 = torch.nn.Conv1d(64, 128, 3, padding=1).to(cuda), torch.nn.Conv1d(128, 32, 5, padding=4, dilation=2).to(cuda)
+    for a, b in ((l1, r1), (l2, r2)):
+        b.weight.data.copy_(a.weight.data)
+        b.bias.data.copy_(a.bias.data)
+    opt = torch.optim.Adam(list(l1.parameters()) + list(l2.parameters()), lr=1e-2)
+    opr = torch.optim.Adam(list(r1.parameters()) + list(r2.parameters()), lr=1e-2)
+
+    def ref_forward():
+        outs, o = [], 0
+        for n in lens:
+            h = torch.relu(r1(x[o:o + n].t().unsqueeze(0)))
+            outs.append(r2(h)[0].t())
+            o += n
+        return torch.cat(outs)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        y = l2(rb, torch.relu(l1(rb, x)))
+        loss = ((y - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        opr.zero_grad()
+        lr_ = ((ref_forward() - tgt) ** 2).mean()
+        lr_.backward()
+        opr.step()
+        losses.append(float(loss.detach()))
+        assert abs(float(loss) - float(lr_)) <= 1e-4 * max(1.0, float(lr_))
+    assert losses[-1] < losses[0]
+    assert maxdiff(l1.weight.data, r1.weight.data) <= 2e-4 and maxdiff(l2.weight.data, r2.weight.data) <= 2e-4
