@@ -225,7 +225,7 @@ def main(argv=None):
                     if not ckpt:
                         raise RuntimeError("feat_list has 'spkemb' and the csv has no spkemb_path column: set spkemb_checkpoint (config) or "
                                            "JATTS_SPKEMB_CHECKPOINT to SpeechBrain's ECAPA embedding_model.ckpt")
-                    spk_extractor = SpkEmbExtractor(device, checkpoint=ckpt)
+                    spk_extractor = SpkEmbExtractor(device, checkpoint=ckpt, **config.get("spkemb_params", {}))   # ECAPA_TDNN kwargs
                 spk = torch.from_numpy(spk_extractor.forward_many([it["ref_wav_path"] for it in batch])).float().to(device)
             r = model.inference_batch(texts, spembs=spk, **kw)
         else:

@@ -162,3 +162,56 @@ def test_recipe_run_sh_stage4(cuda, lib, tmp_path):
     for i in range(3):
         with wave.open(str(out / "wav" / f"utt{i}.wav")) as w:
             assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
+
+
+@pytest.mark.gpu
+def test_stage4_cli_multispeaker_extracts_embeddings(cuda, lib, tmp_path):
+    """feat_list has `spkemb` and the csv carries ref_wav_path (the reference's layout, tts_decode.py:209-212): the CLI runs the
+    speaker-embedding front end on the GPU (jatts_amd.spkemb) and feeds mel-VITS with it."""
+    from jatts_amd.bin import tts_decode
+    from jatts_amd.models import VITS
+    from jatts_amd.spkemb import ECAPA_TDNN
+    from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state, synth_state_dict
+    d = tmp_path
+    tokens = ["<blank>", "<unk>"] + [f"p{i}" for i in range(17)] + ["<sos/eos>"]
+    (d / "tokens.txt").write_text("\n".join(tokens) + "\n")
+    g = torch.Generator().manual_seed(0)
+    refs = []
+    for i in range(2):                                   # two reference speakers, 0.6 s of 16 kHz audio each
+        p = d / f"spk{i}.wav"
+        y = (torch.randn(9600, generator=g) * 0.1).clamp(-1, 1)
+        with wave.open(str(p), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes((y * 32767).round().to(torch.int16).numpy().tobytes())
+        refs.append(str(p))
+    with open(d / "dev.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["sample_id", "phonemes", "ref_wav_path"])
+        w.writeheader()
+        for i, n in enumerate((7, 12, 9)):
+            w.writerow({"sample_id": f"utt{i}", "phonemes": " ".join(tokens[int(j)] for j in torch.randint(2, 19, (n,), generator=g)),
+                        "ref_wav_path": refs[i % 2]})
+    vcfg = dict(odim=80, adim=64, aheads=2, text_encoder_blocks=2, text_encoder_attention_heads=2, dlayers=2, dunits=128, flow_flows=2,
+                flow_layers=2, posterior_encoder_layers=2, duration_predictor_chans=64, spk_embed_dim=192)
+    m = VITS(idim=20, **vcfg)
+    torch.save({"model": synth_state_dict(m.state_dict(), 2)}, d / "checkpoint-1steps.pkl")
+    ecfg = dict(channels=[256, 256, 256, 256, 768], attention_channels=64, se_channels=64, lin_neurons=192, res2net_scale=4)
+    torch.save(synth_state_dict(ECAPA_TDNN(**ecfg).state_dict(), 5), d / "ecapa.ckpt")
+    vparams = dict(HIFIGAN_V1_24K, channels=512)
+    v = d / "hfg"
+    os.makedirs(v)
+    torch.save({"model": {"generator": synth_hifigan_state(vparams, 0)}}, v / "voc.pkl")
+    with open(v / "voc.yml", "w") as f:
+        yaml.safe_dump({"sampling_rate": 24000, "generator_type": "HiFiGANGenerator",
+                        "generator_params": {k: (list(x) if isinstance(x, tuple) else x) for k, x in vparams.items()}}, f)
+    np.savez(d / "stats.npz", mel_mean=np.zeros(80, np.float32), mel_scale=np.ones(80, np.float32))
+    np.savez(v / "vstats.npz", mean=np.zeros(80, np.float32), scale=np.ones(80, np.float32))
+    with open(d / "config.yml", "w") as f:
+        yaml.safe_dump({"model_type": "VITS", "model_params": dict(vcfg, idim=20), "out_feat_type": "mel", "feat_list": ["mel", "spkemb"],
+                        "spkemb_checkpoint": str(d / "ecapa.ckpt"), "spkemb_params": ecfg,
+                        "vocoder": {"checkpoint": str(v / "voc.pkl"), "config": str(v / "voc.yml"), "stats": str(v / "vstats.npz")}}, f)
+    tts_decode.main(["--csv", str(d / "dev.csv"), "--stats", str(d / "stats.npz"), "--token-list", str(d / "tokens.txt"),
+                     "--token-column", "phonemes", "--checkpoint", str(d / "checkpoint-1steps.pkl"), "--outdir", str(d / "out"),
+                     "--verbose", "0", "--batch-size", "2"])
+    for i in range(3):
+        with wave.open(str(d / "out" / "wav" / f"utt{i}.wav")) as w:
+            assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
