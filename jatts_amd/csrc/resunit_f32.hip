@@ -17,20 +17,33 @@ int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s) {
       case 256: return launch_resunit<float, 256, 32, 4, 1>(d, s);
     }
   }
+  // last template argument: residual kept in registers (x fetched once); variant 2 = the re-reading kernels, for A/B runs
+  if (variant == 2) {
+    switch (d.channels) {
+      case 32: return launch_resunit<float, 32, 512, 1, 4, 8, 2>(d, s);
+      case 64: return launch_resunit<float, 64, 256, 1, 2, 8, 2>(d, s);
+      case 128:
+        if ((128 + halo) * 528 + 1024 <= 80 * 1024) return launch_resunit<float, 128, 128, 2, 2, 8, 2>(d, s);
+        return launch_resunit<float, 128, 256, 2, 2, 8, 2>(d, s);
+    }
+  }
   switch (d.channels) {
     case 32:
       if (variant == 1) return launch_resunit<float, 32, 256, 1, 2, 8, 2>(d, s);
-      return launch_resunit<float, 32, 512, 1, 4, 8, 2>(d, s);
+      return launch_resunit<float, 32, 512, 1, 4, 8, 2, true>(d, s);
     case 64:
       if (variant == 1) return launch_resunit<float, 64, 512, 1, 4, 8, 1>(d, s);
-      return launch_resunit<float, 64, 256, 1, 2, 8, 2>(d, s);
+      return launch_resunit<float, 64, 256, 1, 2, 8, 2, true>(d, s);
     case 128:
       // 128 columns (4 waves): two workgroups per CU while (128 + halo) x 528 B fits twice in 160 KiB
-      if (variant != 1 && (128 + halo) * 528 + 1024 <= 80 * 1024) return launch_resunit<float, 128, 128, 2, 2, 8, 2>(d, s);
+      // (register-resident residual: neutral up to k = 7 on the 128-column tile, 3-5 % slower at k = 11 and on the 512-thread tile:
+      //  those keep the re-read -- profiles/r02_notes.md)
+      if (variant != 1 && (128 + halo) * 528 + 1024 <= 80 * 1024)
+        return d.k_w <= 7 ? launch_resunit<float, 128, 128, 2, 2, 8, 2, true>(d, s) : launch_resunit<float, 128, 128, 2, 2, 8, 2>(d, s);
       return launch_resunit<float, 128, 256, 2, 2, 8, 2>(d, s);   // 8 waves, one workgroup per CU
-    case 256:
+    case 256:   // 416 / 344 registers already: no room for 128 / 96 more
       if ((128 + halo) * 1040 + 2048 <= 160 * 1024) return launch_resunit<float, 256, 128, 4, 4, 8, 1>(d, s);
-      return launch_resunit<float, 256, 96, 4, 3, 8, 1>(d, s);
+      return launch_resunit<float, 256, 96, 4, 3, 8, 1, true>(d, s);
   }
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels/dtype (use jatts_conv1d)");
 }

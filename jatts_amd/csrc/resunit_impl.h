@@ -113,7 +113,10 @@ __device__ __forceinline__ void stage_unit(char* lds, int pitch, int rows, int u
 
 // ------------------------------------------------------------ fused HiFi-GAN dilation unit
 // OCC = minimum waves per SIMD the register allocation must leave room for (0: 2 when the accumulators fit 128 registers)
-template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8, int OCC = 0>
+// RREG: the residual x of this lane's output elements is read from the RAW x tile into registers before the tile is activated in place,
+// so x is fetched from HBM once (PMC: the f32 C=128 unit moved 5.98 GB per launch against 3.22 GB algorithmic, 1.61 GB of it the
+// residual re-read of the store pass).  f32 tiles only: 16 more registers per accumulator fragment.
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8, int OCC = 0, bool RREG = false>
 __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 256 && (C / (WN * 32)) * NT * 16 <= 128) ? 2 : 1)) void resunit_kernel(jatts_resunit_desc d, unsigned long long* trace, unsigned trace_cap, unsigned bias_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
@@ -173,9 +176,30 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
   {
     constexpr int NTHR = WN * WT * 64;
     constexpr int UBX = ((WGCOLS + 64) * (C / 8) + NTHR - 1) / NTHR;   // covers halos up to 32 rows a side in one batch
-    stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24)), NTHR>(xs, pitch, rx, C / 8, t0 - p2 - p1, L, seq_row0, xin[0], C, JATTS_ABLATE != 1, d.slope);
+    stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24)), NTHR>(xs, pitch, rx, C / 8, t0 - p2 - p1, L, seq_row0, xin[0], C, JATTS_ABLATE != 1 && !RREG, d.slope);
   }
   __syncthreads();
+  f32x4 resid[RREG ? NF : 1][RREG ? NT : 1][4];   // x at (output column, channel quad) of this lane: C-fragment layout
+  if constexpr (RREG) {
+    static_assert(sizeof(T) == 4, "register-resident residual: f32 tiles");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = col0 + t * 32 + (lane & 31);   // output column col <-> x tile row col + p2 + p1
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          resid[f][t][q] = *reinterpret_cast<const f32x4*>(xs + (size_t)(col + p2 + p1) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T));
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < rx * (C / 8); u += blockDim.x) {   // tile <- lrelu(tile), in place
+      char* p = xs + (size_t)(u / (C / 8)) * pitch + (size_t)(u % (C / 8)) * 8 * sizeof(T);
+      typename Elem<T>::vec8 v = Vec8IO<T>::lds(p);
+      lrelu8(v, d.slope);
+      Vec8IO<T>::sts(p, v);
+    }
+    __syncthreads();
+  }
   JATTS_STAMP(2);
 
   // the accumulators start at the bias (C layout: register 4q+e of fragment f <-> channel 32(nf0+f) + 8q + 4g + e), which
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e];
+          if constexpr (RREG) o += resid[f][t][q];
           *reinterpret_cast<f32x4*>(p) = o;
         }
       }
@@ -288,15 +313,15 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
     const int vrows = min(tt_out, L - t0);
     const int64_t g0 = (seq_row0 + t0) * (int64_t)C;  // the valid rows are contiguous in y: unit u <-> 8 elements at g0 + 8u
     constexpr bool keep_small = C <= 64;   // small-channel kernels live on occupancy (6 workgroups/CU): keep the batch short
-    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true, WN * WT * 64>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
-    else unit_store_pass<T, C, keep_small ? 4 : 8, false, WN * WT * 64>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
+    if (d.add0) unit_store_pass<T, C, keep_small ? 2 : 4, true, WN * WT * 64, !RREG>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);   // + fused MRF mean
+    else unit_store_pass<T, C, keep_small ? 4 : 8, false, WN * WT * 64, !RREG>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
   }
   JATTS_STAMP(7);
   if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();
 #undef JATTS_STAMP
 }
 
-template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8, int OCC = 0>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8, int OCC = 0, bool RREG = false>
 int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   constexpr int WT = WGCOLS / (NT * 32);
   const int K = d.k_w, p2 = (K - 1) / 2, p1 = p2 * d.dil;
@@ -312,7 +337,7 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   if (pad_lds && lds < (size_t)pad_lds) lds = pad_lds;  // experiment knob: force fewer workgroups per CU
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
-  auto kern = resunit_kernel<T, C, WGCOLS, WN, NT, KCGMAX, OCC>;
+  auto kern = resunit_kernel<T, C, WGCOLS, WN, NT, KCGMAX, OCC, RREG>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
