@@ -135,7 +135,9 @@ def pmc_passes(argv_tail, timeout_s=240):
                     agg.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
             for k, v in agg.items():
                 per.setdefault(k, {})[counter] = sum(v) / len(v) * 1024.0
-        res = {k: dict(fetch_bytes=2.0 * v.get("FETCH_SIZE", 0.0), write_bytes=v.get("WRITE_SIZE", 0.0)) for k, v in per.items()}
+                per[k]["launches"] = len(v)
+        res = {k: dict(fetch_bytes=2.0 * v.get("FETCH_SIZE", 0.0), write_bytes=v.get("WRITE_SIZE", 0.0), launches=v.get("launches", 1))
+               for k, v in per.items()}
         for v in res.values():
             v["hbm_bytes"] = v["fetch_bytes"] + v["write_bytes"]
         return res, "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of this run; FETCH_SIZE x2 gfx950 correction)"
@@ -161,7 +163,8 @@ def lookup_traffic(table, esz, c):
     hits = [v for k, v in table.items() if key in k or alt in k]
     if not hits:
         return None
-    return sum(h["hbm_bytes"] for h in hits) / len(hits)   # tile variants of one family: mean over variants
+    n = sum(h.get("launches", 1) for h in hits)             # tile variants of one family: launch-weighted mean
+    return sum(h["hbm_bytes"] * h.get("launches", 1) for h in hits) / n
 
 
 # ------------------------------------------------------------------------------------------- workloads

@@ -35,10 +35,10 @@ class TokenIDConverter:
         self.token2id = {}
         for i, t in enumerate(self.token_list):
             if t in self.token2id:
-                raise RuntimeError(f'Symbol "{t}" is duplicated')
+                raise RuntimeError(f"token list {token_list}: line {i + 1} repeats the symbol {t!r}")
             self.token2id[t] = i
         if unk_symbol not in self.token2id:
-            raise RuntimeError(f"Unknown symbol '{unk_symbol}' doesn't exist in the token_list")
+            raise RuntimeError(f"token list {token_list} has no {unk_symbol!r} entry to map out-of-vocabulary tokens to")
         self.unk_id = self.token2id[unk_symbol]
 
     def tokens2ids(self, tokens):

@@ -285,7 +285,17 @@ class FastSpeech2(torch.nn.Module):
     ) -> Dict[str, torch.Tensor]:
         """Same contract as jatts.models.FastSpeech2.inference (fastspeech2.py:655-735)."""
         if use_teacher_forcing:
-            raise NotImplementedError("use_teacher_forcing is a training-time path (outside stage 4)")
+            # ground-truth duration / pitch / energy (fastspeech2.py:704-717): _forward(is_inference=False) on a batch of one
+            if durations is None or pitch is None or energy is None:
+                raise ValueError("use_teacher_forcing needs durations, pitch and energy")
+            T = int(text.numel())
+            n = torch.tensor([T])
+            To = int(durations.sum())
+            ys = torch.zeros(1, To, self.odim) if feats is None else feats.unsqueeze(0)
+            r = self.forward(text.view(1, T), n, ys, torch.tensor([To]), durations.view(1, T), n, pitch.view(1, T, 1), n,
+                             energy.view(1, T, 1), n, spembs=None if spembs is None else spembs.unsqueeze(0), sids=sids)
+            outs = r["after_outs"] if r["after_outs"] is not None else r["before_outs"]
+            return dict(feat_gen=outs[0], duration=r["d_outs"][0], pitch=r["p_outs"][0], energy=r["e_outs"][0])
         r = self.inference_batch([text], spembs=None if spembs is None else spembs.unsqueeze(0),
                                  sids=sids, alpha=alpha)
         return dict(feat_gen=r["feat_gen"], duration=r["duration"], pitch=r["pitch"].unsqueeze(-1),

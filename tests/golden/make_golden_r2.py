@@ -245,6 +245,22 @@ def vits_forward(VITS):
 
 
 
+def fs2_teacher_forcing(FastSpeech2):
+    """FastSpeech2.inference(use_teacher_forcing=True, durations, pitch, energy) (fastspeech2.py:704-717)."""
+    model = FastSpeech2(idim=20, **FS2_SMALL).eval()
+    ref_sd = model.state_dict()
+    model.load_state_dict(synth_state_dict(ref_sd, 0))
+    g = torch.Generator().manual_seed(71)
+    T = 19
+    text = torch.randint(1, 20, (T,), generator=g)
+    d = torch.randint(0, 5, (T,), generator=g)
+    p, e = torch.randn(T, 1, generator=g), torch.randn(T, 1, generator=g)
+    with torch.no_grad():
+        r = model.inference(text, durations=d, pitch=p, energy=e, use_teacher_forcing=True)
+    np.savez_compressed(os.path.join(HERE, "fs2_teacher_forcing_small.npz"), keys=json.dumps([[k, list(v.shape)] for k, v in ref_sd.items()]),
+                        text=np_(text), durations=np_(d), pitch=np_(p), energy=np_(e), **{"ref_" + k: np_(v) for k, v in r.items()})
+
+
 def fs2_losses():
     """The reference's FastSpeech2 criterion (jatts/losses: MelLoss/L1Loss, DurationPredictorLoss, PitchLoss, EnergyLoss, as
     trainers/fastspeech2.py:62-84 calls them) on the forward() golden -> tests/golden/fs2_losses_small.npz."""
@@ -267,6 +283,7 @@ def main():
     FastSpeech2 = G.import_reference()
     np.savez_compressed(os.path.join(HERE, "fs2_forward_small.npz"), **fs2_forward(FastSpeech2))
     fs2_losses()
+    fs2_teacher_forcing(FastSpeech2)
     VITS = G.import_reference_vits()
     from oracle.vits_oracle import vits_inference
     vz, vmodel = vits_full(VITS)

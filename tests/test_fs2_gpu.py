@@ -158,3 +158,16 @@ def test_fs2_forward_matches_reference_golden(cuda, lib, prec):
         for b, n in enumerate(ol.tolist()):                   # valid frames: tight; padded frames: the same leakage arithmetic
             assert maxdiff(r[k][b, :n], z["ref_" + k][b, :n]) <= tol, (k, b, maxdiff(r[k][b, :n], z["ref_" + k][b, :n]))
         assert maxdiff(r[k], z["ref_" + k]) <= 5 * tol, (k, maxdiff(r[k], z["ref_" + k]))
+
+
+def test_fs2_inference_teacher_forcing_matches_reference(cuda, lib):
+    """inference(use_teacher_forcing=True, durations, pitch, energy): ground-truth variance inputs, predictions still returned
+    (log-domain durations), captured from the reference (fs2_teacher_forcing_small.npz)."""
+    z, keys = load_golden("fs2_teacher_forcing_small.npz")
+    m = _model(FS2_SMALL, 20, keys, 0, cuda, "fp32")
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    r = m.inference(t("text").to(cuda), durations=t("durations"), pitch=t("pitch"), energy=t("energy"), use_teacher_forcing=True)
+    assert set(r) == {"feat_gen", "duration", "pitch", "energy"}
+    for k in r:
+        assert r[k].shape == z["ref_" + k].shape, k
+        assert maxdiff(r[k], z["ref_" + k]) <= ABS["fp32"], (k, maxdiff(r[k], z["ref_" + k]))
