@@ -87,6 +87,40 @@ class AlignmentModule(torch.nn.Module):
         return out
 
 
+def pack_alignment_convs(sd, device, prefix="alignment_module."):
+    """The five convolutions of AlignmentModule (alignments.py:19-25) out of a model state_dict, packed for jatts_conv1d (f32)."""
+    return {n: PackedConv(sd[f"{prefix}{n}.weight"], sd[f"{prefix}{n}.bias"], hip.F32, device)
+            for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
+
+
+@torch.no_grad()
+def padded_alignment(convs, hs, ys, ilens, olens, adim):
+    """AlignmentModule.forward + viterbi_decode on a PADDED batch, as the models' forward() passes call them (alignments.py:26-60,
+    281-310): hs f32 (B*Tm, adim) padded text encodings, ys f32 (B, To, odim) padded features.  The module's k=3 convolutions
+    read across the padding (as in the reference), the softmax runs over each utterance's valid tokens (x_masks -> -inf), every
+    frame row is scored.  -> (log_p_attn (B, To, Tm) with -inf at padded tokens, ds (B, Tm) float, bin_loss)."""
+    dev = hs.device
+    B, To, od = ys.shape
+    Tm = hs.shape[0] // B
+
+    def conv(rb, x, n, relu):
+        pc = convs[n]
+        if x.shape[1] != pc.c_in:
+            x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
+        return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b, act=hip.ACT_RELU if relu else hip.ACT_NONE)
+    rbt, rbf = hip.RaggedBatch([Tm] * B, dev), hip.RaggedBatch([To] * B, dev)
+    tf = conv(rbt, conv(rbt, hs, "t_conv1", True), "t_conv2", False)
+    ff = conv(rbf, conv(rbf, conv(rbf, ys.reshape(B * To, od).contiguous(), "f_conv1", True), "f_conv2", True), "f_conv3", False)
+    rbv = hip.RaggedBatch(ilens, dev)                              # valid tokens, packed (row selection: plumbing)
+    sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
+    lp3 = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, sel).contiguous(), adim).view(B, To, -1)
+    log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
+    for b in range(B):
+        log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
+    ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
+    return log_p_attn, ds, bin_loss
+
+
 @torch.no_grad()
 def viterbi_decode(log_p_attn, text_lengths, feats_lengths, k=None):
     """Reference signature (alignments.py:281): (B, T_feats, T_text) log-probabilities -> (ds (B, T_text) float, bin_loss)."""

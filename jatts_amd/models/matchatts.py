@@ -378,6 +378,8 @@ class _MatchaBase(torch.nn.Module):
             pj = P["proj"]
             sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
             hip.add_seq_vector(rb, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
+        if taps is not None:
+            taps["hs"] = hs.clone()                                 # text encoding (+ speaker): what the alignment module scores
         logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
                                           want_duration=True)
         d_used = d_pred
@@ -423,14 +425,23 @@ class _MatchaBase(torch.nn.Module):
     def inference(self, text, feats=None, durations=None, spembs=None, sids=None, lids=None, n_timesteps: int = 10,
                   temperature: float = 0.667, use_teacher_forcing: bool = False, noise=None):
         """Same contract as jatts.models.MatchaTTS_MAS.inference (matchatts_mas.py:552-642) for feats=None."""
-        if feats is not None or use_teacher_forcing:
-            raise NotImplementedError("alignment / teacher-forcing branches are training-time paths")
+        if use_teacher_forcing:
+            raise NotImplementedError("use_teacher_forcing is broken in the reference itself (matchatts_mas.py:597-612 reads undefined p, e)")
+        taps = {} if feats is not None else None
         r = self.inference_batch([text], n_timesteps=n_timesteps, temperature=temperature,
                                  spembs=None if spembs is None else spembs.unsqueeze(0), sids=sids,
-                                 noise=None if noise is None else [noise])
+                                 noise=None if noise is None else [noise], taps=taps)
         out = dict(feat_gen=r["feat_gen"], duration=r["duration"])
         if self._MAS:
             out.update(log_p_attn=None, ds=None)
+            if feats is not None:   # alignment of the given features against the text encoding (matchatts_mas.py:449-455); B = 1: no padding
+                from ..alignments import pack_alignment_convs, padded_alignment
+                P = self._prepare()
+                if "align" not in P:
+                    P["align"] = pack_alignment_convs(self.state_dict(), P["dev"])
+                lp, ds, _ = padded_alignment(P["align"], taps["hs"], feats.to(P["dev"]).float().unsqueeze(0).contiguous(),
+                                             [int(text.numel())], [int(feats.shape[0])], self.adim)
+                out.update(log_p_attn=lp[0], ds=ds[0])
         return out
 
     @torch.no_grad()
@@ -464,31 +475,13 @@ class _MatchaBase(torch.nn.Module):
         olens_in = [n - n % 2 for n in olens]
         Te = max(olens_in)
         if self._MAS:
-            # ---- alignment module on the PADDED batch (its k=3 convolutions read across the padding, alignments.py:39-49), softmax
-            #      over the valid tokens (x_masks -> -inf), then the batched monotonic alignment search
-            al = P.get("align")
-            if al is None:
-                sd = self.state_dict()
-                al = P["align"] = {n: PackedConv(sd[f"alignment_module.{n}.weight"], sd[f"alignment_module.{n}.bias"], hip.F32, dev)
-                                   for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
-
-            def aconv(rb, x, n, relu):
-                pc = al[n]
-                if x.shape[1] != pc.c_in:
-                    x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
-                return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b, act=ACT_RELU if relu else hip.ACT_NONE)
-            rbf = hip.RaggedBatch([To] * B, dev)
-            tf = aconv(rbt, aconv(rbt, hs, "t_conv1", True), "t_conv2", False)
-            ff = aconv(rbf, aconv(rbf, aconv(rbf, ys.reshape(B * To, od), "f_conv1", True), "f_conv2", True), "f_conv3", False)
+            # ---- alignment module on the PADDED batch + batched monotonic alignment search (jatts_amd.alignments.padded_alignment)
+            from ..alignments import pack_alignment_convs, padded_alignment
+            if "align" not in P:
+                P["align"] = pack_alignment_convs(self.state_dict(), dev)
+            log_p_attn, ds, bin_loss = padded_alignment(P["align"], hs, ys, ilens, olens, A)
             rbv = hip.RaggedBatch(ilens, dev)                          # valid tokens, packed (row selection: plumbing)
             sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
-            lp = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, sel).contiguous(), A)      # (B*To, ld): every frame, padded or not
-            log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
-            lp3 = lp.view(B, To, -1)
-            for b in range(B):
-                log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
-            from ..alignments import viterbi_decode
-            ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
             # ---- duration predictor (log domain, masked) and masked Gaussian upsampling
             d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
             d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()

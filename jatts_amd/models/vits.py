@@ -197,6 +197,31 @@ class VITS(torch.nn.Module):
                        out_f32=True)
         return skips
 
+    def _post(self, P):
+        """Posterior encoder + alignment convolutions: prepared on first use (training-time forward(), inference(feats=...))."""
+        post = P.get("post")
+        if post is None:
+            dt, dev, sd = P["dtype"], P["dev"], self.state_dict()
+            from ..alignments import pack_alignment_convs
+            n_layers = sum(1 for k in sd if k.startswith("posterior_encoder.encoder.") and k.endswith("conv.bias"))
+            post = P["post"] = dict(
+                inp=PackedConv(sd["posterior_encoder.input_conv.weight"], sd["posterior_encoder.input_conv.bias"], dt, dev),
+                layers=self._wn_layers(sd, "posterior_encoder.encoder.", n_layers, dt, dev),
+                proj=PackedConv(sd["posterior_encoder.proj.weight"], sd["posterior_encoder.proj.bias"], dt, dev))
+            P["align"] = pack_alignment_convs(sd, dev)
+        return post
+
+    def _posterior(self, P, rbo, rbs, yv, sp_t, noise_rows):
+        """PosteriorEncoder.forward on ragged valid frames (posterior_encoder.py:96-130): -> (z, stats_q = m_q | logs_q)."""
+        dt, A, post = P["dtype"], self.adim, self._post(P)
+        q = post["inp"]
+        h = hip.conv1d(rbo, hip.affine_cast(yv, dt, ldy=q.c_in), q.w, q.c_in, A, 1, dtype=dt, bias=q.b, out_f32=True)
+        sk = self._wavenet(P, rbo, rbs, h, post["layers"], sp_t)
+        scale_q = torch.full((A,), math.sqrt(1.0 / len(post["layers"])), device=P["dev"])
+        pp = post["proj"]
+        stats_q = hip.conv1d(rbo, hip.affine_cast(sk, dt, scale=scale_q), pp.w, pp.c_in, 2 * A, 1, dtype=dt, bias=pp.b, out_f32=True)
+        return hip.gaussian_sample(stats_q, noise_rows, 1.0), stats_q                    # z = m_q + eps * exp(logs_q)
+
     def _wn_layers(self, sd, prefix, n_layers, dt, dev):
         A, layers = self.adim, []
         for l in range(n_layers):
@@ -234,6 +259,8 @@ class VITS(torch.nn.Module):
         vec = hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b,
                          out_f32=True)
         hip.add_seq_vector(rb, hs, vec)
+        if taps is not None:
+            taps["hs"] = hs.clone()                                        # text encoding + speaker: what the alignment module scores
         logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
                                           want_duration=True)
         d_used = d_pred
@@ -275,15 +302,36 @@ class VITS(torch.nn.Module):
         return dict(feat_gen=out, olens=olens, feats_rb=rbo, text_rb=rb, duration=d_pred, log_duration=logd)
 
     def inference(self, text, feats=None, durations=None, spembs=None, sids=None, lids=None, n_timesteps=None,
-                  temperature=None, noise_scale: float = 0.667, use_teacher_forcing: bool = False, noise=None):
+                  temperature=None, noise_scale: float = 0.667, use_teacher_forcing: bool = False, noise=None, post_noise=None):
         """Same contract as jatts.models.VITS.inference (vits.py:581-679) for feats=None."""
-        if feats is not None or use_teacher_forcing:
-            raise NotImplementedError("alignment / reconstruction branches (feats given) are training-time paths")
+        if use_teacher_forcing:
+            raise NotImplementedError("use_teacher_forcing is broken in the reference itself (vits.py:620-636 reads undefined p, e)")
         if spembs is None:
             raise ValueError("spembs is required (the reference crashes without it, vits.py:485)")
+        taps = {} if feats is not None else None
         r = self.inference_batch([text], spembs.unsqueeze(0), noise=None if noise is None else [noise],
-                                 noise_scale=noise_scale)
-        return dict(feat_gen=r["feat_gen"], duration=r["duration"], log_p_attn=None, ds=None)
+                                 noise_scale=noise_scale, taps=taps)
+        out = dict(feat_gen=r["feat_gen"], duration=r["duration"], log_p_attn=None, ds=None)
+        if feats is not None:
+            # the given features aligned against the text encoding (vits.py:449-455) and reconstructed through posterior encoder +
+            # decoder (`outs_bar`, :546-556); B = 1: no padding.  post_noise: the posterior encoder's randn_like draw.
+            from ..alignments import padded_alignment
+            P = self._prepare()
+            dt, dev, A = P["dtype"], P["dev"], self.adim
+            self._post(P)
+            ys = feats.to(dev).float().unsqueeze(0).contiguous()
+            Tf = int(ys.shape[1])
+            lp, ds, _ = padded_alignment(P["align"], taps["hs"], ys, [int(text.numel())], [Tf], A)
+            rbo, rbs = hip.RaggedBatch([Tf], dev), hip.RaggedBatch([1], dev)
+            sp = spembs.to(dev).float().reshape(1, -1).contiguous()
+            sp_t = hip.affine_cast(sp, dt, ldy=P["flows"][0]["layers"][0]["glo"].c_in)
+            nz = (torch.randn(Tf, A) if post_noise is None else post_noise.float()).to(dev).contiguous()
+            z_bar, _ = self._posterior(P, rbo, rbs, ys[0], sp_t, nz)
+            zs = P["dec"].run(rbo, hip.affine_cast(z_bar, hip.F32, scale=P["sqrtA"]), final_dtype=dt)
+            fo = P["feat_out"]
+            out.update(log_p_attn=lp[0], ds=ds[0],
+                       outs_bar=hip.conv1d(rbo, zs, fo.w, fo.c_in, fo.n_out, 1, dtype=dt, bias=fo.b, out_f32=True))
+        return out
 
     @torch.no_grad()
     def forward(self, text, text_lengths, feats, feats_lengths, durations=None, durations_lengths=None, spembs=None, sids=None,
@@ -316,28 +364,13 @@ class VITS(torch.nn.Module):
         hip.add_seq_vector(rbt, hs, hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt,
                                                bias=pj.b, out_f32=True))
         # ---- posterior encoder + forward flow on the valid frames (ragged)
-        post = P.get("post")
-        if post is None:
-            sd = self.state_dict()
-            post = P["post"] = dict(
-                inp=PackedConv(sd["posterior_encoder.input_conv.weight"], sd["posterior_encoder.input_conv.bias"], dt, dev),
-                layers=self._wn_layers(sd, "posterior_encoder.encoder.", sum(1 for k in sd if k.startswith("posterior_encoder.encoder.")
-                                                                             and k.endswith("conv.bias")), dt, dev),
-                proj=PackedConv(sd["posterior_encoder.proj.weight"], sd["posterior_encoder.proj.bias"], dt, dev))
-            P["align"] = {n: PackedConv(sd[f"alignment_module.{n}.weight"], sd[f"alignment_module.{n}.bias"], hip.F32, dev)
-                          for n in ("t_conv1", "t_conv2", "f_conv1", "f_conv2", "f_conv3")}
+        self._post(P)
         rbo = hip.RaggedBatch(olens, dev)
         fsel = torch.cat([torch.arange(b * To, b * To + olens[b], device=dev) for b in range(B)])     # valid frame rows (plumbing)
         yv = ys.reshape(B * To, od).index_select(0, fsel).contiguous()
         sp_t = hip.affine_cast(spembs, dt, ldy=P["flows"][0]["layers"][0]["glo"].c_in)               # g = spembs, unnormalised
-        pi = post["inp"]
-        h = hip.conv1d(rbo, hip.affine_cast(yv, dt, ldy=pi.c_in), pi.w, pi.c_in, A, 1, dtype=dt, bias=pi.b, out_f32=True)
-        sk = self._wavenet(P, rbo, rbs, h, post["layers"], sp_t)
-        scale_q = torch.full((A,), math.sqrt(1.0 / len(post["layers"])), device=dev)
-        pp = post["proj"]
-        stats_q = hip.conv1d(rbo, hip.affine_cast(sk, dt, scale=scale_q), pp.w, pp.c_in, 2 * A, 1, dtype=dt, bias=pp.b, out_f32=True)
         nz = (torch.randn(B, To, A) if post_noise is None else post_noise[:, :To].float()).to(dev).reshape(B * To, A)
-        z = hip.gaussian_sample(stats_q, nz.index_select(0, fsel).contiguous(), 1.0)                 # m_q + eps * exp(logs_q)
+        z, stats_q = self._posterior(P, rbo, rbs, yv, sp_t, nz.index_select(0, fsel).contiguous())
         half = A // 2
         zp = z.clone()
         skip_scale = P.setdefault("skip_scale", torch.full((A,), math.sqrt(1.0 / self.flow_layers), device=dev))
@@ -349,26 +382,11 @@ class VITS(torch.nn.Module):
             hip.conv1d(rbo, hip.affine_cast(sk, dt, scale=skip_scale), pr.w, pr.c_in, half, 1, dtype=dt, bias=pr.b, alpha=1.0,
                        resid=zp, resid_col0=half, out=zp, out_ld=A, out_col0=half, out_f32=True)
             zp = hip.flip_channels(zp)
-        # ---- alignment module on the padded batch + monotonic alignment search (as MatchaTTS_MAS.forward)
-        al = P["align"]
-
-        def aconv(rb, x, n, relu):
-            pc = al[n]
-            if x.shape[1] != pc.c_in:
-                x = hip.affine_cast(x, hip.F32, ldy=pc.c_in)
-            return hip.conv1d(rb, x, pc.w, pc.c_in, pc.n_out, pc.k, dtype=hip.F32, bias=pc.b,
-                              act=hip.ACT_RELU if relu else hip.ACT_NONE)
-        rbf = hip.RaggedBatch([To] * B, dev)
-        tf = aconv(rbt, aconv(rbt, hs, "t_conv1", True), "t_conv2", False)
-        ff = aconv(rbf, aconv(rbf, aconv(rbf, ys.reshape(B * To, od), "f_conv1", True), "f_conv2", True), "f_conv3", False)
-        rbv = hip.RaggedBatch(ilens, dev)
+        # ---- alignment module on the padded batch + monotonic alignment search (jatts_amd.alignments.padded_alignment)
+        from ..alignments import padded_alignment
+        log_p_attn, ds, bin_loss = padded_alignment(P["align"], hs, ys, ilens, olens, A)
+        rbf, rbv = hip.RaggedBatch([To] * B, dev), hip.RaggedBatch(ilens, dev)
         tsel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
-        lp3 = hip.alignment_logp(rbf, rbv, ff, tf.index_select(0, tsel).contiguous(), A).view(B, To, -1)
-        log_p_attn = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
-        for b in range(B):
-            log_p_attn[b, :, : ilens[b]] = lp3[b, :, : ilens[b]]
-        from ..alignments import viterbi_decode
-        ds, bin_loss = viterbi_decode(log_p_attn, ilens, olens)
         d_outs = hip.zero_pad_rows(rbt, hip.predictor_head(P["dur"].trunk(rbt, hs), P["dur"].w, P["dur"].b), kv).view(B, Tm)
         # ---- prior statistics upsampled with the MAS durations (padded frames take the value of frame 0, length_regulator.py:139-141)
         d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()

@@ -245,6 +245,57 @@ def vits_forward(VITS):
 
 
 
+def with_noises(seed, fn):
+    """Like with_noise, for several randn_like draws: draw i is seeded seed + i; returns (result, [draws])."""
+    draws = []
+    real = torch.randn_like
+
+    def fake(t, *a, **k):
+        draws.append(torch.randn(t.shape, generator=torch.Generator().manual_seed(seed + len(draws))))
+        return draws[-1]
+
+    torch.randn_like = fake
+    try:
+        with torch.no_grad():
+            r = fn()
+    finally:
+        torch.randn_like = real
+    return r, draws
+
+
+def inference_with_feats(Matcha, VITS):
+    """inference(text, feats=...): the alignment branch of MatchaTTS_MAS (log_p_attn, ds) and VITS (+ outs_bar, the posterior
+    reconstruction) -- matchatts_mas.py:449-455, vits.py:449-455,546-556 -> infer_feats_small.npz."""
+    g = torch.Generator().manual_seed(81)
+    out = {}
+    install_additive_mask_attention()
+    m = Matcha(idim=20, **G.MATCHA_SMALL).eval()
+    sd = m.state_dict()
+    out["matcha_keys"] = json.dumps([[k, list(v.shape)] for k, v in sd.items()])
+    out["matcha_config"] = json.dumps(G.MATCHA_SMALL)
+    m.load_state_dict(matcha_golden_tweaks(synth_state_dict(sd, 3)))
+    text = torch.randint(1, 20, (13,), generator=g)
+    feats = torch.randn(47, 80, generator=g)
+    r, z = with_noise(970, lambda: m.inference(text, feats=feats, n_timesteps=4, temperature=0.667))
+    out.update(m_text=np_(text), m_feats=np_(feats), m_noise=np_(z[0].t()), m_feat_gen=np_(r["feat_gen"]), m_duration=np_(r["duration"]),
+               m_log_p_attn=np_(r["log_p_attn"]), m_ds=np_(r["ds"]))
+    v = VITS(idim=20, **G.VITS_SMALL).eval()
+    sd = v.state_dict()
+    out["vits_keys"] = json.dumps([[k, list(x.shape)] for k, x in sd.items()])
+    out["vits_config"] = json.dumps(G.VITS_SMALL)
+    v.load_state_dict(synth_state_dict(sd, 2))
+    text = torch.randint(1, 20, (11,), generator=g)
+    feats = torch.randn(39, 80, generator=g)
+    spemb = torch.randn(16, generator=g)
+    r, draws = with_noises(980, lambda: v.inference(text, feats=feats, spembs=spemb))
+    assert len(draws) == 2                                    # prior sampling, then the posterior encoder of the reconstruction
+    out.update(v_text=np_(text), v_feats=np_(feats), v_spemb=np_(spemb), v_noise=np_(draws[0][0].t()), v_post_noise=np_(draws[1][0].t()),
+               v_feat_gen=np_(r["feat_gen"]), v_duration=np_(r["duration"]), v_log_p_attn=np_(r["log_p_attn"]), v_ds=np_(r["ds"]),
+               v_outs_bar=np_(r["outs_bar"]))
+    print("infer_feats:", {k: tuple(out[k].shape) for k in ("m_log_p_attn", "m_ds", "v_log_p_attn", "v_outs_bar", "v_feat_gen")})
+    return out
+
+
 def fs2_teacher_forcing(FastSpeech2):
     """FastSpeech2.inference(use_teacher_forcing=True, durations, pitch, energy) (fastspeech2.py:704-717)."""
     model = FastSpeech2(idim=20, **FS2_SMALL).eval()
@@ -307,6 +358,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "matcha_forward_small.npz"), **matcha_forward(Matcha))
     np.savez_compressed(os.path.join(HERE, "vits_forward_small.npz"), **vits_forward(VITS))
     np.savez_compressed(os.path.join(HERE, "matcha_tts1_forward_small.npz"), **matcha_tts1_forward())
+    np.savez_compressed(os.path.join(HERE, "infer_feats_small.npz"), **inference_with_feats(Matcha, VITS))
     for f in ("matcha_forward_small.npz", "vits_forward_small.npz", "matcha_tts1_forward_small.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
     for f in ("fs2_forward_small.npz", "vits_jsut.npz", "matcha_jsut.npz", "matcha_tts1_small.npz"):

@@ -157,3 +157,25 @@ def test_matcha_tts1_forward_matches_reference_golden(cuda, lib, prec):
     assert maxdiff(r["hs"], z["ref_hs"]) <= (3e-3 if prec == "fp32" else 5e-2)
     rel = abs(float(r["cfm_loss"]) - float(z["ref_cfm_loss"])) / float(z["ref_cfm_loss"])
     assert rel <= (1e-3 if prec == "fp32" else 2e-2), (float(r["cfm_loss"]), float(z["ref_cfm_loss"]))
+
+
+def test_inference_with_feats_alignment_branches(cuda, lib):
+    """inference(text, feats=...): MatchaTTS_MAS returns the alignment of the given features (log_p_attn, ds), VITS additionally the
+    posterior reconstruction outs_bar -- against the reference (infer_feats_small.npz; noise draws injected)."""
+    from jatts_amd.models import VITS, MatchaTTS_MAS
+    z, _ = load_golden("infer_feats_small.npz")
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    m = MatchaTTS_MAS(idim=20, **json.loads(str(z["matcha_config"])))
+    m.load_state_dict(matcha_golden_tweaks(golden_state(json.loads(str(z["matcha_keys"])), 3)))
+    m = m.to(cuda)
+    r = m.inference(t("m_text").to(cuda), feats=t("m_feats"), n_timesteps=4, temperature=0.667, noise=t("m_noise"))
+    assert torch.equal(r["ds"].cpu(), t("m_ds")) and torch.equal(r["duration"].cpu(), t("m_duration"))
+    assert maxdiff(r["log_p_attn"], z["m_log_p_attn"]) <= 2e-3 and maxdiff(r["feat_gen"], z["m_feat_gen"]) <= 5e-3
+    v = VITS(idim=20, **json.loads(str(z["vits_config"])))
+    v.load_state_dict(golden_state(json.loads(str(z["vits_keys"])), 2))
+    v = v.to(cuda)
+    r = v.inference(t("v_text").to(cuda), feats=t("v_feats"), spembs=t("v_spemb").to(cuda), noise=t("v_noise"), post_noise=t("v_post_noise"))
+    assert set(r) == {"feat_gen", "duration", "log_p_attn", "ds", "outs_bar"}
+    assert torch.equal(r["ds"].cpu(), t("v_ds")) and torch.equal(r["duration"].cpu(), t("v_duration"))
+    assert maxdiff(r["log_p_attn"], z["v_log_p_attn"]) <= 2e-3
+    assert maxdiff(r["feat_gen"], z["v_feat_gen"]) <= 3e-3 and maxdiff(r["outs_bar"], z["v_outs_bar"]) <= 3e-3
