@@ -287,7 +287,8 @@ def run_timed(job, a, world, dist, pipeline=False):
 def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     """Per-kernel live timings (HIP events on the launch stream inside the timed region) -> roofline of the dominant
     fused-unit family + per-shape tables.  Algorithmic work per dilation unit: 4 C^2 k FLOP and
-    2 C sizeof bytes per row."""
+    2 C sizeof bytes per row (x in, y out); the last unit of a stage also reads the other ResBlocks' outputs for the
+    MRF mean its epilogue carries (n_add more reads of C sizeof bytes per row)."""
     fam = {}
     for tag, meta, ms in recs:
         fam.setdefault((tag, meta), []).append(ms)
@@ -295,14 +296,14 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     for (tag, meta), v in fam.items():
         if tag not in ("resunit", "resblock"):
             continue
-        C, k, d, rows = meta
+        C, k, d, rows, n_add = meta
         nu = len(d) if tag == "resblock" else 1     # a fused ResBlock launch = nu dilation units; x in + y out ONCE
         avg = sum(v) / len(v)
-        flops, byts = 4.0 * C * C * k * rows * nu, 2.0 * rows * C * esz
+        flops, byts = 4.0 * C * C * k * rows * nu, (2.0 + n_add) * rows * C * esz
         peak_tf = MFMA_F16_PEAK_TF if esz == 2 else MFMA_F32_PEAK_TF
         ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         u = dict(C=C, k=k, dil=d, rows=rows, launches=len(v), avg_ms=avg, total_ms=sum(v),
-                 tflops=flops / avg / 1e9, gbs=byts / avg / 1e6, ai=flops / byts, units_per_launch=nu)
+                 tflops=flops / avg / 1e9, gbs=byts / avg / 1e6, ai=flops / byts, units_per_launch=nu, mrf_addends=n_add)
         if nu > 1:   # what the same arithmetic costs as nu separate unit launches (SURVEY 8d's per-unit bytes)
             u["unit_equivalent_gbs"] = nu * byts / avg / 1e6
         u["bound"] = "mfma" if u["ai"] >= ridge else "hbm"
@@ -316,7 +317,7 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     dom_ms = sum(u["total_ms"] for u in dom)
     n_launch = sum(u["launches"] for u in dom)
     dom_flops = sum(4.0 * u["C"] ** 2 * u["k"] * u["rows"] * u["launches"] * u["units_per_launch"] for u in dom)
-    dom_bytes = sum(2.0 * u["rows"] * u["C"] * esz * u["launches"] for u in dom)
+    dom_bytes = sum((2.0 + u["mrf_addends"]) * u["rows"] * u["C"] * esz * u["launches"] for u in dom)
     ai = dom_flops / dom_bytes
     peak_tf = MFMA_F16_PEAK_TF if esz == 2 else MFMA_F32_PEAK_TF
     if ai >= peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):

@@ -215,7 +215,7 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
         d.add0 = add[0].data_ptr()
         d.add1 = add[1].data_ptr() if len(add) > 1 else None
     d.out_scale = out_scale
-    with _Timed("resunit", (channels, k_w, dil, rows)):
+    with _Timed("resunit", (channels, k_w, dil, rows, len(add) if add else 0)):
         _abi.check(lib.jatts_hifigan_resunit(C.byref(d), _stream()), "jatts_hifigan_resunit")
     return y
 
@@ -239,7 +239,7 @@ def hifigan_resblock(rb, len_mul, x, y, units, channels, k_w, slope, dtype, add=
         d.add0 = add[0].data_ptr()
         d.add1 = add[1].data_ptr() if len(add) > 1 else None
     d.out_scale = out_scale
-    with _Timed("resblock", (channels, k_w, tuple(u[4] for u in units), rows)):
+    with _Timed("resblock", (channels, k_w, tuple(u[4] for u in units), rows, len(add) if add else 0)):
         _abi.check(lib.jatts_hifigan_resblock(C.byref(d), _stream()), "jatts_hifigan_resblock")
     return y
 

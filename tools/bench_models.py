@@ -18,6 +18,9 @@ from jatts_amd.synthetic import (HIFIGAN_V1_24K, MATCHA_MAS_JSUT, VITS_JSUT, syn
 from jatts_amd.vocoder import Vocoder  # noqa: E402
 
 
+SHAPES = False
+
+
 def timed(fn, steps):
     fn()
     torch.cuda.synchronize()
@@ -25,7 +28,21 @@ def timed(fn, steps):
     for _ in range(steps):
         out = fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps, out
+    dt = (time.perf_counter() - t0) / steps
+    if SHAPES:
+        from jatts_amd import hip
+        hip.profile_begin()
+        fn()
+        fam = {}
+        for tag, meta, ms in hip.profile_end():
+            fam.setdefault((tag, meta), []).append(ms)
+        rows = []
+        for (tag, meta), v in fam.items():
+            fl = 2.0 * meta[0] * meta[1] * meta[2] * meta[3] * len(v) if tag == "conv1d" else 0.0
+            rows.append((sum(v), tag, meta, len(v), fl / sum(v) / 1e9 if fl else 0.0))
+        for tot, tag, meta, n, tf in sorted(rows, key=lambda r: -r[0])[:24]:
+            print(f"  {tag:8s} {str(meta):34s} n={n:4d} total {tot:8.2f} ms  avg {tot / n * 1e3:8.1f} us  {tf:6.1f} TF", file=sys.stderr)
+    return dt, out
 
 
 def main():
@@ -34,7 +51,10 @@ def main():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--model", default="both", choices=["both", "matcha", "vits"])
     ap.add_argument("--no-vocoder", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="per-shape conv1d / attention table from HIP-event records")
     a = ap.parse_args()
+    global SHAPES
+    SHAPES = a.shapes
     dev = torch.device("cuda:0")
     ones, zeros = [1.0] * 80, [0.0] * 80
     voc = Vocoder(synth_hifigan_state(HIFIGAN_V1_24K, 0),
