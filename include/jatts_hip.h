@@ -196,6 +196,67 @@ int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, cons
 /* out[c] += sum over rows of x[row][c] (bias gradient; caller zeroes out). */
 int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Training side, second slice of SURVEY 8 f.4: the backward passes (and train-mode forward pieces) of the FastSpeech2 layers
+ * around the conv op.  All f32, [rows][dim] row-major; every "+=" output is accumulated with f32 atomics (caller zeroes).
+ * The reference has no interface for these: they stand where torch autograd runs for the jatts/modules layers under
+ * jatts/trainers/fastspeech2.py:86-96 (gen_loss.backward(); clip_grad_norm_; optimizer.step()).
+ * ------------------------------------------------------------------------------- */
+/* LayerNorm over the channels (modules/transformer/layer_norm.py:12-42): dx (nullable), dgamma += , dbeta += (both or neither). dim <= 1536. */
+int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* gamma, int64_t rows, int32_t dim,
+                        float eps, float* dx, int32_t lddx, float* dgamma, float* dbeta, void* stream);
+/* Element-wise activations, mode 1 ReLU, 2 tanh, 3 Swish (x sigmoid x, modules/conformer/swish.py); bwd: dx = dy * act'(x). */
+int jatts_act_fwd(int32_t mode, const float* x, float* y, int64_t n, void* stream);
+int jatts_act_bwd(int32_t mode, const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* GLU over the channel halves (convolution.py:66: F.glu(dim=1)): x [rows][2 dim] -> y [rows][dim]. */
+int jatts_glu_fwd(const float* x, float* y, int64_t rows, int32_t dim, void* stream);
+int jatts_glu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int32_t dim, void* stream);
+/* Depthwise Conv1d (groups = channels, convolution.py:44-52), zero padding inside each sequence: y[t][c] = bias[c] +
+ * sum_k w[c][k] x[t + k - pad][c]; flip = 1 uses w[c][k_w-1-k] (the data gradient, with pad' = k_w - 1 - pad). k_w <= 32. */
+int jatts_dwconv(const jatts_ragged* rg, const float* x, const float* w, const float* bias, float* y, int32_t dim, int32_t k_w,
+                 int32_t pad, int32_t flip, void* stream);
+/* dw[c][k] += sum_t dy[t][c] x[t + k - pad][c]. */
+int jatts_dwconv_wgrad(const jatts_ragged* rg, const float* x, const float* dy, float* dw, int32_t dim, int32_t k_w, int32_t pad,
+                       void* stream);
+/* Column sums for batch-statistics BatchNorm1d (train mode of convolution.py:53 / pre_postnets.py:112-143):
+ * mode 0: out0[c] += sum_r (x - shift[c]), out1[c] += sum_r (x - shift[c])^2 (shift nullable);
+ * mode 1: out0[c] += sum_r y2, out1[c] += sum_r y2 * (x - shift[c]) * mul[c]   (y2 = dy, shift = mean, mul = rstd). */
+int jatts_col_stats(const float* x, const float* y2, int32_t ld, int64_t rows, int32_t dim, const float* shift, const float* mul,
+                    int32_t mode, float* out0, float* out1, void* stream);
+/* dx = gamma rstd (dy - s_dy / rows - xhat s_dyx / rows), xhat = (x - mean) rstd. */
+int jatts_bn_bwd_apply(const float* x, const float* dy, int64_t rows, int32_t dim, const float* mean, const float* rstd,
+                       const float* gamma, const float* s_dy, const float* s_dyx, float* dx, void* stream);
+/* dst[idx[r]][c] += scale * src[r][c]; rows with idx == skip or outside [0, n_dst) dropped (Embedding backward, padding_idx). */
+int jatts_index_add_rows(const float* src, int32_t ld, const int64_t* idx, int64_t rows, int32_t dim, float scale, int64_t skip,
+                         int64_t n_dst, float* dst, void* stream);
+/* Length-regulator backward: dhs[token i of sequence b] = sum of dy over the frames [cum[i-1], cum[i]) of b (deterministic). */
+int jatts_lr_segment_sum(const jatts_ragged* rg, const int64_t* cum, const int32_t* cu_out, const float* dy, int32_t dim, float* dhs,
+                         void* stream);
+/* Attention probabilities of LegacyRelPositionMultiHeadedAttention (modules/transformer/attention.py:142-206) on explicit
+ * [n_batch][n_heads][T][T] score matrices: p = softmax_j((ac + rel_shift(bd)) * scale) over the keys j < lens[b], 0 elsewhere
+ * (bd nullable: plain attention).  bwd: ds = p (dp - sum_j dp p) * scale (= d ac), dbd = rel_shift^-1(ds) (nullable). */
+int jatts_shift_softmax_fwd(const float* ac, const float* bd, int32_t n_batch, int32_t n_heads, int32_t t_len, const int32_t* lens,
+                            float scale, float* p, void* stream);
+int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, int32_t n_heads, int32_t t_len, float scale, float* ds,
+                            float* dbd, void* stream);
+/* Rank-1 pieces of Linear(dim -> 1) heads and Conv1d(1 -> dim, k=1) embeddings:
+ * out[r][c] (+)= v[r] w[c] + bias[c];  out[c] += sum_r v[r] x[r][c];  y[r] = bias[0] + sum_c x[r][c] w[c]. */
+int jatts_outer_rows(const float* v, const float* w, const float* bias, int64_t rows, int32_t dim, int32_t accumulate, float* out,
+                     void* stream);
+int jatts_col_wsum(const float* x, int32_t ld, const float* v, int64_t rows, int32_t dim, float* out, void* stream);
+int jatts_row_dot(const float* x, int32_t ld, const float* w, const float* bias, int64_t rows, int32_t dim, float* y, void* stream);
+/* Gradient of jatts_masked_loss w.r.t. a: da = *upstream (NULL: 1) * scale * {sign(a - b'), 2 (a - b')} on valid rows, 0 elsewhere. */
+int jatts_masked_loss_bwd(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
+                          const int32_t* valid_len, int32_t kind, float log_offset, float scale, const float* upstream, float* da,
+                          int32_t ldda, void* stream);
+/* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
+int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by
+ * min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) when grad_sumsq != NULL and max_norm > 0 (clip_grad_norm_). */
+int jatts_sumsq(const float* x, int64_t n, double* out, void* stream);
+int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream);
+
 /* Profiling hook (not part of the reference interface): while `buf` is non-NULL, thread 0 of the first n_workgroups
  * workgroups of every jatts_hifigan_resunit launch writes 16 uint64 to buf[16*wg ..]: {XCC_ID<<32 | HW_ID, s_memtime
  * at start, x staged, conv1 done, h written, conv2 done, y assembled, y stored, then s_memrealtime (100 MHz) at start

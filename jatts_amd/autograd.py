@@ -1,0 +1,255 @@
+"""torch.autograd.Function wrappers around the HIP forward / backward kernels of the training path.
+
+torch.autograd is the tape (it orders the backward calls and sums fan-out gradients); every layer's arithmetic, forward and
+backward, is a HIP kernel from csrc/train_ops.hip / training.hip / the MFMA conv -- except the dense [T x T] products of the
+attention, which are plain batched GEMMs and go to rocBLAS through torch.matmul.  All tensors are f32 and packed
+(rows, channels) row-major with a RaggedBatch describing the sequences; a padded batch is a RaggedBatch of equal lengths.
+Each Function names the reference module whose autograd it stands for.  No CPU fallback.
+"""
+import torch
+
+from . import hip
+from .training import Conv1dFunction  # noqa: F401  (re-exported: the conv / linear op)
+
+LN_EPS = 1e-12
+BN_EPS = 1e-5
+
+
+class LayerNorm(torch.autograd.Function):
+    """modules/transformer/layer_norm.py:12-42 over the channel axis (eps 1e-12)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return hip.layernorm(x, gamma.detach().contiguous(), beta.detach().contiguous(), hip.F32, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dx, dg, db = hip.layernorm_bwd(x, dy.contiguous(), gamma.detach().contiguous(), ctx.eps, ctx.needs_input_grad[0],
+                                       ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dg, db, None
+
+
+class Act(torch.autograd.Function):
+    """ReLU / tanh / Swish (modules/conformer/swish.py), element-wise."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return hip.act_fwd(x, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return hip.act_bwd(x, dy.contiguous(), ctx.mode), None
+
+
+class GLU(torch.autograd.Function):
+    """F.glu over the channel halves (modules/conformer/convolution.py:66)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return hip.glu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return hip.glu_bwd(x, dy.contiguous())
+
+
+class DepthwiseConv(torch.autograd.Function):
+    """nn.Conv1d(C, C, K, padding=(K-1)//2, groups=C) (convolution.py:44-52) on packed rows; weight (C, 1, K)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rb):
+        x = x.contiguous()
+        Cc, _, K = weight.shape
+        ctx.save_for_backward(x, weight)
+        ctx.rb, ctx.pad, ctx.has_bias = rb, (K - 1) // 2, bias is not None
+        return hip.dwconv(rb, x, weight.detach().reshape(Cc, K).contiguous(), None if bias is None else bias.detach().contiguous(), ctx.pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        Cc, _, K = weight.shape
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.dwconv(ctx.rb, dy, weight.detach().reshape(Cc, K).contiguous(), None, K - 1 - ctx.pad, flip=True)
+        if ctx.needs_input_grad[1]:
+            dw = hip.dwconv_wgrad(ctx.rb, x, dy, K, ctx.pad).view(Cc, 1, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = hip.col_sum(dy)
+        return dx, dw, db, None
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm1d in train mode: statistics over every row of the (padded) batch, biased variance for the normalisation;
+    running_mean / running_var (unbiased) are updated in place with ``momentum`` like torch does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        n = x.shape[0]
+        s, _ = hip.col_stats(x)
+        mean = s / n
+        _, q = hip.col_stats(x, shift=mean)           # second pass on centred values (no E[x^2] - E[x]^2 cancellation)
+        var = q / n
+        rstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        scale = gamma.detach() * rstd
+        y = hip.affine_cast(x, hip.F32, scale=scale.contiguous(), shift=(beta.detach() - mean * scale).contiguous())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        s_dy, s_dyx = hip.col_stats(x, y2=dy, shift=mean, mul=rstd)
+        dx = hip.bn_bwd_apply(x, dy, mean, rstd, gamma.detach().contiguous(), s_dy, s_dyx) if ctx.needs_input_grad[0] else None
+        return dx, s_dyx, s_dy, None, None, None, None
+
+
+class Embedding(torch.autograd.Function):
+    """nn.Embedding(padding_idx) followed by the x * sqrt(adim) of the positional encoding (encoder.py:133-137,
+    positional_encoding.py:221-235): rows = table[ids] * scale."""
+
+    @staticmethod
+    def forward(ctx, ids, table, scale, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.scale, ctx.pad, ctx.n = scale, padding_idx, table.shape[0]
+        return hip.embed_scale(ids, table.detach().contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        return None, hip.index_add_rows(dy.contiguous(), ids, ctx.n, ctx.scale, ctx.pad), None, None
+
+
+class LengthRegulate(torch.autograd.Function):
+    """LengthRegulator.forward (length_regulator.py:70-97): repeat token rows by their durations, zero-pad to rb_out."""
+
+    @staticmethod
+    def forward(ctx, hs, rb_in, cum, rb_out):
+        ctx.geom = (rb_in, cum, rb_out)
+        return hip.lr_gather(rb_in, cum, rb_out, hs.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        rb_in, cum, rb_out = ctx.geom
+        return hip.lr_segment_sum(rb_in, cum, rb_out, dy.contiguous()), None, None, None
+
+
+class ShiftSoftmax(torch.autograd.Function):
+    """softmax((matrix_ac + rel_shift(matrix_bd)) / sqrt(d_k)) with the key mask of
+    LegacyRelPositionMultiHeadedAttention.forward / forward_attention (attention.py:63-93,142-206); ac, bd (B, H, T, T)."""
+
+    @staticmethod
+    def forward(ctx, ac, bd, lens, scale):
+        p = hip.shift_softmax_fwd(ac.contiguous(), None if bd is None else bd.contiguous(), lens, scale)
+        ctx.save_for_backward(p)
+        ctx.scale, ctx.has_bd = scale, bd is not None
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        ds, dbd = hip.shift_softmax_bwd(p, dp.contiguous(), ctx.scale, ctx.has_bd and ctx.needs_input_grad[1])
+        return ds, dbd, None, None
+
+
+class RowDot(torch.autograd.Function):
+    """nn.Linear(C, 1) of the predictors (duration_predictor.py:76, variance_predictor.py:63): (rows, C) -> (rows,)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        return hip.row_dot(x, weight.detach().reshape(-1).contiguous(), bias.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = hip.outer_rows(dy, weight.detach().reshape(-1).contiguous()) if ctx.needs_input_grad[0] else None
+        dw = hip.col_wsum(x, dy).view_as(weight) if ctx.needs_input_grad[1] else None
+        db = dy.sum().reshape(1) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class OuterRows(torch.autograd.Function):
+    """nn.Conv1d(1, C, kernel_size=1) of the pitch / energy embeddings (fastspeech2.py:366-393): (rows,) -> (rows, C)."""
+
+    @staticmethod
+    def forward(ctx, v, weight, bias):
+        v = v.contiguous()
+        ctx.save_for_backward(v, weight)
+        return hip.outer_rows(v, weight.detach().reshape(-1).contiguous(), bias.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dv = hip.row_dot(dy, weight.detach().reshape(-1).contiguous()) if ctx.needs_input_grad[0] else None
+        dw = hip.col_wsum(dy, v).view_as(weight) if ctx.needs_input_grad[1] else None
+        db = hip.col_sum(dy) if ctx.needs_input_grad[2] else None
+        return dv, dw, db
+
+
+class MaskRows(torch.autograd.Function):
+    """x * non_pad_mask on a padded batch (variance_predictor.py:81-83, duration_predictor.py:93-96)."""
+
+    @staticmethod
+    def forward(ctx, x, rb, valid):
+        ctx.geom = (rb, valid)
+        y = x.contiguous().clone()
+        return hip.zero_pad_rows(rb, y.view(rb.total, -1), valid).view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rb, valid = ctx.geom
+        d = dy.contiguous().clone()
+        return hip.zero_pad_rows(rb, d.view(rb.total, -1), valid).view_as(dy), None, None
+
+
+class MaskedLoss(torch.autograd.Function):
+    """scale * sum over valid rows of |a - b| (kind 0) or (a - b)^2 (kind 1) -- the masked_select + mean of
+    losses/l1l2_loss.py:43-63, duration_predictor_loss.py, variance_predictor_loss.py with scale = 1 / #selected."""
+
+    @staticmethod
+    def forward(ctx, pred, target, rb, valid, kind, scale, log_offset):
+        pred = pred.contiguous()
+        ctx.save_for_backward(pred, target)
+        ctx.geom = (rb, valid, kind, scale, log_offset)
+        return hip.masked_loss(rb, pred, target, valid, kind, scale, log_offset=log_offset)
+
+    @staticmethod
+    def backward(ctx, up):
+        pred, target = ctx.saved_tensors
+        rb, valid, kind, scale, log_offset = ctx.geom
+        up = up.contiguous().float().reshape(1)
+        return hip.masked_loss_bwd(rb, pred, target, valid, kind, scale, upstream=up, log_offset=log_offset), None, None, None, None, None, None
+
+
+class Dropout(torch.autograd.Function):
+    """Inverted dropout with a counter-based mask (seed, element index): the backward regenerates the mask."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return hip.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None

@@ -1,0 +1,641 @@
+// Training-side kernels, second slice of SURVEY §8 f.4: the backward passes (and the train-mode forward pieces) of the
+// FastSpeech2 layers around the conv op -- LayerNorm, ReLU / tanh / Swish / GLU, depthwise conv, batch-statistics BatchNorm,
+// embedding, the legacy rel_shift + masked softmax of the attention, the length regulator, the masked losses, dropout, Adam.
+// All f32, rows x channels row-major like the inference kernels.  HBM-bound element / row / column reductions: one coalesced
+// read of each operand, f32 atomics only for the [C]-sized parameter gradients.
+// Reference: torch autograd of jatts/modules/conformer/{encoder_layer,convolution}.py, modules/transformer/{attention,layer_norm}.py,
+// modules/{duration_predictor,variance_predictor,length_regulator,pre_postnets}.py, jatts/losses/*.py, jatts/trainers/fastspeech2.py:24-100.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXPL = 24;   // LayerNorm backward: channels per lane (C <= 1536)
+
+// ------------------------------------------------------------------ LayerNorm backward
+// y = (x - mean) * rstd * g + b over the channels of each row (biased variance, eps inside the sqrt).
+// dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * g;  dg += sum_rows dy * xhat;  db += sum_rows dy.
+// One wave per row (lanes stride the channels); per-lane partial dg / db live in registers over the wave's rows and are
+// folded through LDS into one atomicAdd per channel per workgroup.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                            const float* __restrict__ g, int64_t rows, int C, float eps,
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ dg, float* __restrict__ db) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[LN_MAXPL], pb[LN_MAXPL], gv[LN_MAXPL];
+#pragma unroll
+  for (int j = 0; j < LN_MAXPL; ++j) {
+    pg[j] = pb[j] = 0.f;
+    const int c = lane + 64 * j;
+    gv[j] = c < C ? g[c] : 0.f;
+  }
+  const float invC = 1.f / (float)C;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* xr = x + r * ldx;
+    const float* dr = dy + r * lddy;
+    float xv[LN_MAXPL], dv[LN_MAXPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPL; ++j) {
+      const int c = lane + 64 * j;
+      xv[j] = c < C ? xr[c] : 0.f;
+      dv[j] = c < C ? dr[c] : 0.f;
+      s += xv[j];
+    }
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPL; ++j) {
+      const int c = lane + 64 * j;
+      const float d = c < C ? xv[j] - mean : 0.f;
+      xv[j] = d;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPL; ++j) {
+      xv[j] *= rstd;                       // xhat
+      const float dyg = dv[j] * gv[j];
+      s1 += dyg;
+      s2 += dyg * xv[j];
+      pg[j] += dv[j] * xv[j];
+      pb[j] += dv[j];
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+    if (dx) {
+      float* o = dx + r * lddx;
+#pragma unroll
+      for (int j = 0; j < LN_MAXPL; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) o[c] = rstd * (dv[j] * gv[j] - s1 - xv[j] * s2);
+      }
+    }
+  }
+  if (!dg) return;
+  for (int j = 0; j < LN_MAXPL; ++j) {
+    if (64 * j >= C) break;
+    red[0][wave][lane] = pg[j];
+    red[1][wave][lane] = pb[j];
+    __syncthreads();
+    if (wave == 0) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        atomicAdd(&dg[c], red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+        atomicAdd(&db[c], red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ activations
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+// mode: 1 relu, 2 tanh, 3 swish
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int mode) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + i), o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = mode == 1 ? fmaxf(v[e], 0.f) : mode == 2 ? tanhf(v[e]) : v[e] * sigmoidf_(v[e]);
+      *reinterpret_cast<f32x4*>(y + i) = o;
+    } else {
+      for (int64_t k = i; k < n; ++k) y[k] = mode == 1 ? fmaxf(x[k], 0.f) : mode == 2 ? tanhf(x[k]) : x[k] * sigmoidf_(x[k]);
+    }
+  }
+}
+__device__ __forceinline__ float act_grad(float x, int mode) {
+  if (mode == 1) return x > 0.f ? 1.f : 0.f;
+  if (mode == 2) { const float t = tanhf(x); return 1.f - t * t; }
+  const float s = sigmoidf_(x);
+  return s * (1.f + x * (1.f - s));
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                      int64_t n, int mode) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i), d = *reinterpret_cast<const f32x4*>(dy + i);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = d[e] * act_grad(v[e], mode);
+      *reinterpret_cast<f32x4*>(dx + i) = o;
+    } else {
+      for (int64_t k = i; k < n; ++k) dx[k] = dy[k] * act_grad(x[k], mode);
+    }
+  }
+}
+// GLU over the channel halves of a [rows][2C] matrix: y = a * sigmoid(b)
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int C) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    y[i] = x[r * 2 * C + c] * sigmoidf_(x[r * 2 * C + C + c]);
+  }
+}
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                      int64_t rows, int C) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    const float a = x[r * 2 * C + c], s = sigmoidf_(x[r * 2 * C + C + c]), d = dy[i];
+    dx[r * 2 * C + c] = d * s;
+    dx[r * 2 * C + C + c] = d * a * s * (1.f - s);
+  }
+}
+
+// ------------------------------------------------------------------ depthwise conv (groups = channels), zero padding per sequence
+// y[t][c] = b[c] + sum_k w[c][k'] x[t + k - pad][c], k' = k (forward) or K-1-k (flip: the data gradient)
+__global__ __launch_bounds__(256) void dwconv_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y, int C, int K, int pad, int flip) {
+  const int s = blockIdx.y;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  const int64_t n = (int64_t)L * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
+    float acc = b ? b[c] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int p = t + k - pad;
+      if (p >= 0 && p < L) acc += w[c * K + (flip ? K - 1 - k : k)] * x[(int64_t)(row0 + p) * C + c];
+    }
+    y[(int64_t)(row0 + t) * C + c] = acc;
+  }
+}
+// dw[c][k] += sum_t dy[t][c] x[t + k - pad][c]; a workgroup = 64 channels x a slice of (sequence, time); wave w takes rows t = w mod 4
+constexpr int DW_KMAX = 32;
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, int C, int K, int pad) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  float acc[DW_KMAX];
+#pragma unroll
+  for (int k = 0; k < DW_KMAX; ++k) acc[k] = 0.f;
+  if (c < C)
+    for (int t = blockIdx.z * 4 + part; t < L; t += gridDim.z * 4) {
+      const float d = dy[(int64_t)(row0 + t) * C + c];
+#pragma unroll
+      for (int k = 0; k < DW_KMAX; ++k) {
+        const int p = t + k - pad;
+        if (k < K && p >= 0 && p < L) acc[k] += d * x[(int64_t)(row0 + p) * C + c];
+      }
+    }
+  for (int k = 0; k < K; ++k) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < DW_KMAX; ++q) v = q == k ? acc[q] : v;
+    red[part][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (part == 0 && c < C) atomicAdd(&dw[c * K + k], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ column statistics (BatchNorm with batch statistics)
+// out0[c] += sum_r (x - shift), out1[c] += sum_r (x - shift)^2          (mode 0; shift may be null)
+// out0[c] += sum_r dy,          out1[c] += sum_r dy * (x - mean) * rstd  (mode 1: x = x, y2 = dy, shift = mean, mul = rstd)
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, const float* __restrict__ y2, int ld, int64_t rows, int dim,
+                                                        const float* __restrict__ shift, const float* __restrict__ mul, int mode,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float red[2][4][64];
+  float s0 = 0.f, s1 = 0.f;
+  if (c < dim) {
+    const float sh = shift ? shift[c] : 0.f, m = mul ? mul[c] : 1.f;
+    for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) {
+      const float v = x[r * ld + c] - sh;
+      if (mode == 0) { s0 += v; s1 += v * v; }
+      else { const float d = y2[r * ld + c]; s0 += d; s1 += d * v * m; }
+    }
+  }
+  red[0][part][threadIdx.x & 63] = s0;
+  red[1][part][threadIdx.x & 63] = s1;
+  __syncthreads();
+  if (part == 0 && c < dim) {
+    atomicAdd(&out0[c], red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+    atomicAdd(&out1[c], red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  }
+}
+// BatchNorm backward apply: dx = g * rstd * (dy - s_dy / N - xhat * s_dyxhat / N)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t rows, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ g, const float* __restrict__ s_dy,
+                                                           const float* __restrict__ s_dyx, float inv_n, float* __restrict__ dx) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float xh = (x[i] - mean[c]) * rstd[c];
+    dx[i] = g[c] * rstd[c] * (dy[i] - s_dy[c] * inv_n - xh * s_dyx[c] * inv_n);
+  }
+}
+
+// ------------------------------------------------------------------ row-indexed accumulation (embedding backward)
+// dst[idx[r]][c] += scale * src[r][c], rows with idx == skip (padding_idx) or outside [0, n_dst) are dropped
+__global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __restrict__ src, int ld, const int64_t* __restrict__ idx, int64_t rows,
+                                                             int C, float scale, int64_t skip, int64_t n_dst, float* __restrict__ dst) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    const int64_t j = idx[r];
+    if (j == skip || j < 0 || j >= n_dst) continue;
+    atomicAdd(&dst[j * C + c], scale * src[r * ld + c]);
+  }
+}
+
+// ------------------------------------------------------------------ length-regulator backward (segment sums, deterministic)
+// d_hs[token i of sequence b][c] = sum over frames t in [cum[i-1], cum[i]) of dy[cu_out[b] + t][c]   (t < output length of b)
+__global__ __launch_bounds__(128) void lr_segment_sum_kernel(jatts_ragged rg, const int64_t* __restrict__ cum, const int32_t* __restrict__ cu_out,
+                                                             const float* __restrict__ dy, int C, float* __restrict__ dhs) {
+  const int s = blockIdx.y, i = blockIdx.x;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  if (i >= L) return;
+  const int64_t lo = i ? cum[row0 + i - 1] : 0, hi = cum[row0 + i];
+  const int64_t o0 = cu_out[s], Lo = cu_out[s + 1] - cu_out[s];
+  for (int c = threadIdx.x; c < C; c += 128) {
+    float acc = 0.f;
+    for (int64_t t = lo; t < hi && t < Lo; ++t) acc += dy[(o0 + t) * C + c];
+    dhs[(int64_t)(row0 + i) * C + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ attention: legacy rel_shift + key mask + softmax
+// Per (b, h, query i): s[j] = (ac[i][j] + shift(bd)[i][j]) * scale for j < len[b], softmax over those keys, 0 elsewhere
+// (attention.py:63-93 masked_fill(min) -> softmax -> masked_fill(0)).  shift = LegacyRelPositionMultiHeadedAttention.rel_shift
+// (attention.py:142-162) on a T x T matrix: out[i][j] = flat[(i + 1) T + j] of the zero-left-padded T x (T+1) matrix.
+__device__ __forceinline__ float shifted_bd(const float* __restrict__ bd, int T, int i, int j) {
+  const int f = (i + 1) * T + j;
+  const int r = f / (T + 1), c = f - r * (T + 1);
+  return c == 0 ? 0.f : bd[(int64_t)r * T + c - 1];
+}
+__global__ __launch_bounds__(256) void shift_softmax_fwd_kernel(const float* __restrict__ ac, const float* __restrict__ bd, int H, int T,
+                                                                const int32_t* __restrict__ lens, float scale, float* __restrict__ p,
+                                                                int64_t n_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // (b * H + h) * T + i
+  if (row >= n_rows) return;
+  const int i = (int)(row % T);
+  const int64_t bh = row / T;
+  const int b = (int)(bh / H);
+  const int len = lens ? min(max(lens[b], 0), T) : T;
+  const float* acr = ac + row * T;
+  const float* bdm = bd ? bd + bh * (int64_t)T * T : nullptr;
+  float m = -INFINITY;
+  for (int j = lane; j < len; j += 64) {
+    const float s = (acr[j] + (bdm ? shifted_bd(bdm, T, i, j) : 0.f)) * scale;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < len; j += 64) {
+    const float s = (acr[j] + (bdm ? shifted_bd(bdm, T, i, j) : 0.f)) * scale;
+    z += __expf(s - m);
+  }
+  z = wave_sum(z);
+  const float inv = z > 0.f ? 1.f / z : 0.f;
+  float* pr = p + row * T;
+  for (int j = lane; j < T; j += 64) {
+    float v = 0.f;
+    if (j < len) v = __expf((acr[j] + (bdm ? shifted_bd(bdm, T, i, j) : 0.f)) * scale - m) * inv;
+    pr[j] = v;
+  }
+}
+// ds = p * (dp - sum_j dp p) * scale  (written over dp's row into ds)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, int T, float scale,
+                                                          float* __restrict__ ds, int64_t n_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= n_rows) return;
+  const float* pr = p + row * T;
+  const float* dr = dp + row * T;
+  float s = 0.f;
+  for (int j = lane; j < T; j += 64) s += pr[j] * dr[j];
+  s = wave_sum(s);
+  float* o = ds + row * T;
+  for (int j = lane; j < T; j += 64) o[j] = pr[j] * (dr[j] - s) * scale;
+}
+// d_bd[r][c] = ds[i][j] with (i + 1) T + j = r (T + 1) + c + 1 (the inverse of shifted_bd; entries that no output reads get 0)
+__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ ds, int T, int64_t n_mats, float* __restrict__ dbd) {
+  const int64_t n = n_mats * T * T;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t mtx = e / ((int64_t)T * T);
+    const int rc = (int)(e - mtx * T * T);
+    const int r = rc / T, c = rc - r * T;
+    const int f = r * (T + 1) + c + 1;
+    const int i = f / T - 1, j = f % T;
+    dbd[e] = (i >= 0 && i < T) ? ds[mtx * T * T + (int64_t)i * T + j] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ rank-1 helpers (Linear(C -> 1) heads, Conv1d(1 -> C, k=1) embeddings)
+// out[r][c] (+)= v[r] * w[c] + bias[c]
+__global__ __launch_bounds__(256) void outer_rows_kernel(const float* __restrict__ v, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int64_t rows, int C, int accumulate, float* __restrict__ out) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    const float val = v[r] * w[c] + (bias ? bias[c] : 0.f);
+    out[i] = accumulate ? out[i] + val : val;
+  }
+}
+// out[c] += sum_r v[r] * x[r][c]
+__global__ __launch_bounds__(256) void col_wsum_kernel(const float* __restrict__ x, int ld, const float* __restrict__ v, int64_t rows, int dim,
+                                                       float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < dim)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += v[r] * x[r * ld + c];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// y[r] = bias + sum_c x[r][c] w[c]   (one wave per row)
+__global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int64_t rows, int C, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += x[r * ld + c] * w[c];
+  s = wave_sum(s);
+  if (lane == 0) y[r] = s + (bias ? bias[0] : 0.f);
+}
+
+// ------------------------------------------------------------------ masked loss gradient
+// da[t][c] = up * scale * sign(a - b') (kind 0) or up * 2 scale (a - b') (kind 1) for t < valid_len, 0 elsewhere
+__global__ __launch_bounds__(256) void masked_loss_bwd_kernel(jatts_ragged rg, const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                              int ldb, int dim, const int32_t* __restrict__ valid_len, int kind, float log_offset,
+                                                              float scale, const float* __restrict__ upstream, float* __restrict__ da, int ldda) {
+  const int s = blockIdx.y;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  const int v = valid_len ? min(max(valid_len[s], 0), L) : L;
+  const float up = (upstream ? *upstream : 1.f) * scale;
+  const int64_t n = (int64_t)L * dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / dim;
+    const int c = (int)(i - t * dim);
+    float o = 0.f;
+    if (t < v) {
+      float y = b[(row0 + t) * ldb + c];
+      if (log_offset >= 0.f) y = logf(y + log_offset);
+      const float dlt = a[(row0 + t) * lda + c] - y;
+      o = kind == 0 ? (dlt > 0.f ? up : dlt < 0.f ? -up : 0.f) : 2.f * up * dlt;
+    }
+    da[(row0 + t) * ldda + c] = o;
+  }
+}
+
+// ------------------------------------------------------------------ dropout (counter-based mask, recomputed in the backward)
+__device__ __forceinline__ uint32_t mix32(uint64_t k) {   // splitmix64 finaliser
+  k += 0x9E3779B97F4A7C15ull;
+  k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+  k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((k ^ (k >> 31)) >> 32);
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, uint64_t seed) {
+  const float keep_scale = 1.f / (1.f - p);
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = mix32(seed * 0x100000001B3ull + (uint64_t)i) >= thr ? x[i] * keep_scale : 0.f;
+}
+
+// ------------------------------------------------------------------ optimiser
+// sum of squares into a double (gradient-norm clipping: torch.nn.utils.clip_grad_norm_, trainers/fastspeech2.py:90-94)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)x[i] * (double)x[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+// torch.optim.Adam (no amsgrad): g' = g * gscale (+ wd * p); m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+// p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).  gscale = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   const double* __restrict__ sumsq, float max_norm) {
+  float gs = 1.f;
+  if (sumsq && max_norm > 0.f) {
+    const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
+    gs = c < 1.f ? c : 1.f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * gs;
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr / bc1 * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int per_block, unsigned cap = 8192) {
+  const int64_t b = (n + per_block - 1) / per_block;
+  return (unsigned)(b < 1 ? 1 : b > cap ? cap : b);
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+#define NULLCHK(cond, msg) \
+  if (cond) return jatts_set_error_msg(JATTS_ERR_ARG, msg)
+
+extern "C" int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* gamma, int64_t rows, int32_t dim,
+                                   float eps, float* dx, int32_t lddx, float* dgamma, float* dbeta, void* stream) {
+  NULLCHK(!x || !dy || !gamma, "layernorm_bwd: null pointer");
+  NULLCHK((dgamma == nullptr) != (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
+  if (dim < 1 || dim > 64 * LN_MAXPL) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "layernorm_bwd: 1 <= dim <= 1536");
+  if (rows <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks_for(rows, 16, 2048)), dim3(256), 0, S_, x, ldx, dy, lddy, gamma, rows, dim, eps, dx, lddx,
+                     dgamma, dbeta);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_act_fwd(int32_t mode, const float* x, float* y, int64_t n, void* stream) {
+  NULLCHK(!x || !y, "act_fwd: null pointer");
+  NULLCHK(mode < 1 || mode > 3, "act_fwd: mode 1 relu, 2 tanh, 3 swish");
+  if (n <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, S_, x, y, n, mode);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_act_bwd(int32_t mode, const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  NULLCHK(!x || !dy || !dx, "act_bwd: null pointer");
+  NULLCHK(mode < 1 || mode > 3, "act_bwd: mode 1 relu, 2 tanh, 3 swish");
+  if (n <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, S_, x, dy, dx, n, mode);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_glu_fwd(const float* x, float* y, int64_t rows, int32_t dim, void* stream) {
+  NULLCHK(!x || !y, "glu_fwd: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, x, y, rows, dim);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_glu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int32_t dim, void* stream) {
+  NULLCHK(!x || !dy || !dx, "glu_bwd: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, x, dy, dx, rows, dim);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_dwconv(const jatts_ragged* rg, const float* x, const float* w, const float* bias, float* y, int32_t dim, int32_t k_w,
+                            int32_t pad, int32_t flip, void* stream) {
+  NULLCHK(!rg || !x || !w || !y, "dwconv: null pointer");
+  NULLCHK(dim < 1 || k_w < 1 || k_w > DW_KMAX, "dwconv: 1 <= k_w <= 32");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((int64_t)rg->max_len * dim, 256, 1024), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, w, bias,
+                     y, dim, k_w, pad, flip);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_dwconv_wgrad(const jatts_ragged* rg, const float* x, const float* dy, float* dw, int32_t dim, int32_t k_w, int32_t pad,
+                                  void* stream) {
+  NULLCHK(!rg || !x || !dy || !dw, "dwconv_wgrad: null pointer");
+  NULLCHK(dim < 1 || k_w < 1 || k_w > DW_KMAX, "dwconv_wgrad: 1 <= k_w <= 32");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  unsigned gz = (unsigned)((rg->max_len + 63) / 64);
+  if (gz > 64) gz = 64;
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)rg->n_seq, gz), dim3(256), 0, S_, *rg, x, dy, dw, dim, k_w, pad);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_col_stats(const float* x, const float* y2, int32_t ld, int64_t rows, int32_t dim, const float* shift, const float* mul,
+                               int32_t mode, float* out0, float* out1, void* stream) {
+  NULLCHK(!x || !out0 || !out1 || (mode == 1 && !y2), "col_stats: null pointer");
+  NULLCHK(mode != 0 && mode != 1, "col_stats: mode 0 (moments) or 1 (dy sums)");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  const int64_t gy = (rows + 255) / 256;
+  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, y2, ld, rows, dim, shift,
+                     mul, mode, out0, out1);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_bn_bwd_apply(const float* x, const float* dy, int64_t rows, int32_t dim, const float* mean, const float* rstd,
+                                  const float* gamma, const float* s_dy, const float* s_dyx, float* dx, void* stream) {
+  NULLCHK(!x || !dy || !mean || !rstd || !gamma || !s_dy || !s_dyx || !dx, "bn_bwd_apply: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, x, dy, rows, dim, mean, rstd, gamma, s_dy, s_dyx,
+                     1.f / (float)rows, dx);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_index_add_rows(const float* src, int32_t ld, const int64_t* idx, int64_t rows, int32_t dim, float scale, int64_t skip,
+                                    int64_t n_dst, float* dst, void* stream) {
+  NULLCHK(!src || !idx || !dst, "index_add_rows: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(index_add_rows_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, src, ld, idx, rows, dim, scale, skip, n_dst, dst);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_lr_segment_sum(const jatts_ragged* rg, const int64_t* cum, const int32_t* cu_out, const float* dy, int32_t dim, float* dhs,
+                                    void* stream) {
+  NULLCHK(!rg || !cum || !cu_out || !dy || !dhs, "lr_segment_sum: null pointer");
+  if (rg->n_seq <= 0 || rg->max_len <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(lr_segment_sum_kernel, dim3((unsigned)rg->max_len, (unsigned)rg->n_seq), dim3(128), 0, S_, *rg, cum, cu_out, dy, dim, dhs);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_shift_softmax_fwd(const float* ac, const float* bd, int32_t n_batch, int32_t n_heads, int32_t t_len, const int32_t* lens,
+                                       float scale, float* p, void* stream) {
+  NULLCHK(!ac || !p, "shift_softmax_fwd: null pointer");
+  NULLCHK(n_batch < 1 || n_heads < 1 || t_len < 1, "shift_softmax_fwd: bad geometry");
+  const int64_t n_rows = (int64_t)n_batch * n_heads * t_len;
+  hipLaunchKernelGGL(shift_softmax_fwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, ac, bd, n_heads, t_len, lens, scale, p, n_rows);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, int32_t n_heads, int32_t t_len, float scale, float* ds,
+                                       float* dbd, void* stream) {
+  NULLCHK(!p || !dp || !ds, "shift_softmax_bwd: null pointer");
+  NULLCHK(n_batch < 1 || n_heads < 1 || t_len < 1, "shift_softmax_bwd: bad geometry");
+  const int64_t n_rows = (int64_t)n_batch * n_heads * t_len;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, p, dp, t_len, scale, ds, n_rows);
+  if (dbd)
+    hipLaunchKernelGGL(unshift_kernel, dim3(blocks_for(n_rows * t_len, 256)), dim3(256), 0, S_, ds, t_len, (int64_t)n_batch * n_heads, dbd);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_outer_rows(const float* v, const float* w, const float* bias, int64_t rows, int32_t dim, int32_t accumulate, float* out,
+                                void* stream) {
+  NULLCHK(!v || !w || !out, "outer_rows: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(outer_rows_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, v, w, bias, rows, dim, accumulate, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_col_wsum(const float* x, int32_t ld, const float* v, int64_t rows, int32_t dim, float* out, void* stream) {
+  NULLCHK(!x || !v || !out, "col_wsum: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  const int64_t gy = (rows + 255) / 256;
+  hipLaunchKernelGGL(col_wsum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, ld, v, rows, dim, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_row_dot(const float* x, int32_t ld, const float* w, const float* bias, int64_t rows, int32_t dim, float* y, void* stream) {
+  NULLCHK(!x || !w || !y, "row_dot: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, x, ld, w, bias, rows, dim, y);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_masked_loss_bwd(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
+                                     const int32_t* valid_len, int32_t kind, float log_offset, float scale, const float* upstream, float* da,
+                                     int32_t ldda, void* stream) {
+  NULLCHK(!rg || !a || !b || !da, "masked_loss_bwd: null pointer");
+  NULLCHK(kind != 0 && kind != 1, "masked_loss_bwd: kind must be 0 (L1) or 1 (L2)");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3(blocks_for((int64_t)rg->max_len * dim, 256, 256), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, a, lda,
+                     b, ldb, dim, valid_len, kind, log_offset, scale, upstream, da, ldda);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+  NULLCHK(!x || !y, "dropout: null pointer");
+  NULLCHK(!(p >= 0.f && p < 1.f), "dropout: 0 <= p < 1");
+  if (n <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, y, n, p, seed);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_sumsq(const float* x, int64_t n, double* out, void* stream) {
+  NULLCHK(!x || !out, "sumsq: null pointer");
+  if (n <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n, 4096, 1024)), dim3(256), 0, S_, x, n, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream) {
+  NULLCHK(!p || !g || !m || !v, "adam_step: null pointer");
+  NULLCHK(step < 1, "adam_step: step counts from 1");
+  if (n <= 0) return JATTS_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, S_, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                     sqrtf(bc2), grad_sumsq, max_norm);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}

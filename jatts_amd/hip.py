@@ -632,3 +632,205 @@ def col_sum(x, dim=None):
     out = torch.zeros(dim, dtype=torch.float32, device=x.device)
     _abi.check(lib.jatts_col_sum(_dev(x).data_ptr(), x.shape[1], x.shape[0], dim, out.data_ptr(), _stream()), "jatts_col_sum")
     return out
+
+
+# ------------------------------------------------------------------------------------------ training ops (train_ops.hip)
+ACT_MODE = {"relu": 1, "tanh": 2, "swish": 3}
+
+
+def _f32c(t):
+    t = _dev(t)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("training ops take contiguous f32 device tensors")
+    return t
+
+
+def layernorm_bwd(x, dy, gamma, eps, need_dx=True, need_dparam=True):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    rows, dim = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dg = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
+    db = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
+    _abi.check(lib.jatts_layernorm_bwd(x.data_ptr(), dim, dy.data_ptr(), dim, _f32c(gamma).data_ptr(), rows, dim, float(eps), _ptr(dx), dim,
+                                       _ptr(dg), _ptr(db), _stream()), "jatts_layernorm_bwd")
+    return dx, dg, db
+
+
+def act_fwd(x, mode):
+    lib = _abi.load()
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _abi.check(lib.jatts_act_fwd(ACT_MODE[mode], x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "jatts_act_fwd")
+    return y
+
+
+def act_bwd(x, dy, mode):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dx = torch.empty_like(x)
+    _abi.check(lib.jatts_act_bwd(ACT_MODE[mode], x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "jatts_act_bwd")
+    return dx
+
+
+def glu_fwd(x):
+    lib = _abi.load()
+    x = _f32c(x)
+    rows, c2 = x.shape
+    y = torch.empty(rows, c2 // 2, dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_glu_fwd(x.data_ptr(), y.data_ptr(), rows, c2 // 2, _stream()), "jatts_glu_fwd")
+    return y
+
+
+def glu_bwd(x, dy):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dx = torch.empty_like(x)
+    _abi.check(lib.jatts_glu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1] // 2, _stream()), "jatts_glu_bwd")
+    return dx
+
+
+def dwconv(rb, x, w, bias, pad, flip=False):
+    """depthwise conv on packed rows: w (C, K); flip=True is the data gradient (call with pad' = K - 1 - pad)."""
+    lib = _abi.load()
+    x, w = _f32c(x), _f32c(w)
+    y = torch.empty_like(x)
+    rg = rb.struct()
+    _abi.check(lib.jatts_dwconv(C.byref(rg), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), x.shape[1], w.shape[1], pad, int(flip),
+                                _stream()), "jatts_dwconv")
+    return y
+
+
+def dwconv_wgrad(rb, x, dy, k_w, pad):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dw = torch.zeros(x.shape[1], k_w, dtype=torch.float32, device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_dwconv_wgrad(C.byref(rg), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[1], k_w, pad, _stream()),
+               "jatts_dwconv_wgrad")
+    return dw
+
+
+def col_stats(x, y2=None, shift=None, mul=None):
+    """y2 None -> (sum (x - shift), sum (x - shift)^2); else (sum y2, sum y2 (x - shift) mul), per column."""
+    lib = _abi.load()
+    x = _f32c(x)
+    rows, dim = x.shape
+    o0 = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    o1 = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_col_stats(x.data_ptr(), _ptr(y2), dim, rows, dim, _ptr(shift), _ptr(mul), 0 if y2 is None else 1, o0.data_ptr(),
+                                   o1.data_ptr(), _stream()), "jatts_col_stats")
+    return o0, o1
+
+
+def bn_bwd_apply(x, dy, mean, rstd, gamma, s_dy, s_dyx):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dx = torch.empty_like(x)
+    _abi.check(lib.jatts_bn_bwd_apply(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], mean.data_ptr(), rstd.data_ptr(),
+                                      _f32c(gamma).data_ptr(), s_dy.data_ptr(), s_dyx.data_ptr(), dx.data_ptr(), _stream()), "jatts_bn_bwd_apply")
+    return dx
+
+
+def index_add_rows(src, idx, n_dst, scale=1.0, skip=-1):
+    lib = _abi.load()
+    src = _f32c(src)
+    dst = torch.zeros(n_dst, src.shape[1], dtype=torch.float32, device=src.device)
+    _abi.check(lib.jatts_index_add_rows(src.data_ptr(), src.shape[1], _dev(idx).data_ptr(), src.shape[0], src.shape[1], float(scale), int(skip),
+                                        n_dst, dst.data_ptr(), _stream()), "jatts_index_add_rows")
+    return dst
+
+
+def lr_segment_sum(rb_in, cum, rb_out, dy):
+    lib = _abi.load()
+    dy = _f32c(dy)
+    dhs = torch.empty(rb_in.total, dy.shape[1], dtype=torch.float32, device=dy.device)
+    rg = rb_in.struct()
+    _abi.check(lib.jatts_lr_segment_sum(C.byref(rg), _dev(cum).data_ptr(), rb_out.cu.data_ptr(), dy.data_ptr(), dy.shape[1], dhs.data_ptr(),
+                                        _stream()), "jatts_lr_segment_sum")
+    return dhs
+
+
+def shift_softmax_fwd(ac, bd, lens, scale):
+    """ac, bd: (B, H, T, T) f32 -> attention probabilities (legacy rel_shift applied to bd; bd None = plain attention)."""
+    lib = _abi.load()
+    ac = _f32c(ac)
+    B, H, T, _ = ac.shape
+    p = torch.empty_like(ac)
+    _abi.check(lib.jatts_shift_softmax_fwd(ac.data_ptr(), _ptr(bd), B, H, T, _ptr(lens), float(scale), p.data_ptr(), _stream()),
+               "jatts_shift_softmax_fwd")
+    return p
+
+
+def shift_softmax_bwd(p, dp, scale, need_dbd=True):
+    lib = _abi.load()
+    p, dp = _f32c(p), _f32c(dp)
+    B, H, T, _ = p.shape
+    ds = torch.empty_like(p)
+    dbd = torch.empty_like(p) if need_dbd else None
+    _abi.check(lib.jatts_shift_softmax_bwd(p.data_ptr(), dp.data_ptr(), B, H, T, float(scale), ds.data_ptr(), _ptr(dbd), _stream()),
+               "jatts_shift_softmax_bwd")
+    return ds, dbd
+
+
+def outer_rows(v, w, bias=None, out=None):
+    lib = _abi.load()
+    v, w = _f32c(v), _f32c(w)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(v.numel(), w.numel(), dtype=torch.float32, device=v.device)
+    _abi.check(lib.jatts_outer_rows(v.data_ptr(), w.data_ptr(), _ptr(bias), v.numel(), w.numel(), int(acc), out.data_ptr(), _stream()),
+               "jatts_outer_rows")
+    return out
+
+
+def col_wsum(x, v):
+    lib = _abi.load()
+    x, v = _f32c(x), _f32c(v)
+    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_col_wsum(x.data_ptr(), x.shape[1], v.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "jatts_col_wsum")
+    return out
+
+
+def row_dot(x, w, bias=None):
+    lib = _abi.load()
+    x, w = _f32c(x), _f32c(w)
+    y = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_row_dot(x.data_ptr(), x.shape[1], w.data_ptr(), _ptr(bias), x.shape[0], x.shape[1], y.data_ptr(), _stream()),
+               "jatts_row_dot")
+    return y
+
+
+def masked_loss_bwd(rb, a, b, valid_len, kind, scale, upstream=None, log_offset=-1.0):
+    lib = _abi.load()
+    a2 = _f32c(a if a.dim() == 2 else a.reshape(-1, 1))
+    b2 = _f32c(b if b.dim() == 2 else b.reshape(-1, 1))
+    da = torch.empty_like(a2)
+    rg = rb.struct()
+    _abi.check(lib.jatts_masked_loss_bwd(C.byref(rg), a2.data_ptr(), a2.shape[1], b2.data_ptr(), b2.shape[1], a2.shape[1], _ptr(valid_len), kind,
+                                         float(log_offset), float(scale), _ptr(upstream), da.data_ptr(), a2.shape[1], _stream()),
+               "jatts_masked_loss_bwd")
+    return da.view_as(a)
+
+
+def dropout(x, p, seed):
+    lib = _abi.load()
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _abi.check(lib.jatts_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "jatts_dropout")
+    return y
+
+
+def sumsq(x, out):
+    """out (f64 scalar tensor on the device) += sum x^2"""
+    lib = _abi.load()
+    x = _f32c(x)
+    _abi.check(lib.jatts_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "jatts_sumsq")
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq=None, max_norm=0.0):
+    lib = _abi.load()
+    _abi.check(lib.jatts_adam_step(_f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(m).data_ptr(), _f32c(v).data_ptr(), p.numel(), float(lr),
+                                   float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _ptr(grad_sumsq), float(max_norm),
+                                   _stream()), "jatts_adam_step")

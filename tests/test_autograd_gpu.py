@@ -1,0 +1,233 @@
+"""SURVEY §8 f.4, second slice: every HIP forward / backward pair of jatts_amd/autograd.py against torch autograd of the
+reference module's own torch ops in fp64 on the CPU (same seeded inputs, padded-batch geometry where the reference pads)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-5
+
+
+def _leaf(t, cuda):
+    return t.clone().double().requires_grad_(), t.clone().to(cuda).requires_grad_()
+
+
+def _check(pairs, tol=TOL):
+    for name, got, want in pairs:
+        e = relerr(got.detach().cpu().double(), want.detach().double())
+        assert e <= tol, (name, e)
+
+
+@pytest.mark.parametrize("rows,dim", [(37, 384), (5, 64), (130, 256), (9, 80)])
+def test_layernorm_backward(cuda, lib, rows, dim):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(rows + dim)
+    x, w, b, gy = torch.randn(rows, dim, generator=g) * 2 + 0.3, torch.randn(dim, generator=g), torch.randn(dim, generator=g), torch.randn(rows, dim, generator=g)
+    (xr, xd), (wr, wd), (br, bd) = _leaf(x, cuda), _leaf(w, cuda), _leaf(b, cuda)
+    yr = F.layer_norm(xr, (dim,), wr, br, 1e-12)
+    yr.backward(gy.double())
+    y = A.LayerNorm.apply(xd, wd, bd, 1e-12)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dg", wd.grad, wr.grad), ("db", bd.grad, br.grad)])
+
+
+@pytest.mark.parametrize("mode", ["relu", "tanh", "swish"])
+def test_activation_backward(cuda, lib, mode):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(3)
+    x, gy = torch.randn(77, 50, generator=g) * 2, torch.randn(77, 50, generator=g)
+    xr, xd = _leaf(x, cuda)
+    fn = {"relu": torch.relu, "tanh": torch.tanh, "swish": lambda t: t * torch.sigmoid(t)}[mode]
+    yr = fn(xr)
+    yr.backward(gy.double())
+    y = A.Act.apply(xd, mode)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad)])
+
+
+def test_glu_backward(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(4)
+    x, gy = torch.randn(41, 2 * 48, generator=g), torch.randn(41, 48, generator=g)
+    xr, xd = _leaf(x, cuda)
+    yr = F.glu(xr, dim=1)
+    yr.backward(gy.double())
+    y = A.GLU.apply(xd)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad)])
+
+
+@pytest.mark.parametrize("dim,k,lens", [(64, 7, [50, 50]), (96, 31, [40, 40, 40]), (32, 3, [9, 70])])
+def test_depthwise_conv_backward(cuda, lib, dim, k, lens):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(dim + k)
+    R = sum(lens)
+    x, w, b, gy = torch.randn(R, dim, generator=g), torch.randn(dim, 1, k, generator=g) / math.sqrt(k), torch.randn(dim, generator=g), torch.randn(R, dim, generator=g)
+    (xr, xd), (wr, wd), (br, bd) = _leaf(x, cuda), _leaf(w, cuda), _leaf(b, cuda)
+    outs, o = [], 0
+    for n in lens:
+        outs.append(F.conv1d(xr[o:o + n].t().unsqueeze(0), wr, br, padding=(k - 1) // 2, groups=dim)[0].t())
+        o += n
+    yr = torch.cat(outs)
+    yr.backward(gy.double())
+    y = A.DepthwiseConv.apply(xd, wd, bd, hip.RaggedBatch(lens, cuda))
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)])
+
+
+def test_batchnorm_train_backward_and_running_stats(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(6)
+    B, T, dim = 3, 29, 48
+    x, w, b, gy = torch.randn(B * T, dim, generator=g) * 1.5 + 0.7, torch.randn(dim, generator=g), torch.randn(dim, generator=g), torch.randn(B * T, dim, generator=g)
+    (xr, xd), (wr, wd), (br, bd) = _leaf(x, cuda), _leaf(w, cuda), _leaf(b, cuda)
+    bn = torch.nn.BatchNorm1d(dim).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(w)
+        bn.bias.copy_(b)
+    yr = F.batch_norm(xr.view(B, T, dim).transpose(1, 2), bn.running_mean, bn.running_var, wr, br, True, 0.1, 1e-5).transpose(1, 2).reshape(B * T, dim)
+    yr.backward(gy.double())
+    rm, rv = torch.zeros(dim, device=cuda), torch.ones(dim, device=cuda)
+    y = A.BatchNormTrain.apply(xd, wd, bd, rm, rv, 0.1, 1e-5)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dg", wd.grad, wr.grad), ("db", bd.grad, br.grad),
+            ("running_mean", rm, bn.running_mean), ("running_var", rv, bn.running_var)])
+
+
+def test_embedding_backward(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 20, (90,), generator=g)
+    table, gy = torch.randn(20, 64, generator=g), torch.randn(90, 64, generator=g)
+    tr, td = _leaf(table, cuda)
+    yr = F.embedding(ids, tr, padding_idx=0) * 8.0
+    yr.backward(gy.double())
+    y = A.Embedding.apply(ids.to(cuda), td, 8.0, 0)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dtable", td.grad, tr.grad)])
+    assert float(td.grad[0].abs().max()) == 0.0
+
+
+def test_length_regulator_backward(cuda, lib):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(8)
+    B, Tm, dim = 3, 11, 32
+    d = torch.randint(0, 5, (B, Tm), generator=g)
+    d[1, 7:] = 0
+    hs, To = torch.randn(B * Tm, dim, generator=g), int(d.sum(1).max())
+    gy = torch.randn(B * To, dim, generator=g)
+    hr, hd = _leaf(hs, cuda)
+    outs = [F.pad(torch.repeat_interleave(hr.view(B, Tm, dim)[b], d[b], dim=0), (0, 0, 0, To - int(d[b].sum()))) for b in range(B)]
+    yr = torch.cat(outs)
+    yr.backward(gy.double())
+    rb = hip.RaggedBatch([Tm] * B, cuda)
+    _, cum, ol, _ = hip.lr_durations(rb, d.reshape(-1).to(cuda), 1.0, zero_rule=0)
+    y = A.LengthRegulate.apply(hd, rb, cum, hip.RaggedBatch([To] * B, cuda))
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dhs", hd.grad, hr.grad)])
+
+
+def _rel_shift_legacy(x):
+    """attention.py:142-162 (zero_triu False), restated on a (B, H, T, T) tensor."""
+    b, h, t1, t2 = x.shape
+    xp = torch.cat([torch.zeros(b, h, t1, 1, dtype=x.dtype), x], dim=-1).view(b, h, t2 + 1, t1)
+    return xp[:, :, 1:].reshape(b, h, t1, t2)
+
+
+@pytest.mark.parametrize("T,lens", [(24, [24, 17]), (65, [65, 3, 40])])
+def test_shift_softmax_backward(cuda, lib, T, lens):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(T)
+    B, H = len(lens), 2
+    ac, bd, gp = (torch.randn(B, H, T, T, generator=g) for _ in range(3))
+    (ar, ad), (br, bd_) = _leaf(ac, cuda), _leaf(bd, cuda)
+    scale = 1.0 / math.sqrt(24)
+    s = (ar + _rel_shift_legacy(br)) * scale
+    mask = (torch.arange(T)[None, :] >= torch.tensor(lens)[:, None])[:, None, None, :]      # (B, 1, 1, T): True on padded keys
+    pr = torch.softmax(s.masked_fill(mask, torch.finfo(torch.float32).min), dim=-1).masked_fill(mask, 0.0)
+    pr.backward(gp.double())
+    p = A.ShiftSoftmax.apply(ad, bd_, torch.tensor(lens, dtype=torch.int32, device=cuda), scale)
+    p.backward(gp.to(cuda))
+    _check([("p", p, pr), ("dac", ad.grad, ar.grad), ("dbd", bd_.grad, br.grad)])
+
+
+def test_rank1_heads_backward(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(9)
+    x, w, b, gy = torch.randn(53, 256, generator=g), torch.randn(1, 256, generator=g) / 16, torch.randn(1, generator=g), torch.randn(53, generator=g)
+    (xr, xd), (wr, wd), (br, bd) = _leaf(x, cuda), _leaf(w, cuda), _leaf(b, cuda)
+    yr = F.linear(xr, wr, br).squeeze(-1)
+    yr.backward(gy.double())
+    y = A.RowDot.apply(xd, wd, bd)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)])
+    v, w2, b2, gy2 = torch.randn(53, generator=g), torch.randn(96, 1, 1, generator=g), torch.randn(96, generator=g), torch.randn(53, 96, generator=g)
+    (vr, vd), (w2r, w2d), (b2r, b2d) = _leaf(v, cuda), _leaf(w2, cuda), _leaf(b2, cuda)
+    yr = F.conv1d(vr.view(1, 1, -1), w2r, b2r)[0].t()
+    yr.backward(gy2.double())
+    y = A.OuterRows.apply(vd, w2d, b2d)
+    y.backward(gy2.to(cuda))
+    _check([("y", y, yr), ("dv", vd.grad, vr.grad), ("dw", w2d.grad, w2r.grad), ("db", b2d.grad, b2r.grad)])
+
+
+@pytest.mark.parametrize("kind,log_offset", [(0, -1.0), (1, -1.0), (1, 1.0)])
+def test_masked_loss_backward(cuda, lib, kind, log_offset):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(10 + kind)
+    B, T, dim = 3, 14, 5 if kind == 0 else 1
+    lens = [14, 9, 2]
+    a, b = torch.randn(B * T, dim, generator=g), torch.rand(B * T, dim, generator=g) * 4
+    ar, ad = _leaf(a, cuda)
+    m = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).reshape(-1)
+    tgt = torch.log(b.double() + log_offset) if log_offset >= 0 else b.double()
+    sel_a, sel_b = ar[m], tgt[m]
+    lr_ = (sel_a - sel_b).abs().mean() if kind == 0 else ((sel_a - sel_b) ** 2).mean()
+    (lr_ * 1.7).backward()
+    n = float(sum(lens) * dim)
+    rb = hip.RaggedBatch([T] * B, cuda)
+    loss = A.MaskedLoss.apply(ad, b.to(cuda), rb, torch.tensor(lens, dtype=torch.int32, device=cuda), kind, 1.0 / n, log_offset)
+    (loss * 1.7).backward()
+    _check([("loss", loss, lr_), ("da", ad.grad, ar.grad)])
+
+
+def test_mask_rows_and_dropout(cuda, lib):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(11)
+    B, T, dim = 2, 10, 8
+    x = torch.randn(B * T, dim, generator=g).to(cuda).requires_grad_()
+    rb = hip.RaggedBatch([T] * B, cuda)
+    valid = torch.tensor([10, 4], dtype=torch.int32, device=cuda)
+    y = A.MaskRows.apply(x, rb, valid)
+    y.sum().backward()
+    keep = (torch.arange(T)[None, :] < torch.tensor([10, 4])[:, None]).reshape(-1, 1).float().to(cuda)
+    assert torch.equal(y.detach(), x.detach() * keep) and torch.equal(x.grad, keep.expand(-1, dim))
+    z = torch.ones(200000, device=cuda, requires_grad=True)
+    d = A.Dropout.apply(z, 0.2, 1234)
+    d.sum().backward()
+    kept = (d.detach() != 0).float()
+    assert abs(float(kept.mean()) - 0.8) < 5e-3
+    assert torch.allclose(d.detach(), kept / 0.8) and torch.equal(z.grad, d.detach())
+    d2 = A.Dropout.apply(z, 0.2, 1235)
+    assert not torch.equal(d2.detach(), d.detach())
+
+
+def test_adam_step_and_grad_clip_match_torch(cuda, lib):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(12)
+    p0, grads = torch.randn(1000, generator=g), [torch.randn(1000, generator=g) * 3 for _ in range(4)]
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+    pd, m, v = p0.clone().to(cuda), torch.zeros(1000, device=cuda), torch.zeros(1000, device=cuda)
+    for step, gr in enumerate(grads, 1):
+        pr.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        ss = torch.zeros((), dtype=torch.float64, device=cuda)
+        gd = gr.to(cuda)
+        hip.sumsq(gd, ss)
+        hip.adam_step(pd, gd, m, v, 1e-2, 0.9, 0.98, 1e-9, 0.0, step, grad_sumsq=ss, max_norm=1.0)
+        assert relerr(pd.cpu(), pr.detach()) <= 1e-5, step
