@@ -130,6 +130,15 @@ class FastSpeech2(torch.nn.Module):
         if postnet_layers > 0:
             S.postnet_spec(spec, "postnet.", odim, postnet_layers, postnet_chans, postnet_filts, use_batch_norm)
         S.build_from_spec(self, spec)
+        # train-mode behaviour (models/fastspeech2_train.py): the dropout sites of the reference and the predictor detaches
+        self.dropout_rates = dict(
+            enc=transformer_enc_dropout_rate, enc_pos=transformer_enc_positional_dropout_rate, enc_attn=transformer_enc_attn_dropout_rate,
+            dec=transformer_dec_dropout_rate, dec_pos=transformer_dec_positional_dropout_rate, dec_attn=transformer_dec_attn_dropout_rate,
+            dur=duration_predictor_dropout_rate, pitch=pitch_predictor_dropout, energy=energy_predictor_dropout,
+            pitch_embed=pitch_embed_dropout, energy_embed=energy_embed_dropout, postnet=postnet_dropout_rate)
+        self.stop_gradient_from_pitch_predictor = stop_gradient_from_pitch_predictor
+        self.stop_gradient_from_energy_predictor = stop_gradient_from_energy_predictor
+        self._train_calls = 0
         self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
@@ -146,6 +155,13 @@ class FastSpeech2(torch.nn.Module):
     def load_state_dict(self, *a, **k):
         self._prep = None
         return super().load_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        """train(True) also turns the parameters' requires_grad on (they are created frozen for the inference path)."""
+        super().train(mode)
+        if mode:
+            self.requires_grad_(True)
+        return self
 
     def _apply(self, fn, *a, **k):
         self._prep = None
@@ -301,8 +317,26 @@ class FastSpeech2(torch.nn.Module):
         return dict(feat_gen=r["feat_gen"], duration=r["duration"], pitch=r["pitch"].unsqueeze(-1),
                     energy=r["energy"].unsqueeze(-1))
 
-    @torch.no_grad()
     def forward(
+        self, text: torch.Tensor, text_lengths: torch.Tensor, feats: torch.Tensor, feats_lengths: torch.Tensor,
+        durations: torch.Tensor, durations_lengths: torch.Tensor, pitch: torch.Tensor, pitch_lengths: torch.Tensor,
+        energy: torch.Tensor, energy_lengths: torch.Tensor, spembs: Optional[torch.Tensor] = None,
+        sids: Optional[torch.Tensor] = None, lids: Optional[torch.Tensor] = None, joint_training: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        """The reference's training-time call (fastspeech2.py:473-564).  In train() mode with gradients enabled this is the
+        differentiable HIP forward of models/fastspeech2_train.py (f32; batch-statistics BatchNorm, dropout); otherwise the
+        no-grad eval-mode pass below."""
+        if self.training and torch.is_grad_enabled():
+            from .fastspeech2_train import train_forward
+            self._train_calls += 1
+            self._prep = None   # the parameters are about to change under the packed inference weights
+            return train_forward(self, text, text_lengths, feats, feats_lengths, durations, durations_lengths, pitch, pitch_lengths,
+                                 energy, energy_lengths, seed=self._train_calls)
+        with torch.no_grad():
+            return self._forward_eval(text, text_lengths, feats, feats_lengths, durations, durations_lengths, pitch, pitch_lengths,
+                                      energy, energy_lengths, spembs, sids, lids, joint_training)
+
+    def _forward_eval(
         self, text: torch.Tensor, text_lengths: torch.Tensor, feats: torch.Tensor, feats_lengths: torch.Tensor,
         durations: torch.Tensor, durations_lengths: torch.Tensor, pitch: torch.Tensor, pitch_lengths: torch.Tensor,
         energy: torch.Tensor, energy_lengths: torch.Tensor, spembs: Optional[torch.Tensor] = None,

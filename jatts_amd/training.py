@@ -6,9 +6,10 @@ jatts/losses/) evaluated by HIP kernels on the dict that `FastSpeech2.forward()`
 (2) the backward of the hot path's work-horse op: `Conv1dFunction`, a torch.autograd.Function whose forward is jatts_conv1d and
 whose backward is three HIP launches (dx = jatts_conv1d on flipped / transposed weights, dW = jatts_conv1d_wgrad, db =
 jatts_col_sum), in f32; (3) `allreduce_gradients`: bucketed, flat gradient all-reduce over RCCL (what DDP does for the
-reference), usable after any backward.  What is NOT here yet: backward passes of the attention / LayerNorm / GLU / GroupNorm
-kernels and the train-mode behaviour of the models (dropout, batch-statistics BatchNorm) -- the models' forward() is the
-eval-mode arithmetic.  No CPU fallback: CPU tensors raise.
+reference), usable after any backward; (4) `FastSpeech2Trainer`: the whole `_train_step` -- FastSpeech2.forward() in train()
+mode (models/fastspeech2_train.py on the HIP forward / backward pairs of jatts_amd/autograd.py), the criterion, backward, the
+gradient all-reduce, clip_grad_norm_ + Adam as HIP kernels, the reference's WarmupLR schedule.  What is NOT here yet: the
+training paths of Matcha-TTS / VITS, speaker-conditioned FastSpeech2, f16 training.  No CPU fallback: CPU tensors raise.
 """
 import torch
 import torch.distributed as dist
@@ -127,3 +128,62 @@ def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True)
         n_coll += 1
         i = j
     return n_coll
+
+
+# ------------------------------------------------------------------------------------------ _train_step
+def warmup_lr(base_lr, step_num, warmup_steps):
+    """jatts/schedulers/warmup_lr.py:55-62: lr * warmup^0.5 * min(step^-0.5, step * warmup^-1.5), step_num counts from 1."""
+    return base_lr * warmup_steps ** 0.5 * min(step_num ** -0.5, step_num * warmup_steps ** -1.5)
+
+
+class FastSpeech2Trainer:
+    """`FastSpeech2Trainer._train_step` (jatts/trainers/fastspeech2.py:24-100) on one GPU of a data-parallel job:
+    forward (train mode) -> MelLoss + DurationPredictorLoss + PitchLoss + EnergyLoss -> backward -> gradient all-reduce over
+    the ranks (when torch.distributed is initialised) -> clip_grad_norm_(grad_norm) -> Adam -> WarmupLR.
+    The optimiser state is one flat f32 pair (m, v) per parameter; clip + Adam run as HIP kernels (jatts_sumsq / jatts_adam_step),
+    the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
+
+    def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None):
+        self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
+        self.grad_norm, self.warmup_steps, self.group = grad_norm, warmup_steps, group
+        model.train()   # (turns requires_grad on: the inference classes create frozen parameters)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.steps = 0
+        self.last_lr = None
+
+    def train_step(self, batch):
+        """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
+        energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
+        from .models.fastspeech2_train import criterion
+        m = self.model
+        m.train()
+        for p in self.params:
+            p.grad = None
+        ret = m(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"], batch["pitch"],
+                batch["pitch_lens"], batch["energys"], batch["energy_lens"])
+        losses = criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
+        losses["loss"].backward()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            allreduce_gradients(self.params, self.group)
+        self.steps += 1
+        lr = warmup_lr(self.base_lr, self.steps, self.warmup_steps) if self.warmup_steps else self.base_lr
+        self.last_lr = lr
+        ss = None
+        if self.grad_norm and self.grad_norm > 0:
+            ss = torch.zeros((), dtype=torch.float64, device=self.params[0].device)
+            for p in self.params:
+                if p.grad is not None:
+                    hip.sumsq(p.grad.contiguous(), ss)
+        with torch.no_grad():
+            for p, mm, vv in zip(self.params, self.m, self.v):
+                if p.grad is None:
+                    continue
+                hip.adam_step(p.data, p.grad.contiguous(), mm, vv, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps,
+                              grad_sumsq=ss, max_norm=self.grad_norm or 0.0)
+        m._prep = None
+        losses = {k: v.detach() for k, v in losses.items()}
+        if ss is not None:
+            losses["grad_norm"] = ss.sqrt()
+        return losses

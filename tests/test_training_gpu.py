@@ -102,3 +102,103 @@ def test_one_optimiser_step_through_the_hip_conv(cuda, lib):
         assert abs(float(loss) - float(lr_)) <= 1e-4 * max(1.0, float(lr_))
     assert losses[-1] < losses[0]
     assert maxdiff(l1.weight.data, r1.weight.data) <= 2e-4 and maxdiff(l2.weight.data, r2.weight.data) <= 2e-4
+
+
+def _train_golden():
+    import json
+    z, keys = load_golden("fs2_train_small.npz")
+    zi, _ = load_golden("fs2_forward_small.npz")
+    cfg = json.loads(str(z["config"]))
+    return z, zi, keys, cfg
+
+
+def test_fastspeech2_train_step_matches_reference(cuda, lib):
+    """One whole `_train_step` (trainers/fastspeech2.py:24-100) against the REAL reference run on the CPU
+    (tests/golden/make_golden_train.py): train()-mode forward on the padded batch (batch-statistics BatchNorm, dropout 0),
+    the four losses, EVERY parameter's gradient norm, full gradients of 22 parameters spread over all layer types, the total
+    norm, the BatchNorm running statistics, and the parameters after clip_grad_norm_(1.0) + Adam under WarmupLR."""
+    import json
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    m = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+    sd0 = golden_state(keys, 0)
+    m.load_state_dict(sd0)
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+    tr = FastSpeech2Trainer(m, lr=0.0008, grad_norm=1.0, warmup_steps=4000)
+    # forward + backward only first (gradients are consumed by the step)
+    m.train()
+    from jatts_amd.models.fastspeech2_train import criterion
+    ret = m(batch["xs"], il, batch["ys"], ol, batch["durations"], il, batch["pitch"], il, batch["energys"], il)
+    for k in ("before_outs", "after_outs", "d_outs", "p_outs", "e_outs"):
+        assert relerr(ret[k].detach(), z["ref_" + k]) <= 2e-5, (k, relerr(ret[k].detach(), z["ref_" + k]))
+    losses = criterion(ret, batch["durations"], batch["pitch"], batch["energys"], il)
+    for k in ("mel_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(losses[k]) - float(z[k])) <= 2e-5 * max(1.0, abs(float(z[k]))), (k, float(losses[k]), float(z[k]))
+    losses["loss"].backward()
+    names = json.loads(str(z["grad_names"]))
+    P = dict(m.named_parameters())
+    worst = ("", 0.0)
+    for n, ref_norm in zip(names, z["grad_norms"]):
+        g = P[n].grad
+        assert g is not None, n
+        e = abs(float(g.norm()) - ref_norm) / max(ref_norm, 1e-4)   # (linear_k.bias has an exactly-zero true gradient: 1e-8 noise on both sides)
+        worst = max(worst, (n, e), key=lambda v: v[1])
+        assert e <= 2e-3, (n, float(g.norm()), ref_norm)
+    for f in z.files:
+        if f.startswith("grad:"):
+            e = relerr(P[f[5:]].grad, z[f])
+            assert e <= 2e-3, (f, e)
+    tot = math.sqrt(sum(float(P[n].grad.double().pow(2).sum()) for n in names))
+    assert abs(tot - float(z["total_grad_norm"])) <= 1e-3 * float(z["total_grad_norm"])
+    B = dict(m.named_buffers())
+    for f in z.files:
+        if f.startswith("buf:"):
+            assert relerr(B[f[4:]], z[f]) <= 2e-5, f
+    # the whole step from the same starting point: parameters after clip + Adam + WarmupLR(step 1)
+    m2 = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+    m2.load_state_dict(sd0)
+    m2 = m2.to(cuda)
+    tr = FastSpeech2Trainer(m2, lr=0.0008, grad_norm=1.0, warmup_steps=4000)
+    out = tr.train_step(batch)
+    assert abs(tr.last_lr - float(z["lr_step1"])) <= 1e-12
+    assert abs(float(out["grad_norm"]) - float(z["total_grad_norm"])) <= 1e-3 * float(z["total_grad_norm"])
+    P2 = dict(m2.named_parameters())
+    for f in z.files:
+        if f.startswith("after:"):
+            n = f[6:]
+            before, after_ref, after = sd0[n].double(), torch.tensor(z[f]).double(), P2[n].detach().cpu().double()
+            step_ref, step = after_ref - before, after - before
+            # the first Adam step is -lr * g / (|g| + eps): compare the update itself, not the (1e7 x larger) parameter
+            # (plus one f32 ulp of the parameter on either side: the update is 2e-7 on values of order 0.1)
+            tol = 0.05 * tr.last_lr + 2.0 * float(before.abs().max()) * 2.0 ** -23
+            assert float((step - step_ref).abs().max()) <= tol, (n, float((step - step_ref).abs().max()), tol)
+            assert float(step.abs().max()) > 0.5 * tr.last_lr
+
+
+def test_fastspeech2_training_reduces_the_loss(cuda, lib):
+    """Twelve `_train_step`s with the v1 recipe's dropout rates ON (counter-based masks), lr without warm-up: the loss falls,
+    everything stays finite, eval-mode forward() afterwards sees the updated weights."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    m = FastSpeech2(idim=20, **{**FS2_SMALL, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+    m.eval()
+    y0 = m(batch["xs"], il, batch["ys"], ol, batch["durations"], il, batch["pitch"], il, batch["energys"], il)["after_outs"].clone()
+    tr = FastSpeech2Trainer(m, lr=2e-3, grad_norm=1.0, warmup_steps=0)
+    hist = [float(tr.train_step(batch)["loss"]) for _ in range(12)]
+    assert all(math.isfinite(v) for v in hist)
+    assert min(hist[-3:]) < 0.8 * hist[0], hist
+    m.eval()
+    y1 = m(batch["xs"], il, batch["ys"], ol, batch["durations"], il, batch["pitch"], il, batch["energys"], il)["after_outs"]
+    assert maxdiff(y0, y1) > 1e-3 and bool(torch.isfinite(y1).all())
