@@ -130,6 +130,22 @@ def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True)
     return n_coll
 
 
+def allreduce_flat(flat, group=None, bucket_bytes=64 << 20, average=True):
+    """All-reduce a flat gradient buffer in place, bucket_bytes at a time (slices: no packing copies).  -> number of collectives."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    per = max(1, bucket_bytes // flat.element_size())
+    n = 0
+    for o in range(0, flat.numel(), per):
+        sl = flat[o:o + per]
+        dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            sl /= world
+        n += 1
+    return n
+
+
 # ------------------------------------------------------------------------------------------ _train_step
 def warmup_lr(base_lr, step_num, warmup_steps):
     """jatts/schedulers/warmup_lr.py:55-62: lr * warmup^0.5 * min(step^-0.5, step * warmup^-1.5), step_num counts from 1."""
@@ -143,13 +159,31 @@ class FastSpeech2Trainer:
     The optimiser state is one flat f32 pair (m, v) per parameter; clip + Adam run as HIP kernels (jatts_sumsq / jatts_adam_step),
     the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
 
-    def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None):
+    def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
+                 bucket_bytes=64 << 20):
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
-        self.grad_norm, self.warmup_steps, self.group = grad_norm, warmup_steps, group
+        self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
         model.train()   # (turns requires_grad on: the inference classes create frozen parameters)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.m = [torch.zeros_like(p) for p in self.params]
-        self.v = [torch.zeros_like(p) for p in self.params]
+        if not self.params or self.params[0].device.type != "cuda":
+            raise hip._abi.JattsHipError("FastSpeech2Trainer needs the model on the GPU (no CPU fallback)")
+        # one flat f32 buffer each for parameters, gradients and the two Adam moments; every parameter / .grad is a view into it:
+        # zero_grad is one fill, the norm one reduction, Adam one launch, and the all-reduce runs on slices of the gradient
+        # buffer with no packing copies (288 GB of HBM: the 4 x 281 MB of FastSpeech2 are nothing)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        o = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat_p[o:o + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + k].view(p.shape)
+                p.grad = self.flat_g[o:o + k].view(p.shape)
+                o += k
         self.steps = 0
         self.last_lr = None
 
@@ -159,29 +193,27 @@ class FastSpeech2Trainer:
         from .models.fastspeech2_train import criterion
         m = self.model
         m.train()
-        for p in self.params:
-            p.grad = None
+        self.flat_g.zero_()
+        o = 0
+        for p in self.params:       # (re-attach: a caller may have set .grad to None)
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+            o += p.numel()
         ret = m(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"], batch["pitch"],
                 batch["pitch_lens"], batch["energys"], batch["energy_lens"])
         losses = criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
         losses["loss"].backward()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            allreduce_gradients(self.params, self.group)
+            allreduce_flat(self.flat_g, self.group, self.bucket_bytes)
         self.steps += 1
         lr = warmup_lr(self.base_lr, self.steps, self.warmup_steps) if self.warmup_steps else self.base_lr
         self.last_lr = lr
         ss = None
         if self.grad_norm and self.grad_norm > 0:
-            ss = torch.zeros((), dtype=torch.float64, device=self.params[0].device)
-            for p in self.params:
-                if p.grad is not None:
-                    hip.sumsq(p.grad.contiguous(), ss)
-        with torch.no_grad():
-            for p, mm, vv in zip(self.params, self.m, self.v):
-                if p.grad is None:
-                    continue
-                hip.adam_step(p.data, p.grad.contiguous(), mm, vv, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps,
-                              grad_sumsq=ss, max_norm=self.grad_norm or 0.0)
+            ss = torch.zeros((), dtype=torch.float64, device=self.flat_g.device)
+            hip.sumsq(self.flat_g, ss)
+        hip.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps,
+                      grad_sumsq=ss, max_norm=self.grad_norm or 0.0)
         m._prep = None
         losses = {k: v.detach() for k, v in losses.items()}
         if ss is not None:

@@ -80,6 +80,11 @@ def _grad_worker(rank, world, port, q):
     n = allreduce_gradients(params, bucket_bytes=1 << 20)     # 1 MiB buckets -> the 1.2 MB tensor gets its own collective
     want = [(sum(range(1, world + 1)) / world) * (i + 1) for i in range(len(params))]
     ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(params, want))
+    # the trainer's flat gradient buffer: slices of one tensor, no packing (FastSpeech2Trainer.train_step)
+    from jatts_amd.training import allreduce_flat
+    flat = torch.arange(700000, dtype=torch.float32) * float(rank + 1)
+    n2 = allreduce_flat(flat, bucket_bytes=1 << 20)
+    ok = ok and n2 == 3 and torch.allclose(flat, torch.arange(700000, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
     q.put((rank, ok, n))
     dist.barrier()
     dist.destroy_process_group()
