@@ -2,6 +2,8 @@
 // gradients of jatts_conv1d.  The data gradient of a conv is jatts_conv1d itself on flipped, transposed weights.
 // Reference: jatts/trainers/fastspeech2.py:24-100 (_train_step), jatts/losses/{l1l2_loss,duration_predictor_loss,
 // variance_predictor_loss}.py, torch.nn.Conv1d's autograd.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -82,6 +84,84 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
     }
 }
 
+// The same reduction on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: A = dy^T fragment [32 n][2 t], B = x fragment [2 t][32 c], the
+// contraction runs over TIME).  In the time-major layout both operands of a 2-step MFMA are two coalesced 128-byte row pieces, so the
+// fragments come straight out of row-major LDS tiles with one ds_read_b32 each.  A workgroup (4 waves, one 32 x 32 fragment each)
+// owns a 64(n) x 64(c) tile for ALL taps (accumulators [KW] x 16 registers): dy and x are staged once per 32-step chunk instead of
+// once per tap.  Split over the sequences like the VALU kernel; partial tiles are added with f32 atomics.
+template <int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                              int ldy, int c_in, int n_out, int dil, int pad, int seq_groups,
+                                                              float* __restrict__ dw) {
+  constexpr int TT = 32, P = 68;
+  extern __shared__ float sm[];
+  float* dys = sm;
+  float* xs = sm + TT * P;
+  const int halo = (KW - 1) * dil;
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, grp = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wn = wave >> 1, wc = wave & 1, hi = lane >> 5, lo = lane & 31;
+  const bool vec_dy = (ldy & 3) == 0 && n0 + 64 <= n_out && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+  const bool vec_x = (ldx & 3) == 0 && c0 + 64 <= c_in && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  f32x16 acc[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  for (int s = grp; s < rg.n_seq; s += seq_groups) {
+    const int64_t row0 = (int64_t)rg.cu_rows[s] * rg.len_mul;
+    const int L = (rg.cu_rows[s + 1] - rg.cu_rows[s]) * rg.len_mul;
+    for (int t0 = 0; t0 < L; t0 += TT) {
+      for (int i = threadIdx.x; i < TT * 16; i += 256) {
+        const int r = i >> 4, q = (i & 15) * 4;
+        const int tt = t0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tt < L) {
+          const float* src = dy + (row0 + tt) * ldy + n0 + q;
+          if (vec_dy) v = *reinterpret_cast<const f32x4*>(src);
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n0 + q + e < n_out) v[e] = src[e];
+        }
+        *reinterpret_cast<f32x4*>(&dys[r * P + q]) = v;
+      }
+      for (int i = threadIdx.x; i < (TT + halo) * 16; i += 256) {
+        const int r = i >> 4, q = (i & 15) * 4;
+        const int p = t0 - pad + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p >= 0 && p < L) {
+          const float* src = x + (row0 + p) * ldx + c0 + q;
+          if (vec_x) v = *reinterpret_cast<const f32x4*>(src);
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c0 + q + e < c_in) v[e] = src[e];
+        }
+        *reinterpret_cast<f32x4*>(&xs[r * P + q]) = v;
+      }
+      __syncthreads();
+      const float* ap = dys + hi * P + wn * 32 + lo;
+      const float* bp = xs + hi * P + wc * 32 + lo;
+#pragma unroll 4
+      for (int tp = 0; tp < TT / 2; ++tp) {
+        const float a = ap[2 * tp * P];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(2 * tp + k * dil) * P], acc[k], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  // C/D map: column (lane & 31) = c, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = n
+  const int c = c0 + wc * 32 + lo;
+  if (c < c_in)
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (n < n_out) atomicAdd(&dw[((int64_t)n * c_in + c) * KW + k], acc[k][r]);
+      }
+}
+
 // out[c] += sum over rows of x[row][c]
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, int64_t rows, int dim, float* out) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -122,6 +202,20 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
   int groups = (1024 + tiles - 1) / tiles;            // enough workgroups to fill the chip; each group strides over the sequences
   if (groups > rg->n_seq) groups = rg->n_seq;
   if (groups < 1) groups = 1;
+  static const int use_mfma = [] { const char* e = getenv("JATTS_WGRAD_MFMA"); return e ? atoi(e) : 1; }();
+  if (use_mfma && (k_w == 1 || k_w == 3 || k_w == 5) && (k_w - 1) * dil <= 32) {
+    const int tiles_m = ((n_out + 63) / 64) * ((c_in + 63) / 64);
+    int g = (1536 + tiles_m - 1) / tiles_m;
+    if (g > rg->n_seq) g = rg->n_seq;
+    if (g < 1) g = 1;
+    const dim3 grid((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)g);
+    const size_t lds = (size_t)(64 + (k_w - 1) * dil) * 68 * sizeof(float);
+    if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw);
+    else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw);
+    else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw);
+    JATTS_CHECK_LAUNCH();
+    return JATTS_OK;
+  }
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)(k_w * groups)), dim3(256), 0, S_,
                      *rg, x, ldx, dy, ldy, c_in, n_out, k_w, dil, pad, groups, dw);
   JATTS_CHECK_LAUNCH();
