@@ -162,6 +162,79 @@ __global__ __launch_bounds__(256) void dwconv_kernel(jatts_ragged rg, const floa
     y[(int64_t)(row0 + t) * C + c] = acc;
   }
 }
+// Tiled variants for the conformer kernel sizes (7 encoder, 31 decoder): a workgroup stages a [64 + K - 1 steps][64 channels] window
+// of x in LDS once; thread (channel, quarter) slides a register window over its 16 consecutive steps, so each x value is read from
+// LDS once per thread instead of K times from L1/L2 (the naive kernel above is 17x off the HBM bound at K = 31).
+constexpr int DWT = 64;   // time steps per workgroup
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_tiled_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y, int C, int pad, int flip) {
+  __shared__ float xs[DWT + K - 1][64];
+  const int s = blockIdx.y, c0 = blockIdx.z * 64, t0 = blockIdx.x * DWT;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  if (t0 >= L) return;
+  const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6, c = c0 + cl;
+  for (int i = threadIdx.x; i < (DWT + K - 1) * 64; i += 256) {
+    const int r = i >> 6, j = i & 63, p = t0 - pad + r;
+    xs[r][j] = (p >= 0 && p < L && c0 + j < C) ? x[(int64_t)(row0 + p) * C + c0 + j] : 0.f;
+  }
+  float wv[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wv[k] = c < C ? w[c * K + (flip ? K - 1 - k : k)] : 0.f;
+  const float bias = (b && c < C) ? b[c] : 0.f;
+  __syncthreads();
+  float win[16 + K - 1];
+#pragma unroll
+  for (int i = 0; i < 16 + K - 1; ++i) win[i] = xs[tq * 16 + i][cl];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float acc = bias;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc += wv[k] * win[i + k];
+    const int t = t0 + tq * 16 + i;
+    if (t < L && c < C) y[(int64_t)(row0 + t) * C + c] = acc;
+  }
+}
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ dw, int C, int pad, int tiles_per_block) {
+  __shared__ float xs[DWT + K - 1][64];
+  __shared__ float red[4][64];
+  const int s = blockIdx.y, c0 = blockIdx.z * 64;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6, c = c0 + cl;
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  for (int tile = 0; tile < tiles_per_block; ++tile) {
+    const int t0 = (blockIdx.x * tiles_per_block + tile) * DWT;
+    if (t0 >= L) break;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (DWT + K - 1) * 64; i += 256) {
+      const int r = i >> 6, j = i & 63, p = t0 - pad + r;
+      xs[r][j] = (p >= 0 && p < L && c0 + j < C) ? x[(int64_t)(row0 + p) * C + c0 + j] : 0.f;
+    }
+    __syncthreads();
+    float win[16 + K - 1];
+#pragma unroll
+    for (int i = 0; i < 16 + K - 1; ++i) win[i] = xs[tq * 16 + i][cl];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = t0 + tq * 16 + i;
+      const float d = (t < L && c < C) ? dy[(int64_t)(row0 + t) * C + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += d * win[i + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+    red[tq][cl] = acc[k];
+    __syncthreads();
+    if (tq == 0 && c < C) atomicAdd(&dw[c * K + k], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  }
+}
+
 // dw[c][k] += sum_t dy[t][c] x[t + k - pad][c]; a workgroup = 64 channels x a slice of (sequence, time); wave w takes rows t = w mod 4
 constexpr int DW_KMAX = 32;
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy,
@@ -499,8 +572,12 @@ extern "C" int jatts_dwconv(const jatts_ragged* rg, const float* x, const float*
   NULLCHK(!rg || !x || !w || !y, "dwconv: null pointer");
   NULLCHK(dim < 1 || k_w < 1 || k_w > DW_KMAX, "dwconv: 1 <= k_w <= 32");
   if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((int64_t)rg->max_len * dim, 256, 1024), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, w, bias,
-                     y, dim, k_w, pad, flip);
+  const dim3 tgrid((unsigned)((rg->max_len + DWT - 1) / DWT), (unsigned)rg->n_seq, (unsigned)((dim + 63) / 64));
+  if (k_w == 7) hipLaunchKernelGGL(dwconv_tiled_kernel<7>, tgrid, dim3(256), 0, S_, *rg, x, w, bias, y, dim, pad, flip);
+  else if (k_w == 31) hipLaunchKernelGGL(dwconv_tiled_kernel<31>, tgrid, dim3(256), 0, S_, *rg, x, w, bias, y, dim, pad, flip);
+  else
+    hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((int64_t)rg->max_len * dim, 256, 1024), (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, w, bias,
+                       y, dim, k_w, pad, flip);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -509,6 +586,15 @@ extern "C" int jatts_dwconv_wgrad(const jatts_ragged* rg, const float* x, const 
   NULLCHK(!rg || !x || !dy || !dw, "dwconv_wgrad: null pointer");
   NULLCHK(dim < 1 || k_w < 1 || k_w > DW_KMAX, "dwconv_wgrad: 1 <= k_w <= 32");
   if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  if (k_w == 7 || k_w == 31) {
+    const int tiles = (rg->max_len + DWT - 1) / DWT;
+    const int tpb = tiles > 8 ? 4 : 1;     // a few tiles per workgroup: 4x fewer atomics on long sequences
+    const dim3 tgrid((unsigned)((tiles + tpb - 1) / tpb), (unsigned)rg->n_seq, (unsigned)((dim + 63) / 64));
+    if (k_w == 7) hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<7>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb);
+    else hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<31>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb);
+    JATTS_CHECK_LAUNCH();
+    return JATTS_OK;
+  }
   unsigned gz = (unsigned)((rg->max_len + 63) / 64);
   if (gz > 64) gz = 64;
   hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)rg->n_seq, gz), dim3(256), 0, S_, *rg, x, dy, dw, dim, k_w, pad);

@@ -146,7 +146,7 @@ def test_fastspeech2_train_step_matches_reference(cuda, lib):
     for n, ref_norm in zip(names, z["grad_norms"]):
         g = P[n].grad
         assert g is not None, n
-        e = abs(float(g.norm()) - ref_norm) / max(ref_norm, 1e-4)   # (linear_k.bias has an exactly-zero true gradient: 1e-8 noise on both sides)
+        e = abs(float(g.norm()) - ref_norm) / max(ref_norm, 1e-3)   # (linear_k.bias and the conv biases in front of a batch-stat BatchNorm have exactly-zero true gradients: 1e-8 .. 1e-6 of rounding noise on both sides)
         worst = max(worst, (n, e), key=lambda v: v[1])
         assert e <= 2e-3, (n, float(g.norm()), ref_norm)
     for f in z.files:
