@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--vocoder", default="22k", choices=["22k", "24k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the f16 fast-mode leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the FastSpeech2 train-step line")
     ap.add_argument("--no-configs", action="store_true", help="skip the Matcha-TTS / VITS config lines")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child: one step, no JSON
@@ -349,6 +350,38 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     )
 
 
+def train_step_line(dev, steps, batch=32, t_text=128, frames=6):
+    """FastSpeech2Trainer.train_step (jatts/trainers/fastspeech2.py:24-100) on the conf/fastspeech2.v1.yaml model: forward in
+    train mode, the four losses, backward, clip + Adam -- f32, synthetic weights / targets, the recipe's batch_size 32."""
+    import torch
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.synthetic import FS2_JSUT, synth_state_dict
+    from jatts_amd.training import FastSpeech2Trainer
+    m = FastSpeech2(idim=45, **{**FS2_JSUT, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    il = torch.full((batch,), t_text, dtype=torch.long)
+    ds = torch.full((batch, t_text), frames, dtype=torch.long)
+    ol = ds.sum(1)
+    b = dict(xs=torch.randint(1, 45, (batch, t_text), generator=g).to(dev), ilens=il, ys=torch.randn(batch, int(ol.max()), 80, generator=g).to(dev),
+             olens=ol, durations=ds.to(dev), duration_lens=il, pitch=torch.randn(batch, t_text, 1, generator=g).to(dev), pitch_lens=il,
+             energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il)
+    tr = FastSpeech2Trainer(m, lr=1e-4, grad_norm=1.0, warmup_steps=0)
+    first = float(tr.train_step(b)["loss"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = tr.train_step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_frames = int(ol.sum())
+    return {"workload": f"FastSpeech2 (fastspeech2.v1.yaml) _train_step, batch {batch} x {t_text} phonemes x {frames} frames", "dtype": "f32",
+            "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": n_frames / dt, "dense_tflops_per_step": 3 * 67.4e-3 * batch,
+            "achieved_tflops": 3 * 67.4e-3 * batch / dt, "loss_first": first, "loss_last": float(o["loss"]),
+            "parity": "tests/test_training_gpu.py (one whole step vs the real reference: every parameter gradient)"}
+
+
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate"}
 
 
@@ -474,6 +507,11 @@ def main():
         out["configs"] = cfgs
         out["configs_note"] = ("configs[0] is the reference's own CPU case (see cpu_baseline); configs[3] = this line's workload on "
                                "8 GPUs (bench.py --gpus 8); configs[4] = 8 x the VITS line's per-GPU share")
+
+    # ---- one FastSpeech2 `_train_step` at the recipe's batch size (not part of `value`): N == 1 only
+    if world == 1 and not a.no_train:
+        out["training"] = train_step_line(dev, max(2, min(3, a.steps)))
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from jatts_amd.synthetic import synth_texts
