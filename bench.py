@@ -226,7 +226,7 @@ class Job:
         return self.m.inference_batch(self.texts, self.spk, noise_scale=0.667, durations=self.dur, noise=self.noise)
 
 
-def run_timed(job, a, world, dist, pipeline=False):
+def run_timed(job, a, world, dist, pipeline=False, record=True):
     """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks.  -> dict"""
     import torch
     from jatts_amd import hip
@@ -254,7 +254,8 @@ def run_timed(job, a, world, dist, pipeline=False):
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    hip.profile_begin()
+    if record:   # per-kernel HIP events (the roofline block); off for the many-small-launch configs, where they cost ~10 us each
+        hip.profile_begin()
     stage_ev.clear()
     t0 = time.perf_counter()
     if pipeline and job.kind == "fs2":
@@ -272,7 +273,7 @@ def run_timed(job, a, world, dist, pipeline=False):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    recs = hip.profile_end()
+    recs = hip.profile_end() if record else []
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=job.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -488,7 +489,7 @@ def main():
             ref = None
             for p in ("fp32", "fp16"):
                 j.set_precision(p)
-                r = run_timed(j, aa, 1, None)
+                r = run_timed(j, aa, 1, None, record=False)
                 e = {"value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "rtf": r["rtf"],
                      "stage_ms_per_step": r["stages"]}
                 if p == "fp32":

@@ -187,6 +187,60 @@ class FastSpeech2Trainer:
         self.steps = 0
         self.last_lr = None
 
+    # -- checkpoints in the reference's format (jatts/trainers/base.py:85-124): {"model", "optimizer", "scheduler", "steps", "epochs"};
+    # "optimizer" is a torch.optim.Adam state_dict (state indexed by the position in model.parameters()), so a checkpoint written here
+    # resumes under the reference trainer and vice versa.
+    def _views(self, flat):
+        out, o = [], 0
+        for p in self.params:
+            out.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        return out
+
+    def state_dict(self, epochs=0):
+        m, v = self._views(self.flat_m), self._views(self.flat_v)
+        opt = {"state": {}, "param_groups": [dict(lr=self.last_lr if self.last_lr is not None else self.base_lr, betas=tuple(self.betas),
+                                                  eps=self.eps, weight_decay=self.wd, amsgrad=False, maximize=False, foreach=None,
+                                                  capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False,
+                                                  initial_lr=self.base_lr, params=list(range(len(self.params))))]}
+        if self.steps > 0:
+            for i in range(len(self.params)):
+                opt["state"][i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[i].detach().cpu().clone(),
+                                   "exp_avg_sq": v[i].detach().cpu().clone()}
+        sch = {"warmup_steps": self.warmup_steps, "base_lrs": [self.base_lr], "last_epoch": self.steps, "_step_count": self.steps + 1,
+               "_get_lr_called_within_step": False, "_last_lr": [self.last_lr if self.last_lr is not None else self.base_lr]}
+        return {"model": {k: t.detach().cpu().clone() for k, t in self.model.state_dict().items()}, "optimizer": opt, "scheduler": sch,
+                "steps": self.steps, "epochs": epochs}
+
+    def save_checkpoint(self, checkpoint_path, epochs=0):
+        import os
+        d = os.path.dirname(checkpoint_path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        torch.save(self.state_dict(epochs), checkpoint_path)
+
+    def load_checkpoint(self, checkpoint_path, load_only_params=False):
+        sd = torch.load(checkpoint_path, map_location="cpu") if isinstance(checkpoint_path, str) else checkpoint_path
+        with torch.no_grad():      # copy INTO the flat views (load_state_dict copies in place: the views stay attached)
+            self.model.load_state_dict(sd["model"])
+        self.model._prep = None
+        if load_only_params:
+            return
+        self.steps = int(sd["steps"])
+        st = sd["optimizer"]["state"]
+        if len(st) not in (0, len(self.params)):
+            raise ValueError("optimizer state does not match the model's parameter list")
+        with torch.no_grad():
+            for i, (mv, vv) in enumerate(zip(self._views(self.flat_m), self._views(self.flat_v))):
+                if i in st:
+                    mv.copy_(st[i]["exp_avg"])
+                    vv.copy_(st[i]["exp_avg_sq"])
+        g = sd["optimizer"]["param_groups"][0]
+        self.betas, self.eps, self.wd = tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self.base_lr = g.get("initial_lr", self.base_lr)
+        if "scheduler" in sd and sd["scheduler"]:
+            self.warmup_steps = sd["scheduler"].get("warmup_steps", self.warmup_steps)
+
     def train_step(self, batch):
         """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""

@@ -202,3 +202,40 @@ def test_fastspeech2_training_reduces_the_loss(cuda, lib):
     m.eval()
     y1 = m(batch["xs"], il, batch["ys"], ol, batch["durations"], il, batch["pitch"], il, batch["energys"], il)["after_outs"]
     assert maxdiff(y0, y1) > 1e-3 and bool(torch.isfinite(y1).all())
+
+
+def test_trainer_checkpoint_is_the_reference_format_and_resumes(cuda, lib, tmp_path):
+    """jatts/trainers/base.py:85-124: {"model", "optimizer", "scheduler", "steps", "epochs"} with a torch.optim.Adam state_dict
+    (torch's own Adam must accept it, indexed like the reference's parameter order); a resumed trainer continues bit-for-bit."""
+    import json
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+
+    def make():
+        m = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+        m.load_state_dict(golden_state(keys, 0))
+        return m.to(cuda)
+    a = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=10)
+    assert [n for n, _ in a.model.named_parameters()] == json.loads(str(z["grad_names"]))   # the reference's parameter order
+    for _ in range(2):
+        a.train_step(batch)
+    path = str(tmp_path / "ckpt" / "checkpoint-2steps.pkl")
+    a.save_checkpoint(path, epochs=1)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "scheduler", "steps", "epochs"} and ck["steps"] == 2
+    ref_model = make()
+    ref_model.train()
+    topt = torch.optim.Adam(ref_model.parameters(), lr=1e-3)
+    topt.load_state_dict(ck["optimizer"])                                                     # torch accepts the layout
+    assert len(topt.state_dict()["state"]) == len(list(ref_model.parameters()))
+    b = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=10)
+    b.load_checkpoint(path)
+    assert b.steps == 2
+    la, lb = a.train_step(batch), b.train_step(batch)
+    assert abs(float(la["loss"]) - float(lb["loss"])) <= 1e-6 * abs(float(la["loss"]))
+    assert maxdiff(a.flat_p, b.flat_p) <= 1e-7 and abs(a.last_lr - b.last_lr) == 0.0
