@@ -207,6 +207,26 @@ class OuterRows(torch.autograd.Function):
         return dv, dw, db
 
 
+class AddSeqVector(torch.autograd.Function):
+    """hs + vec.unsqueeze(1): one vector per sequence added to all of its rows (speaker / sid embeddings,
+    fastspeech2.py:589-597,750-753).  d_vec[b] = sum of d_hs over the rows of sequence b."""
+
+    @staticmethod
+    def forward(ctx, hs, vec, rb):
+        ctx.rb = rb
+        return hip.add_seq_vector(rb, hs.contiguous().clone(), vec.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        rb = ctx.rb
+        dvec = None
+        if ctx.needs_input_grad[1]:
+            dy = dy.contiguous()
+            lens = torch.tensor(rb.lens, dtype=torch.float32, device=dy.device).unsqueeze(1)
+            dvec = hip.seq_mean_std(rb, dy, dy.shape[1], want_std=False) * lens
+        return dy, dvec, None
+
+
 class MaskRows(torch.autograd.Function):
     """x * non_pad_mask on a padded batch (variance_predictor.py:81-83, duration_predictor.py:93-96)."""
 

@@ -331,7 +331,7 @@ class FastSpeech2(torch.nn.Module):
             self._train_calls += 1
             self._prep = None   # the parameters are about to change under the packed inference weights
             return train_forward(self, text, text_lengths, feats, feats_lengths, durations, durations_lengths, pitch, pitch_lengths,
-                                 energy, energy_lengths, seed=self._train_calls)
+                                 energy, energy_lengths, spembs=spembs, sids=sids, seed=self._train_calls)
         with torch.no_grad():
             return self._forward_eval(text, text_lengths, feats, feats_lengths, durations, durations_lengths, pitch, pitch_lengths,
                                       energy, energy_lengths, spembs, sids, lids, joint_training)

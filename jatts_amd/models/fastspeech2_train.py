@@ -125,7 +125,7 @@ def _embed1(c, name, v, rb):
 
 
 def train_forward(model, text, text_lengths, feats, feats_lengths, durations, durations_lengths, pitch, pitch_lengths, energy,
-                  energy_lengths, seed=0):
+                  energy_lengths, spembs=None, sids=None, seed=0):
     """-> the reference's return dict {before_outs, after_outs, d_outs, p_outs, e_outs, ys, olens}, differentiable."""
     dev = model.feat_out.weight.device
     if dev.type != "cuda":
@@ -150,8 +150,14 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     x = A.Embedding.apply(ids, c.p["encoder.embed.0.weight"], math.sqrt(Ad), model.padding_idx)
     x = c.drop(x, R["enc_pos"])
     hs = _conformer(c, "encoder.", x, rb, kv, model.aheads, dict(pos=R["enc_pos"], layer=R["enc"], ffn=R["enc"], attn=R["enc_attn"]))
-    if model.spks is not None or model.spk_embed_dim is not None:
-        raise NotImplementedError("speaker conditioning is not wired into the training path yet")
+    if model.spks is not None:                                       # fastspeech2.py:589-592
+        rbs = hip.RaggedBatch([1] * B, dev)
+        sid = A.Embedding.apply(sids.to(dev).view(-1).to(torch.int64).contiguous(), c.p["sid_emb.weight"], 1.0, -1)
+        hs = A.AddSeqVector.apply(hs, sid, rb)
+    if model.spk_embed_dim is not None:                              # :594-597, _integrate_with_spk_embed "add" (:750-753)
+        rbs = hip.RaggedBatch([1] * B, dev)
+        sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), hip.F32)
+        hs = A.AddSeqVector.apply(hs, c.conv(sp, "projection", rbs), rb)
     p_outs = A.MaskRows.apply(_predictor(c, "pitch_predictor.", hs.detach() if model.stop_gradient_from_pitch_predictor else hs, rb,
                                          R["pitch"]), rb, kv)
     e_outs = A.MaskRows.apply(_predictor(c, "energy_predictor.", hs.detach() if model.stop_gradient_from_energy_predictor else hs, rb,

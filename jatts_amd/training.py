@@ -9,7 +9,7 @@ jatts_col_sum), in f32; (3) `allreduce_gradients`: bucketed, flat gradient all-r
 reference), usable after any backward; (4) `FastSpeech2Trainer`: the whole `_train_step` -- FastSpeech2.forward() in train()
 mode (models/fastspeech2_train.py on the HIP forward / backward pairs of jatts_amd/autograd.py), the criterion, backward, the
 gradient all-reduce, clip_grad_norm_ + Adam as HIP kernels, the reference's WarmupLR schedule.  What is NOT here yet: the
-training paths of Matcha-TTS / VITS, speaker-conditioned FastSpeech2, f16 training.  No CPU fallback: CPU tensors raise.
+training paths of Matcha-TTS / VITS, f16 training.  No CPU fallback: CPU tensors raise.
 """
 import torch
 import torch.distributed as dist
@@ -254,7 +254,7 @@ class FastSpeech2Trainer:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
             o += p.numel()
         ret = m(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"], batch["pitch"],
-                batch["pitch_lens"], batch["energys"], batch["energy_lens"])
+                batch["pitch_lens"], batch["energys"], batch["energy_lens"], batch.get("spkembs"), batch.get("sids"))
         losses = criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
         losses["loss"].backward()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:

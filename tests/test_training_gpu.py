@@ -99,7 +99,7 @@ def test_one_optimiser_step_through_the_hip_conv(cuda, lib):
         lr_.backward()
         opr.step()
         losses.append(float(loss.detach()))
-        assert abs(float(loss) - float(lr_)) <= 1e-4 * max(1.0, float(lr_))
+        assert abs(float(loss.detach()) - float(lr_.detach())) <= 1e-4 * max(1.0, float(lr_.detach()))
     assert losses[-1] < losses[0]
     assert maxdiff(l1.weight.data, r1.weight.data) <= 2e-4 and maxdiff(l2.weight.data, r2.weight.data) <= 2e-4
 
@@ -239,3 +239,30 @@ def test_trainer_checkpoint_is_the_reference_format_and_resumes(cuda, lib, tmp_p
     la, lb = a.train_step(batch), b.train_step(batch)
     assert abs(float(la["loss"]) - float(lb["loss"])) <= 1e-6 * abs(float(la["loss"]))
     assert maxdiff(a.flat_p, b.flat_p) <= 1e-7 and abs(a.last_lr - b.last_lr) == 0.0
+
+
+def test_fastspeech2_speaker_conditioned_train_step_matches_reference(cuda, lib):
+    """The same step with spk_embed_dim=16 ("add" integration: F.normalize -> projection) and 3 speaker ids (sid_emb), against the
+    real reference (fs2_train_spk_small.npz): outputs, losses, every parameter's gradient norm, the two new parameters' gradients."""
+    import json
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.models.fastspeech2_train import criterion
+    _, zi, _, cfg = _train_golden()
+    z, keys = load_golden("fs2_train_spk_small.npz")
+    m = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg, "spk_embed_dim": 16, "spks": 3})
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda).train()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    ret = m(t("text"), il, t("feats"), ol, t("durations"), il, t("pitch"), il, t("energy"), il, spembs=torch.tensor(z["spembs"]),
+            sids=torch.tensor(z["sids"]))
+    assert relerr(ret["after_outs"].detach(), z["ref_after_outs"]) <= 2e-5
+    losses = criterion(ret, t("durations"), t("pitch"), t("energy"), il)
+    for k in ("mel_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(losses[k]) - float(z[k])) <= 2e-5 * max(1.0, abs(float(z[k]))), k
+    losses["loss"].backward()
+    P = dict(m.named_parameters())
+    for n, ref_norm in zip(json.loads(str(z["grad_names"])), z["grad_norms"]):
+        assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, 1e-3) <= 2e-3, n
+    for n in ("projection.weight", "sid_emb.weight"):
+        assert relerr(P[n].grad, z["grad:" + n]) <= 2e-3, n
