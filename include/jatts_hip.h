@@ -205,7 +205,7 @@ int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* 
 /* LayerNorm over the channels (modules/transformer/layer_norm.py:12-42): dx (nullable), dgamma += , dbeta += (both or neither). dim <= 1536. */
 int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* gamma, int64_t rows, int32_t dim,
                         float eps, float* dx, int32_t lddx, float* dgamma, float* dbeta, void* stream);
-/* Element-wise activations, mode 1 ReLU, 2 tanh, 3 Swish (x sigmoid x, modules/conformer/swish.py); bwd: dx = dy * act'(x). */
+/* Element-wise activations, mode 1 ReLU, 2 tanh, 3 Swish (x sigmoid x, modules/conformer/swish.py), 4 Mish; bwd: dx = dy * act'(x). */
 int jatts_act_fwd(int32_t mode, const float* x, float* y, int64_t n, void* stream);
 int jatts_act_bwd(int32_t mode, const float* x, const float* dy, float* dx, int64_t n, void* stream);
 /* GLU over the channel halves (convolution.py:66: F.glu(dim=1)): x [rows][2 dim] -> y [rows][dim]. */
@@ -249,6 +249,19 @@ int jatts_row_dot(const float* x, int32_t ld, const float* w, const float* bias,
 int jatts_masked_loss_bwd(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
                           const int32_t* valid_len, int32_t kind, float log_offset, float scale, const float* upstream, float* da,
                           int32_t ldda, void* stream);
+/* torch.nn.GroupNorm(groups, dim) over each sequence's [rows][dim / groups] slabs (matchatts/decoder.py:66-78 Block1D; the
+ * statistics run over every row of the sequence as laid out, i.e. the padded length of a padded batch).  fwd also returns the
+ * per-(sequence, group) mean / rstd [n_seq * groups] for the backward; bwd: dx (nullable), dgamma +=, dbeta += (both or neither).
+ * dim / groups must divide 256. */
+int jatts_groupnorm_fwd(const jatts_ragged* rg, const float* x, int32_t dim, int32_t groups, const float* gamma, const float* beta,
+                        float eps, float* y, float* mean, float* rstd, void* stream);
+int jatts_groupnorm_bwd(const jatts_ragged* rg, const float* x, const float* dy, int32_t dim, int32_t groups, const float* gamma,
+                        const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, void* stream);
+/* SnakeBeta with log-scale parameters (matchatts/transformer.py:84-102): y = x + sin^2(exp(alpha) x) / (exp(beta) + 1e-9);
+ * bwd: dx, dalpha +=, dbeta += (gradients w.r.t. the LOG parameters, as stored). */
+int jatts_snakebeta_fwd(const float* x, float* y, int64_t rows, int32_t dim, const float* alpha, const float* beta, void* stream);
+int jatts_snakebeta_bwd(const float* x, const float* dy, int64_t rows, int32_t dim, const float* alpha, const float* beta, float* dx,
+                        float* dalpha, float* dbeta, void* stream);
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by

@@ -64,6 +64,40 @@ class GLU(torch.autograd.Function):
         return hip.glu_bwd(x, dy.contiguous())
 
 
+class GroupNorm(torch.autograd.Function):
+    """torch.nn.GroupNorm(groups, C) on each sequence of the (padded) batch (matchatts/decoder.py:66-78)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rb, groups, eps):
+        x = x.contiguous()
+        y, mean, rstd = hip.groupnorm_fwd(rb, x, groups, gamma.detach().contiguous(), beta.detach().contiguous(), eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.rb, ctx.groups = rb, groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = hip.groupnorm_bwd(ctx.rb, x, dy.contiguous(), ctx.groups, gamma.detach().contiguous(), mean, rstd,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dg, db, None, None, None
+
+
+class SnakeBeta(torch.autograd.Function):
+    """SnakeBeta activation with log-scale alpha / beta (matchatts/transformer.py:84-102), after its Linear."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta):
+        x = x.contiguous()
+        ctx.save_for_backward(x, alpha, beta)
+        return hip.snakebeta_fwd(x, alpha.detach().contiguous(), beta.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha, beta = ctx.saved_tensors
+        return hip.snakebeta_bwd(x, dy.contiguous(), alpha.detach().contiguous(), beta.detach().contiguous())
+
+
 class DepthwiseConv(torch.autograd.Function):
     """nn.Conv1d(C, C, K, padding=(K-1)//2, groups=C) (convolution.py:44-52) on packed rows; weight (C, 1, K)."""
 

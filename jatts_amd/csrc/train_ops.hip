@@ -91,16 +91,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------ activations
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
-// mode: 1 relu, 2 tanh, 3 swish
+// mode: 1 relu, 2 tanh, 3 swish, 4 mish (x tanh(softplus x), torch's softplus threshold 20)
+__device__ __forceinline__ float act_val(float x, int mode) {
+  if (mode == 1) return fmaxf(x, 0.f);
+  if (mode == 2) return tanhf(x);
+  if (mode == 3) return x * sigmoidf_(x);
+  return x * tanhf(x > 20.f ? x : log1pf(expf(x)));
+}
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int mode) {
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 3 < n) {
       f32x4 v = *reinterpret_cast<const f32x4*>(x + i), o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = mode == 1 ? fmaxf(v[e], 0.f) : mode == 2 ? tanhf(v[e]) : v[e] * sigmoidf_(v[e]);
+      for (int e = 0; e < 4; ++e) o[e] = act_val(v[e], mode);
       *reinterpret_cast<f32x4*>(y + i) = o;
     } else {
-      for (int64_t k = i; k < n; ++k) y[k] = mode == 1 ? fmaxf(x[k], 0.f) : mode == 2 ? tanhf(x[k]) : x[k] * sigmoidf_(x[k]);
+      for (int64_t k = i; k < n; ++k) y[k] = act_val(x[k], mode);
     }
   }
 }
@@ -108,7 +114,9 @@ __device__ __forceinline__ float act_grad(float x, int mode) {
   if (mode == 1) return x > 0.f ? 1.f : 0.f;
   if (mode == 2) { const float t = tanhf(x); return 1.f - t * t; }
   const float s = sigmoidf_(x);
-  return s * (1.f + x * (1.f - s));
+  if (mode == 3) return s * (1.f + x * (1.f - s));
+  const float t = tanhf(x > 20.f ? x : log1pf(expf(x)));     // mish: d/dx [x tanh(sp)] = tanh(sp) + x (1 - tanh^2(sp)) sigmoid(x)
+  return t + x * (1.f - t * t) * (x > 20.f ? 1.f : s);
 }
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
                                                       int64_t n, int mode) {
@@ -513,6 +521,114 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ------------------------------------------------------------------ GroupNorm over (channels of a group) x (rows of a sequence)
+// torch.nn.GroupNorm(G, C) on (B, C, T) (matchatts/decoder.py:66-78 Block1D): one workgroup per (sequence, group); thread t owns
+// channel t % cg of the group and the rows t / cg, t / cg + 256 / cg, ...  Two passes for the statistics (mean, then centred
+// squares), a third applies; the group's [L][cg] slab is a few hundred KB and stays in L2 between them.
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void groupnorm_fwd_kernel(jatts_ragged rg, const float* __restrict__ x, int C, int G, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ float red[4];
+  const int s = blockIdx.y, g = blockIdx.x, cg = C / G;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  const int c = g * cg + threadIdx.x % cg, r0 = threadIdx.x / cg, rs = 256 / cg;
+  const float inv_n = 1.f / ((float)L * (float)cg);
+  float a = 0.f;
+  for (int t = r0; t < L; t += rs) a += x[(int64_t)(row0 + t) * C + c];
+  const float mean = block_sum256(a, red) * inv_n;
+  a = 0.f;
+  for (int t = r0; t < L; t += rs) { const float d = x[(int64_t)(row0 + t) * C + c] - mean; a += d * d; }
+  const float rstd = rsqrtf(block_sum256(a, red) * inv_n + eps);
+  const float gm = gamma[c] * rstd, bt = beta[c] - mean * gamma[c] * rstd;
+  for (int t = r0; t < L; t += rs) y[(int64_t)(row0 + t) * C + c] = x[(int64_t)(row0 + t) * C + c] * gm + bt;
+  if (threadIdx.x == 0) { mean_out[s * G + g] = mean; rstd_out[s * G + g] = rstd; }
+}
+// dx = rstd (dy g - mean_grp(dy g) - xhat mean_grp(dy g xhat)); dgamma[c] += sum_t dy xhat; dbeta[c] += sum_t dy
+__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy, int C, int G,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ float red[4];
+  __shared__ float cred[2][256];
+  const int s = blockIdx.y, g = blockIdx.x, cg = C / G;
+  const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
+  const int c = g * cg + threadIdx.x % cg, r0 = threadIdx.x / cg, rs = 256 / cg;
+  const float mean = mean_in[s * G + g], rstd = rstd_in[s * G + g], gm = gamma[c];
+  const float inv_n = 1.f / ((float)L * (float)cg);
+  float s1 = 0.f, s2 = 0.f, pg = 0.f, pb = 0.f;
+  for (int t = r0; t < L; t += rs) {
+    const int64_t i = (int64_t)(row0 + t) * C + c;
+    const float xh = (x[i] - mean) * rstd, d = dy[i];
+    s1 += d * gm;
+    s2 += d * gm * xh;
+    pg += d * xh;
+    pb += d;
+  }
+  s1 = block_sum256(s1, red) * inv_n;
+  s2 = block_sum256(s2, red) * inv_n;
+  if (dx)
+    for (int t = r0; t < L; t += rs) {
+      const int64_t i = (int64_t)(row0 + t) * C + c;
+      const float xh = (x[i] - mean) * rstd;
+      dx[i] = rstd * (dy[i] * gm - s1 - xh * s2);
+    }
+  if (!dgamma) return;
+  cred[0][threadIdx.x] = pg;
+  cred[1][threadIdx.x] = pb;
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    float a = 0.f, b = 0.f;
+    for (int j = threadIdx.x; j < 256; j += cg) { a += cred[0][j]; b += cred[1][j]; }
+    atomicAdd(&dgamma[c], a);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
+// ------------------------------------------------------------------ SnakeBeta (matchatts/transformer.py:84-102, log-scale alpha / beta)
+// y = x + sin^2(a x) / (b + 1e-9), a = exp(alpha[c]), b = exp(beta[c]).
+__global__ __launch_bounds__(256) void snakebeta_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int C,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float sn = sinf(x[i] * expf(alpha[c]));
+    y[i] = x[i] + sn * sn / (expf(beta[c]) + 1e-9f);
+  }
+}
+// dx = dy (1 + a sin(2 a x) / (b + e)); dalpha[c] += sum dy x a sin(2 a x) / (b + e); dbeta[c] += sum dy (-b sin^2(a x) / (b + e)^2)
+__global__ __launch_bounds__(256) void snakebeta_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t rows, int C,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                            float* __restrict__ dx, float* __restrict__ dalpha, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float red[2][4][64];
+  float sa = 0.f, sb = 0.f;
+  if (c < C) {
+    const float a = expf(alpha[c]), b = expf(beta[c]), ib = 1.f / (b + 1e-9f);
+    for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) {
+      const float xv = x[r * C + c], d = dy[r * C + c];
+      const float sn = sinf(xv * a), s2 = sinf(2.f * xv * a);
+      dx[r * C + c] = d * (1.f + a * s2 * ib);
+      sa += d * xv * a * s2 * ib;
+      sb -= d * b * sn * sn * ib * ib;
+    }
+  }
+  red[0][part][threadIdx.x & 63] = sa;
+  red[1][part][threadIdx.x & 63] = sb;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    atomicAdd(&dalpha[c], red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+    atomicAdd(&dbeta[c], red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  }
+}
+
 inline unsigned blocks_for(int64_t n, int per_block, unsigned cap = 8192) {
   const int64_t b = (n + per_block - 1) / per_block;
   return (unsigned)(b < 1 ? 1 : b > cap ? cap : b);
@@ -538,7 +654,7 @@ extern "C" int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy,
 
 extern "C" int jatts_act_fwd(int32_t mode, const float* x, float* y, int64_t n, void* stream) {
   NULLCHK(!x || !y, "act_fwd: null pointer");
-  NULLCHK(mode < 1 || mode > 3, "act_fwd: mode 1 relu, 2 tanh, 3 swish");
+  NULLCHK(mode < 1 || mode > 4, "act_fwd: mode 1 relu, 2 tanh, 3 swish, 4 mish");
   if (n <= 0) return JATTS_OK;
   hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, S_, x, y, n, mode);
   JATTS_CHECK_LAUNCH();
@@ -546,7 +662,7 @@ extern "C" int jatts_act_fwd(int32_t mode, const float* x, float* y, int64_t n, 
 }
 extern "C" int jatts_act_bwd(int32_t mode, const float* x, const float* dy, float* dx, int64_t n, void* stream) {
   NULLCHK(!x || !dy || !dx, "act_bwd: null pointer");
-  NULLCHK(mode < 1 || mode > 3, "act_bwd: mode 1 relu, 2 tanh, 3 swish");
+  NULLCHK(mode < 1 || mode > 4, "act_bwd: mode 1 relu, 2 tanh, 3 swish, 4 mish");
   if (n <= 0) return JATTS_OK;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, S_, x, dy, dx, n, mode);
   JATTS_CHECK_LAUNCH();
@@ -722,6 +838,47 @@ extern "C" int jatts_adam_step(float* p, const float* g, float* m, float* v, int
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, S_, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
                      sqrtf(bc2), grad_sumsq, max_norm);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_groupnorm_fwd(const jatts_ragged* rg, const float* x, int32_t dim, int32_t groups, const float* gamma, const float* beta,
+                                   float eps, float* y, float* mean, float* rstd, void* stream) {
+  NULLCHK(!rg || !x || !gamma || !beta || !y || !mean || !rstd, "groupnorm_fwd: null pointer");
+  NULLCHK(groups < 1 || dim % groups != 0 || dim / groups > 256 || 256 % (dim / groups) != 0,
+          "groupnorm_fwd: channels per group must divide 256");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3((unsigned)groups, (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, dim, groups, gamma, beta, eps, y, mean,
+                     rstd);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_groupnorm_bwd(const jatts_ragged* rg, const float* x, const float* dy, int32_t dim, int32_t groups, const float* gamma,
+                                   const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, void* stream) {
+  NULLCHK(!rg || !x || !dy || !gamma || !mean || !rstd, "groupnorm_bwd: null pointer");
+  NULLCHK((dgamma == nullptr) != (dbeta == nullptr), "groupnorm_bwd: dgamma and dbeta go together");
+  NULLCHK(groups < 1 || dim % groups != 0 || dim / groups > 256 || 256 % (dim / groups) != 0,
+          "groupnorm_bwd: channels per group must divide 256");
+  if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)groups, (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, dy, dim, groups, gamma, mean, rstd, dx,
+                     dgamma, dbeta);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_snakebeta_fwd(const float* x, float* y, int64_t rows, int32_t dim, const float* alpha, const float* beta, void* stream) {
+  NULLCHK(!x || !y || !alpha || !beta, "snakebeta_fwd: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(snakebeta_fwd_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, x, y, rows, dim, alpha, beta);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_snakebeta_bwd(const float* x, const float* dy, int64_t rows, int32_t dim, const float* alpha, const float* beta, float* dx,
+                                   float* dalpha, float* dbeta, void* stream) {
+  NULLCHK(!x || !dy || !alpha || !beta || !dx || !dalpha || !dbeta, "snakebeta_bwd: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  const int64_t gy = (rows + 255) / 256;
+  hipLaunchKernelGGL(snakebeta_bwd_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, dy, rows, dim, alpha,
+                     beta, dx, dalpha, dbeta);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

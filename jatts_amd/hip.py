@@ -635,7 +635,7 @@ def col_sum(x, dim=None):
 
 
 # ------------------------------------------------------------------------------------------ training ops (train_ops.hip)
-ACT_MODE = {"relu": 1, "tanh": 2, "swish": 3}
+ACT_MODE = {"relu": 1, "tanh": 2, "swish": 3, "mish": 4}
 
 
 def _f32c(t):
@@ -834,3 +834,49 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq=
     _abi.check(lib.jatts_adam_step(_f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(m).data_ptr(), _f32c(v).data_ptr(), p.numel(), float(lr),
                                    float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _ptr(grad_sumsq), float(max_norm),
                                    _stream()), "jatts_adam_step")
+
+
+def groupnorm_fwd(rb, x, groups, gamma, beta, eps):
+    """-> (y, mean, rstd); mean / rstd (n_seq * groups,) for groupnorm_bwd."""
+    lib = _abi.load()
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    mean = torch.empty(rb.n_seq * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    rg = rb.struct()
+    _abi.check(lib.jatts_groupnorm_fwd(C.byref(rg), x.data_ptr(), x.shape[1], groups, _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), float(eps),
+                                       y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream()), "jatts_groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(rb, x, dy, groups, gamma, mean, rstd, need_dx=True, need_dparam=True):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dim = x.shape[1]
+    dx = torch.empty_like(x) if need_dx else None
+    dg = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
+    db = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
+    rg = rb.struct()
+    _abi.check(lib.jatts_groupnorm_bwd(C.byref(rg), x.data_ptr(), dy.data_ptr(), dim, groups, _f32c(gamma).data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), _stream()), "jatts_groupnorm_bwd")
+    return dx, dg, db
+
+
+def snakebeta_fwd(x, alpha, beta):
+    lib = _abi.load()
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _abi.check(lib.jatts_snakebeta_fwd(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
+                                       _stream()), "jatts_snakebeta_fwd")
+    return y
+
+
+def snakebeta_bwd(x, dy, alpha, beta):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dx = torch.empty_like(x)
+    da = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    db = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _abi.check(lib.jatts_snakebeta_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
+                                       dx.data_ptr(), da.data_ptr(), db.data_ptr(), _stream()), "jatts_snakebeta_bwd")
+    return dx, da, db

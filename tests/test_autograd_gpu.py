@@ -231,3 +231,46 @@ def test_adam_step_and_grad_clip_match_torch(cuda, lib):
         hip.sumsq(gd, ss)
         hip.adam_step(pd, gd, m, v, 1e-2, 0.9, 0.98, 1e-9, 0.0, step, grad_sumsq=ss, max_norm=1.0)
         assert relerr(pd.cpu(), pr.detach()) <= 1e-5, step
+
+
+def test_mish_backward(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(13)
+    x, gy = torch.randn(90, 33, generator=g) * 3, torch.randn(90, 33, generator=g)
+    x[0, :3] = torch.tensor([25.0, -30.0, 19.5])
+    xr, xd = _leaf(x, cuda)
+    yr = F.mish(xr)
+    yr.backward(gy.double())
+    y = A.Act.apply(xd, "mish")
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad)])
+
+
+@pytest.mark.parametrize("dim,groups,lens", [(64, 8, [30, 30]), (512, 8, [26, 26, 26]), (256, 8, [7, 40])])
+def test_groupnorm_backward(cuda, lib, dim, groups, lens):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(dim)
+    R = sum(lens)
+    x, w, b, gy = torch.randn(R, dim, generator=g) * 1.3 + 0.4, torch.randn(dim, generator=g), torch.randn(dim, generator=g), torch.randn(R, dim, generator=g)
+    (xr, xd), (wr, wd), (br, bd) = _leaf(x, cuda), _leaf(w, cuda), _leaf(b, cuda)
+    outs, o = [], 0
+    for n in lens:
+        outs.append(F.group_norm(xr[o:o + n].t().unsqueeze(0), groups, wr, br, 1e-5)[0].t())
+        o += n
+    yr = torch.cat(outs)
+    yr.backward(gy.double())
+    y = A.GroupNorm.apply(xd, wd, bd, hip.RaggedBatch(lens, cuda), groups, 1e-5)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dg", wd.grad, wr.grad), ("db", bd.grad, br.grad)])
+
+
+def test_snakebeta_backward(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(14)
+    x, al, be, gy = torch.randn(70, 96, generator=g) * 2, torch.randn(96, generator=g) * 0.5, torch.randn(96, generator=g) * 0.5, torch.randn(70, 96, generator=g)
+    (xr, xd), (ar, ad), (br, bd) = _leaf(x, cuda), _leaf(al, cuda), _leaf(be, cuda)
+    yr = xr + (1.0 / (torch.exp(br) + 1e-9)) * torch.sin(xr * torch.exp(ar)) ** 2
+    yr.backward(gy.double())
+    y = A.SnakeBeta.apply(xd, ad, bd)
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dalpha", ad.grad, ar.grad), ("dbeta", bd.grad, br.grad)])
