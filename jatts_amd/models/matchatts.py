@@ -232,9 +232,20 @@ class _MatchaBase(torch.nn.Module):
         S._norm(spec, e + "final_block.block.1", up[-1])
         S._conv(spec, e + "final_proj", odim, up[-1], 1)
         S.build_from_spec(self, spec)
+        # train-mode behaviour (models/matchatts_train.py): the reference's dropout sites
+        self.dropout_rates = dict(enc=transformer_enc_dropout_rate, enc_pos=transformer_enc_positional_dropout_rate,
+                                  enc_attn=transformer_enc_attn_dropout_rate, dur=duration_predictor_dropout_rate, decoder=decoder_dropout)
+        self._train_calls = 0
         self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
+
+    def train(self, mode: bool = True):
+        """train(True) also turns the parameters' requires_grad on (they are created frozen for the inference path)."""
+        super().train(mode)
+        if mode:
+            self.requires_grad_(True)
+        return self
 
     def set_precision(self, precision):
         if precision not in ("fp16", "fp32"):
@@ -444,7 +455,6 @@ class _MatchaBase(torch.nn.Module):
                 out.update(log_p_attn=lp[0], ds=ds[0])
         return out
 
-    @torch.no_grad()
     def forward(self, text, text_lengths, feats, feats_lengths, durations=None, durations_lengths=None, spembs=None, sids=None,
                 lids=None, joint_training=False, cfm_t=None, cfm_noise=None):
         """The reference's training-time call, forward only (matchatts_mas.py:337-550 with is_inference=False): padded batch ->
@@ -454,7 +464,20 @@ class _MatchaBase(torch.nn.Module):
         (flow_matching.py:115-117), injectable for parity; drawn with torch.rand / randn when omitted.
         Padded-batch arithmetic as in the reference: key masks in the encoder attention, mask multiplications inside the
         U-Net (GroupNorm statistics run over the padded length), the attention mask of the U-Net's transformer blocks added to
-        the scores."""
+        the scores.  In train() mode with gradients enabled the tts1 MatchaTTS returns the differentiable HIP forward of
+        models/matchatts_train.py instead (criterion / backward: jatts_amd.training.MatchaTTSTrainer)."""
+        if self.training and torch.is_grad_enabled() and not self._MAS:
+            from .matchatts_train import train_forward
+            self._train_calls += 1
+            self._prep = None
+            return train_forward(self, text, text_lengths, feats, feats_lengths, durations, durations_lengths, spembs=spembs, sids=sids,
+                                 cfm_t=cfm_t, cfm_noise=cfm_noise, seed=self._train_calls)
+        with torch.no_grad():
+            return self._forward_eval(text, text_lengths, feats, feats_lengths, durations, durations_lengths, spembs, sids, lids,
+                                      joint_training, cfm_t, cfm_noise)
+
+    def _forward_eval(self, text, text_lengths, feats, feats_lengths, durations=None, durations_lengths=None, spembs=None, sids=None,
+                      lids=None, joint_training=False, cfm_t=None, cfm_noise=None):
         P = self._prepare()
         dt, dev, A, od = P["dtype"], P["dev"], self.adim, self.odim
         ilens = [int(v) for v in text_lengths.tolist()]

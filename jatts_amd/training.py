@@ -241,10 +241,16 @@ class FastSpeech2Trainer:
         if "scheduler" in sd and sd["scheduler"]:
             self.warmup_steps = sd["scheduler"].get("warmup_steps", self.warmup_steps)
 
+    def compute_losses(self, batch):
+        """forward + criterion of trainers/fastspeech2.py:44-84 -> dict of differentiable scalars incl. "loss"."""
+        from .models.fastspeech2_train import criterion
+        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"], batch["pitch"],
+                         batch["pitch_lens"], batch["energys"], batch["energy_lens"], batch.get("spkembs"), batch.get("sids"))
+        return criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
+
     def train_step(self, batch):
         """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
-        from .models.fastspeech2_train import criterion
         m = self.model
         m.train()
         self.flat_g.zero_()
@@ -253,9 +259,7 @@ class FastSpeech2Trainer:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
             o += p.numel()
-        ret = m(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"], batch["pitch"],
-                batch["pitch_lens"], batch["energys"], batch["energy_lens"], batch.get("spkembs"), batch.get("sids"))
-        losses = criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
+        losses = self.compute_losses(batch)
         losses["loss"].backward()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             allreduce_flat(self.flat_g, self.group, self.bucket_bytes)
@@ -273,3 +277,20 @@ class FastSpeech2Trainer:
         if ss is not None:
             losses["grad_norm"] = ss.sqrt()
         return losses
+
+
+class MatchaTTSTrainer(FastSpeech2Trainer):
+    """`MatchaTTSTrainer._train_step` (jatts/trainers/matchatts.py:23-120) for the tts1 recipe (ground-truth durations; criterions
+    CFMLoss + EncoderPriorLoss + DurationPredictorLoss, conf/matcha_tts.v1.prior.steplr.large.yaml): same flat-buffer optimiser,
+    all-reduce and checkpoint layout as FastSpeech2Trainer; the duration loss joins once `steps > dp_train_start_steps`
+    (trainers/matchatts.py:66-75).  ``cfm_t`` / ``cfm_noise`` in the batch inject the two random draws of CFM.compute_loss."""
+
+    def __init__(self, model, dp_train_start_steps=0, **kw):
+        super().__init__(model, **kw)
+        self.dp_train_start_steps = dp_train_start_steps
+
+    def compute_losses(self, batch):
+        from .models.matchatts_train import criterion
+        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"],
+                         batch.get("spkembs"), batch.get("sids"), cfm_t=batch.get("cfm_t"), cfm_noise=batch.get("cfm_noise"))
+        return criterion(ret, batch["durations"], batch["ilens"], duration_loss=self.steps > self.dp_train_start_steps)

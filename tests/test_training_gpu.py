@@ -266,3 +266,61 @@ def test_fastspeech2_speaker_conditioned_train_step_matches_reference(cuda, lib)
         assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, 1e-3) <= 2e-3, n
     for n in ("projection.weight", "sid_emb.weight"):
         assert relerr(P[n].grad, z["grad:" + n]) <= 2e-3, n
+
+
+def test_matcha_tts1_train_step_matches_reference(cuda, lib):
+    """One `_train_step` of jatts/trainers/matchatts.py:23-120 for the tts1 MatchaTTS against the REAL reference on the CPU
+    (make_golden_train.py -> matcha_tts1_train_small.npz; train() mode, dropout 0, CFM draws injected, the diffusers attention
+    stand-in of the forward goldens): the three losses, d_outs, every parameter's gradient norm, 12 full gradients (U-Net GroupNorm /
+    SnakeBeta log-parameters / strided and transposed convs / time MLP / attention, encoder_proj, the text encoder)."""
+    import json
+    from jatts_amd.models import MatchaTTS
+    from jatts_amd.models.matchatts_train import criterion
+    z, keys = load_golden("matcha_tts1_train_small.npz")
+    zi, _ = load_golden("matcha_tts1_forward_small.npz")
+    cfg = json.loads(str(z["config"]))
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    m = MatchaTTS(idim=20, **cfg)
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 4)))
+    m = m.to(cuda).train()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    ret = m(t("text"), il, t("feats"), ol, t("durations"), il, cfm_t=t("t"), cfm_noise=t("z"))
+    assert relerr(ret["d_outs"].detach(), z["ref_d_outs"]) <= 2e-5
+    losses = criterion(ret, t("durations"), il)
+    for k in ("cfm_loss", "encoder_prior_loss", "duration_loss"):
+        assert abs(float(losses[k]) - float(z[k])) <= 3e-5 * max(1.0, abs(float(z[k]))), (k, float(losses[k]), float(z[k]))
+    losses["loss"].backward()
+    P = dict(m.named_parameters())
+    names = json.loads(str(z["grad_names"]))
+    assert [n for n, _ in m.named_parameters()] == names
+    for n, ref_norm in zip(names, z["grad_norms"]):
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, 1e-3) <= 3e-3, (n, float(P[n].grad.norm()), ref_norm)
+    for f in z.files:
+        if f.startswith("grad:"):
+            assert relerr(P[f[5:]].grad, z[f]) <= 3e-3, (f, relerr(P[f[5:]].grad, z[f]))
+
+
+def test_matcha_tts1_training_reduces_the_loss(cuda, lib):
+    """MatchaTTSTrainer: ten steps with the recipe's dropout rates on and fixed CFM draws: the loss falls and stays finite; the
+    duration loss joins after the first step (dp_train_start_steps = 0: `steps > 0`)."""
+    import json
+    from jatts_amd.models import MatchaTTS
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    from jatts_amd.training import MatchaTTSTrainer
+    z, keys = load_golden("matcha_tts1_train_small.npz")
+    zi, _ = load_golden("matcha_tts1_forward_small.npz")
+    cfg = {**json.loads(str(z["config"])), "transformer_enc_dropout_rate": 0.1, "decoder_dropout": 0.05}
+    m = MatchaTTS(idim=20, **cfg)
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 4)))
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il = t("text_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=t("feats_lengths"), durations=t("durations"), duration_lens=il,
+                 cfm_t=t("t"), cfm_noise=t("z"))
+    tr = MatchaTTSTrainer(m, lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    out = [tr.train_step(batch) for _ in range(10)]
+    assert "duration_loss" not in out[0] and "duration_loss" in out[1]
+    cfm = [float(o["cfm_loss"]) + float(o["encoder_prior_loss"]) for o in out]
+    assert all(math.isfinite(v) for v in cfm) and min(cfm[-3:]) < 0.9 * cfm[0], cfm
