@@ -351,15 +351,22 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     )
 
 
-def train_step_line(dev, steps, batch=32, t_text=128, frames=6):
-    """FastSpeech2Trainer.train_step (jatts/trainers/fastspeech2.py:24-100) on the conf/fastspeech2.v1.yaml model: forward in
-    train mode, the four losses, backward, clip + Adam -- f32, synthetic weights / targets, the recipe's batch_size 32."""
+def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
+    """One `_train_step` of the reference trainers on the recipes' models (jatts/trainers/fastspeech2.py:24-100 on
+    conf/fastspeech2.v1.yaml; jatts/trainers/matchatts.py:23-120 on the tts1 conf/matcha_tts.v1.prior.steplr.large.yaml): forward in
+    train mode, the losses, backward, clip + Adam -- f32, synthetic weights / targets, batch 32."""
     import torch
-    from jatts_amd.models import FastSpeech2
-    from jatts_amd.synthetic import FS2_JSUT, synth_state_dict
-    from jatts_amd.training import FastSpeech2Trainer
-    m = FastSpeech2(idim=45, **{**FS2_JSUT, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
-    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    from jatts_amd.models import FastSpeech2, MatchaTTS
+    from jatts_amd.synthetic import FS2_JSUT, MATCHA_MAS_JSUT, matcha_golden_tweaks, synth_state_dict
+    from jatts_amd.training import FastSpeech2Trainer, MatchaTTSTrainer
+    if kind == "fs2":
+        m = FastSpeech2(idim=45, **{**FS2_JSUT, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+        m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+        name, flop_per_utt = "FastSpeech2 (fastspeech2.v1.yaml)", 3 * 67.4e-3
+    else:
+        m = MatchaTTS(idim=45, **MATCHA_MAS_JSUT)      # the tts1 yaml's model_params equal the MAS recipe's
+        m.load_state_dict(matcha_golden_tweaks(synth_state_dict(m.state_dict(), 0)))
+        name, flop_per_utt = "MatchaTTS tts1 (matcha_tts.v1.prior.steplr.large.yaml)", None
     m = m.to(dev)
     g = torch.Generator().manual_seed(5)
     il = torch.full((batch,), t_text, dtype=torch.long)
@@ -368,7 +375,7 @@ def train_step_line(dev, steps, batch=32, t_text=128, frames=6):
     b = dict(xs=torch.randint(1, 45, (batch, t_text), generator=g).to(dev), ilens=il, ys=torch.randn(batch, int(ol.max()), 80, generator=g).to(dev),
              olens=ol, durations=ds.to(dev), duration_lens=il, pitch=torch.randn(batch, t_text, 1, generator=g).to(dev), pitch_lens=il,
              energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il)
-    tr = FastSpeech2Trainer(m, lr=1e-4, grad_norm=1.0, warmup_steps=0)
+    tr = (FastSpeech2Trainer if kind == "fs2" else MatchaTTSTrainer)(m, lr=1e-4, grad_norm=1.0, warmup_steps=0)
     first = float(tr.train_step(b)["loss"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -377,10 +384,12 @@ def train_step_line(dev, steps, batch=32, t_text=128, frames=6):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     n_frames = int(ol.sum())
-    return {"workload": f"FastSpeech2 (fastspeech2.v1.yaml) _train_step, batch {batch} x {t_text} phonemes x {frames} frames", "dtype": "f32",
-            "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": n_frames / dt, "dense_tflops_per_step": 3 * 67.4e-3 * batch,
-            "achieved_tflops": 3 * 67.4e-3 * batch / dt, "loss_first": first, "loss_last": float(o["loss"]),
+    line = {"workload": f"{name} _train_step, batch {batch} x {t_text} phonemes x {frames} frames", "dtype": "f32",
+            "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": n_frames / dt, "loss_first": first, "loss_last": float(o["loss"]),
             "parity": "tests/test_training_gpu.py (one whole step vs the real reference: every parameter gradient)"}
+    if flop_per_utt:
+        line.update(dense_tflops_per_step=flop_per_utt * batch, achieved_tflops=flop_per_utt * batch / dt)
+    return line
 
 
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate"}
@@ -511,8 +520,10 @@ def main():
 
     # ---- one FastSpeech2 `_train_step` at the recipe's batch size (not part of `value`): N == 1 only
     if world == 1 and not a.no_train:
-        out["training"] = train_step_line(dev, max(2, min(3, a.steps)))
-        torch.cuda.empty_cache()
+        out["training"] = []
+        for kind in ("fs2", "matcha"):
+            out["training"].append(train_step_line(dev, max(2, min(3, a.steps)), kind))
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from jatts_amd.synthetic import synth_texts
