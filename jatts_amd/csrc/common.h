@@ -70,6 +70,13 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// Mish = v tanh(softplus v).  tanh(log(1 + w)) = (w^2 + 2w) / (w^2 + 2w + 2) with w = e^v: one exp and one divide instead of
+// exp + log1p + tanh (the activation was VALU-bound in the GroupNorm apply kernel).  v > 20: torch's softplus threshold (= v).
+__device__ __forceinline__ float mish_f(float v) {
+  if (v > 20.f) return v;
+  const float w = expf(v), n = w * (w + 2.f);
+  return v * n / (n + 2.f);
+}
 
 // Apply the fused epilogue activation.
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -77,7 +84,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case JATTS_ACT_RELU: return v > 0.f ? v : 0.f;
     case JATTS_ACT_TANH: return tanhf(v);
     case JATTS_ACT_SWISH: return v / (1.f + __expf(-v));
-    case JATTS_ACT_MISH: return v * tanhf(v > 20.f ? v : log1pf(expf(v)));  // torch softplus threshold 20
+    case JATTS_ACT_MISH: return mish_f(v);
     default: return v;
   }
 }

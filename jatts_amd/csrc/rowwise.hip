@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(jatts_ragged rg, co
   for (int i = threadIdx.x; i < n; i += 256) {
     const int r = i / gc, c = c0 + i % gc;
     float v = (to_f32(xb[(int64_t)r * C + (i % gc)]) - mean) * rstd * gamma[c] + beta[c];
-    v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+    v = mish_f(v);
     if (addvec) v += addvec[(int64_t)b * C + c];
     y[(int64_t)(row0 + r) * C + c] = from_f32<TO>(v);
   }
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(jatts_ragged rg, const T*
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = (v[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
-      t = t * tanhf(t > 20.f ? t : log1pf(expf(t)));
+      t = mish_f(t);
       if (addvec) t += addvec[(int64_t)b * C + c + e];
       o[e] = t;
     }

@@ -96,7 +96,7 @@ __device__ __forceinline__ float act_val(float x, int mode) {
   if (mode == 1) return fmaxf(x, 0.f);
   if (mode == 2) return tanhf(x);
   if (mode == 3) return x * sigmoidf_(x);
-  return x * tanhf(x > 20.f ? x : log1pf(expf(x)));
+  return mish_f(x);
 }
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int mode) {
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
@@ -115,8 +115,9 @@ __device__ __forceinline__ float act_grad(float x, int mode) {
   if (mode == 2) { const float t = tanhf(x); return 1.f - t * t; }
   const float s = sigmoidf_(x);
   if (mode == 3) return s * (1.f + x * (1.f - s));
-  const float t = tanhf(x > 20.f ? x : log1pf(expf(x)));     // mish: d/dx [x tanh(sp)] = tanh(sp) + x (1 - tanh^2(sp)) sigmoid(x)
-  return t + x * (1.f - t * t) * (x > 20.f ? 1.f : s);
+  if (x > 20.f) return 1.f;
+  const float w = expf(x), n = w * (w + 2.f), t = n / (n + 2.f);     // mish: d/dx [x tanh(sp)] = tanh(sp) + x (1 - tanh^2(sp)) sigmoid(x)
+  return t + x * (1.f - t * t) * s;
 }
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
                                                       int64_t n, int mode) {
