@@ -262,6 +262,13 @@ int jatts_groupnorm_bwd(const jatts_ragged* rg, const float* x, const float* dy,
 int jatts_snakebeta_fwd(const float* x, float* y, int64_t rows, int32_t dim, const float* alpha, const float* beta, void* stream);
 int jatts_snakebeta_bwd(const float* x, const float* dy, int64_t rows, int32_t dim, const float* alpha, const float* beta, float* dx,
                         float* dalpha, float* dbeta, void* stream);
+/* ForwardSumLoss of the alignment framework (losses/forward_sum_loss.py:41-78): per utterance b, F.ctc_loss(reduction "mean",
+ * zero_infinity) on log_p[b][t][j] (t < olens[b], j < ilens[b]; the caller has already added the beta-binomial prior) with a
+ * constant blank column log_blank and targets 1..ilens[b].  nll[b] = -log p / ilens[b] (0 when impossible).  grad (nullable,
+ * [n_batch][t_max][ld]) = grad_scale * d nll[b] / d log_p as torch's ctc backward computes it.  workspace: 2 * n_batch * t_max *
+ * (2 * max_ilen + 1) floats. */
+int jatts_ctc_forward_sum(const float* log_p, int32_t n_batch, int32_t t_max, int32_t ld, const int32_t* ilens, const int32_t* olens,
+                          int32_t max_ilen, float log_blank, float* workspace, float* nll, float* grad, float grad_scale, void* stream);
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by

@@ -307,3 +307,19 @@ class Dropout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return hip.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+class ForwardSum(torch.autograd.Function):
+    """ForwardSumLoss.forward after the prior has been added (losses/forward_sum_loss.py:58-78): mean over the batch of the
+    per-utterance CTC losses; the gradient is the one torch's ctc_loss backward produces."""
+
+    @staticmethod
+    def forward(ctx, log_p, ilens, olens, log_blank):
+        nll, grad = hip.ctc_forward_sum(log_p.contiguous(), ilens, olens, log_blank, want_grad=True, grad_scale=1.0 / log_p.shape[0])
+        ctx.save_for_backward(grad)
+        return nll.sum() / log_p.shape[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        (grad,) = ctx.saved_tensors
+        return grad * up, None, None, None

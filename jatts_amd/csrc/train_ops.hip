@@ -630,6 +630,74 @@ __global__ __launch_bounds__(256) void snakebeta_bwd_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ forward-sum (CTC) loss of the alignment framework
+// ForwardSumLoss (losses/forward_sum_loss.py:41-78): per utterance F.ctc_loss on lp[t][1 + j] = log_p_attn[t][j] + prior[t][j],
+// lp[t][0] = log(blank_prob), targets 1..N (every token once, in order), reduction "mean" (nll / N), zero_infinity.
+// Lattice states s = 0..2N: blank for even s, token (s-1)/2 for odd s; all tokens differ, so the skip s-2 -> s is always allowed
+// for odd s.  One workgroup per utterance: threads own states, time is sequential (a barrier per step); alpha / beta live in a
+// global workspace [T][2N+1] each.  The gradient is torch's (LossCTC.cpp): exp(lp) - exp(logsumexp_s(alpha + beta) + nll - lp),
+// which presumes log-softmax inputs -- reproduced as is, because that is what the reference back-propagates.
+__device__ __forceinline__ float lse2(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}
+__global__ __launch_bounds__(256) void ctc_forward_sum_kernel(const float* __restrict__ lp, int Tmax, int ld, const int32_t* __restrict__ ilens,
+                                                              const int32_t* __restrict__ olens, float log_blank, float* __restrict__ alpha,
+                                                              float* __restrict__ beta, int smax, float* __restrict__ nll_out,
+                                                              float* __restrict__ grad, float grad_scale) {
+  const int b = blockIdx.x;
+  const int N = ilens[b], T = olens[b], S = 2 * N + 1;
+  const float* l = lp + (int64_t)b * Tmax * ld;
+  float* al = alpha + (int64_t)b * Tmax * smax;
+  float* be = beta + (int64_t)b * Tmax * smax;
+  float* g = grad ? grad + (int64_t)b * Tmax * ld : nullptr;
+  auto emit = [&](int t, int s) { return (s & 1) ? l[(int64_t)t * ld + (s >> 1)] : log_blank; };
+  for (int s = threadIdx.x; s < S; s += 256) al[s] = s == 0 ? log_blank : s == 1 ? l[0] : -INFINITY;
+  __syncthreads();
+  for (int t = 1; t < T; ++t) {
+    for (int s = threadIdx.x; s < S; s += 256) {
+      const float* p = al + (int64_t)(t - 1) * smax;
+      float a = p[s];
+      if (s >= 1) a = lse2(a, p[s - 1]);
+      if ((s & 1) && s >= 3) a = lse2(a, p[s - 2]);
+      al[(int64_t)t * smax + s] = a == -INFINITY ? -INFINITY : a + emit(t, s);
+    }
+    __syncthreads();
+  }
+  const float* last = al + (int64_t)(T - 1) * smax;
+  const float ll = lse2(last[S - 1], S >= 2 ? last[S - 2] : -INFINITY);
+  const float nll = -ll;
+  const bool inf = !(nll < INFINITY);                     // zero_infinity: an impossible alignment contributes 0 loss, 0 gradient
+  if (threadIdx.x == 0) nll_out[b] = inf ? 0.f : nll / (float)N;
+  if (!g) return;
+  for (int s = threadIdx.x; s < S; s += 256) be[(int64_t)(T - 1) * smax + s] = s == S - 1 ? log_blank : s == S - 2 ? l[(int64_t)(T - 1) * ld + (s >> 1)] : -INFINITY;
+  __syncthreads();
+  for (int t = T - 2; t >= 0; --t) {
+    for (int s = threadIdx.x; s < S; s += 256) {
+      const float* p = be + (int64_t)(t + 1) * smax;
+      float a = p[s];
+      if (s + 1 < S) a = lse2(a, p[s + 1]);
+      if ((s & 1) && s + 2 < S) a = lse2(a, p[s + 2]);
+      be[(int64_t)t * smax + s] = a == -INFINITY ? -INFINITY : a + emit(t, s);
+    }
+    __syncthreads();
+  }
+  // gradient w.r.t. the token columns (the blank column is a constant): one odd state per token
+  const float sc = grad_scale / (float)N;
+  for (int i = threadIdx.x; i < Tmax * ld; i += 256) {
+    const int t = i / ld, j = i - t * ld;
+    float v = 0.f;
+    if (!inf && t < T && j < N) {
+      const float lpv = l[i];
+      const float ab = al[(int64_t)t * smax + 2 * j + 1] + be[(int64_t)t * smax + 2 * j + 1];
+      v = (expf(lpv) - expf(ab + nll - lpv)) * sc;
+    }
+    g[i] = v;
+  }
+}
+
 inline unsigned blocks_for(int64_t n, int per_block, unsigned cap = 8192) {
   const int64_t b = (n + per_block - 1) / per_block;
   return (unsigned)(b < 1 ? 1 : b > cap ? cap : b);
@@ -880,6 +948,19 @@ extern "C" int jatts_snakebeta_bwd(const float* x, const float* dy, int64_t rows
   const int64_t gy = (rows + 255) / 256;
   hipLaunchKernelGGL(snakebeta_bwd_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, dy, rows, dim, alpha,
                      beta, dx, dalpha, dbeta);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_ctc_forward_sum(const float* log_p, int32_t n_batch, int32_t t_max, int32_t ld, const int32_t* ilens, const int32_t* olens,
+                                     int32_t max_ilen, float log_blank, float* workspace, float* nll, float* grad, float grad_scale, void* stream) {
+  NULLCHK(!log_p || !ilens || !olens || !workspace || !nll, "ctc_forward_sum: null pointer");
+  NULLCHK(n_batch < 1 || t_max < 1 || ld < max_ilen || max_ilen < 1, "ctc_forward_sum: bad geometry");
+  const int smax = 2 * max_ilen + 1;
+  float* alpha = workspace;
+  float* beta = workspace + (size_t)n_batch * t_max * smax;
+  hipLaunchKernelGGL(ctc_forward_sum_kernel, dim3((unsigned)n_batch), dim3(256), 0, S_, log_p, t_max, ld, ilens, olens, log_blank, alpha, beta, smax, nll,
+                     grad, grad_scale);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -880,3 +880,19 @@ def snakebeta_bwd(x, dy, alpha, beta):
     _abi.check(lib.jatts_snakebeta_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
                                        dx.data_ptr(), da.data_ptr(), db.data_ptr(), _stream()), "jatts_snakebeta_bwd")
     return dx, da, db
+
+
+def ctc_forward_sum(log_p, ilens, olens, log_blank, want_grad=True, grad_scale=1.0):
+    """log_p: (B, T, N) f32 (prior already added; entries beyond ilens / olens are ignored).  -> (nll (B,) = -log p / ilens, grad or None)."""
+    lib = _abi.load()
+    log_p = _f32c(log_p)
+    B, T, ld = log_p.shape
+    max_i = int(ilens.max())
+    ws = torch.empty(2 * B * T * (2 * max_i + 1), dtype=torch.float32, device=log_p.device)
+    nll = torch.empty(B, dtype=torch.float32, device=log_p.device)
+    grad = torch.empty_like(log_p) if want_grad else None
+    il = ilens.to(device=log_p.device, dtype=torch.int32).contiguous()
+    ol = olens.to(device=log_p.device, dtype=torch.int32).contiguous()
+    _abi.check(lib.jatts_ctc_forward_sum(log_p.data_ptr(), B, T, ld, il.data_ptr(), ol.data_ptr(), max_i, float(log_blank), ws.data_ptr(),
+                                         nll.data_ptr(), _ptr(grad), float(grad_scale), _stream()), "jatts_ctc_forward_sum")
+    return nll, grad

@@ -274,3 +274,27 @@ def test_snakebeta_backward(cuda, lib):
     y = A.SnakeBeta.apply(xd, ad, bd)
     y.backward(gy.to(cuda))
     _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dalpha", ad.grad, ar.grad), ("dbeta", bd.grad, br.grad)])
+
+
+def test_forward_sum_ctc_matches_torch(cuda, lib):
+    """ForwardSumLoss's inner loop (losses/forward_sum_loss.py:58-78) against torch's own F.ctc_loss + autograd on the CPU, on
+    un-normalised inputs (log_p_attn + prior), ragged lengths, including an utterance with more tokens than frames (zero_infinity)."""
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(15)
+    ilens, olens = torch.tensor([9, 5, 12, 6]), torch.tensor([31, 14, 40, 4])
+    B, T, N = 4, 40, 12
+    lp = torch.log_softmax(torch.randn(B, T, N, generator=g) * 2, dim=-1) + torch.randn(B, T, N, generator=g) * 0.3
+    lr_ = lp.clone().double().requires_grad_()
+    blank = math.log(math.e ** -1)
+    pd = F.pad(lr_, (1, 0, 0, 0, 0, 0), value=blank)
+    loss = 0
+    for b in range(B):
+        loss = loss + F.ctc_loss(pd[b, : olens[b], : ilens[b] + 1].unsqueeze(1), torch.arange(1, int(ilens[b]) + 1).unsqueeze(0),
+                                 olens[b:b + 1], ilens[b:b + 1], zero_infinity=True)
+    loss = loss / B
+    (loss * 1.3).backward()
+    ld = lp.clone().to(cuda).requires_grad_()
+    out = A.ForwardSum.apply(ld, ilens, olens, blank)
+    (out * 1.3).backward()
+    assert abs(float(out.detach()) - float(loss.detach())) <= 2e-5 * abs(float(loss.detach()))
+    assert relerr(ld.grad, lr_.grad) <= 5e-5, relerr(ld.grad, lr_.grad)
