@@ -143,3 +143,31 @@ def viterbi_decode(log_p_attn, text_lengths, feats_lengths, k=None):
         o += tl[b]
     bin_loss = -(score / torch.tensor(fl, dtype=torch.float64, device=dev)).sum() / B
     return ds, bin_loss.float()
+
+
+@torch.no_grad()
+def viterbi_path(log_p_attn, text_lengths, feats_lengths):
+    """Monotonic alignment search on a padded (B, T_feats, T_text) matrix -> (ds (B, T_text) float, path (B, T_feats) int64: the
+    token index of every valid frame, 0 at padded frames).  One jatts_mas_viterbi launch; used by the training forward, which
+    needs the path itself for the binarisation loss (alignments.py:303-308)."""
+    B, Tf, Tt = log_p_attn.shape
+    dev = log_p_attn.device
+    tl = [int(v) for v in text_lengths]
+    fl = [int(v) for v in feats_lengths]
+    rb_t, rb_f = hip.RaggedBatch(tl, dev), hip.RaggedBatch(fl, dev)
+    ld = hip.round_up(Tt, 8)
+    lp = torch.zeros(rb_f.total, ld, dtype=torch.float32, device=dev)
+    o = 0
+    for b in range(B):
+        lp[o:o + fl[b], :Tt] = log_p_attn[b, : fl[b]].float()
+        o += fl[b]
+    path, dur, _ = hip.mas_viterbi(rb_f, rb_t, lp)
+    ds = torch.zeros((B, Tt), device=dev)
+    pth = torch.zeros((B, Tf), dtype=torch.int64, device=dev)
+    o = q = 0
+    for b in range(B):
+        ds[b, : tl[b]] = dur[o:o + tl[b]].float()
+        pth[b, : fl[b]] = path[q:q + fl[b]]
+        o += tl[b]
+        q += fl[b]
+    return ds, pth

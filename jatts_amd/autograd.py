@@ -323,3 +323,43 @@ class ForwardSum(torch.autograd.Function):
     def backward(ctx, up):
         (grad,) = ctx.saved_tensors
         return grad * up, None, None, None
+
+
+class AlignLogProb(torch.autograd.Function):
+    """AlignmentModule.forward after its convolutions (alignments.py:50-60): log_softmax over the valid text tokens of
+    -||feats_i - text_j||_2, -inf at padded tokens.  ff (B*To, A) frame features, tf (B*Tm, A) padded token features.
+    forward: jatts_alignment_logp.  backward: log-softmax backward, then with w = -d_score / dist,
+    d_ff_i = (sum_j w_ij) f_i - sum_j w_ij t_j and d_tf_j = (sum_i w_ij) t_j - sum_i w_ij f_i: two batched GEMMs (rocBLAS) and
+    element-wise ops on the (B, To, Tm) matrices (f64 for the distance recomputed in its GEMM form)."""
+
+    @staticmethod
+    def forward(ctx, ff, tf, B, ilens):
+        dev = ff.device
+        A_ = ff.shape[1]
+        To, Tm = ff.shape[0] // B, tf.shape[0] // B
+        rbf, rbv = hip.RaggedBatch([To] * B, dev), hip.RaggedBatch(ilens, dev)
+        sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
+        lp3 = hip.alignment_logp(rbf, rbv, ff.contiguous(), tf.index_select(0, sel).contiguous(), A_).view(B, To, -1)
+        valid = torch.arange(Tm, device=dev).unsqueeze(0) < torch.tensor(ilens, device=dev).unsqueeze(1)       # (B, Tm)
+        lp = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
+        n = min(Tm, lp3.shape[2])
+        lp[:, :, :n] = lp3[:, :, :n]
+        lp = lp.masked_fill(~valid.unsqueeze(1), float("-inf"))
+        ctx.save_for_backward(ff, tf, lp, valid)
+        ctx.B = B
+        return lp
+
+    @staticmethod
+    def backward(ctx, dlp):
+        ff, tf, lp, valid = ctx.saved_tensors
+        B = ctx.B
+        To, Tm, A_ = ff.shape[0] // B, tf.shape[0] // B, ff.shape[1]
+        vm = valid.unsqueeze(1)
+        g = dlp.double().masked_fill(~vm, 0.0)
+        dscore = g - torch.exp(lp.double()) * g.sum(-1, keepdim=True)
+        F_, T_ = ff.view(B, To, A_).double(), tf.view(B, Tm, A_).double()
+        d2 = (F_ * F_).sum(-1).unsqueeze(2) + (T_ * T_).sum(-1).unsqueeze(1) - 2.0 * torch.matmul(F_, T_.transpose(1, 2))
+        w = (-dscore / torch.sqrt(d2.clamp_min(1e-24))).masked_fill(~vm, 0.0)
+        dF = w.sum(-1, keepdim=True) * F_ - torch.matmul(w, T_)
+        dT = w.sum(1).unsqueeze(-1) * T_ - torch.matmul(w.transpose(1, 2), F_)
+        return dF.reshape(B * To, A_).float(), dT.reshape(B * Tm, A_).float(), None, None

@@ -466,7 +466,7 @@ class _MatchaBase(torch.nn.Module):
         U-Net (GroupNorm statistics run over the padded length), the attention mask of the U-Net's transformer blocks added to
         the scores.  In train() mode with gradients enabled the tts1 MatchaTTS returns the differentiable HIP forward of
         models/matchatts_train.py instead (criterion / backward: jatts_amd.training.MatchaTTSTrainer)."""
-        if self.training and torch.is_grad_enabled() and not self._MAS:
+        if self.training and torch.is_grad_enabled():
             from .matchatts_train import train_forward
             self._train_calls += 1
             self._prep = None

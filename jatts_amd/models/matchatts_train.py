@@ -1,12 +1,13 @@
-"""Differentiable train-mode forward of the tts1 Matcha-TTS (reference jatts/models/matchatts.py:317-480 with ground-truth
-durations; trainer jatts/trainers/matchatts.py:23-120) on the MI355X path -- SURVEY §8 f.4.  Same padded-batch arithmetic as
+"""Differentiable train-mode forward of Matcha-TTS on the MI355X path -- SURVEY §8 f.4: the tts1 MatchaTTS (reference
+jatts/models/matchatts.py:317-480, ground-truth durations + hard length regulator) and the tts2 MatchaTTS_MAS
+(jatts/models/matchatts_mas.py:415-550: alignment module + monotonic alignment search + masked Gaussian upsampling); trainer
+jatts/trainers/matchatts.py:23-120.  Same padded-batch arithmetic as
 MatchaTTS.forward() (eval), rebuilt from the HIP forward / backward pairs of jatts_amd.autograd: conformer text encoder ->
 duration predictor -> hard length regulator -> encoder_proj (mu) -> conditional flow matching: y_t = (1 - (1 - s) t) z + t x1,
 u = x1 - (1 - s) z, U-Net estimator (ResnetBlock1D = [Conv1d k3 -> GroupNorm(8) -> Mish] x 2 + time vector + 1x1 residual conv;
 BasicTransformerBlock = LayerNorm -> attention with the additive 1/0 frame mask -> LayerNorm -> SnakeBeta feed-forward; strided
 down / transposed up convolutions) -> masked MSE.  The strided conv is the stride-1 conv with every second row kept, the
 transposed conv a stride-1 conv (flipped taps) over the zero-stuffed input: both reuse the MFMA conv forward / dgrad / wgrad.
-The MAS variant (alignment module + forward-sum loss) has no training path yet.
 """
 import math
 
@@ -105,12 +106,10 @@ def _estimator(c, model, rb, rb2, rbs, y, mu, t, v1, v2, rate):
 def train_forward(model, text, text_lengths, feats, feats_lengths, durations, durations_lengths, spembs=None, sids=None, cfm_t=None,
                   cfm_noise=None, seed=0):
     """-> {d_outs, ys, hs, olens_in, cfm_loss} like the reference's forward(), differentiable (cfm_loss, hs = mu, d_outs)."""
-    if model._MAS:
-        raise NotImplementedError("training path: tts1 MatchaTTS (ground-truth durations) only; MatchaTTS_MAS.forward() is forward-only")
     dev = model.encoder_proj.weight.device
     if dev.type != "cuda":
         raise hip._abi.JattsHipError("jatts_amd Matcha-TTS trains on the GPU only (no CPU fallback); call .to('cuda')")
-    if durations is None:
+    if durations is None and not model._MAS:
         raise ValueError("MatchaTTS.forward needs durations")
     hip._abi.load()
     c = _Ctx(model, seed)
@@ -136,13 +135,37 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     d_outs = A.MaskRows.apply(_predictor(c, "duration_predictor.", hs, rbt, R["dur"]), rbt, kv)
     olens_in = [n - n % 2 for n in olens]
     Te = max(olens_in)
-    d_flat = durations[:, : int(durations_lengths.max())].to(dev).reshape(-1).to(torch.int64).contiguous()
-    if d_flat.numel() != B * Tm:
-        raise ValueError("durations must be padded to the text length")
-    _, cum, _, _ = hip.lr_durations(rbt, d_flat, 1.0, zero_rule=0)
     rbe = hip.RaggedBatch([Te] * B, dev)
     rb2 = hip.RaggedBatch([Te // 2] * B, dev)
-    mu = c.conv(A.LengthRegulate.apply(hs, rbt, cum, rbe), "encoder_proj", rbe)            # (B*Te, odim): "hs" of the return dict
+    extra = {}
+    if model._MAS:
+        # alignment module on the padded batch (alignments.py:26-60), monotonic alignment search (no gradient), binarisation loss
+        rbf = hip.RaggedBatch([To] * B, dev)
+        a = "alignment_module."
+        tfe = c.conv(A.Act.apply(c.conv(hs, a + "t_conv1", rbt), "relu"), a + "t_conv2", rbt)
+        ffe = A.Act.apply(c.conv(ys.reshape(B * To, od), a + "f_conv1", rbf), "relu")
+        ffe = c.conv(A.Act.apply(c.conv(ffe, a + "f_conv2", rbf), "relu"), a + "f_conv3", rbf)
+        log_p_attn = A.AlignLogProb.apply(ffe, tfe, B, ilens)                              # (B, To, Tm), -inf at padded tokens
+        from ..alignments import viterbi_path
+        ds, path = viterbi_path(log_p_attn.detach(), ilens, olens)                         # ds (B, Tm) float, path (B, To) int64
+        fm = (torch.arange(To, device=dev).unsqueeze(0) < torch.tensor(olens, device=dev).unsqueeze(1)).float()
+        picked = torch.gather(log_p_attn, 2, path.unsqueeze(-1)).squeeze(-1).masked_fill(fm == 0, 0.0)
+        bin_loss = -(picked.sum(1) / torch.tensor(olens, dtype=torch.float32, device=dev)).mean()     # alignments.py:307-309
+        # masked Gaussian upsampling (length_regulator.py:110-154): the weights depend on the (integer) durations only
+        tpos = torch.arange(To, device=dev).float().unsqueeze(0) * fm                       # padded frames sit at t = 0
+        cen = ds.cumsum(-1) - ds / 2
+        energy = -0.1 * (tpos.unsqueeze(-1) - cen.unsqueeze(1)) ** 2
+        tm_ = torch.arange(Tm, device=dev).unsqueeze(0) < torch.tensor(ilens, device=dev).unsqueeze(1)
+        p_up = torch.softmax(energy.masked_fill(~tm_.unsqueeze(1), float("-inf")), dim=2)
+        up = torch.matmul(p_up, hs.view(B, Tm, Ad))[:, :Te].reshape(B * Te, Ad)             # rocBLAS batched GEMM
+        extra = dict(bin_loss=bin_loss, log_p_attn=log_p_attn, ds=ds)
+    else:
+        d_flat = durations[:, : int(durations_lengths.max())].to(dev).reshape(-1).to(torch.int64).contiguous()
+        if d_flat.numel() != B * Tm:
+            raise ValueError("durations must be padded to the text length")
+        _, cum, _, _ = hip.lr_durations(rbt, d_flat, 1.0, zero_rule=0)
+        up = A.LengthRegulate.apply(hs, rbt, cum, rbe)
+    mu = c.conv(up, "encoder_proj", rbe)                                                    # (B*Te, odim): "hs" of the return dict
     ys_e = ys[:, :Te].contiguous()
     t = (torch.rand(B) if cfm_t is None else cfm_t.reshape(B).float().cpu())
     z = (torch.randn(B, Te, od) if cfm_noise is None else cfm_noise[:, :Te].float()).to(dev).reshape(B * Te, od).contiguous()
@@ -154,12 +177,33 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     # F.mse_loss(pred, u, "sum") / (sum(mask) n_feats): the sum runs over the padded frames too (pred is 0 there)
     cfm_loss = A.MaskedLoss.apply(pred, u, rbe, None, 1, 1.0 / n_sel, -1.0)
     return {"d_outs": d_outs.view(B, Tm), "ys": ys_e, "hs": mu.view(B, Te, od), "olens_in": torch.tensor(olens_in), "cfm_loss": cfm_loss,
-            "_rb": (rbt, rbe, kv, v1, n_sel)}
+            "_rb": (rbt, rbe, kv, v1, n_sel), **extra}
 
 
-def criterion(ret, durations, ilens, duration_loss=True):
-    """The loss block of MatchaTTSTrainer._train_step (trainers/matchatts.py:47-103) for the tts1 recipe's criterions
-    (CFMLoss, EncoderPriorLoss, DurationPredictorLoss).  ``duration_loss`` mirrors `steps > dp_train_start_steps`."""
+_PRIOR_CACHE = {}
+
+
+def beta_binomial_prior(ilens, olens, w=1.0):
+    """ForwardSumLoss._generate_prior (losses/forward_sum_loss.py:80-118): (B, max olen, max ilen) log beta-binomial alignment prior,
+    -inf outside each utterance's (olen, ilen) box.  Host-side scipy, cached per (T, N) like the reference."""
+    import numpy as np
+    from scipy.stats import betabinom
+    B, Tt, Tf = len(ilens), max(ilens), max(olens)
+    out = torch.full((B, Tf, Tt), float("-inf"))
+    for b, (N, T) in enumerate(zip(ilens, olens)):
+        if (T, N) not in _PRIOR_CACHE:
+            al = w * np.arange(1, T + 1, dtype=float)
+            be = w * np.array([T - t + 1 for t in al])
+            _PRIOR_CACHE[(T, N)] = torch.from_numpy(betabinom.logpmf(np.arange(N)[..., None], N, al, be)).transpose(0, 1).float()
+        out[b, :T, :N] = _PRIOR_CACHE[(T, N)]
+    return out
+
+
+def criterion(ret, durations, ilens, duration_loss=True, olens=None, forward_sum=False, bin_loss=False, lambda_align=2.0):
+    """The loss block of MatchaTTSTrainer._train_step (trainers/matchatts.py:47-103): CFMLoss + EncoderPriorLoss, the duration loss
+    once `steps > dp_train_start_steps` (``duration_loss``); for the MAS model also lambda_align x ForwardSumLoss while
+    `steps < dp_train_start_steps` (``forward_sum``) and lambda_align x the binarisation loss once `steps > bin_loss_start_steps`
+    (``bin_loss``).  ``durations``: ground truth (tts1) -- the MAS model regresses on its own ret["ds"]."""
     rbt, rbe, kv, v1, n_sel = ret["_rb"]
     B, Te, od = ret["hs"].shape
     Tm = ret["d_outs"].shape[1]
@@ -168,7 +212,17 @@ def criterion(ret, durations, ilens, duration_loss=True):
         + LOG_2PI                                                                            # losses/flow_matching.py:53-60
     out = dict(cfm_loss=ret["cfm_loss"], encoder_prior_loss=prior)
     total = ret["cfm_loss"] + prior
+    if forward_sum:
+        il, ol = [int(v) for v in ilens.tolist()], [int(v) for v in olens.tolist()]
+        lp = ret["log_p_attn"] + beta_binomial_prior(il, ol).to(dev)
+        out["forward_sum_loss"] = A.ForwardSum.apply(lp, ilens, olens, -1.0)                # blank_prob = e^-1
+        total = total + lambda_align * out["forward_sum_loss"]
+    if bin_loss:
+        out["bin_loss"] = ret["bin_loss"]
+        total = total + lambda_align * ret["bin_loss"]
     if duration_loss:
+        if "ds" in ret:
+            durations = ret["ds"]
         tgt = durations[:, :Tm].to(dev).float().reshape(B * Tm, 1).contiguous()
         out["duration_loss"] = A.MaskedLoss.apply(ret["d_outs"].reshape(B * Tm, 1), tgt, rbt, kv, 1, 1.0 / float(int(ilens.sum())), 1.0)
         total = total + out["duration_loss"]

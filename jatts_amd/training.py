@@ -285,12 +285,15 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
     all-reduce and checkpoint layout as FastSpeech2Trainer; the duration loss joins once `steps > dp_train_start_steps`
     (trainers/matchatts.py:66-75).  ``cfm_t`` / ``cfm_noise`` in the batch inject the two random draws of CFM.compute_loss."""
 
-    def __init__(self, model, dp_train_start_steps=0, **kw):
+    def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, **kw):
         super().__init__(model, **kw)
-        self.dp_train_start_steps = dp_train_start_steps
+        self.dp_train_start_steps, self.bin_loss_start_steps, self.lambda_align = dp_train_start_steps, bin_loss_start_steps, lambda_align
 
     def compute_losses(self, batch):
         from .models.matchatts_train import criterion
-        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"],
+        mas = self.model._MAS      # tts2 MatchaTTS_MAS: alignment module + MAS; + ForwardSumLoss / binarisation loss by schedule
+        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch.get("durations"), batch.get("duration_lens"),
                          batch.get("spkembs"), batch.get("sids"), cfm_t=batch.get("cfm_t"), cfm_noise=batch.get("cfm_noise"))
-        return criterion(ret, batch["durations"], batch["ilens"], duration_loss=self.steps > self.dp_train_start_steps)
+        return criterion(ret, batch.get("durations"), batch["ilens"], duration_loss=self.steps > self.dp_train_start_steps,
+                         olens=batch["olens"], forward_sum=mas and self.steps < self.dp_train_start_steps,
+                         bin_loss=mas and self.steps > self.bin_loss_start_steps, lambda_align=self.lambda_align)

@@ -324,3 +324,59 @@ def test_matcha_tts1_training_reduces_the_loss(cuda, lib):
     assert "duration_loss" not in out[0] and "duration_loss" in out[1]
     cfm = [float(o["cfm_loss"]) + float(o["encoder_prior_loss"]) for o in out]
     assert all(math.isfinite(v) for v in cfm) and min(cfm[-3:]) < 0.9 * cfm[0], cfm
+
+
+def test_matcha_mas_train_step_matches_reference(cuda, lib):
+    """MatchaTTS_MAS (tts2 recipe) with every loss term of jatts/trainers/matchatts.py:47-103 switched on at once -- CFM + prior +
+    duration + 2 x ForwardSumLoss (beta-binomial prior, CTC) + 2 x binarisation -- against the REAL reference on the CPU
+    (matcha_mas_train_small.npz): durations from the alignment search, the five losses, every parameter's gradient norm, six full
+    gradients (alignment module, encoder_proj, text encoder, duration predictor)."""
+    import json
+    from jatts_amd.models import MatchaTTS_MAS
+    from jatts_amd.models.matchatts_train import criterion
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    z, keys = load_golden("matcha_mas_train_small.npz")
+    zi, _ = load_golden("matcha_forward_small.npz")
+    m = MatchaTTS_MAS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 3)))
+    m = m.to(cuda).train()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    ret = m(t("text"), il, t("feats"), ol, cfm_t=t("t"), cfm_noise=t("z"))
+    assert torch.equal(ret["ds"].cpu(), torch.tensor(z["ref_ds"]))
+    losses = criterion(ret, None, il, duration_loss=True, olens=ol, forward_sum=True, bin_loss=True, lambda_align=2.0)
+    for k in ("cfm_loss", "encoder_prior_loss", "duration_loss", "forward_sum_loss", "bin_loss"):
+        assert abs(float(losses[k].detach()) - float(z[k])) <= 3e-5 * max(1.0, abs(float(z[k]))), (k, float(losses[k].detach()), float(z[k]))
+    losses["loss"].backward()
+    P = dict(m.named_parameters())
+    names = json.loads(str(z["grad_names"]))
+    assert [n for n, _ in m.named_parameters()] == names
+    for n, ref_norm in zip(names, z["grad_norms"]):
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, 1e-3) <= 3e-3, (n, float(P[n].grad.norm()), ref_norm)
+    for f in z.files:
+        if f.startswith("grad:"):
+            assert relerr(P[f[5:]].grad, z[f]) <= 3e-3, (f, relerr(P[f[5:]].grad, z[f]))
+
+
+def test_matcha_mas_trainer_schedule(cuda, lib):
+    """MatchaTTSTrainer on MatchaTTS_MAS with the recipe's schedule shape (dp_train_start_steps 3, bin_loss_start_steps 5): forward-sum
+    loss first, the duration loss after step 3, the binarisation loss after step 5; all finite."""
+    import json
+    from jatts_amd.models import MatchaTTS_MAS
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    from jatts_amd.training import MatchaTTSTrainer
+    z, keys = load_golden("matcha_mas_train_small.npz")
+    zi, _ = load_golden("matcha_forward_small.npz")
+    m = MatchaTTS_MAS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 3)))
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    batch = dict(xs=t("text"), ilens=t("text_lengths"), ys=t("feats"), olens=t("feats_lengths"), cfm_t=t("t"), cfm_noise=t("z"))
+    tr = MatchaTTSTrainer(m, dp_train_start_steps=3, bin_loss_start_steps=5, lr=5e-4, grad_norm=1.0, warmup_steps=0)
+    out = [tr.train_step(batch) for _ in range(7)]
+    assert "forward_sum_loss" in out[0] and "duration_loss" not in out[0] and "bin_loss" not in out[0]
+    assert "forward_sum_loss" not in out[4] and "duration_loss" in out[4] and "bin_loss" not in out[4]
+    assert "bin_loss" in out[6] and "duration_loss" in out[6]
+    assert all(math.isfinite(float(o["loss"])) for o in out)
+    assert float(out[2]["forward_sum_loss"]) < float(out[0]["forward_sum_loss"])
