@@ -236,9 +236,13 @@ int jatts_lr_segment_sum(const jatts_ragged* rg, const int64_t* cum, const int32
  * [n_batch][n_heads][T][T] score matrices: p = softmax_j((ac + rel_shift(bd)) * scale) over the keys j < lens[b], 0 elsewhere
  * (bd nullable: plain attention).  bwd: ds = p (dp - sum_j dp p) * scale (= d ac), dbd = rel_shift^-1(ds) (nullable). */
 int jatts_shift_softmax_fwd(const float* ac, const float* bd, int32_t n_batch, int32_t n_heads, int32_t t_len, const int32_t* lens,
-                            float scale, float* p, void* stream);
-int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, int32_t n_heads, int32_t t_len, float scale, float* ds,
-                            float* dbd, void* stream);
+                            float scale, int32_t shift_mode, float* p, void* stream);
+int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, int32_t n_heads, int32_t t_len, float scale,
+                            int32_t shift_mode, float* ds, float* dbd, void* stream);
+/* shift_mode 1: the legacy rel_shift above (bd [T][T]); 2: RelPositionMultiHeadedAttention.rel_shift (attention.py:236-258, VITS):
+ * bd [T][2T-1], shifted[i][j] = bd[i][j - i + T - 1]. */
+/* WaveNet gate backward (vits/wavenet/residual_block.py:150-156): y = tanh(a) sigmoid(b), x = [a | b] [rows][2 dim]. */
+int jatts_gate_bwd(const float* x, const float* dy, float* dx, int64_t rows, int32_t dim, void* stream);
 /* Rank-1 pieces of Linear(dim -> 1) heads and Conv1d(1 -> dim, k=1) embeddings:
  * out[r][c] (+)= v[r] w[c] + bias[c];  out[c] += sum_r v[r] x[r][c];  y[r] = bias[0] + sum_c x[r][c] w[c]. */
 int jatts_outer_rows(const float* v, const float* w, const float* bias, int64_t rows, int32_t dim, int32_t accumulate, float* out,

@@ -190,17 +190,19 @@ class ShiftSoftmax(torch.autograd.Function):
     LegacyRelPositionMultiHeadedAttention.forward / forward_attention (attention.py:63-93,142-206); ac, bd (B, H, T, T)."""
 
     @staticmethod
-    def forward(ctx, ac, bd, lens, scale):
-        p = hip.shift_softmax_fwd(ac.contiguous(), None if bd is None else bd.contiguous(), lens, scale)
+    def forward(ctx, ac, bd, lens, scale, mode=1):
+        """mode 1: legacy rel_shift, bd (B, H, T, T); mode 2: RelPositionMultiHeadedAttention.rel_shift (attention.py:236-258),
+        bd (B, H, T, 2T-1)."""
+        p = hip.shift_softmax_fwd(ac.contiguous(), None if bd is None else bd.contiguous(), lens, scale, mode)
         ctx.save_for_backward(p)
-        ctx.scale, ctx.has_bd = scale, bd is not None
+        ctx.scale, ctx.has_bd, ctx.mode = scale, bd is not None, mode
         return p
 
     @staticmethod
     def backward(ctx, dp):
         (p,) = ctx.saved_tensors
-        ds, dbd = hip.shift_softmax_bwd(p, dp.contiguous(), ctx.scale, ctx.has_bd and ctx.needs_input_grad[1])
-        return ds, dbd, None, None
+        ds, dbd = hip.shift_softmax_bwd(p, dp.contiguous(), ctx.scale, ctx.has_bd and ctx.needs_input_grad[1], ctx.mode)
+        return ds, dbd, None, None, None
 
 
 class RowDot(torch.autograd.Function):
@@ -363,3 +365,18 @@ class AlignLogProb(torch.autograd.Function):
         dF = w.sum(-1, keepdim=True) * F_ - torch.matmul(w, T_)
         dT = w.sum(1).unsqueeze(-1) * T_ - torch.matmul(w.transpose(1, 2), F_)
         return dF.reshape(B * To, A_).float(), dT.reshape(B * Tm, A_).float(), None, None
+
+
+class Gate(torch.autograd.Function):
+    """WaveNet gated activation tanh(a) * sigmoid(b) on [a | b] (vits/wavenet/residual_block.py:150-156)."""
+
+    @staticmethod
+    def forward(ctx, x, rb):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return hip.gated_tanh_sigmoid(rb, x, None, x.shape[1] // 2, hip.F32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return hip.gate_bwd(x, dy.contiguous()), None

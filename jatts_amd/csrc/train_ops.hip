@@ -348,14 +348,16 @@ __global__ __launch_bounds__(128) void lr_segment_sum_kernel(jatts_ragged rg, co
 // Per (b, h, query i): s[j] = (ac[i][j] + shift(bd)[i][j]) * scale for j < len[b], softmax over those keys, 0 elsewhere
 // (attention.py:63-93 masked_fill(min) -> softmax -> masked_fill(0)).  shift = LegacyRelPositionMultiHeadedAttention.rel_shift
 // (attention.py:142-162) on a T x T matrix: out[i][j] = flat[(i + 1) T + j] of the zero-left-padded T x (T+1) matrix.
-__device__ __forceinline__ float shifted_bd(const float* __restrict__ bd, int T, int i, int j) {
+// mode 2 = RelPositionMultiHeadedAttention.rel_shift (attention.py:236-258) on a T x (2T-1) matrix: out[i][j] = bd[i][j - i + T - 1].
+__device__ __forceinline__ float shifted_bd(const float* __restrict__ bd, int T, int i, int j, int mode) {
+  if (mode == 2) return bd[(int64_t)i * (2 * T - 1) + (j - i + T - 1)];
   const int f = (i + 1) * T + j;
   const int r = f / (T + 1), c = f - r * (T + 1);
   return c == 0 ? 0.f : bd[(int64_t)r * T + c - 1];
 }
 __global__ __launch_bounds__(256) void shift_softmax_fwd_kernel(const float* __restrict__ ac, const float* __restrict__ bd, int H, int T,
                                                                 const int32_t* __restrict__ lens, float scale, float* __restrict__ p,
-                                                                int64_t n_rows) {
+                                                                int64_t n_rows, int mode) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // (b * H + h) * T + i
   if (row >= n_rows) return;
@@ -364,16 +366,16 @@ __global__ __launch_bounds__(256) void shift_softmax_fwd_kernel(const float* __r
   const int b = (int)(bh / H);
   const int len = lens ? min(max(lens[b], 0), T) : T;
   const float* acr = ac + row * T;
-  const float* bdm = bd ? bd + bh * (int64_t)T * T : nullptr;
+  const float* bdm = bd ? bd + bh * (int64_t)T * (mode == 2 ? 2 * T - 1 : T) : nullptr;
   float m = -INFINITY;
   for (int j = lane; j < len; j += 64) {
-    const float s = (acr[j] + (bdm ? shifted_bd(bdm, T, i, j) : 0.f)) * scale;
+    const float s = (acr[j] + (bdm ? shifted_bd(bdm, T, i, j, mode) : 0.f)) * scale;
     m = fmaxf(m, s);
   }
   m = wave_max(m);
   float z = 0.f;
   for (int j = lane; j < len; j += 64) {
-    const float s = (acr[j] + (bdm ? shifted_bd(bdm, T, i, j) : 0.f)) * scale;
+    const float s = (acr[j] + (bdm ? shifted_bd(bdm, T, i, j, mode) : 0.f)) * scale;
     z += __expf(s - m);
   }
   z = wave_sum(z);
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void shift_softmax_fwd_kernel(const float* __r
   float* pr = p + row * T;
   for (int j = lane; j < T; j += 64) {
     float v = 0.f;
-    if (j < len) v = __expf((acr[j] + (bdm ? shifted_bd(bdm, T, i, j) : 0.f)) * scale - m) * inv;
+    if (j < len) v = __expf((acr[j] + (bdm ? shifted_bd(bdm, T, i, j, mode) : 0.f)) * scale - m) * inv;
     pr[j] = v;
   }
 }
@@ -400,15 +402,33 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int j = lane; j < T; j += 64) o[j] = pr[j] * (dr[j] - s) * scale;
 }
 // d_bd[r][c] = ds[i][j] with (i + 1) T + j = r (T + 1) + c + 1 (the inverse of shifted_bd; entries that no output reads get 0)
-__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ ds, int T, int64_t n_mats, float* __restrict__ dbd) {
-  const int64_t n = n_mats * T * T;
+__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ ds, int T, int64_t n_mats, float* __restrict__ dbd, int mode) {
+  const int W = mode == 2 ? 2 * T - 1 : T;
+  const int64_t n = n_mats * T * W;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int64_t mtx = e / ((int64_t)T * T);
-    const int rc = (int)(e - mtx * T * T);
-    const int r = rc / T, c = rc - r * T;
+    const int64_t mtx = e / ((int64_t)T * W);
+    const int rc = (int)(e - mtx * T * W);
+    const int r = rc / W, c = rc - r * W;
+    if (mode == 2) {
+      const int j = c - T + 1 + r;
+      dbd[e] = (j >= 0 && j < T) ? ds[mtx * T * T + (int64_t)r * T + j] : 0.f;
+      continue;
+    }
     const int f = r * (T + 1) + c + 1;
     const int i = f / T - 1, j = f % T;
     dbd[e] = (i >= 0 && i < T) ? ds[mtx * T * T + (int64_t)i * T + j] : 0.f;
+  }
+}
+// WaveNet gate (residual_block.py:150-156): y = tanh(a) sigmoid(b) on x = [a | b]; dx = [dy sigmoid(b) (1 - tanh^2 a) | dy tanh(a) s (1 - s)]
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                       int64_t rows, int C) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    const float t = tanhf(x[r * 2 * C + c]), sg = sigmoidf_(x[r * 2 * C + C + c]), d = dy[i];
+    dx[r * 2 * C + c] = d * sg * (1.f - t * t);
+    dx[r * 2 * C + C + c] = d * t * sg * (1.f - sg);
   }
 }
 
@@ -826,23 +846,34 @@ extern "C" int jatts_lr_segment_sum(const jatts_ragged* rg, const int64_t* cum, 
   return JATTS_OK;
 }
 
-extern "C" int jatts_shift_softmax_fwd(const float* ac, const float* bd, int32_t n_batch, int32_t n_heads, int32_t t_len, const int32_t* lens,
-                                       float scale, float* p, void* stream) {
-  NULLCHK(!ac || !p, "shift_softmax_fwd: null pointer");
-  NULLCHK(n_batch < 1 || n_heads < 1 || t_len < 1, "shift_softmax_fwd: bad geometry");
-  const int64_t n_rows = (int64_t)n_batch * n_heads * t_len;
-  hipLaunchKernelGGL(shift_softmax_fwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, ac, bd, n_heads, t_len, lens, scale, p, n_rows);
+extern "C" int jatts_gate_bwd(const float* x, const float* dy, float* dx, int64_t rows, int32_t dim, void* stream) {
+  NULLCHK(!x || !dy || !dx, "gate_bwd: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, x, dy, dx, rows, dim);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
-extern "C" int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, int32_t n_heads, int32_t t_len, float scale, float* ds,
-                                       float* dbd, void* stream) {
+
+extern "C" int jatts_shift_softmax_fwd(const float* ac, const float* bd, int32_t n_batch, int32_t n_heads, int32_t t_len, const int32_t* lens,
+                                       float scale, int32_t shift_mode, float* p, void* stream) {
+  NULLCHK(!ac || !p, "shift_softmax_fwd: null pointer");
+  NULLCHK(n_batch < 1 || n_heads < 1 || t_len < 1, "shift_softmax_fwd: bad geometry");
+  const int64_t n_rows = (int64_t)n_batch * n_heads * t_len;
+  NULLCHK(shift_mode != 1 && shift_mode != 2, "shift_softmax_fwd: shift_mode 1 (legacy) or 2 (new)");
+  hipLaunchKernelGGL(shift_softmax_fwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, ac, bd, n_heads, t_len, lens, scale, p, n_rows,
+                     shift_mode);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, int32_t n_heads, int32_t t_len, float scale,
+                                       int32_t shift_mode, float* ds, float* dbd, void* stream) {
   NULLCHK(!p || !dp || !ds, "shift_softmax_bwd: null pointer");
   NULLCHK(n_batch < 1 || n_heads < 1 || t_len < 1, "shift_softmax_bwd: bad geometry");
   const int64_t n_rows = (int64_t)n_batch * n_heads * t_len;
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, p, dp, t_len, scale, ds, n_rows);
   if (dbd)
-    hipLaunchKernelGGL(unshift_kernel, dim3(blocks_for(n_rows * t_len, 256)), dim3(256), 0, S_, ds, t_len, (int64_t)n_batch * n_heads, dbd);
+    hipLaunchKernelGGL(unshift_kernel, dim3(blocks_for(n_rows * (shift_mode == 2 ? 2 * t_len - 1 : t_len), 256)), dim3(256), 0, S_, ds, t_len,
+                       (int64_t)n_batch * n_heads, dbd, shift_mode);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

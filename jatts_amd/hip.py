@@ -751,26 +751,35 @@ def lr_segment_sum(rb_in, cum, rb_out, dy):
     return dhs
 
 
-def shift_softmax_fwd(ac, bd, lens, scale):
-    """ac, bd: (B, H, T, T) f32 -> attention probabilities (legacy rel_shift applied to bd; bd None = plain attention)."""
+def shift_softmax_fwd(ac, bd, lens, scale, mode=1):
+    """ac (B, H, T, T), bd (B, H, T, T) [mode 1, legacy rel_shift] or (B, H, T, 2T-1) [mode 2, new rel_shift] -> attention
+    probabilities (bd None = plain attention)."""
     lib = _abi.load()
     ac = _f32c(ac)
     B, H, T, _ = ac.shape
     p = torch.empty_like(ac)
-    _abi.check(lib.jatts_shift_softmax_fwd(ac.data_ptr(), _ptr(bd), B, H, T, _ptr(lens), float(scale), p.data_ptr(), _stream()),
+    _abi.check(lib.jatts_shift_softmax_fwd(ac.data_ptr(), _ptr(bd), B, H, T, _ptr(lens), float(scale), mode, p.data_ptr(), _stream()),
                "jatts_shift_softmax_fwd")
     return p
 
 
-def shift_softmax_bwd(p, dp, scale, need_dbd=True):
+def shift_softmax_bwd(p, dp, scale, need_dbd=True, mode=1):
     lib = _abi.load()
     p, dp = _f32c(p), _f32c(dp)
     B, H, T, _ = p.shape
     ds = torch.empty_like(p)
-    dbd = torch.empty_like(p) if need_dbd else None
-    _abi.check(lib.jatts_shift_softmax_bwd(p.data_ptr(), dp.data_ptr(), B, H, T, float(scale), ds.data_ptr(), _ptr(dbd), _stream()),
+    dbd = torch.empty(B, H, T, 2 * T - 1 if mode == 2 else T, dtype=torch.float32, device=p.device) if need_dbd else None
+    _abi.check(lib.jatts_shift_softmax_bwd(p.data_ptr(), dp.data_ptr(), B, H, T, float(scale), mode, ds.data_ptr(), _ptr(dbd), _stream()),
                "jatts_shift_softmax_bwd")
     return ds, dbd
+
+
+def gate_bwd(x, dy):
+    lib = _abi.load()
+    x, dy = _f32c(x), _f32c(dy)
+    dx = torch.empty_like(x)
+    _abi.check(lib.jatts_gate_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1] // 2, _stream()), "jatts_gate_bwd")
+    return dx
 
 
 def outer_rows(v, w, bias=None, out=None):

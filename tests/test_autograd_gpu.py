@@ -298,3 +298,38 @@ def test_forward_sum_ctc_matches_torch(cuda, lib):
     (out * 1.3).backward()
     assert abs(float(out.detach()) - float(loss.detach())) <= 2e-5 * abs(float(loss.detach()))
     assert relerr(ld.grad, lr_.grad) <= 5e-5, relerr(ld.grad, lr_.grad)
+
+
+def _rel_shift_new(x):
+    """attention.py:236-258 (zero_triu False) on (B, H, T, 2T-1)."""
+    b, h, t, w = x.shape
+    xp = torch.cat([torch.zeros(b, h, t, 1, dtype=x.dtype), x], dim=-1).view(b, h, w + 1, t)
+    return xp[:, :, 1:].reshape(b, h, t, w)[:, :, :, : w // 2 + 1]
+
+
+def test_shift_softmax_new_style_backward(cuda, lib):
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(16)
+    B, H, T, lens = 2, 2, 19, [19, 11]
+    ac, bd, gp = torch.randn(B, H, T, T, generator=g), torch.randn(B, H, T, 2 * T - 1, generator=g), torch.randn(B, H, T, T, generator=g)
+    (ar, ad), (br, bd_) = _leaf(ac, cuda), _leaf(bd, cuda)
+    scale = 0.2
+    s = (ar + _rel_shift_new(br)) * scale
+    mask = (torch.arange(T)[None, :] >= torch.tensor(lens)[:, None])[:, None, None, :]
+    pr = torch.softmax(s.masked_fill(mask, torch.finfo(torch.float32).min), dim=-1).masked_fill(mask, 0.0)
+    pr.backward(gp.double())
+    p = A.ShiftSoftmax.apply(ad, bd_, torch.tensor(lens, dtype=torch.int32, device=cuda), scale, 2)
+    p.backward(gp.to(cuda))
+    _check([("p", p, pr), ("dac", ad.grad, ar.grad), ("dbd", bd_.grad, br.grad)])
+
+
+def test_wavenet_gate_backward(cuda, lib):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(17)
+    x, gy = torch.randn(45, 2 * 40, generator=g) * 2, torch.randn(45, 40, generator=g)
+    xr, xd = _leaf(x, cuda)
+    yr = torch.tanh(xr[:, :40]) * torch.sigmoid(xr[:, 40:])
+    yr.backward(gy.double())
+    y = A.Gate.apply(xd, hip.RaggedBatch([20, 25], cuda))
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad)])
