@@ -12,7 +12,7 @@ import torch
 
 from .. import autograd as A
 from .. import hip
-from ._conformer import BN_EPS, LN_EPS, PE_TABLE_LEN, legacy_rel_pos_table
+from ._conformer import BN_EPS, LN_EPS, PE_TABLE_LEN, legacy_rel_pos_table, rel_pos_table_new
 
 BN_MOMENTUM = 0.1
 
@@ -54,14 +54,20 @@ class _Ctx:
         return x * s + (self.p[name + ".bias"] - self.b[name + ".running_mean"] * s)
 
 
-def _conformer(c, prefix, x, rb, kv, H, rates):
-    """conformer/encoder.py:233-289 after the input layer: x (rows, A) is already x * sqrt(A) (+ positional dropout)."""
+def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
+    """conformer/encoder.py:233-289 after the input layer: x (rows, A) is already x * sqrt(A) (+ positional dropout).
+    rel_style "legacy": LegacyRelPositionalEncoding / LegacyRelPositionMultiHeadedAttention (FastSpeech2, Matcha-TTS);
+    "new": RelPositionalEncoding / RelPositionMultiHeadedAttention (VITS: 2T-1 relative positions, attention.py:209-305)."""
     B, T = rb.n_seq, rb.max_len
     Ad = x.shape[1]
     dk = Ad // H
-    pos = legacy_rel_pos_table(T, Ad, max(PE_TABLE_LEN, T)).to(x.device)          # pe[:, :T] (positional_encoding.py:221-235)
+    if rel_style == "new":
+        pos = rel_pos_table_new(T, Ad).to(x.device)                                # (2T-1, A) (positional_encoding.py:265-309)
+    else:
+        pos = legacy_rel_pos_table(T, Ad, max(PE_TABLE_LEN, T)).to(x.device)      # pe[:, :T] (positional_encoding.py:221-235)
+    n_pos = pos.shape[0]
     pos = c.drop(pos, rates["pos"])
-    rbp = hip.RaggedBatch([T], x.device)
+    rbp = hip.RaggedBatch([n_pos], x.device)
     i = 0
     while (prefix + f"encoders.{i}.norm_mha.weight") in c.p:
         q = prefix + f"encoders.{i}."
@@ -82,10 +88,10 @@ def _conformer(c, prefix, x, rb, kv, H, rates):
         bqkv = torch.cat([c.p[a + "linear_q.bias"], c.p[a + "linear_k.bias"], c.p[a + "linear_v.bias"]], 0)
         qkv = A.Conv1dFunction.apply(h, wqkv, bqkv, rb, 1, 0).view(B, T, 3, H, dk)
         qh, kh, vh = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))                   # (B, H, T, dk)
-        ph = A.Conv1dFunction.apply(pos, c.p[a + "linear_pos.weight"].unsqueeze(-1), None, rbp, 1, 0).view(T, H, dk).permute(1, 0, 2)
+        ph = A.Conv1dFunction.apply(pos, c.p[a + "linear_pos.weight"].unsqueeze(-1), None, rbp, 1, 0).view(n_pos, H, dk).permute(1, 0, 2)
         ac = torch.matmul(qh + c.p[a + "pos_bias_u"][None, :, None, :], kh.transpose(-2, -1))        # rocBLAS batched GEMMs
         bd = torch.matmul(qh + c.p[a + "pos_bias_v"][None, :, None, :], ph.transpose(-2, -1)[None])
-        p_attn = A.ShiftSoftmax.apply(ac, bd, kv, 1.0 / math.sqrt(dk))
+        p_attn = A.ShiftSoftmax.apply(ac, bd, kv, 1.0 / math.sqrt(dk), 2 if rel_style == "new" else 1)
         p_attn = c.drop(p_attn, rates["attn"])
         ctxv = torch.matmul(p_attn, vh).permute(0, 2, 1, 3).reshape(B * T, Ad)
         x = x + c.drop(c.conv(ctxv, a + "linear_out", rb), rates["layer"])

@@ -129,9 +129,22 @@ class VITS(torch.nn.Module):
                          conformer_dec_kernel_size, attn_type="rel_selfattn", normalize_before=decoder_normalize_before)
         S._lin(spec, "feat_out", odim, adim)
         S.build_from_spec(self, spec)
+        # train-mode behaviour (models/vits_train.py): the reference's dropout sites
+        self.dropout_rates = dict(te=text_encoder_dropout_rate, te_pos=text_encoder_positional_dropout_rate,
+                                  te_attn=text_encoder_attention_dropout_rate, dec=transformer_dec_dropout_rate,
+                                  dec_pos=transformer_dec_positional_dropout_rate, dec_attn=transformer_dec_attn_dropout_rate,
+                                  dur=duration_predictor_dropout_rate, post=posterior_encoder_dropout_rate, flow=flow_dropout_rate)
+        self._train_calls = 0
         self.precision = "fp32"   # the reference's arithmetic; set_precision("fp16") selects the fast mode
         self._prep = None
         self.eval()
+
+    def train(self, mode: bool = True):
+        """train(True) also turns the parameters' requires_grad on (they are created frozen for the inference path)."""
+        super().train(mode)
+        if mode:
+            self.requires_grad_(True)
+        return self
 
     def set_precision(self, precision):
         if precision not in ("fp16", "fp32"):
@@ -333,7 +346,6 @@ class VITS(torch.nn.Module):
                        outs_bar=hip.conv1d(rbo, zs, fo.w, fo.c_in, fo.n_out, 1, dtype=dt, bias=fo.b, out_f32=True))
         return out
 
-    @torch.no_grad()
     def forward(self, text, text_lengths, feats, feats_lengths, durations=None, durations_lengths=None, spembs=None, sids=None,
                 lids=None, joint_training=False, post_noise=None):
         """The reference's training-time call, forward only (vits.py:342-579 with is_inference=False): padded batch -> text encoder,
@@ -343,6 +355,15 @@ class VITS(torch.nn.Module):
         ``post_noise`` (B, T_feats, adim): the posterior encoder's randn_like draw (posterior_encoder.py:128), injectable.
         The conformers run on the PADDED batch (key masks only, convolutions read the padding, as in the reference); the
         WaveNet parts run ragged -- there the reference masks after every layer, which is the ragged layout."""
+        if self.training and torch.is_grad_enabled():   # differentiable HIP forward (models/vits_train.py; jatts_amd.training.VITSTrainer)
+            from .vits_train import train_forward
+            self._train_calls += 1
+            self._prep = None
+            return train_forward(self, text, text_lengths, feats, feats_lengths, spembs, post_noise=post_noise, seed=self._train_calls)
+        with torch.no_grad():
+            return self._forward_eval(text, text_lengths, feats, feats_lengths, spembs, post_noise)
+
+    def _forward_eval(self, text, text_lengths, feats, feats_lengths, spembs, post_noise=None):
         if spembs is None:
             raise ValueError("spembs is required (the reference crashes without it, vits.py:485)")
         P = self._prepare()

@@ -297,3 +297,22 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
         return criterion(ret, batch.get("durations"), batch["ilens"], duration_loss=self.steps > self.dp_train_start_steps,
                          olens=batch["olens"], forward_sum=mas and self.steps < self.dp_train_start_steps,
                          bin_loss=mas and self.steps > self.bin_loss_start_steps, lambda_align=self.lambda_align)
+
+
+class VITSTrainer(FastSpeech2Trainer):
+    """`VITSTrainer._train_step` (jatts/trainers/vits.py:23-140) for the mel-VITS: lambda_mel x MelLoss + KLDivergenceLoss, the
+    duration loss after `dp_train_start_steps`, lambda_align x ForwardSumLoss before it, lambda_align x the binarisation loss
+    after `bin_loss_start_steps`; same flat-buffer optimiser / all-reduce / checkpoint layout.  ``post_noise`` in the batch
+    injects the posterior encoder's random draw.  (gradient_accumulate_steps = 1.)"""
+
+    def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, lambda_mel=1.0, **kw):
+        super().__init__(model, **kw)
+        self.dp_train_start_steps, self.bin_loss_start_steps = dp_train_start_steps, bin_loss_start_steps
+        self.lambda_align, self.lambda_mel = lambda_align, lambda_mel
+
+    def compute_losses(self, batch):
+        from .models.vits_train import criterion
+        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], spembs=batch["spkembs"], post_noise=batch.get("post_noise"))
+        return criterion(ret, batch["ilens"], batch["olens"], duration_loss=self.steps > self.dp_train_start_steps,
+                         forward_sum=self.steps < self.dp_train_start_steps, bin_loss=self.steps > self.bin_loss_start_steps,
+                         lambda_align=self.lambda_align, lambda_mel=self.lambda_mel)

@@ -380,3 +380,56 @@ def test_matcha_mas_trainer_schedule(cuda, lib):
     assert "bin_loss" in out[6] and "duration_loss" in out[6]
     assert all(math.isfinite(float(o["loss"])) for o in out)
     assert float(out[2]["forward_sum_loss"]) < float(out[0]["forward_sum_loss"])
+
+
+def test_vits_train_step_matches_reference(cuda, lib):
+    """mel-VITS with every loss term of jatts/trainers/vits.py:47-110 on at once -- mel + KL + duration + 2 x ForwardSumLoss + 2 x
+    binarisation -- against the REAL reference on the CPU (vits_train_small.npz): MAS durations, the five losses, every parameter's
+    gradient norm, ten full gradients (weight-normalised WaveNet g / v, flow projection, text-encoder statistics projection, the
+    new-style relative-position parameters of both conformers, feat_out, the speaker projection)."""
+    import json
+    from jatts_amd.models import VITS
+    from jatts_amd.models.vits_train import criterion
+    z, keys = load_golden("vits_train_small.npz")
+    zi, _ = load_golden("vits_forward_small.npz")
+    m = VITS(idim=20, **json.loads(str(z["config"])))
+    m.load_state_dict(golden_state(keys, 2))
+    m = m.to(cuda).train()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    ret = m(t("text"), il, t("feats"), ol, spembs=t("spembs"), post_noise=t("noise"))
+    assert torch.equal(ret["ds"].cpu(), torch.tensor(z["ref_ds"]))
+    losses = criterion(ret, il, ol, duration_loss=True, forward_sum=True, bin_loss=True, lambda_align=2.0)
+    for k in ("mel_loss", "kl_loss", "duration_loss", "forward_sum_loss", "bin_loss"):
+        assert abs(float(losses[k].detach()) - float(z[k])) <= 3e-5 * max(1.0, abs(float(z[k]))), (k, float(losses[k].detach()), float(z[k]))
+    losses["loss"].backward()
+    P = dict(m.named_parameters())
+    names = json.loads(str(z["grad_names"]))
+    assert [n for n, _ in m.named_parameters()] == names
+    floor = 1e-5 * float(np.sqrt((z["grad_norms"] ** 2).sum()))   # exactly-zero true gradients (conv biases in front of a batch-stat
+    for n, ref_norm in zip(names, z["grad_norms"]):                # BatchNorm, linear_k.bias) carry rounding noise of the global scale
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, floor, 1e-3) <= 3e-3, (n, float(P[n].grad.norm()), ref_norm)
+    for f in z.files:
+        if f.startswith("grad:"):
+            assert relerr(P[f[5:]].grad, z[f]) <= 3e-3, (f, relerr(P[f[5:]].grad, z[f]))
+
+
+def test_vits_trainer_steps(cuda, lib):
+    """VITSTrainer with the recipe's schedule shape: forward-sum first, duration after dp_train_start_steps, finite, mel loss falling."""
+    import json
+    from jatts_amd.models import VITS
+    from jatts_amd.training import VITSTrainer
+    z, keys = load_golden("vits_train_small.npz")
+    zi, _ = load_golden("vits_forward_small.npz")
+    m = VITS(idim=20, **{**json.loads(str(z["config"])), "text_encoder_dropout_rate": 0.1, "transformer_dec_dropout_rate": 0.1})
+    m.load_state_dict(golden_state(keys, 2))
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    batch = dict(xs=t("text"), ilens=t("text_lengths"), ys=t("feats"), olens=t("feats_lengths"), spkembs=t("spembs"), post_noise=t("noise"))
+    tr = VITSTrainer(m, dp_train_start_steps=3, bin_loss_start_steps=4, lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    out = [tr.train_step(batch) for _ in range(8)]
+    assert "forward_sum_loss" in out[0] and "duration_loss" not in out[0]
+    assert "duration_loss" in out[4] and "forward_sum_loss" not in out[4] and "bin_loss" in out[5]
+    assert all(math.isfinite(float(o["loss"])) for o in out)
+    assert float(out[-1]["mel_loss"]) < float(out[0]["mel_loss"])
