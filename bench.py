@@ -356,17 +356,28 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     conf/fastspeech2.v1.yaml; jatts/trainers/matchatts.py:23-120 on the tts1 conf/matcha_tts.v1.prior.steplr.large.yaml): forward in
     train mode, the losses, backward, clip + Adam -- f32, synthetic weights / targets, batch 32."""
     import torch
-    from jatts_amd.models import FastSpeech2, MatchaTTS
-    from jatts_amd.synthetic import FS2_JSUT, MATCHA_MAS_JSUT, matcha_golden_tweaks, synth_state_dict
-    from jatts_amd.training import FastSpeech2Trainer, MatchaTTSTrainer
+    from jatts_amd.models import VITS, FastSpeech2, MatchaTTS, MatchaTTS_MAS
+    from jatts_amd.synthetic import FS2_JSUT, MATCHA_MAS_JSUT, VITS_JSUT, matcha_golden_tweaks, synth_state_dict
+    from jatts_amd.training import FastSpeech2Trainer, MatchaTTSTrainer, VITSTrainer
+    extra = {}
     if kind == "fs2":
         m = FastSpeech2(idim=45, **{**FS2_JSUT, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
         m.load_state_dict(synth_state_dict(m.state_dict(), 0))
         name, flop_per_utt = "FastSpeech2 (fastspeech2.v1.yaml)", 3 * 67.4e-3
-    else:
+    elif kind == "matcha":
         m = MatchaTTS(idim=45, **MATCHA_MAS_JSUT)      # the tts1 yaml's model_params equal the MAS recipe's
         m.load_state_dict(matcha_golden_tweaks(synth_state_dict(m.state_dict(), 0)))
         name, flop_per_utt = "MatchaTTS tts1 (matcha_tts.v1.prior.steplr.large.yaml)", None
+    elif kind == "matcha_mas":
+        m = MatchaTTS_MAS(idim=45, **MATCHA_MAS_JSUT)
+        m.load_state_dict(matcha_golden_tweaks(synth_state_dict(m.state_dict(), 0)))
+        name, flop_per_utt = "MatchaTTS_MAS tts2 (matcha_tts.mas.v1.yaml; forward-sum phase)", None
+        extra = dict(dp_train_start_steps=10000, bin_loss_start_steps=15000)
+    else:
+        m = VITS(idim=45, spk_embed_dim=192, **VITS_JSUT)
+        m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+        name, flop_per_utt = "mel-VITS (vits.v1.bs32.yaml + 192-d spkemb; forward-sum phase)", None
+        extra = dict(dp_train_start_steps=10000, bin_loss_start_steps=15000)
     m = m.to(dev)
     g = torch.Generator().manual_seed(5)
     il = torch.full((batch,), t_text, dtype=torch.long)
@@ -374,8 +385,10 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     ol = ds.sum(1)
     b = dict(xs=torch.randint(1, 45, (batch, t_text), generator=g).to(dev), ilens=il, ys=torch.randn(batch, int(ol.max()), 80, generator=g).to(dev),
              olens=ol, durations=ds.to(dev), duration_lens=il, pitch=torch.randn(batch, t_text, 1, generator=g).to(dev), pitch_lens=il,
-             energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il)
-    tr = (FastSpeech2Trainer if kind == "fs2" else MatchaTTSTrainer)(m, lr=1e-4, grad_norm=1.0, warmup_steps=0)
+             energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il,
+             spkembs=torch.randn(batch, 192, generator=g).to(dev) if kind == "vits" else None)
+    cls = {"fs2": FastSpeech2Trainer, "matcha": MatchaTTSTrainer, "matcha_mas": MatchaTTSTrainer, "vits": VITSTrainer}[kind]
+    tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, **extra)
     first = float(tr.train_step(b)["loss"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -521,7 +534,7 @@ def main():
     # ---- one FastSpeech2 `_train_step` at the recipe's batch size (not part of `value`): N == 1 only
     if world == 1 and not a.no_train:
         out["training"] = []
-        for kind in ("fs2", "matcha"):
+        for kind in ("fs2", "matcha", "matcha_mas", "vits"):
             out["training"].append(train_step_line(dev, max(2, min(3, a.steps)), kind))
             torch.cuda.empty_cache()
 
