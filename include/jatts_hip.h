@@ -193,6 +193,11 @@ int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const
  * caller zeroes dw; accumulation order is not fixed: f32 atomics). */
 int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
                        int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, void* stream);
+/* Pack a torch-layout f32 weight (n_out, c_in, k_w) into jatts_conv1d's fragment order (zero padded: n to 32, c to c_mult) as
+ * `dtype`, in one launch.  mode 0: the weight itself; mode 1: the data-gradient operand W'[c][n][k'] = W[n][c][k_w-1-k'] (a conv from
+ * n_out to c_in channels; padded sizes follow the swapped roles).  out: k_w * pad32(n) * pad(c, c_mult) elements. */
+int jatts_pack_conv_weight(const float* w, int32_t n_out, int32_t c_in, int32_t k_w, int32_t c_mult, int32_t mode, int32_t dtype,
+                           void* out, void* stream);
 /* out[c] += sum over rows of x[row][c] (bias gradient; caller zeroes out). */
 int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* out, void* stream);
 

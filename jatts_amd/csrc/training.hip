@@ -162,6 +162,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
       }
 }
 
+// Weight packing for jatts_conv1d ([tap][c/16][n/32][g][n%32][8], include/jatts_hip.h) in ONE launch: zero padding of n to 32 and c
+// to c_mult, the permutation, the cast -- and for the data gradient (mode 1) the transposition / tap flip of
+// W'[c][n][k'] = W[n][c][K-1-k'] on the fly.  The training step re-packs every weight twice per step (forward, dgrad); as torch
+// ops that was a zero fill + two copies (+ permute / flip copies) per use, a third of all launches of a step.
+template <typename TO>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, int n_out, int c_in, int K, int n_pad, int c_pad,
+                                                               int mode, TO* __restrict__ out) {
+  const int64_t total = (int64_t)K * n_pad * c_pad;
+  const int KC16 = c_pad / 16, NFR = n_pad / 32;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int e = (int)(i & 7), nl = (int)((i >> 3) & 31), g = (int)((i >> 8) & 1);
+    int64_t r = i >> 9;
+    const int nf = (int)(r % NFR);
+    r /= NFR;
+    const int c16 = (int)(r % KC16), tap = (int)(r / KC16);
+    const int n = nf * 32 + nl, c = c16 * 16 + g * 8 + e;
+    float v = 0.f;
+    if (mode == 0) {
+      if (n < n_out && c < c_in) v = w[((int64_t)n * c_in + c) * K + tap];
+    } else {          // packed "n" runs over the original input channels, packed "c" over the original output channels
+      if (n < c_in && c < n_out) v = w[((int64_t)c * c_in + n) * K + (K - 1 - tap)];
+    }
+    out[i] = from_f32<TO>(v);
+  }
+}
+
 // out[c] += sum over rows of x[row][c]
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, int64_t rows, int dim, float* out) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -227,6 +253,25 @@ extern "C" int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t d
   if (rows <= 0 || dim <= 0) return JATTS_OK;
   const int64_t gy = (rows + 255) / 256;
   hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, ld, rows, dim, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_pack_conv_weight(const float* w, int32_t n_out, int32_t c_in, int32_t k_w, int32_t c_mult, int32_t mode, int32_t dtype,
+                                      void* out, void* stream) {
+  if (!w || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "pack_conv_weight: null pointer");
+  if (n_out < 1 || c_in < 1 || k_w < 1 || c_mult < 16 || c_mult % 16 != 0 || (mode != 0 && mode != 1))
+    return jatts_set_error_msg(JATTS_ERR_ARG, "pack_conv_weight: bad geometry");
+  const int pn = mode == 0 ? n_out : c_in, pc = mode == 0 ? c_in : n_out;
+  const int n_pad = (pn + 31) / 32 * 32, c_pad = (pc + c_mult - 1) / c_mult * c_mult;
+  const int64_t total = (int64_t)k_w * n_pad * c_pad;
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == JATTS_F32)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(blocks), dim3(256), 0, S_, w, n_out, c_in, k_w, n_pad, c_pad, mode, (float*)out);
+  else if (dtype == JATTS_F16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<f16>, dim3(blocks), dim3(256), 0, S_, w, n_out, c_in, k_w, n_pad, c_pad, mode, (f16*)out);
+  else
+    return jatts_set_error_msg(JATTS_ERR_ARG, "pack_conv_weight: dtype");
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

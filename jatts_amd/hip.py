@@ -125,6 +125,22 @@ def pack_conv_weight(w, dtype_code, c_mult=64):
     return wp.to(torch_dtype(dtype_code))
 
 
+def pack_conv_weight_dev(w, dtype_code, c_mult=64, dgrad=False):
+    """pack_conv_weight as ONE HIP launch on a device f32 weight (n_out, c_in, k); dgrad=True packs the data-gradient operand
+    W'[c][n][k-1-tap] directly (no permute / flip copies).  -> (packed, padded c_in of the packed conv)."""
+    lib = _abi.load()
+    w = _dev(w)
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    n, c, k = w.shape
+    pn, pc = (c, n) if dgrad else (n, c)
+    n_pad, c_pad = round_up(pn, 32), round_up(pc, c_mult)
+    out = torch.empty(k * n_pad * c_pad, dtype=torch_dtype(dtype_code), device=w.device)
+    _abi.check(lib.jatts_pack_conv_weight(w.data_ptr(), n, c, k, c_mult, int(dgrad), dtype_code, out.data_ptr(), _stream()),
+               "jatts_pack_conv_weight")
+    return out, c_pad
+
+
 def convtranspose_as_conv(w, stride, padding):
     """ConvTranspose1d weight (c_in, c_out, K) -> polyphase Conv1d weight
     (stride*c_out, c_in, taps) + input offset `pad`, such that the conv output row j,

@@ -60,9 +60,9 @@ class Conv1dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rb, dil, pad):
         n_out, c_in, k = weight.shape
-        pc = PackedConv(weight, bias, hip.F32, x.device)
-        xin = x.contiguous() if c_in == pc.c_in else hip.affine_cast(x.contiguous(), hip.F32, ldy=pc.c_in)
-        y = hip.conv1d(rb, xin, pc.w, pc.c_in, n_out, k, dtype=hip.F32, dil=dil, pad=pad, bias=pc.b)
+        wp, c_pad = hip.pack_conv_weight_dev(weight.detach(), hip.F32)
+        xin = x.contiguous() if c_in == c_pad else hip.affine_cast(x.contiguous(), hip.F32, ldy=c_pad)
+        y = hip.conv1d(rb, xin, wp, c_pad, n_out, k, dtype=hip.F32, dil=dil, pad=pad, bias=None if bias is None else bias.detach().contiguous())
         ctx.save_for_backward(x, weight)
         ctx.geom = (rb, dil, pad, bias is not None)
         return y
@@ -75,9 +75,9 @@ class Conv1dFunction(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            pcb = PackedConv(weight.detach().permute(1, 0, 2).flip(2).contiguous(), None, hip.F32, dy.device)
-            dyp = dy if n_out == pcb.c_in else hip.affine_cast(dy, hip.F32, ldy=pcb.c_in)
-            dx = hip.conv1d(rb, dyp, pcb.w, pcb.c_in, c_in, k, dtype=hip.F32, dil=dil, pad=(k - 1) * dil - pad)
+            wp, c_pad = hip.pack_conv_weight_dev(weight.detach(), hip.F32, dgrad=True)       # W'[c][n][k-1-tap], packed in one launch
+            dyp = dy if n_out == c_pad else hip.affine_cast(dy, hip.F32, ldy=c_pad)
+            dx = hip.conv1d(rb, dyp, wp, c_pad, c_in, k, dtype=hip.F32, dil=dil, pad=(k - 1) * dil - pad)
         if ctx.needs_input_grad[1]:
             dw = hip.conv1d_wgrad(rb, x.detach().contiguous().float(), dy, c_in, n_out, k, dil, pad)
         if has_bias and ctx.needs_input_grad[2]:

@@ -433,3 +433,15 @@ def test_vits_trainer_steps(cuda, lib):
     assert "duration_loss" in out[4] and "forward_sum_loss" not in out[4] and "bin_loss" in out[5]
     assert all(math.isfinite(float(o["loss"])) for o in out)
     assert float(out[-1]["mel_loss"]) < float(out[0]["mel_loss"])
+
+
+@pytest.mark.parametrize("n,c,k", [(96, 80, 3), (1, 256, 1), (384, 1, 1), (64, 64, 5), (33, 17, 4)])
+def test_pack_conv_weight_kernel_matches_the_host_packing(cuda, lib, n, c, k):
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(n + c + k)
+    w = torch.randn(n, c, k, generator=g).to(cuda)
+    for dt in (hip.F32, hip.F16):
+        got, c_pad = hip.pack_conv_weight_dev(w, dt)
+        assert c_pad == hip.round_up(c, 64) and torch.equal(got, hip.pack_conv_weight(w, dt))
+        got, c_pad = hip.pack_conv_weight_dev(w, dt, dgrad=True)
+        assert c_pad == hip.round_up(n, 64) and torch.equal(got, hip.pack_conv_weight(w.permute(1, 0, 2).flip(2).contiguous(), dt))
