@@ -189,10 +189,12 @@ int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream);
 int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
                       const int32_t* valid_len, int32_t kind, float log_offset, double scale, float* out, double* workspace,
                       void* stream);
-/* dw[n][c][tap] += sum_t dy[t][n] * x[t + tap*dil - pad][c] over all sequences (torch weight layout (n_out, c_in, k_w), f32;
- * caller zeroes dw; accumulation order is not fixed: f32 atomics). */
+/* dw[n][c][tap] = sum_t dy[t][n] * x[t + tap*dil - pad][c] over all sequences (torch weight layout (n_out, c_in, k_w), f32).
+ * workspace != NULL (n_seq * k_w * pad64(n_out) * pad64(c_in) floats): split-K partials are written there and summed by a second
+ * launch, dw is OVERWRITTEN (deterministic, no atomics).  workspace == NULL: dw += with f32 atomics (caller zeroes dw; order not
+ * fixed). */
 int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
-                       int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, void* stream);
+                       int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* workspace, void* stream);
 /* Pack a torch-layout f32 weight (n_out, c_in, k_w) into jatts_conv1d's fragment order (zero padded: n to 32, c to c_mult) as
  * `dtype`, in one launch.  mode 0: the weight itself; mode 1: the data-gradient operand W'[c][n][k'] = W[n][c][k_w-1-k'] (a conv from
  * n_out to c_in channels; padded sizes follow the swapped roles).  out: k_w * pad32(n) * pad(c, c_mult) elements. */

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
 template <int KW>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, const float* __restrict__ x, int ldx, const float* __restrict__ dy,
                                                               int ldy, int c_in, int n_out, int dil, int pad, int seq_groups,
-                                                              float* __restrict__ dw) {
+                                                              float* __restrict__ dw, float* __restrict__ ws) {
   constexpr int TT = 32, P = 68;
   extern __shared__ float sm[];
   float* dys = sm;
@@ -152,6 +152,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
   }
   // C/D map: column (lane & 31) = c, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = n
   const int c = c0 + wc * 32 + lo;
+  if (ws) {   // split-K partial of this sequence group: ws[grp][tap][n][c] (c fastest: 128-byte row stores), summed by wgrad_reduce_kernel
+    const int n64 = gridDim.x * 64, c64 = gridDim.y * 64;
+    float* o = ws + (int64_t)grp * KW * n64 * c64;
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        o[((int64_t)k * n64 + n) * c64 + c] = acc[k][r];
+      }
+    return;
+  }
   if (c < c_in)
 #pragma unroll
     for (int k = 0; k < KW; ++k)
@@ -160,6 +172,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
         const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (n < n_out) atomicAdd(&dw[((int64_t)n * c_in + c) * KW + k], acc[k][r]);
       }
+}
+// dw[n][c][k] = sum over groups of ws[g][k][n][c]  (overwrites dw: no zero fill, no atomics -- 32-way contended f32 atomics on a
+// 368 k-element gradient were 85 % of the k = 5 launches' time)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int groups, int K, int n64, int c64, int n_out, int c_in,
+                                                           float* __restrict__ dw) {
+  const int64_t total = (int64_t)n_out * c_in * K;
+  const int64_t gstride = (int64_t)K * n64 * c64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const int64_t nc = i / K;
+    const int c = (int)(nc % c_in), n = (int)(nc / c_in);
+    const float* p = ws + ((int64_t)k * n64 + n) * c64 + c;
+    float a = 0.f;
+    for (int g = 0; g < groups; ++g) a += p[g * gstride];
+    dw[i] = a;
+  }
 }
 
 // Weight packing for jatts_conv1d ([tap][c/16][n/32][g][n%32][8], include/jatts_hip.h) in ONE launch: zero padding of n to 32 and c
@@ -220,7 +248,7 @@ extern "C" int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t
 }
 
 extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
-                                  int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, void* stream) {
+                                  int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* workspace, void* stream) {
   if (!rg || !x || !dy || !dw) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: null pointer");
   if (c_in < 1 || n_out < 1 || k_w < 1 || dil < 1) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: bad geometry");
   if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
@@ -236,11 +264,20 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
     if (g < 1) g = 1;
     const dim3 grid((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)g);
     const size_t lds = (size_t)(64 + (k_w - 1) * dil) * 68 * sizeof(float);
-    if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw);
-    else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw);
-    else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw);
+    if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
+    else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
+    else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
+    if (workspace) {
+      const int64_t total = (int64_t)n_out * c_in * k_w;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, S_, workspace, g, k_w,
+                         (int)grid.x * 64, (int)grid.y * 64, n_out, c_in, dw);
+    }
     JATTS_CHECK_LAUNCH();
     return JATTS_OK;
+  }
+  if (workspace) {   // the VALU fallback accumulates with atomics: it needs a zeroed dw
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)n_out * c_in * k_w * sizeof(float), S_);
+    if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)(k_w * groups)), dim3(256), 0, S_,
                      *rg, x, ldx, dy, ldy, c_in, n_out, k_w, dil, pad, groups, dw);

@@ -635,10 +635,11 @@ def masked_loss(rb, a, b, valid_len, kind, scale, log_offset=-1.0):
 
 def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1):
     lib = _abi.load()
-    dw = torch.zeros(n_out, c_in, k_w, dtype=torch.float32, device=x.device)
+    dw = torch.empty(n_out, c_in, k_w, dtype=torch.float32, device=x.device)
+    ws = torch.empty(rb.n_seq * k_w * round_up(n_out, 64) * round_up(c_in, 64), dtype=torch.float32, device=x.device)   # split-K partials
     rg = rb.struct(len_mul)
     _abi.check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
-                                      pad, dw.data_ptr(), _stream()), "jatts_conv1d_wgrad")
+                                      pad, dw.data_ptr(), ws.data_ptr(), _stream()), "jatts_conv1d_wgrad")
     return dw
 
 
