@@ -280,6 +280,9 @@ int jatts_snakebeta_bwd(const float* x, const float* dy, int64_t rows, int32_t d
  * (2 * max_ilen + 1) floats. */
 int jatts_ctc_forward_sum(const float* log_p, int32_t n_batch, int32_t t_max, int32_t ld, const int32_t* ilens, const int32_t* olens,
                           int32_t max_ilen, float log_blank, float* workspace, float* nll, float* grad, float grad_scale, void* stream);
+/* out[s][c] += sum over the rows of sequence s of x[row][c] (f32 atomics; caller zeroes out [n_seq][dim]): the gradient of a
+ * per-sequence vector added to every row (speaker / time embeddings, WaveNet global conditioning). */
+int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim, float* out, void* stream);
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by

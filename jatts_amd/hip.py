@@ -922,3 +922,13 @@ def ctc_forward_sum(log_p, ilens, olens, log_blank, want_grad=True, grad_scale=1
     _abi.check(lib.jatts_ctc_forward_sum(log_p.data_ptr(), B, T, ld, il.data_ptr(), ol.data_ptr(), max_i, float(log_blank), ws.data_ptr(),
                                          nll.data_ptr(), _ptr(grad), float(grad_scale), _stream()), "jatts_ctc_forward_sum")
     return nll, grad
+
+
+def seq_sum(rb, x):
+    """-> (n_seq, dim) f32: per-sequence column sums."""
+    lib = _abi.load()
+    x = _f32c(x)
+    out = torch.zeros(rb.n_seq, x.shape[1], dtype=torch.float32, device=x.device)
+    rg = rb.struct()
+    _abi.check(lib.jatts_seq_sum(C.byref(rg), x.data_ptr(), x.shape[1], out.data_ptr(), _stream()), "jatts_seq_sum")
+    return out

@@ -333,3 +333,17 @@ def test_wavenet_gate_backward(cuda, lib):
     y = A.Gate.apply(xd, hip.RaggedBatch([20, 25], cuda))
     y.backward(gy.to(cuda))
     _check([("y", y, yr), ("dx", xd.grad, xr.grad)])
+
+
+def test_add_seq_vector_backward(cuda, lib):
+    from jatts_amd import autograd as A, hip
+    g = torch.Generator().manual_seed(18)
+    lens, dim = [70, 3, 129], 200
+    R = sum(lens)
+    x, v, gy = torch.randn(R, dim, generator=g), torch.randn(len(lens), dim, generator=g), torch.randn(R, dim, generator=g)
+    (xr, xd), (vr, vd) = _leaf(x, cuda), _leaf(v, cuda)
+    yr = xr + torch.repeat_interleave(vr, torch.tensor(lens), dim=0)
+    yr.backward(gy.double())
+    y = A.AddSeqVector.apply(xd, vd, hip.RaggedBatch(lens, cuda))
+    y.backward(gy.to(cuda))
+    _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dv", vd.grad, vr.grad)])
