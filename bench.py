@@ -526,6 +526,8 @@ def main():
                 del r
             cfgs.append(line)
             del j, ref
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
         out["configs"] = cfgs
         out["configs_note"] = ("configs[0] is the reference's own CPU case (see cpu_baseline); configs[3] = this line's workload on "
@@ -533,10 +535,12 @@ def main():
 
     # ---- one FastSpeech2 `_train_step` at the recipe's batch size (not part of `value`): N == 1 only
     if world == 1 and not a.no_train:
+        import gc
         out["training"] = []
         for kind in ("fs2", "matcha", "matcha_mas", "vits"):
-            out["training"].append(train_step_line(dev, max(2, min(3, a.steps)), kind))
+            gc.collect()               # (the inference jobs above hold reference cycles; a live 10+ GB job slows the step by 20 %)
             torch.cuda.empty_cache()
+            out["training"].append(train_step_line(dev, max(2, min(3, a.steps)), kind))
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from jatts_amd.synthetic import synth_texts

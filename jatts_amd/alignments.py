@@ -145,29 +145,30 @@ def viterbi_decode(log_p_attn, text_lengths, feats_lengths, k=None):
     return ds, bin_loss.float()
 
 
+def frame_token_indices(text_lengths, feats_lengths, Tt, Tf, device):
+    """Row indices of the valid tokens / frames of a padded batch, as device int64 tensors (one host -> device copy each; build them
+    BEFORE queueing GPU work: a mid-forward torch.tensor(..., device=...) stalls the host behind everything already queued)."""
+    tsel = hip.h2d([b * Tt + i for b, n in enumerate(text_lengths) for i in range(int(n))], torch.int64, device)
+    fsel = hip.h2d([b * Tf + t for b, n in enumerate(feats_lengths) for t in range(int(n))], torch.int64, device)
+    return tsel, fsel
+
+
 @torch.no_grad()
-def viterbi_path(log_p_attn, text_lengths, feats_lengths):
+def viterbi_path(log_p_attn, text_lengths, feats_lengths, tsel=None, fsel=None):
     """Monotonic alignment search on a padded (B, T_feats, T_text) matrix -> (ds (B, T_text) float, path (B, T_feats) int64: the
-    token index of every valid frame, 0 at padded frames).  One jatts_mas_viterbi launch; used by the training forward, which
-    needs the path itself for the binarisation loss (alignments.py:303-308)."""
+    token index of every valid frame, 0 at padded frames).  One jatts_mas_viterbi launch plus three row gathers / scatters; used by
+    the training forward, which needs the path itself for the binarisation loss (alignments.py:303-308)."""
     B, Tf, Tt = log_p_attn.shape
     dev = log_p_attn.device
     tl = [int(v) for v in text_lengths]
     fl = [int(v) for v in feats_lengths]
+    if tsel is None or fsel is None:
+        tsel, fsel = frame_token_indices(tl, fl, Tt, Tf, dev)
     rb_t, rb_f = hip.RaggedBatch(tl, dev), hip.RaggedBatch(fl, dev)
     ld = hip.round_up(Tt, 8)
     lp = torch.zeros(rb_f.total, ld, dtype=torch.float32, device=dev)
-    o = 0
-    for b in range(B):
-        lp[o:o + fl[b], :Tt] = log_p_attn[b, : fl[b]].float()
-        o += fl[b]
+    lp[:, :Tt] = log_p_attn.reshape(B * Tf, Tt).index_select(0, fsel).float()
     path, dur, _ = hip.mas_viterbi(rb_f, rb_t, lp)
-    ds = torch.zeros((B, Tt), device=dev)
-    pth = torch.zeros((B, Tf), dtype=torch.int64, device=dev)
-    o = q = 0
-    for b in range(B):
-        ds[b, : tl[b]] = dur[o:o + tl[b]].float()
-        pth[b, : fl[b]] = path[q:q + fl[b]]
-        o += tl[b]
-        q += fl[b]
+    ds = torch.zeros(B * Tt, device=dev).index_copy_(0, tsel, dur.float()).view(B, Tt)
+    pth = torch.zeros(B * Tf, dtype=torch.int64, device=dev).index_copy_(0, fsel, path).view(B, Tf)
     return ds, pth

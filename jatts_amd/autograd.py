@@ -333,14 +333,18 @@ class AlignLogProb(torch.autograd.Function):
     element-wise ops on the (B, To, Tm) matrices (f64 for the distance recomputed in its GEMM form)."""
 
     @staticmethod
-    def forward(ctx, ff, tf, B, ilens):
+    def forward(ctx, ff, tf, B, ilens, tsel=None, valid=None):
+        """tsel (rows of the valid tokens in tf) / valid ((B, Tm) bool token mask): optional, precomputed by the caller so that no
+        host -> device copy happens in the middle of the forward."""
         dev = ff.device
         A_ = ff.shape[1]
         To, Tm = ff.shape[0] // B, tf.shape[0] // B
         rbf, rbv = hip.RaggedBatch([To] * B, dev), hip.RaggedBatch(ilens, dev)
-        sel = torch.cat([torch.arange(b * Tm, b * Tm + ilens[b], device=dev) for b in range(B)])
-        lp3 = hip.alignment_logp(rbf, rbv, ff.contiguous(), tf.index_select(0, sel).contiguous(), A_).view(B, To, -1)
-        valid = torch.arange(Tm, device=dev).unsqueeze(0) < torch.tensor(ilens, device=dev).unsqueeze(1)       # (B, Tm)
+        if tsel is None:
+            tsel = torch.tensor([b * Tm + i for b in range(B) for i in range(ilens[b])], dtype=torch.int64, device=dev)
+        if valid is None:
+            valid = torch.arange(Tm, device=dev).unsqueeze(0) < torch.tensor(ilens, device=dev).unsqueeze(1)       # (B, Tm)
+        lp3 = hip.alignment_logp(rbf, rbv, ff.contiguous(), tf.index_select(0, tsel).contiguous(), A_).view(B, To, -1)
         lp = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
         n = min(Tm, lp3.shape[2])
         lp[:, :, :n] = lp3[:, :, :n]
@@ -362,7 +366,7 @@ class AlignLogProb(torch.autograd.Function):
         w = (-dscore / torch.sqrt(d2.clamp_min(1e-24))).masked_fill(~vm, 0.0)
         dF = w.sum(-1, keepdim=True) * F_ - torch.matmul(w, T_)
         dT = w.sum(1).unsqueeze(-1) * T_ - torch.matmul(w.transpose(1, 2), F_)
-        return dF.reshape(B * To, A_).float(), dT.reshape(B * Tm, A_).float(), None, None
+        return dF.reshape(B * To, A_).float(), dT.reshape(B * Tm, A_).float(), None, None, None, None
 
 
 class Gate(torch.autograd.Function):

@@ -75,6 +75,16 @@ def _dev(t):
     return t
 
 
+def h2d(values, dtype, device):
+    """Small host list -> device tensor WITHOUT stalling the host: staged through pinned memory and copied asynchronously on the
+    current stream.  torch.tensor(values, device=...) copies from pageable memory, which blocks the host until everything already
+    queued on the stream has run -- one pipeline drain per call in the middle of a forward pass."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 class RaggedBatch:
     """Packed ragged batch geometry: sequence b owns rows cu[b]..cu[b+1]-1."""
 
@@ -88,7 +98,7 @@ class RaggedBatch:
         self.n_seq = len(self.lens)
         self.max_len = max(self.lens) if self.lens else 0
         self.device = device
-        self.cu = torch.tensor(cu, dtype=torch.int32, device=device)
+        self.cu = h2d(cu, torch.int32, device)
 
     def struct(self, len_mul=1):
         return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul)
@@ -101,7 +111,7 @@ class RaggedBatch:
             for v in self.lens:
                 col.append(c)
                 c += round_up(v, 8)
-            self._vt = (torch.tensor(col or [0], dtype=torch.int32, device=self.device), c + 8)
+            self._vt = (h2d(col or [0], torch.int32, self.device), c + 8)
         return self._vt
 
 

@@ -151,7 +151,10 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     if ds.shape[1] != Tm or ps.shape[1] != Tm or es.shape[1] != Tm:
         raise ValueError("durations / pitch / energy must be padded to the text length")
     rb = hip.RaggedBatch([Tm] * B, dev)
-    kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+    # length-derived device tensors and the one host read-back (output lengths = duration sums) happen here, before GPU work is queued
+    kv = hip.h2d(ilens, torch.int32, dev)
+    kvo = olens.to(device=dev, dtype=torch.int32).contiguous()
+    ol_h = [int(v) for v in ds.sum(1).tolist()]
     ids = xs.reshape(-1).to(torch.int64).contiguous()
     x = A.Embedding.apply(ids, c.p["encoder.embed.0.weight"], math.sqrt(Ad), model.padding_idx)
     x = c.drop(x, R["enc_pos"])
@@ -173,16 +176,15 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     e_emb = c.drop(_embed1(c, "energy_embed.0", es.reshape(-1).contiguous(), rb), R["energy_embed"])
     hs = hs + e_emb + p_emb
     d_used = ds.reshape(-1).to(torch.int64).contiguous()
-    _, cum, ol, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=0)
-    ol_h = ol.tolist()
-    if sum(ol_h) == 0:
-        _, cum, ol, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=1)
-        ol_h = ol.tolist()
+    if sum(ol_h) == 0:     # (length_regulator.py:85-94: the whole-batch all-zero rule -> every duration becomes 1)
+        _, cum, _, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=1)
+        ol_h = [Tm] * B
+    else:
+        _, cum, _, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=0)
     To = max(ol_h)
     rbo = hip.RaggedBatch([To] * B, dev)
     yl = A.LengthRegulate.apply(hs, rb, cum, rbo) * math.sqrt(Ad)
     yl = c.drop(yl, R["dec_pos"])
-    kvo = olens.to(device=dev, dtype=torch.int32).contiguous()
     zs = _conformer(c, "decoder.", yl, rbo, kvo, model.aheads, dict(pos=R["dec_pos"], layer=R["dec"], ffn=R["dec"], attn=R["dec_attn"]))
     before = c.conv(zs, "feat_out", rbo)
     after = None

@@ -57,15 +57,19 @@ def _tblock(c, p, x, rb, heads, key_bias, rate):
     return x + c.conv(c.drop(u, rate), p + "ff.net.2", rb)
 
 
-def _estimator(c, model, rb, rb2, rbs, y, mu, t, v1, v2, rate):
+def sinusoidal_time_embedding(t, od):
+    """SinusoidalPosEmb(2 odim) of decoder.py:48-63 on the host: (B,) -> (B, 2 odim)."""
+    freq = torch.exp(torch.arange(od).float() * -(math.log(10000) / (od - 1)))
+    emb = 1000.0 * t.reshape(-1, 1).float().cpu() * freq.unsqueeze(0)
+    return torch.cat((emb.sin(), emb.cos()), dim=-1).contiguous()
+
+
+def _estimator(c, model, rb, rb2, rbs, y, mu, temb, v1, v2, rate):
     """Decoder.forward (decoder.py:413-487) on a padded batch: -> v(y, mu, t) * mask, (B*Te, odim)."""
     e = "decoder.estimator."
     dev = y.device
     B, Te = rb.n_seq, rb.max_len
     heads, od = model.dec_heads, model.odim
-    freq = torch.exp(torch.arange(od).float() * -(math.log(10000) / (od - 1)))
-    emb = 1000.0 * t.reshape(B, 1).float().cpu() * freq.unsqueeze(0)
-    temb = torch.cat((emb.sin(), emb.cos()), dim=-1).to(dev).contiguous()                  # SinusoidalPosEmb (decoder.py:48-63)
     tm = c.conv(A.Act.apply(c.conv(temb, e + "time_mlp.linear_1", rbs), "swish"), e + "time_mlp.linear_2", rbs)
     tmish = A.Act.apply(tm, "mish")
     kb1 = (torch.arange(Te, device=dev).unsqueeze(0) < v1.unsqueeze(1)).float()
@@ -122,7 +126,25 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     ys = feats[:, :To].to(dev).float().contiguous()
     rbt = hip.RaggedBatch([Tm] * B, dev)
     rbs = hip.RaggedBatch([1] * B, dev)
-    kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+    # every length-derived device tensor is built HERE, before GPU work is queued (a host -> device copy in mid-forward stalls the host
+    # behind the whole queue)
+    kv = hip.h2d(ilens, torch.int32, dev)
+    olens_in = [n - n % 2 for n in olens]
+    Te = max(olens_in)
+    v1 = hip.h2d(olens_in, torch.int32, dev)
+    v2 = hip.h2d([n // 2 for n in olens_in], torch.int32, dev)
+    t = (torch.rand(B) if cfm_t is None else cfm_t.reshape(B).float().cpu())
+    t_dev = t.to(dev).contiguous()
+    temb = sinusoidal_time_embedding(t, od).to(dev)
+    z = (torch.randn(B, Te, od) if cfm_noise is None else cfm_noise[:, :Te].float()).to(dev).reshape(B * Te, od).contiguous()
+    extra = {}
+    if model._MAS:
+        from ..alignments import frame_token_indices
+        extra["_prior"] = beta_binomial_prior(ilens, olens).to(dev)                         # ForwardSumLoss's static prior (host scipy)
+        kvo = hip.h2d(olens, torch.int32, dev)
+        tsel, fsel = frame_token_indices(ilens, olens, Tm, To, dev)
+        tm_ = torch.arange(Tm, device=dev).unsqueeze(0) < kv.unsqueeze(1)                   # (B, Tm) valid tokens
+        fm = (torch.arange(To, device=dev).unsqueeze(0) < kvo.unsqueeze(1)).float()         # (B, To) valid frames
     x = A.Embedding.apply(xs.reshape(-1).to(torch.int64).contiguous(), c.p["encoder.embed.0.weight"], math.sqrt(Ad), 0)
     x = c.drop(x, R["enc_pos"])
     hs = _conformer(c, "encoder.", x, rbt, kv, model.aheads, dict(pos=R["enc_pos"], layer=R["enc"], ffn=R["enc"], attn=R["enc_attn"]))
@@ -133,11 +155,8 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
         sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), hip.F32)
         hs = A.AddSeqVector.apply(hs, c.conv(sp, "projection", rbs), rbt)
     d_outs = A.MaskRows.apply(_predictor(c, "duration_predictor.", hs, rbt, R["dur"]), rbt, kv)
-    olens_in = [n - n % 2 for n in olens]
-    Te = max(olens_in)
     rbe = hip.RaggedBatch([Te] * B, dev)
     rb2 = hip.RaggedBatch([Te // 2] * B, dev)
-    extra = {}
     if model._MAS:
         # alignment module on the padded batch (alignments.py:26-60), monotonic alignment search (no gradient), binarisation loss
         rbf = hip.RaggedBatch([To] * B, dev)
@@ -145,20 +164,18 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
         tfe = c.conv(A.Act.apply(c.conv(hs, a + "t_conv1", rbt), "relu"), a + "t_conv2", rbt)
         ffe = A.Act.apply(c.conv(ys.reshape(B * To, od), a + "f_conv1", rbf), "relu")
         ffe = c.conv(A.Act.apply(c.conv(ffe, a + "f_conv2", rbf), "relu"), a + "f_conv3", rbf)
-        log_p_attn = A.AlignLogProb.apply(ffe, tfe, B, ilens)                              # (B, To, Tm), -inf at padded tokens
+        log_p_attn = A.AlignLogProb.apply(ffe, tfe, B, ilens, tsel, tm_)                   # (B, To, Tm), -inf at padded tokens
         from ..alignments import viterbi_path
-        ds, path = viterbi_path(log_p_attn.detach(), ilens, olens)                         # ds (B, Tm) float, path (B, To) int64
-        fm = (torch.arange(To, device=dev).unsqueeze(0) < torch.tensor(olens, device=dev).unsqueeze(1)).float()
+        ds, path = viterbi_path(log_p_attn.detach(), ilens, olens, tsel, fsel)             # ds (B, Tm) float, path (B, To) int64
         picked = torch.gather(log_p_attn, 2, path.unsqueeze(-1)).squeeze(-1).masked_fill(fm == 0, 0.0)
-        bin_loss = -(picked.sum(1) / torch.tensor(olens, dtype=torch.float32, device=dev)).mean()     # alignments.py:307-309
+        bin_loss = -(picked.sum(1) / kvo.float()).mean()                                   # alignments.py:307-309
         # masked Gaussian upsampling (length_regulator.py:110-154): the weights depend on the (integer) durations only
         tpos = torch.arange(To, device=dev).float().unsqueeze(0) * fm                       # padded frames sit at t = 0
         cen = ds.cumsum(-1) - ds / 2
         energy = -0.1 * (tpos.unsqueeze(-1) - cen.unsqueeze(1)) ** 2
-        tm_ = torch.arange(Tm, device=dev).unsqueeze(0) < torch.tensor(ilens, device=dev).unsqueeze(1)
         p_up = torch.softmax(energy.masked_fill(~tm_.unsqueeze(1), float("-inf")), dim=2)
         up = torch.matmul(p_up, hs.view(B, Tm, Ad))[:, :Te].reshape(B * Te, Ad)             # rocBLAS batched GEMM
-        extra = dict(bin_loss=bin_loss, log_p_attn=log_p_attn, ds=ds)
+        extra.update(bin_loss=bin_loss, log_p_attn=log_p_attn, ds=ds)
     else:
         d_flat = durations[:, : int(durations_lengths.max())].to(dev).reshape(-1).to(torch.int64).contiguous()
         if d_flat.numel() != B * Tm:
@@ -167,12 +184,8 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
         up = A.LengthRegulate.apply(hs, rbt, cum, rbe)
     mu = c.conv(up, "encoder_proj", rbe)                                                    # (B*Te, odim): "hs" of the return dict
     ys_e = ys[:, :Te].contiguous()
-    t = (torch.rand(B) if cfm_t is None else cfm_t.reshape(B).float().cpu())
-    z = (torch.randn(B, Te, od) if cfm_noise is None else cfm_noise[:, :Te].float()).to(dev).reshape(B * Te, od).contiguous()
-    y, u = hip.cfm_mix(rbe, ys_e.view(B * Te, od), z, t.to(dev).contiguous(), model.sigma_min)
-    v1 = torch.tensor(olens_in, dtype=torch.int32, device=dev)
-    v2 = torch.tensor([n // 2 for n in olens_in], dtype=torch.int32, device=dev)
-    pred = _estimator(c, model, rbe, rb2, rbs, y, mu, t, v1, v2, R["decoder"])
+    y, u = hip.cfm_mix(rbe, ys_e.view(B * Te, od), z, t_dev, model.sigma_min)
+    pred = _estimator(c, model, rbe, rb2, rbs, y, mu, temb, v1, v2, R["decoder"])
     n_sel = float(sum(olens_in)) * od
     # F.mse_loss(pred, u, "sum") / (sum(mask) n_feats): the sum runs over the padded frames too (pred is 0 there)
     cfm_loss = A.MaskedLoss.apply(pred, u, rbe, None, 1, 1.0 / n_sel, -1.0)
@@ -214,7 +227,7 @@ def criterion(ret, durations, ilens, duration_loss=True, olens=None, forward_sum
     total = ret["cfm_loss"] + prior
     if forward_sum:
         il, ol = [int(v) for v in ilens.tolist()], [int(v) for v in olens.tolist()]
-        lp = ret["log_p_attn"] + beta_binomial_prior(il, ol).to(dev)
+        lp = ret["log_p_attn"] + (ret["_prior"] if "_prior" in ret else beta_binomial_prior(il, ol).to(dev))
         out["forward_sum_loss"] = A.ForwardSum.apply(lp, ilens, olens, -1.0)                # blank_prob = e^-1
         total = total + lambda_align * out["forward_sum_loss"]
     if bin_loss:

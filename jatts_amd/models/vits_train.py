@@ -59,26 +59,33 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, spembs, post_
     xs = text[:, :Tm].to(dev)
     ys = feats[:, :To].to(dev).float().contiguous()
     rbt, rbs, rbf = hip.RaggedBatch([Tm] * B, dev), hip.RaggedBatch([1] * B, dev), hip.RaggedBatch([To] * B, dev)
-    kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
-    kvo = torch.tensor(olens, dtype=torch.int32, device=dev)
+    # every length-derived device tensor is built here, before GPU work is queued (no host -> device copy in mid-forward)
+    kv = hip.h2d(ilens, torch.int32, dev)
+    kvo = hip.h2d(olens, torch.int32, dev)
+    from ..alignments import frame_token_indices
+    from .matchatts_train import beta_binomial_prior
+    tsel, fsel = frame_token_indices(ilens, olens, Tm, To, dev)
+    prior = beta_binomial_prior(ilens, olens).to(dev)                                          # ForwardSumLoss's static prior
+    nz_all = (torch.randn(B, To, Ad) if post_noise is None else post_noise[:, :To].float()).to(dev).reshape(B * To, Ad)
+    spk = spembs.to(dev).float().reshape(B, -1).contiguous()
+    tmk = torch.arange(Tm, device=dev).unsqueeze(0) < kv.unsqueeze(1)
+    fm = (torch.arange(To, device=dev).unsqueeze(0) < kvo.unsqueeze(1)).float()
     # ---- text encoder (text_encoder.py:104-140): emb * sqrt(A), conformer (x * sqrt(A) again inside its positional encoding)
     x = A.Embedding.apply(xs.reshape(-1).to(torch.int64).contiguous(), c.p["text_encoder.emb.weight"], float(Ad), -1)
     x = c.drop(x, R["te_pos"])
     hs = _conformer(c, "text_encoder.encoder.", x, rbt, kv, model.te_heads, dict(pos=R["te_pos"], layer=R["te"], ffn=R["te"], attn=R["te_attn"]),
                     rel_style="new")
     stats_p = A.MaskRows.apply(c.conv(hs, "text_encoder.proj", rbt), rbt, kv)                  # proj(x) * x_mask: m_p | logs_p
-    spk = spembs.to(dev).float().reshape(B, -1).contiguous()
     hs = A.AddSeqVector.apply(hs, c.conv(hip.l2_normalize(spk, hip.F32), "projection", rbs), rbt)
     # ---- posterior encoder + forward flow on the valid frames (posterior_encoder.py:96-130, residual_coupling.py:189-227)
     rbo = hip.RaggedBatch(olens, dev)
-    fsel = torch.cat([torch.arange(b * To, b * To + olens[b], device=dev) for b in range(B)])
     yv = ys.reshape(B * To, od).index_select(0, fsel).contiguous()
     n_post = sum(1 for k in c.p if k.startswith("posterior_encoder.encoder.") and k.endswith("conv.bias"))
     h = A.Conv1dFunction.apply(yv, _wn_weight(c, "posterior_encoder.input_conv"), c.p["posterior_encoder.input_conv.bias"], rbo, 1, 0)
     sk = _wavenet(c, "posterior_encoder.encoder.", h, spk, rbo, rbs, n_post, R["post"])
     stats_q = A.Conv1dFunction.apply(sk, _wn_weight(c, "posterior_encoder.proj"), c.p["posterior_encoder.proj.bias"], rbo, 1, 0)
     m_q, logs_q = stats_q[:, :Ad], stats_q[:, Ad:]
-    nz = (torch.randn(B, To, Ad) if post_noise is None else post_noise[:, :To].float()).to(dev).reshape(B * To, Ad).index_select(0, fsel)
+    nz = nz_all.index_select(0, fsel)
     z = m_q + nz * torch.exp(logs_q)
     half = Ad // 2
     zp = z
@@ -94,17 +101,15 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, spembs, post_
     tfe = c.conv(A.Act.apply(c.conv(hs, a + "t_conv1", rbt), "relu"), a + "t_conv2", rbt)
     ffe = A.Act.apply(c.conv(ys.reshape(B * To, od), a + "f_conv1", rbf), "relu")
     ffe = c.conv(A.Act.apply(c.conv(ffe, a + "f_conv2", rbf), "relu"), a + "f_conv3", rbf)
-    log_p_attn = A.AlignLogProb.apply(ffe, tfe, B, ilens)
+    log_p_attn = A.AlignLogProb.apply(ffe, tfe, B, ilens, tsel, tmk)
     from ..alignments import viterbi_path
-    ds, path = viterbi_path(log_p_attn.detach(), ilens, olens)
-    fm = (torch.arange(To, device=dev).unsqueeze(0) < kvo.unsqueeze(1)).float()
+    ds, path = viterbi_path(log_p_attn.detach(), ilens, olens, tsel, fsel)
     picked = torch.gather(log_p_attn, 2, path.unsqueeze(-1)).squeeze(-1).masked_fill(fm == 0, 0.0)
     bin_loss = -(picked.sum(1) / kvo.float()).mean()
     d_outs = A.MaskRows.apply(_predictor(c, "duration_predictor.", hs, rbt, R["dur"]), rbt, kv)
     # ---- prior statistics upsampled with the MAS durations (length_regulator.py:110-154; padded frames sit at t = 0)
     tpos = torch.arange(To, device=dev).float().unsqueeze(0) * fm
     cen = ds.cumsum(-1) - ds / 2
-    tmk = torch.arange(Tm, device=dev).unsqueeze(0) < kv.unsqueeze(1)
     p_up = torch.softmax((-0.1 * (tpos.unsqueeze(-1) - cen.unsqueeze(1)) ** 2).masked_fill(~tmk.unsqueeze(1), float("-inf")), dim=2)
     up = torch.matmul(p_up, stats_p.view(B, Tm, 2 * Ad))                                       # (B, To, 2A), rocBLAS
 
@@ -121,7 +126,8 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, spembs, post_
     tr = lambda v: v.transpose(1, 2)   # noqa: E731  the reference keeps these channel-first
     return {"m_q": tr(pad_frames(m_q)), "logs_q": tr(pad_frames(logs_q)), "outs": outs, "d_outs": d_outs.view(B, Tm), "ys": ys,
             "hs": tr(hs.view(B, Tm, Ad)), "olens_in": feats_lengths, "bin_loss": bin_loss, "log_p_attn": log_p_attn, "ds": ds,
-            "m_p": tr(up[..., :Ad]), "logs_p": tr(up[..., Ad:]), "z": tr(z_pad), "y_mask": y_mask, "z_p": tr(pad_frames(zp))}
+            "m_p": tr(up[..., :Ad]), "logs_p": tr(up[..., Ad:]), "z": tr(z_pad), "y_mask": y_mask, "z_p": tr(pad_frames(zp)),
+            "_prior": prior}
 
 
 def criterion(ret, ilens, olens, duration_loss=True, forward_sum=False, bin_loss=False, lambda_align=2.0, lambda_mel=1.0):
@@ -149,7 +155,8 @@ def criterion(ret, ilens, olens, duration_loss=True, forward_sum=False, bin_loss
         total = total + out["duration_loss"]
     if forward_sum:
         il, ol = [int(v) for v in ilens.tolist()], [int(v) for v in olens.tolist()]
-        out["forward_sum_loss"] = A.ForwardSum.apply(ret["log_p_attn"] + beta_binomial_prior(il, ol).to(dev), ilens, olens, -1.0)
+        prior = ret["_prior"] if "_prior" in ret else beta_binomial_prior(il, ol).to(dev)
+        out["forward_sum_loss"] = A.ForwardSum.apply(ret["log_p_attn"] + prior, ilens, olens, -1.0)
         total = total + lambda_align * out["forward_sum_loss"]
     if bin_loss:
         out["bin_loss"] = ret["bin_loss"]
