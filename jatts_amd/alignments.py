@@ -141,7 +141,7 @@ def viterbi_decode(log_p_attn, text_lengths, feats_lengths, k=None):
     for b in range(B):
         ds[b, : tl[b]] = dur[o:o + tl[b]].float()
         o += tl[b]
-    bin_loss = -(score / torch.tensor(fl, dtype=torch.float64, device=dev)).sum() / B
+    bin_loss = -(score / hip.h2d(fl, torch.float64, dev)).sum() / B
     return ds, bin_loss.float()
 
 

@@ -341,9 +341,9 @@ class AlignLogProb(torch.autograd.Function):
         To, Tm = ff.shape[0] // B, tf.shape[0] // B
         rbf, rbv = hip.RaggedBatch([To] * B, dev), hip.RaggedBatch(ilens, dev)
         if tsel is None:
-            tsel = torch.tensor([b * Tm + i for b in range(B) for i in range(ilens[b])], dtype=torch.int64, device=dev)
+            tsel = hip.h2d([b * Tm + i for b in range(B) for i in range(ilens[b])], torch.int64, dev)
         if valid is None:
-            valid = torch.arange(Tm, device=dev).unsqueeze(0) < torch.tensor(ilens, device=dev).unsqueeze(1)       # (B, Tm)
+            valid = torch.arange(Tm, device=dev).unsqueeze(0) < hip.h2d(ilens, torch.int64, dev).unsqueeze(1)       # (B, Tm)
         lp3 = hip.alignment_logp(rbf, rbv, ff.contiguous(), tf.index_select(0, tsel).contiguous(), A_).view(B, To, -1)
         lp = torch.full((B, To, Tm), float("-inf"), dtype=torch.float32, device=dev)
         n = min(Tm, lp3.shape[2])

@@ -365,7 +365,7 @@ class FastSpeech2(torch.nn.Module):
         if ds.shape[1] != Tm or ps.shape[1] != Tm or es.shape[1] != Tm:
             raise ValueError("durations / pitch / energy must be padded to the text length")
         rb = hip.RaggedBatch([Tm] * B, dev)                          # padded geometry: every sequence Tm rows
-        kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+        kv = hip.h2d(ilens, torch.int32, dev)
         ids = xs.reshape(-1).to(torch.int64).contiguous()
         x = hip.embed_scale(ids, P["emb"], math.sqrt(A))
         hs = P["enc"].run(rb, x, kv_len=kv)                          # f32 (B*Tm, A)

@@ -422,15 +422,19 @@ class _MatchaBase(torch.nn.Module):
         half = od  # SinusoidalPosEmb(in_channels = 2*odim): half_dim = odim
         freq = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
         c_t = P["t1"].c_in
+        # the whole schedule's time embeddings in ONE asynchronous upload before the loop (a per-step .to(dev) from pageable memory
+        # drains the launch queue ten times per batch)
+        sched, tembs = [], torch.zeros(n_timesteps, B, c_t)
         for step in range(1, n_timesteps + 1):
             emb = 1000.0 * t * freq
-            temb = torch.zeros(B, c_t)
-            temb[:, :2 * half] = torch.cat((emb.sin(), emb.cos()))
-            self._estimator_step(P, rbo, rb2, rbs, x, mu_t, temb.to(dev).to(hip.torch_dtype(dt)), float(dt_s),
-                                 tkey=(int(n_timesteps), step, B))
+            tembs[step - 1, :, :2 * half] = torch.cat((emb.sin(), emb.cos()))
+            sched.append(float(dt_s))
             t = t + dt_s
             if step < n_timesteps:
                 dt_s = t_span[step + 1] - t
+        tembs = tembs.pin_memory().to(dev, non_blocking=True).to(hip.torch_dtype(dt))
+        for step in range(1, n_timesteps + 1):
+            self._estimator_step(P, rbo, rb2, rbs, x, mu_t, tembs[step - 1], sched[step - 1], tkey=(int(n_timesteps), step, B))
         return dict(feat_gen=x, olens=olens, feats_rb=rbo, text_rb=rb, duration=d_pred, log_duration=logd)
 
     def inference(self, text, feats=None, durations=None, spembs=None, sids=None, lids=None, n_timesteps: int = 10,
@@ -486,7 +490,7 @@ class _MatchaBase(torch.nn.Module):
         xs = text[:, :Tm].to(dev)
         ys = feats[:, :To].to(dev).float().contiguous()
         rbt = hip.RaggedBatch([Tm] * B, dev)                       # padded text geometry
-        kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+        kv = hip.h2d(ilens, torch.int32, dev)
         rbs = hip.RaggedBatch([1] * B, dev)
         hs = P["enc"].run(rbt, hip.embed_scale(xs.reshape(-1).to(torch.int64).contiguous(), P["emb"], math.sqrt(A)), kv_len=kv)
         if self.spks is not None:
@@ -512,7 +516,7 @@ class _MatchaBase(torch.nn.Module):
             up = hip.gaussian_upsample(rbv, d_int, rbo, hs.index_select(0, sel).contiguous())    # valid frames of every utterance
             # h_masks zero the frame index of padded frames (length_regulator.py:139-141): they all equal frame 0 of their utterance
             cu = rbo.cu_host
-            rows = torch.tensor([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(Te)], dtype=torch.int64, device=dev)
+            rows = hip.h2d([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(Te)], torch.int64, dev)
             up_pad = up.index_select(0, rows).contiguous()
         else:   # tts1: ground-truth durations, hard length regulator, zero padding (length_regulator.py:70-97)
             if durations is None:
@@ -533,8 +537,8 @@ class _MatchaBase(torch.nn.Module):
         t = (torch.rand(B) if cfm_t is None else cfm_t.reshape(B).float().cpu())
         z = (torch.randn(B, Te, od) if cfm_noise is None else cfm_noise[:, :Te].float()).to(dev).reshape(B * Te, od).contiguous()
         y, u = hip.cfm_mix(rbe, ys_e.view(B * Te, od), z, t.to(dev).contiguous(), self.sigma_min)
-        v1 = torch.tensor(olens_in, dtype=torch.int32, device=dev)
-        v2 = torch.tensor([n // 2 for n in olens_in], dtype=torch.int32, device=dev)
+        v1 = hip.h2d(olens_in, torch.int32, dev)
+        v2 = hip.h2d([n // 2 for n in olens_in], torch.int32, dev)
         heads, scale = self.dec_heads, P["d0"][1][0].dh ** -0.5 if P["d0"][1] else 1.0
 
         def key_bias(T, vl):   # the (B, T) 1/0 frame mask as an additive score bias (after scaling): ku = mask / scale

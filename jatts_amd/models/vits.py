@@ -374,7 +374,7 @@ class VITS(torch.nn.Module):
         xs = text[:, :Tm].to(dev)
         ys = feats[:, :To].to(dev).float().contiguous()
         rbt, rbs = hip.RaggedBatch([Tm] * B, dev), hip.RaggedBatch([1] * B, dev)
-        kv = torch.tensor(ilens, dtype=torch.int32, device=dev)
+        kv = hip.h2d(ilens, torch.int32, dev)
         # ---- text encoder on the padded batch (text_encoder.py:104-140)
         hs = P["tenc"].run(rbt, hip.embed_scale(xs.reshape(-1).to(torch.int64).contiguous(), P["emb"], float(A)), kv_len=kv)
         tp = P["te_proj"]
@@ -413,7 +413,7 @@ class VITS(torch.nn.Module):
         d_int = torch.cat([ds[b, : ilens[b]] for b in range(B)]).to(torch.int64).contiguous()
         up = hip.gaussian_upsample(rbv, d_int, rbo, stats_p.index_select(0, tsel).contiguous())      # (valid frames, 2A)
         cu = rbo.cu_host
-        rows = torch.tensor([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(To)], dtype=torch.int64, device=dev)
+        rows = hip.h2d([cu[b] + (t if t < olens[b] else 0) for b in range(B) for t in range(To)], torch.int64, dev)
         up_pad = up.index_select(0, rows).view(B, To, 2 * A)
         # ---- decoder on the padded batch (z is zero at padded frames; key mask = olens)
         def pad_frames(v):     # ragged (valid frames, C) -> padded (B, To, C) with zeros
@@ -421,7 +421,7 @@ class VITS(torch.nn.Module):
             out[fsel] = v
             return out.view(B, To, -1)
         z_pad = pad_frames(z)
-        kvo = torch.tensor(olens, dtype=torch.int32, device=dev)
+        kvo = hip.h2d(olens, torch.int32, dev)
         zs_t = P["dec"].run(rbf, hip.affine_cast(z_pad.view(B * To, A), hip.F32, scale=P["sqrtA"]), final_dtype=dt, kv_len=kvo)
         fo = P["feat_out"]
         outs = hip.conv1d(rbf, zs_t, fo.w, fo.c_in, fo.n_out, 1, dtype=dt, bias=fo.b, out_f32=True).view(B, To, od)

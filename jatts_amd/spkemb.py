@@ -201,7 +201,7 @@ class FbankFrontEnd:
         for n in ns:
             cu.append(cu[-1] + n)
         rb = hip.RaggedBatch([1 + n // self.hop for n in ns], dev)
-        frames = hip.frame_signal(rb, torch.tensor(cu, dtype=torch.int32, device=dev), x, self.window, self.n_fft, self.hop, self.ldf)
+        frames = hip.frame_signal(rb, hip.h2d(cu, torch.int32, dev), x, self.window, self.n_fft, self.hop, self.ldf)
         spec = hip.conv1d(rb, frames, self.dft.w, self.dft.c_in, 2 * self.nbp, 1, dtype=F32)            # [re | im]
         power = hip.power_spectrum(spec, self.nbp, self.ldp)
         mel = hip.conv1d(rb, power, self.mel.w, self.mel.c_in, self.n_mels, 1, dtype=F32)
