@@ -34,3 +34,29 @@ def test_gather_audio_on_rccl_world1(cuda, lib):
         assert torch.equal(got[0], y) and lens_out == [lens]
     finally:
         dist.destroy_process_group()
+
+
+def test_data_parallel_training_world2(cuda, lib):
+    """Two data-parallel FastSpeech2Trainer ranks (child processes sharing this box's GPU, gradient all-reduce over gloo) train on
+    different data for three steps: the replicas stay bit-identical (same averaged gradients, same clip + Adam), the per-rank losses
+    differ, everything is finite.  The N > 1 training path of SURVEY §8(e)/(f.4) end to end on the HIP kernels."""
+    import json
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+    for o in outs:
+        assert o["finite"] and o["replica_spread"] == 0.0, o
+    l0, l1 = outs[0]["losses"]
+    assert l0 != l1 and outs[0]["losses"] == outs[1]["losses"]
