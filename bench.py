@@ -433,12 +433,18 @@ def main():
 
     import torch
 
-    dev = torch.device("cuda", local)
+    # JATTS_BENCH_SHARED_GPU=1 (tests/test_distributed_gpu.py only): every rank on cuda:0 with gloo collectives, to exercise the
+    # N > 1 code path on a one-GPU test box (RCCL refuses two ranks per device).  Never set by the driver; the line says so.
+    shared = os.environ.get("JATTS_BENCH_SHARED_GPU") == "1"
+    dev = torch.device("cuda", 0 if shared else local)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:   # one process per GPU, RCCL over xGMI (backend "nccl" on ROCm); rendezvous from the torchrun env
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     job = Job("fs2", a, dev, rank, a.batch)
     if a.pmc_child:   # profiled child: one f32 and one f16 step, nothing printed
@@ -464,7 +470,8 @@ def main():
                                f"{a.frames_per_token} frames per GPU",
                    "utterances_per_gpu": a.batch, "phonemes": a.t_text, "frames_per_utt": a.t_text * a.frames_per_token,
                    "hop": job.hop, "sampling_rate": job.sr,
-                   "parallelism": f"dp{world} (utterance sharding, int16 PCM all-gather)"},
+                   "parallelism": f"dp{world} (utterance sharding, int16 PCM all-gather)"
+                                  + (" [shared-GPU test mode: all ranks on cuda:0, gloo]" if shared else "")},
         "rtf": head["rtf"], "stage_ms_per_step": head["stages"],
         "executor": "two-stream pipeline (jatts_amd.pipeline)" if a.pipeline else "sequential",
     }

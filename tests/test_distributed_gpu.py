@@ -60,3 +60,29 @@ def test_data_parallel_training_world2(cuda, lib):
         assert o["finite"] and o["replica_spread"] == 0.0, o
     l0, l1 = outs[0]["losses"]
     assert l0 != l1 and outs[0]["losses"] == outs[1]["losses"]
+
+
+def test_bench_two_ranks_on_the_shared_gpu(cuda, lib):
+    """bench.py's N > 1 path (the driver's `torch.distributed.run --nproc-per-node N bench.py --gpus N` launch: sharding by rank,
+    barrier-bracketed timing, max over ranks, int16 PCM all-gather inside the step) with two ranks on this box's one GPU
+    (JATTS_BENCH_SHARED_GPU=1: gloo instead of RCCL).  The line must report the whole job: n_gpus 2, twice one rank's samples."""
+    import json
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JATTS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-fast-mode"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 1 and j["cpu_baseline"] is None
+    per_rank = 8 * 128 * 6 * j["config"]["hop"]
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 2 * per_rank) <= 1e-6 * per_rank
+    assert j["stage_ms_per_step"]["audio_all_gather"] > 0.0 and "shared-GPU test mode" in j["config"]["parallelism"]
