@@ -179,9 +179,10 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
     stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24)), NTHR>(xs, pitch, rx, C / 8, t0 - p2 - p1, L, seq_row0, xin[0], C, JATTS_ABLATE != 1 && !RREG, d.slope);
   }
   __syncthreads();
-  f32x4 resid[RREG ? NF : 1][RREG ? NT : 1][4];   // x at (output column, channel quad) of this lane: C-fragment layout
+  // x at (output column, channel quad) of this lane, C-fragment layout, in the tile's own type (f16 tiles: 2 registers per quad)
+  typedef T resid_t __attribute__((ext_vector_type(4)));
+  resid_t resid[RREG ? NF : 1][RREG ? NT : 1][4];
   if constexpr (RREG) {
-    static_assert(sizeof(T) == 4, "register-resident residual: f32 tiles");
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int col = col0 + t * 32 + (lane & 31);   // output column col <-> x tile row col + p2 + p1
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          resid[f][t][q] = *reinterpret_cast<const f32x4*>(xs + (size_t)(col + p2 + p1) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T));
+          resid[f][t][q] = *reinterpret_cast<const resid_t*>(xs + (size_t)(col + p2 + p1) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T));
     }
     __syncthreads();
     for (int u = threadIdx.x; u < rx * (C / 8); u += blockDim.x) {   // tile <- lrelu(tile), in place
@@ -296,13 +297,19 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
         if (sizeof(T) == 2) {
           f16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)acc[f][t][4 * q + e];
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[f][t][4 * q + e];
+            if constexpr (RREG) v += (float)resid[f][t][q][e];
+            o[e] = (f16)v;
+          }
           *reinterpret_cast<f16x4*>(p) = o;
         } else {
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e];
-          if constexpr (RREG) o += resid[f][t][q];
+          for (int e = 0; e < 4; ++e) {
+            o[e] = acc[f][t][4 * q + e];
+            if constexpr (RREG) o[e] += (float)resid[f][t][q][e];
+          }
           *reinterpret_cast<f32x4*>(p) = o;
         }
       }
