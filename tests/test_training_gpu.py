@@ -445,3 +445,27 @@ def test_pack_conv_weight_kernel_matches_the_host_packing(cuda, lib, n, c, k):
         assert c_pad == hip.round_up(c, 64) and torch.equal(got, hip.pack_conv_weight(w, dt))
         got, c_pad = hip.pack_conv_weight_dev(w, dt, dgrad=True)
         assert c_pad == hip.round_up(n, 64) and torch.equal(got, hip.pack_conv_weight(w.permute(1, 0, 2).flip(2).contiguous(), dt))
+
+
+def test_fastspeech2_train_step_nine_tap_embeddings(cuda, lib):
+    """The constructor-default 9-tap pitch / energy embedding convolutions (Conv1d(1, adim, 9): the MFMA conv with its single input
+    channel zero-padded) and no stop-gradient on the pitch predictor, against the real reference (fs2_train_embed9_small.npz)."""
+    import json
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.models.fastspeech2_train import criterion
+    _, zi, _, _ = _train_golden()
+    z, keys = load_golden("fs2_train_embed9_small.npz")
+    m = FastSpeech2(idim=20, **{**FS2_SMALL, **json.loads(str(z["config"]))})
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda).train()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    ret = m(t("text"), il, t("feats"), ol, t("durations"), il, t("pitch"), il, t("energy"), il)
+    losses = criterion(ret, t("durations"), t("pitch"), t("energy"), il)
+    for k in ("mel_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(losses[k].detach()) - float(z[k])) <= 2e-5 * max(1.0, abs(float(z[k]))), k
+    losses["loss"].backward()
+    P = dict(m.named_parameters())
+    for n, ref_norm in zip(json.loads(str(z["grad_names"])), z["grad_norms"]):
+        assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, 1e-3) <= 2e-3, (n, float(P[n].grad.norm()), ref_norm)
+    assert relerr(P["pitch_embed.0.weight"].grad, z["grad:pitch_embed.0.weight"]) <= 2e-3
