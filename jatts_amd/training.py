@@ -160,9 +160,10 @@ class FastSpeech2Trainer:
     the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
 
     def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
-                 bucket_bytes=64 << 20):
+                 bucket_bytes=64 << 20, overlap=True):
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
+        self.overlap = overlap
         model.train()   # (turns requires_grad on: the inference classes create frozen parameters)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params or self.params[0].device.type != "cuda":
@@ -186,6 +187,48 @@ class FastSpeech2Trainer:
                 o += k
         self.steps = 0
         self.last_lr = None
+        self._buckets = None
+
+    # -- gradient all-reduce overlapped with backward (what DistributedDataParallel's reducer does for the reference): the flat gradient
+    # buffer is cut into bucket_bytes slices; a post-accumulate hook on every parameter counts its bucket down and, when the last
+    # gradient of a bucket has been accumulated, issues that slice's all-reduce asynchronously (RCCL orders it after the compute
+    # stream's work so far and runs it on its own stream while backward continues).  Backward produces gradients roughly in reverse
+    # parameter order, so the LAST slices go first.  train_step waits for the handles, launches whatever never fired, averages.
+    def _setup_overlap(self):
+        per = max(1, self.bucket_bytes // 4)
+        n = self.flat_g.numel()
+        edges = list(range(0, n, per)) + [n]
+        self._buckets = [dict(lo=edges[i], hi=edges[i + 1], total=0, left=0, work=None) for i in range(len(edges) - 1)]
+        o = 0
+        for p in self.params:
+            touched = range(o // per, (o + p.numel() - 1) // per + 1)     # a parameter may straddle bucket edges
+            for b in touched:
+                self._buckets[b]["total"] += 1
+
+            def hook(_p, touched=touched):
+                for b in touched:
+                    bk = self._buckets[b]
+                    bk["left"] -= 1
+                    if bk["left"] == 0:
+                        bk["work"] = dist.all_reduce(self.flat_g[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            p.register_post_accumulate_grad_hook(hook)
+            o += p.numel()
+
+    def _arm_overlap(self):
+        for bk in self._buckets:
+            bk["left"], bk["work"] = bk["total"], None
+
+    def _finish_overlap(self):
+        world = dist.get_world_size(self.group)
+        n = 0
+        for bk in self._buckets:
+            if bk["work"] is None:      # a parameter of this slice got no gradient this step: reduce the slice now
+                bk["work"] = dist.all_reduce(self.flat_g[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            n += 1
+        for bk in self._buckets:
+            bk["work"].wait()
+        self.flat_g /= world
+        return n
 
     # -- checkpoints in the reference's format (jatts/trainers/base.py:85-124): {"model", "optimizer", "scheduler", "steps", "epochs"};
     # "optimizer" is a torch.optim.Adam state_dict (state indexed by the position in model.parameters()), so a checkpoint written here
@@ -259,9 +302,16 @@ class FastSpeech2Trainer:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
             o += p.numel()
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if multi and self.overlap:
+            if self._buckets is None:
+                self._setup_overlap()
+            self._arm_overlap()
         losses = self.compute_losses(batch)
         losses["loss"].backward()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if multi and self.overlap:
+            self._finish_overlap()
+        elif multi:
             allreduce_flat(self.flat_g, self.group, self.bucket_bytes)
         self.steps += 1
         lr = warmup_lr(self.base_lr, self.steps, self.warmup_steps) if self.warmup_steps else self.base_lr

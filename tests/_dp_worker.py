@@ -16,6 +16,7 @@ sys.path.insert(0, HERE)
 
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    overlap = len(sys.argv) < 5 or sys.argv[4] != "0"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from helpers import golden_state, load_golden
@@ -33,7 +34,7 @@ def main():
     feats = t("feats") + 0.25 * rank                                   # every rank trains on different data
     batch = dict(xs=t("text"), ilens=il, ys=feats, olens=t("feats_lengths"), durations=t("durations"), duration_lens=il, pitch=t("pitch") * (1 + rank),
                  pitch_lens=il, energys=t("energy"), energy_lens=il)
-    tr = FastSpeech2Trainer(m, lr=1e-3, grad_norm=1.0, warmup_steps=0, bucket_bytes=256 << 10)     # small buckets: several collectives
+    tr = FastSpeech2Trainer(m, lr=1e-3, grad_norm=1.0, warmup_steps=0, bucket_bytes=256 << 10, overlap=overlap)     # small buckets: several collectives
     losses = [float(tr.train_step(batch)["loss"]) for _ in range(3)]
     p = tr.flat_p.detach().cpu()
     hi, lo = p.clone(), p.clone()
@@ -41,7 +42,8 @@ def main():
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     ls = [None] * world
     dist.all_gather_object(ls, losses)
-    print(json.dumps({"rank": rank, "replica_spread": float((hi - lo).abs().max()), "losses": ls, "finite": bool(np.isfinite(losses).all())}),
+    print(json.dumps({"rank": rank, "replica_spread": float((hi - lo).abs().max()), "losses": ls, "finite": bool(np.isfinite(losses).all()),
+                      "checksum": float(p.double().abs().sum()), "buckets": len(tr._buckets) if tr._buckets else 0}),
           flush=True)
     dist.barrier()
     dist.destroy_process_group()
