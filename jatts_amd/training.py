@@ -160,10 +160,13 @@ class FastSpeech2Trainer:
     the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
 
     def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
-                 bucket_bytes=64 << 20, overlap=True):
+                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1):
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
         self.overlap = overlap
+        # trainers/base.py:64,135 / vits.py:113-121: `gradient_accumulate_steps` forward / backward passes (loss / G each) per optimiser
+        # step; `steps` (and with it the loss schedules and WarmupLR) counts optimiser steps
+        self.accumulate, self._micro = max(1, int(gradient_accumulate_steps)), 0
         model.train()   # (turns requires_grad on: the inference classes create frozen parameters)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params or self.params[0].device.type != "cuda":
@@ -214,9 +217,9 @@ class FastSpeech2Trainer:
             p.register_post_accumulate_grad_hook(hook)
             o += p.numel()
 
-    def _arm_overlap(self):
+    def _arm_overlap(self, live=True):
         for bk in self._buckets:
-            bk["left"], bk["work"] = bk["total"], None
+            bk["left"], bk["work"] = (bk["total"] if live else 1 << 60), None
 
     def _finish_overlap(self):
         world = dist.get_world_size(self.group)
@@ -296,19 +299,25 @@ class FastSpeech2Trainer:
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
         m = self.model
         m.train()
-        self.flat_g.zero_()
+        if self._micro == 0:
+            self.flat_g.zero_()
         o = 0
         for p in self.params:       # (re-attach: a caller may have set .grad to None)
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
             o += p.numel()
+        last = self._micro == self.accumulate - 1
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         if multi and self.overlap:
             if self._buckets is None:
                 self._setup_overlap()
-            self._arm_overlap()
+            self._arm_overlap(last)              # the exchange belongs to the last micro-batch's backward only
         losses = self.compute_losses(batch)
-        losses["loss"].backward()
+        (losses["loss"] / self.accumulate if self.accumulate > 1 else losses["loss"]).backward()
+        self._micro += 1
+        if not last:
+            return {k: v.detach() for k, v in losses.items()}
+        self._micro = 0
         if multi and self.overlap:
             self._finish_overlap()
         elif multi:

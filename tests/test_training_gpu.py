@@ -469,3 +469,29 @@ def test_fastspeech2_train_step_nine_tap_embeddings(cuda, lib):
     for n, ref_norm in zip(json.loads(str(z["grad_names"])), z["grad_norms"]):
         assert abs(float(P[n].grad.norm()) - ref_norm) / max(ref_norm, 1e-3) <= 2e-3, (n, float(P[n].grad.norm()), ref_norm)
     assert relerr(P["pitch_embed.0.weight"].grad, z["grad:pitch_embed.0.weight"]) <= 2e-3
+
+
+def test_gradient_accumulation_equals_one_big_step(cuda, lib):
+    """trainers/base.py:135 / vits.py:113-121: with gradient_accumulate_steps = 2, two calls on the same micro-batch (each loss / 2)
+    make ONE optimiser step equal to a plain step on that batch; `steps` counts optimiser steps."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+
+    def make():
+        m = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+        m.load_state_dict(golden_state(keys, 0))
+        return m.to(cuda)
+    a = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0, gradient_accumulate_steps=2)
+    b = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    o1 = a.train_step(batch)
+    assert a.steps == 0 and "grad_norm" not in o1 and maxdiff(a.flat_p, b.flat_p) == 0.0      # nothing applied yet
+    o2 = a.train_step(batch)
+    ob = b.train_step(batch)
+    assert a.steps == 1 and b.steps == 1
+    assert abs(float(o2["grad_norm"]) - float(ob["grad_norm"])) <= 1e-4 * float(ob["grad_norm"])
+    assert maxdiff(a.flat_p, b.flat_p) <= 2e-6          # first Adam step ~ lr * sign(g): equal up to gradient rounding noise near g = 0
