@@ -1,6 +1,8 @@
 // HBM-bound row-wise kernels of the jatts hot path (gfx950): embedding, LayerNorm,
 // affine/cast, conformer GLU+depthwise+BN+Swish, predictor heads, variance embeddings,
 // length regulator (bit-exact integer path), Gaussian upsampling, HiFi-GAN output conv.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -401,6 +403,64 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(jatts_ragged rg, const T*
       o[e] = t;
     }
     TO* dst = y + (int64_t)(row0 + r0 + r) * C + c;
+    if (sizeof(TO) == 2) *reinterpret_cast<f16x8*>(dst) = f16x8{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
+    else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>((float*)dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
+// Row-streaming form of the apply pass: a workgroup takes GN_TCH full rows (ALL groups: contiguous C-element rows instead of one
+// group's 256-byte pieces 2 KB apart), merges the chunk statistics of every group of its utterance once into LDS, then streams.
+constexpr int GN_MAXG = 32;
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(jatts_ragged rg, const T* __restrict__ x, TO* __restrict__ y, int C, int groups,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ addvec, const float* __restrict__ ws, int n_chunks) {
+  __shared__ float s_mean[GN_MAXG], s_rstd[GN_MAXG];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int row0 = rg.cu_rows[b];
+  const int L = rg.cu_rows[b + 1] - row0;
+  const int r0 = ch * GN_TCH;
+  if (r0 >= L) return;
+  if (threadIdx.x < groups) {
+    const float* st = ws + ((int64_t)b * groups + threadIdx.x) * n_chunks * 3;
+    float na = 0.f, ma = 0.f, m2a = 0.f;   // Chan et al.: merge (n, mean, M2) pairs
+    for (int i = 0; i < n_chunks; ++i) {
+      const float nb = st[3 * i], mb = st[3 * i + 1], m2b = st[3 * i + 2];
+      if (nb > 0.f) {
+        const float nn = na + nb, dlt = mb - ma;
+        ma += dlt * (nb / nn);
+        m2a += m2b + dlt * dlt * (na * nb / nn);
+        na = nn;
+      }
+    }
+    s_mean[threadIdx.x] = ma;
+    s_rstd[threadIdx.x] = rsqrtf(m2a / na + eps);
+  }
+  __syncthreads();
+  const int rows = min(GN_TCH, L - r0);
+  const int gc = C / groups, upr = C >> 3, total = rows * upr;
+  const T* xb = x + (int64_t)(row0 + r0) * C;
+  TO* yb = y + (int64_t)(row0 + r0) * C;
+  const float* av = addvec ? addvec + (int64_t)b * C : nullptr;
+  for (int u = threadIdx.x; u < total; u += 256) {
+    const int r = u / upr, c = (u - r * upr) * 8;
+    const int g = c / gc;
+    const float mean = s_mean[g], rstd = s_rstd[g];
+    float v[8], o[8];
+    load8f<T>(xb + (int64_t)r * C + c, v);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (v[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+      t = mish_f(t);
+      if (av) t += av[c + e];
+      o[e] = t;
+    }
+    TO* dst = yb + (int64_t)r * C + c;
     if (sizeof(TO) == 2) *reinterpret_cast<f16x8*>(dst) = f16x8{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
     else {
       *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
@@ -906,10 +966,15 @@ extern "C" int jatts_groupnorm_mish(const jatts_ragged* rg, const void* x, int32
   if (workspace && (gc & 7) == 0 && GN_TCH * gc <= 256 * GN_MAXU * 8) {   // time-split two-launch form
     const int n_chunks = (rg->max_len + GN_TCH - 1) / GN_TCH;
     dim3 grid3((unsigned)groups, (unsigned)rg->n_seq, (unsigned)n_chunks), blk3(256);
+    static const int rows_env = [] { const char* e = getenv("JATTS_GN_ROWS"); return e ? atoi(e) : 1; }();
+    const bool rows_form = rows_env && groups <= GN_MAXG && (channels & 7) == 0;
 #define GN2_GO(TI, TO)                                                                                                   \
   do {                                                                                                                   \
     hipLaunchKernelGGL((gn_partial_kernel<TI>), grid3, blk3, 0, S_, *rg, (const TI*)x, channels, groups, workspace, n_chunks); \
-    hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid3, blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
+    if (rows_form)                                                                                                          \
+      hipLaunchKernelGGL((gn_apply_rows_kernel<TI, TO>), dim3((unsigned)n_chunks, (unsigned)rg->n_seq), blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid3, blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
   } while (0)
     if (in_dtype == JATTS_F32 && out_dtype == JATTS_F32) GN2_GO(float, float);
     else if (in_dtype == JATTS_F32 && out_dtype == JATTS_F16) GN2_GO(float, f16);
