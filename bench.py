@@ -391,14 +391,17 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, **extra)
     first = float(tr.train_step(b)["loss"])
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    per = []
+    for _ in range(steps):       # every step timed on its own (a step ends in the optimiser kernels: nothing to overlap with the next one);
+        t0 = time.perf_counter()  # the MEDIAN is reported: these steps launch 2 300-6 200 kernels each and a busy host shows up as outliers
         o = tr.train_step(b)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        per.append(time.perf_counter() - t0)
+    dt = sorted(per)[len(per) // 2]
     n_frames = int(ol.sum())
     line = {"workload": f"{name} _train_step, batch {batch} x {t_text} phonemes x {frames} frames", "dtype": "f32",
-            "steps": steps, "ms_per_step": dt * 1e3, "frames_per_s": n_frames / dt, "loss_first": first, "loss_last": float(o["loss"]),
+            "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_all": [round(v * 1e3, 2) for v in per], "frames_per_s": n_frames / dt,
+            "loss_first": first, "loss_last": float(o["loss"]),
             "parity": "tests/test_training_gpu.py (one whole step vs the real reference: every parameter gradient)"}
     if flop_per_utt:
         line.update(dense_tflops_per_step=flop_per_utt * batch, achieved_tflops=flop_per_utt * batch / dt)
@@ -547,7 +550,7 @@ def main():
         for kind in ("fs2", "matcha", "matcha_mas", "vits"):
             gc.collect()               # (the inference jobs above hold reference cycles; a live 10+ GB job slows the step by 20 %)
             torch.cuda.empty_cache()
-            out["training"].append(train_step_line(dev, max(2, min(3, a.steps)), kind))
+            out["training"].append(train_step_line(dev, 5, kind))
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from jatts_amd.synthetic import synth_texts
