@@ -85,8 +85,15 @@ def h2d(values, dtype, device):
     return t.to(device)
 
 
+_GEOM_CACHE = {}      # (lens, device) -> (cu tensor, upload-complete event); insertion-ordered, oldest evicted
+_GEOM_CACHE_MAX = 512
+
+
 class RaggedBatch:
-    """Packed ragged batch geometry: sequence b owns rows cu[b]..cu[b+1]-1."""
+    """Packed ragged batch geometry: sequence b owns rows cu[b]..cu[b+1]-1.
+
+    The device copy of ``cu`` is cached per (lengths, device): a forward / training step builds the same handful of geometries
+    (``[T] * B`` padded forms, the valid-length forms) dozens of times, and every upload is a launch plus a pinned staging copy."""
 
     def __init__(self, lens, device):
         self.lens = [int(v) for v in lens]
@@ -98,7 +105,22 @@ class RaggedBatch:
         self.n_seq = len(self.lens)
         self.max_len = max(self.lens) if self.lens else 0
         self.device = device
-        self.cu = h2d(cu, torch.int32, device)
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            self.cu = torch.tensor(cu, dtype=torch.int32, device=dev)
+            return
+        key = (tuple(self.lens), dev.index if dev.index is not None else torch.cuda.current_device())
+        hit = _GEOM_CACHE.get(key)
+        if hit is None:
+            t = h2d(cu, torch.int32, dev)
+            ev = torch.cuda.Event()
+            ev.record()
+            if len(_GEOM_CACHE) >= _GEOM_CACHE_MAX:
+                _GEOM_CACHE.pop(next(iter(_GEOM_CACHE)))
+            _GEOM_CACHE[key] = hit = (t, ev, torch.cuda.current_stream().cuda_stream)
+        elif hit[2] != torch.cuda.current_stream().cuda_stream and not hit[1].query():
+            torch.cuda.current_stream().wait_event(hit[1])     # uploaded on another stream and still in flight
+        self.cu = hit[0]
 
     def struct(self, len_mul=1):
         return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul)
