@@ -215,3 +215,44 @@ def test_stage4_cli_multispeaker_extracts_embeddings(cuda, lib, tmp_path):
     for i in range(3):
         with wave.open(str(d / "out" / "wav" / f"utt{i}.wav")) as w:
             assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
+
+
+@pytest.mark.gpu
+def test_trained_checkpoint_feeds_stage4(cuda, lib, tmp_path):
+    """Train -> save -> decode: a checkpoint written by FastSpeech2Trainer.save_checkpoint (the reference's layout,
+    trainers/base.py:85-105) is what stage 4 loads (`torch.load(ckpt)["model"]`, tts_decode.py:141) -- the CLI synthesises from it and
+    the result differs from the untrained model's."""
+    from jatts_amd.bin import tts_decode
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.synthetic import FS2_SMALL
+    from jatts_amd.training import FastSpeech2Trainer
+    d = tmp_path
+    _make_expdir(d)
+    sd0 = torch.load(d / "checkpoint-1steps.pkl")["model"]
+    m = FastSpeech2(idim=20, **FS2_SMALL)
+    m.load_state_dict(sd0)
+    m = m.to(cuda)
+    g = torch.Generator().manual_seed(3)
+    il = torch.tensor([9, 14])
+    xs, ds = torch.zeros(2, 14, dtype=torch.long), torch.zeros(2, 14, dtype=torch.long)
+    for b in range(2):
+        xs[b, : il[b]] = torch.randint(2, 19, (int(il[b]),), generator=g)
+        ds[b, : il[b]] = torch.randint(1, 5, (int(il[b]),), generator=g)
+    ol = ds.sum(1)
+    mask = (torch.arange(14)[None, :] < il[:, None]).float().unsqueeze(-1)
+    batch = dict(xs=xs, ilens=il, ys=torch.randn(2, int(ol.max()), 80, generator=g), olens=ol, durations=ds, duration_lens=il,
+                 pitch=torch.randn(2, 14, 1, generator=g) * mask, pitch_lens=il, energys=torch.randn(2, 14, 1, generator=g) * mask, energy_lens=il)
+    tr = FastSpeech2Trainer(m, lr=5e-3, warmup_steps=0)
+    for _ in range(3):
+        tr.train_step(batch)
+    tr.save_checkpoint(str(d / "checkpoint-4steps.pkl"))
+    args = ["--csv", str(d / "dev.csv"), "--stats", str(d / "stats.npz"), "--token-list", str(d / "tokens.txt"), "--token-column", "phonemes",
+            "--verbose", "0", "--batch-size", "3"]
+    tts_decode.main(args + ["--checkpoint", str(d / "checkpoint-4steps.pkl"), "--outdir", str(d / "out_trained")])
+    tts_decode.main(args + ["--checkpoint", str(d / "checkpoint-1steps.pkl"), "--outdir", str(d / "out_init")])
+    changed = 0
+    for i in range(3):
+        with wave.open(str(d / "out_trained" / "wav" / f"utt{i}.wav")) as w, wave.open(str(d / "out_init" / "wav" / f"utt{i}.wav")) as w0:
+            assert w.getframerate() == 24000 and w.getnframes() > 0
+            changed += int(w.getnframes() != w0.getnframes() or w.readframes(w.getnframes()) != w0.readframes(w0.getnframes()))
+    assert changed == 3
