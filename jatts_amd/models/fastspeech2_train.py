@@ -24,7 +24,10 @@ class _Ctx:
         self.p = dict(model.named_parameters())
         self.b = dict(model.named_buffers())
         self.train = model.training
-        self.seed = int(seed) * 1000003
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()          # data-parallel replicas draw different dropout masks
+        self.seed = (int(seed) * 4099 + rank) * 1000003
         self.n_drop = 0
 
     def drop(self, x, rate):
