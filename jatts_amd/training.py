@@ -289,10 +289,24 @@ class FastSpeech2Trainer:
 
     def compute_losses(self, batch):
         """forward + criterion of trainers/fastspeech2.py:44-84 -> dict of differentiable scalars incl. "loss"."""
-        from .models.fastspeech2_train import criterion
-        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"], batch["pitch"],
-                         batch["pitch_lens"], batch["energys"], batch["energy_lens"], batch.get("spkembs"), batch.get("sids"))
+        from .models.fastspeech2_train import criterion, train_forward
+        m = self.model
+        m._train_calls += 1
+        ret = train_forward(m, batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"],
+                            batch["pitch"], batch["pitch_lens"], batch["energys"], batch["energy_lens"], spembs=batch.get("spkembs"),
+                            sids=batch.get("sids"), seed=m._train_calls)
         return criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
+
+    @torch.no_grad()
+    def eval_step(self, batch):
+        """`_eval_step` of the reference trainers (e.g. trainers/fastspeech2.py:150-215): the same forward + criterion in eval() mode
+        (running-statistics BatchNorm, no dropout), no gradients, no update.  -> dict of loss tensors."""
+        was = self.model.training
+        self.model.eval()
+        try:
+            return {k: v.detach() for k, v in self.compute_losses(batch).items()}
+        finally:
+            self.model.train(was)
 
     def train_step(self, batch):
         """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
@@ -349,10 +363,13 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
         self.dp_train_start_steps, self.bin_loss_start_steps, self.lambda_align = dp_train_start_steps, bin_loss_start_steps, lambda_align
 
     def compute_losses(self, batch):
-        from .models.matchatts_train import criterion
-        mas = self.model._MAS      # tts2 MatchaTTS_MAS: alignment module + MAS; + ForwardSumLoss / binarisation loss by schedule
-        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch.get("durations"), batch.get("duration_lens"),
-                         batch.get("spkembs"), batch.get("sids"), cfm_t=batch.get("cfm_t"), cfm_noise=batch.get("cfm_noise"))
+        from .models.matchatts_train import criterion, train_forward
+        m = self.model
+        mas = m._MAS      # tts2 MatchaTTS_MAS: alignment module + MAS; + ForwardSumLoss / binarisation loss by schedule
+        m._train_calls += 1
+        ret = train_forward(m, batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch.get("durations"), batch.get("duration_lens"),
+                            spembs=batch.get("spkembs"), sids=batch.get("sids"), cfm_t=batch.get("cfm_t"), cfm_noise=batch.get("cfm_noise"),
+                            seed=m._train_calls)
         return criterion(ret, batch.get("durations"), batch["ilens"], duration_loss=self.steps > self.dp_train_start_steps,
                          olens=batch["olens"], forward_sum=mas and self.steps < self.dp_train_start_steps,
                          bin_loss=mas and self.steps > self.bin_loss_start_steps, lambda_align=self.lambda_align)
@@ -370,8 +387,11 @@ class VITSTrainer(FastSpeech2Trainer):
         self.lambda_align, self.lambda_mel = lambda_align, lambda_mel
 
     def compute_losses(self, batch):
-        from .models.vits_train import criterion
-        ret = self.model(batch["xs"], batch["ilens"], batch["ys"], batch["olens"], spembs=batch["spkembs"], post_noise=batch.get("post_noise"))
+        from .models.vits_train import criterion, train_forward
+        m = self.model
+        m._train_calls += 1
+        ret = train_forward(m, batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["spkembs"], post_noise=batch.get("post_noise"),
+                            seed=m._train_calls)
         return criterion(ret, batch["ilens"], batch["olens"], duration_loss=self.steps > self.dp_train_start_steps,
                          forward_sum=self.steps < self.dp_train_start_steps, bin_loss=self.steps > self.bin_loss_start_steps,
                          lambda_align=self.lambda_align, lambda_mel=self.lambda_mel)

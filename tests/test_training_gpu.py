@@ -495,3 +495,30 @@ def test_gradient_accumulation_equals_one_big_step(cuda, lib):
     assert a.steps == 1 and b.steps == 1
     assert abs(float(o2["grad_norm"]) - float(ob["grad_norm"])) <= 1e-4 * float(ob["grad_norm"])
     assert maxdiff(a.flat_p, b.flat_p) <= 2e-6          # first Adam step ~ lr * sign(g): equal up to gradient rounding noise near g = 0
+
+
+def test_eval_step_equals_the_reference_eval_losses(cuda, lib):
+    """Trainer.eval_step = forward + criterion in eval() mode without gradients: on the forward() golden batch it must give the losses
+    the reference's loss classes give on the reference's eval-mode forward() (fs2_losses_small.npz), leave the parameters, the
+    BatchNorm running statistics and the step counter alone, and return to train mode."""
+    import os
+    from helpers import GOLDEN
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, keys = load_golden("fs2_forward_small.npz")
+    ref = np.load(os.path.join(GOLDEN, "fs2_losses_small.npz"))
+    m = FastSpeech2(idim=20, **FS2_SMALL)
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda)
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+    tr = FastSpeech2Trainer(m, lr=1e-3, warmup_steps=0)
+    p0 = tr.flat_p.clone()
+    rm0 = dict(m.named_buffers())["postnet.postnet.0.1.running_mean"].clone()
+    out = tr.eval_step(batch)
+    for k in ("mel_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(out[k]) - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, float(out[k]), float(ref[k]))
+    assert m.training and tr.steps == 0 and torch.equal(tr.flat_p, p0)
+    assert torch.equal(dict(m.named_buffers())["postnet.postnet.0.1.running_mean"], rm0)
