@@ -152,6 +152,21 @@ def warmup_lr(base_lr, step_num, warmup_steps):
     return base_lr * warmup_steps ** 0.5 * min(step_num ** -0.5, step_num * warmup_steps ** -1.5)
 
 
+def scheduled_lr(kind, base_lr, step_num, **params):
+    """Learning rate of optimiser step ``step_num`` (1-based) under the recipes' schedulers: "warmuplr" (fastspeech2.v1 / vits.v1:
+    jatts/schedulers/warmup_lr.py), "steplr" (the Matcha recipes: torch.optim.lr_scheduler.StepLR(step_size, gamma), stepped once
+    per optimiser step) or None / "none" (constant)."""
+    kind = (kind or "none").lower()
+    if kind == "warmuplr":
+        w = params.get("warmup_steps", 4000)
+        return warmup_lr(base_lr, step_num, w) if w else base_lr
+    if kind == "steplr":
+        return base_lr * params.get("gamma", 0.1) ** ((step_num - 1) // params["step_size"])
+    if kind == "none":
+        return base_lr
+    raise ValueError(f"unknown scheduler {kind!r} (warmuplr, steplr, none)")
+
+
 class FastSpeech2Trainer:
     """`FastSpeech2Trainer._train_step` (jatts/trainers/fastspeech2.py:24-100) on one GPU of a data-parallel job:
     forward (train mode) -> MelLoss + DurationPredictorLoss + PitchLoss + EnergyLoss -> backward -> gradient all-reduce over
@@ -160,10 +175,11 @@ class FastSpeech2Trainer:
     the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
 
     def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
-                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1):
+                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1, scheduler="warmuplr", scheduler_params=None):
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
         self.overlap = overlap
+        self.scheduler, self.scheduler_params = scheduler, dict(scheduler_params or {})      # e.g. "steplr", {"step_size": 10000, "gamma": 0.5}
         # trainers/base.py:64,135 / vits.py:113-121: `gradient_accumulate_steps` forward / backward passes (loss / G each) per optimiser
         # step; `steps` (and with it the loss schedules and WarmupLR) counts optimiser steps
         self.accumulate, self._micro = max(1, int(gradient_accumulate_steps)), 0
@@ -253,8 +269,10 @@ class FastSpeech2Trainer:
             for i in range(len(self.params)):
                 opt["state"][i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[i].detach().cpu().clone(),
                                    "exp_avg_sq": v[i].detach().cpu().clone()}
-        sch = {"warmup_steps": self.warmup_steps, "base_lrs": [self.base_lr], "last_epoch": self.steps, "_step_count": self.steps + 1,
-               "_get_lr_called_within_step": False, "_last_lr": [self.last_lr if self.last_lr is not None else self.base_lr]}
+        sch = {"base_lrs": [self.base_lr], "last_epoch": self.steps, "_step_count": self.steps + 1, "_get_lr_called_within_step": False,
+               "_last_lr": [self.last_lr if self.last_lr is not None else self.base_lr], **self.scheduler_params}
+        if (self.scheduler or "").lower() == "warmuplr":
+            sch["warmup_steps"] = self.warmup_steps
         return {"model": {k: t.detach().cpu().clone() for k, t in self.model.state_dict().items()}, "optimizer": opt, "scheduler": sch,
                 "steps": self.steps, "epochs": epochs}
 
@@ -337,7 +355,10 @@ class FastSpeech2Trainer:
         elif multi:
             allreduce_flat(self.flat_g, self.group, self.bucket_bytes)
         self.steps += 1
-        lr = warmup_lr(self.base_lr, self.steps, self.warmup_steps) if self.warmup_steps else self.base_lr
+        sp = dict(self.scheduler_params)
+        if (self.scheduler or "").lower() == "warmuplr":
+            sp.setdefault("warmup_steps", self.warmup_steps)
+        lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **sp)
         self.last_lr = lr
         ss = None
         if self.grad_norm and self.grad_norm > 0:

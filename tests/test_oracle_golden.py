@@ -187,3 +187,21 @@ def test_mas_oracle_matches_reference(golden_dir):
     ds, bin_loss, _ = viterbi_decode(ref, tl, fl, literal=True)
     assert np.array_equal(ds.numpy(), z["ds"])
     assert abs(float(bin_loss) - float(z["bin_loss"])) <= 1e-6
+
+
+def test_training_lr_schedules_match_torch_and_the_reference_formula():
+    """jatts_amd.training.scheduled_lr (host logic of the trainers): "steplr" against torch.optim.lr_scheduler.StepLR stepped once per
+    optimiser step (the Matcha recipes: step_size 10000, gamma 0.5), "warmuplr" against jatts/schedulers/warmup_lr.py:55-62."""
+    import torch
+    from jatts_amd.training import scheduled_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=7, gamma=0.5)
+    for step in range(1, 40):
+        assert abs(scheduled_lr("steplr", 1e-4, step, step_size=7, gamma=0.5) - opt.param_groups[0]["lr"]) <= 1e-18
+        opt.step()
+        sch.step()
+    for step in (1, 2, 3999, 4000, 4001, 100000):
+        want = 0.0008 * 4000 ** 0.5 * min(step ** -0.5, step * 4000 ** -1.5)
+        assert abs(scheduled_lr("warmuplr", 0.0008, step, warmup_steps=4000) - want) <= 1e-18
+    assert scheduled_lr(None, 3e-4, 17) == 3e-4
