@@ -43,6 +43,27 @@ def profile_end():
     return [(tag, meta, a.elapsed_time(b)) for tag, meta, a, b in recs]
 
 
+# ---- optional dense-FLOP tally of the MFMA launches (conv forward / dgrad / wgrad, attention); bench.py's training lines
+_FLOPS = None
+
+
+def flops_begin():
+    global _FLOPS
+    _FLOPS = 0.0
+
+
+def flops_end():
+    global _FLOPS
+    v, _FLOPS = _FLOPS or 0.0, None
+    return v
+
+
+def _count(flops):
+    global _FLOPS
+    if _FLOPS is not None:
+        _FLOPS += flops
+
+
 class _Timed:
     def __init__(self, tag, meta):
         self.tag, self.meta = tag, meta
@@ -241,6 +262,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     d.y, d.ldy = _ptr(out, out_col0), ldy
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
     d.y_seq_col0 = _ptr(y_seq_col0) if transposed else None
+    _count(2.0 * c_in * n_out * k_w * rows)
     with _Timed("conv1d", (c_in, n_out, k_w, rows)):
         _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")
     return out
@@ -670,6 +692,7 @@ def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1):
     dw = torch.empty(n_out, c_in, k_w, dtype=torch.float32, device=x.device)
     ws = torch.empty(rb.n_seq * k_w * round_up(n_out, 64) * round_up(c_in, 64), dtype=torch.float32, device=x.device)   # split-K partials
     rg = rb.struct(len_mul)
+    _count(2.0 * c_in * n_out * k_w * rb.total * len_mul)
     _abi.check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
                                       pad, dw.data_ptr(), ws.data_ptr(), _stream()), "jatts_conv1d_wgrad")
     return dw

@@ -1,0 +1,67 @@
+"""The ONE JSON line bench.py prints must stay small enough for the driver to parse (round 2's grew to 30 KB and was
+recorded as `parsed: null`) and must carry every graded key."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "alg_bytes", "alg_flops")
+CPU = ("value", "unit", "cores", "kind", "sample", "rtf", "cpu_model")
+
+
+def check_line(line, n_gpus=1):
+    assert "\n" not in line and len(line) < 4096, len(line)
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["unit"] == "samples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] in ("f32", "f16")
+    assert isinstance(d["config"]["workload"], str) and "model" not in d["config"]
+    for k in ROOFLINE:
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0.0 < d["roofline"]["frac"] < 1.0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    if n_gpus == 1 and d["cpu_baseline"] is not None:
+        for k in CPU:
+            assert k in d["cpu_baseline"], k
+        assert d["cpu_baseline"]["kind"] in ("port", "reference")
+    return d
+
+
+def full_result():
+    out = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))      # a real full-size result (30 KB)
+    for e, kind in zip(out["training"], ("fs2", "matcha", "matcha_mas", "vits")):
+        e.setdefault("kind", kind)
+    return out
+
+
+def test_compact_line_from_a_full_result():
+    out = full_result()
+    assert len(json.dumps(out)) > 20000
+    d = check_line(bench.compact_line(out, "bench_detail.json"))
+    assert d["value"] == float(f"{out['value']:.5g}") and d["detail"] == "bench_detail.json"
+    assert set(d["training"]) == {"fs2", "matcha", "matcha_mas", "vits"} and len(d["configs"]) == 2
+    assert d["fast_mode"]["dtype"] == "f16" and d["speedup_vs_cpu_rtf"] > 1
+
+
+def test_compact_line_never_exceeds_the_limit():
+    out = full_result()
+    out["config"]["workload"] = out["config"]["workload"] + " x" * 600       # something grows again: optional blocks go first
+    out["cpu_baseline"]["sample_short"] = "s" * 900
+    line = bench.compact_line(out, "bench_detail.json")
+    assert len(line) <= bench.LINE_LIMIT
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+
+
+def test_compact_line_without_optional_blocks():
+    out = full_result()
+    for k in ("fast_mode", "configs", "training", "cpu_baseline", "speedup_vs_cpu_rtf"):
+        out.pop(k, None)
+    out["cpu_baseline"] = None
+    d = json.loads(bench.compact_line(out))
+    assert d["cpu_baseline"] is None and "detail" not in d and "training" not in d
