@@ -542,7 +542,11 @@ def main():
     elif rank == 0 and not a.pmc_child:
         traffic_table, traffic_source = committed_traffic()
 
+    if world > 1:      # N launch-heavy host loops on one node: keep each rank's CPU-side torch work on one thread (torchrun's default too)
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
     import torch
+    if world > 1:
+        torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
 
     # JATTS_BENCH_SHARED_GPU=1 (tests/test_distributed_gpu.py only): every rank on cuda:0 with gloo collectives, to exercise the
     # N > 1 code path on a one-GPU test box (RCCL refuses two ranks per device).  Never set by the driver; the line says so.

@@ -286,10 +286,11 @@ int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim, float* ou
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by
- * min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) when grad_sumsq != NULL and max_norm > 0 (clip_grad_norm_). */
+ * min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) when grad_sumsq != NULL and max_norm > 0 (clip_grad_norm_).  The hyper-parameters
+ * are doubles: bias corrections and step size are computed in double (torch computes them as Python floats) and rounded once. */
 int jatts_sumsq(const float* x, int64_t n, double* out, void* stream);
-int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream);
+int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream);
 
 /* Profiling hook (not part of the reference interface): while `buf` is non-NULL, thread 0 of the first n_workgroups
  * workgroups of every jatts_hifigan_resunit launch writes 16 uint64 to buf[16*wg ..]: {XCC_ID<<32 | HW_ID, s_memtime

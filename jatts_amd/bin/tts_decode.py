@@ -185,6 +185,8 @@ def main(argv=None):
     items = read_items(args.csv, args.token_column, converter)
     logging.info(f"Dataset size = {len(items)}.")
     if world > 1:
+        from jatts_amd.distributed import pin_host_threads
+        pin_host_threads(1)
         mine = shard_utterances([len(it["token_indices"]) for it in items], world)[rank]
         items = [items[i] for i in mine]
 

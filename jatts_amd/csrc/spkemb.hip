@@ -6,13 +6,8 @@
 
 namespace {
 
-__device__ __forceinline__ int reflect_idx(int p, int n) {
-  if (p < 0) p = -p;
-  if (p >= n) p = 2 * (n - 1) - p;
-  return p;
-}
-
-// frames[row(b, t)][n] = window[n] * x_b[reflect(t * hop + n - n_fft / 2)]   (torch.stft, center=True, reflect)
+// frames[row(b, t)][n] = window[n] * x_b[t * hop + n - n_fft / 2], zero outside the signal (torch.stft, center=True,
+// pad_mode="constant": SpeechBrain's STFT default [recalled]; torch.stft's own default would be "reflect")
 __global__ __launch_bounds__(256) void frame_signal_kernel(jatts_ragged rg, const int32_t* cu_samples, const float* x, const float* window,
                                                            int n_fft, int hop, float* out, int ldo) {
   const int b = blockIdx.y;
@@ -23,10 +18,8 @@ __global__ __launch_bounds__(256) void frame_signal_kernel(jatts_ragged rg, cons
     for (int i = threadIdx.x; i < ldo; i += 256) {
       float v = 0.f;
       if (i < n_fft) {
-        int p = t * hop + i - n_fft / 2;
-        p = reflect_idx(p, n);
-        p = min(max(p, 0), n - 1);   // signals shorter than n_fft / 2: clamp (torch refuses them)
-        v = window[i] * x[s0 + p];
+        const int p = t * hop + i - n_fft / 2;
+        if (p >= 0 && p < n) v = window[i] * x[s0 + p];
       }
       o[i] = v;
     }

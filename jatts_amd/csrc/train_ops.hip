@@ -537,9 +537,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, red[0]);
 }
 // torch.optim.Adam (no amsgrad): g' = g * gscale (+ wd * p); m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
-// p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).  gscale = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given.
+// p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps); the scalars (bias corrections, step size, 1 - beta) are computed in double on the
+// host like torch's Python floats and rounded to f32 once.  gscale = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   int64_t n, float step_size, float w1, float b2, float w2, float eps, float wd, float bc2_sqrt,
                                                    const double* __restrict__ sumsq, float max_norm) {
   float gs = 1.f;
   if (sumsq && max_norm > 0.f) {
@@ -549,11 +550,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float gi = g[i] * gs;
     if (wd != 0.f) gi += wd * p[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float m0 = m[i];
+    const float mi = m0 + w1 * (gi - m0);                  // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + w2 * gi * gi;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi;
     v[i] = vi;
-    p[i] -= lr / bc1 * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));   // param.addcdiv_(exp_avg, denom, value=-step_size)
   }
 }
 
@@ -945,14 +947,14 @@ extern "C" int jatts_sumsq(const float* x, int64_t n, double* out, void* stream)
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
-extern "C" int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream) {
+extern "C" int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                               double weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream) {
   NULLCHK(!p || !g || !m || !v, "adam_step: null pointer");
   NULLCHK(step < 1, "adam_step: step counts from 1");
   if (n <= 0) return JATTS_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, S_, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
-                     sqrtf(bc2), grad_sumsq, max_norm);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, S_, p, g, m, v, n, (float)(lr / bc1), (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), grad_sumsq, max_norm);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

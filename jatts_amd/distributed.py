@@ -12,19 +12,27 @@ import torch.distributed as dist
 from .hostlogic import shard_utterances  # noqa: F401  (re-exported)
 
 
+def pin_host_threads(n=1):
+    """One process per GPU: every rank is a launch-heavy host loop, and eight of them each spinning up torch's default intra-op
+    pool (all cores) fight for the same cores.  Call before any torch CPU work; honours an OMP_NUM_THREADS the user set."""
+    import os
+    if "OMP_NUM_THREADS" not in os.environ:
+        os.environ["OMP_NUM_THREADS"] = str(n)
+        torch.set_num_threads(n)
+
+
 def gather_audio(wave, lens, max_utts=None, group=None, pcm16=None):
-    """All-gather-v of variable-length audio: flat buffer + offsets, no padding to the longest rank.
+    """All-gather of variable-length audio: one dense collective, ragged shards padded to the longest rank.
 
     wave: (sum(lens),) packed waveforms of this rank (f32 in [-1, 1], or int16 PCM already); lens: samples per local
     utterance.  Float audio on the GPU is first converted to int16 PCM by the jatts_pcm16 kernel -- the format
     tts_decode.py:250-255 stores anyway (sf.write(..., "PCM_16")) and half the bytes on xGMI.  ``pcm16=False`` keeps
     the input dtype.  ``max_utts``: an upper bound on utterances per rank known to every rank (the batch size); when
     omitted it is agreed on with one extra tiny all-reduce.
-    Returns (list over ranks of packed tensors -- views of one flat buffer --, list over ranks of lens).
+    Returns (list over ranks of packed tensors -- views of one (world, slot) buffer --, list over ranks of lens).
 
     Two collectives: (1) one fixed-size header all-gather [n_utts, n_samples, lens...]; (2) the payload as ONE
-    grouped all-gather-v (RCCL: torch's uneven all_gather = a coalesced group of broadcasts straight into the flat
-    buffer; gloo, used by the CPU tests: the same broadcasts issued one by one).
+    all_gather_into_tensor of `slot = max over ranks of n_samples` elements per rank (the same call on RCCL and gloo).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -49,25 +57,22 @@ def gather_audio(wave, lens, max_utts=None, group=None, pcm16=None):
     dist.all_gather_into_tensor(heads, head.to(dev), group=group)
     heads = heads.view(world, max_utts + 2).cpu()
     n_utts, n_samp = heads[:, 0].tolist(), heads[:, 1].tolist()
-    offs = [0]
-    for n in n_samp:
-        offs.append(offs[-1] + n)
-    flat = torch.empty(offs[-1], dtype=wave.dtype, device=dev)
-    parts = [flat[offs[r]:offs[r + 1]] for r in range(world)]
+    # ONE dense all-gather for every backend and every shape of shard: each rank contributes max(n_samp) samples (ragged shards
+    # are padded -- int16 PCM of a 64-utterance shard is 25 MB, the padding costs microseconds on xGMI), so the ragged case runs
+    # the very collective the equal-shard bench exercises; no uneven all_gather / grouped broadcasts that only a multi-GPU ragged
+    # run would ever reach.
+    slot = max(n_samp)
     esz = wave.element_size()
     as_bytes = (lambda t: t.view(torch.uint8)) if esz != 1 and wave.dtype == torch.int16 else (lambda t: t)  # RCCL has no int16 type
-    if offs[-1] > 0:
-        backend = dist.get_backend(group)
-        if len(set(n_samp)) == 1:            # equal shards (the weak-scaling bench): the plain dense all-gather
-            dist.all_gather_into_tensor(as_bytes(flat), as_bytes(wave), group=group)
-        elif backend == "nccl" and all(n > 0 for n in n_samp):
-            dist.all_gather([as_bytes(p) for p in parts], as_bytes(wave), group=group)
+    buf = torch.empty(world, slot, dtype=wave.dtype, device=dev)
+    if slot > 0:
+        if wave.numel() == slot:
+            send = wave
         else:
-            parts[rank].copy_(wave)
-            works = [dist.broadcast(as_bytes(parts[r]), src=dist.get_global_rank(group, r) if group is not None else r,
-                                    group=group, async_op=True) for r in range(world) if n_samp[r] > 0]
-            for w in works:
-                w.wait()
+            send = torch.zeros(slot, dtype=wave.dtype, device=dev)
+            send[:wave.numel()].copy_(wave)
+        dist.all_gather_into_tensor(as_bytes(buf.view(-1)), as_bytes(send), group=group)
+    parts = [buf[r, :n_samp[r]] for r in range(world)]
     lens_out = [heads[r, 2:2 + n_utts[r]].tolist() for r in range(world)]
     return parts, lens_out
 

@@ -356,15 +356,67 @@ def rowdot(x, ldx, rows, n_heads, d_k, vec, col0=0):
     return out
 
 
+_BAD_IDS = {}      # device index -> int64 (1,) counter of out-of-range embedding ids seen by launches that passed no counter of their own
+
+
+def _bad_counter(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _BAD_IDS.get(key)
+    if t is None:
+        t = _BAD_IDS[key] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return t
+
+
 def embed_scale(ids, table, scale, n_bad=None):
-    """n_bad: optional int64 (1,) device counter (zeroed by the caller) of ids outside the table -- read at the caller's next
-    host synchronisation (lr_sizes(..., check=n_bad)) instead of a dedicated ids.max()/min() round trip per batch."""
+    """rows = table[ids] * scale.  The kernel ALWAYS bounds-checks: an id outside the table yields a zero row (never a read outside
+    the table) and is counted -- in ``n_bad`` (int64 (1,) device counter zeroed by the caller, read at the caller's next host
+    synchronisation: lr_sizes(..., check=n_bad)) or, when none is passed, in the device's shared counter, which
+    check_bad_ids() / bad_ids_async() turn into the IndexError torch.nn.Embedding would have raised."""
     lib = _abi.load()
+    if n_bad is None:
+        n_bad = _bad_counter(_dev(ids).device)
     out = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=ids.device)
     _abi.check(lib.jatts_embed_scale(_dev(ids).data_ptr(), ids.numel(), table.data_ptr(), table.shape[1],
-                                     float(scale), out.data_ptr(), table.shape[0] if n_bad is not None else 0,
-                                     _ptr(n_bad), _stream()), "jatts_embed_scale")
+                                     float(scale), out.data_ptr(), table.shape[0], _ptr(n_bad), _stream()), "jatts_embed_scale")
     return out
+
+
+def check_bad_ids(device):
+    """Read the device's shared bad-id counter (a host synchronisation: call it right after one the caller needs anyway) and raise
+    IndexError like torch.nn.Embedding if a launch since the last check saw an id outside its table."""
+    t = _BAD_IDS.get(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+    if t is None:
+        return
+    n = int(t)
+    if n:
+        t.zero_()
+        raise IndexError(f"index out of range in self ({n} token ids outside the embedding table)")
+
+
+def bad_ids_async(device):
+    """Stream-ordered snapshot of the shared counter into pinned memory, no host wait.  -> resolve() which raises IndexError once the
+    copy has landed and the count is non-zero (returns False while the copy is still in flight)."""
+    dev = torch.device(device)
+    t = _BAD_IDS.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if t is None:
+        return lambda wait=False: True
+    host = torch.zeros(1, dtype=torch.int64).pin_memory()
+    host.copy_(t, non_blocking=True)
+    t.zero_()
+    ev = torch.cuda.Event()
+    ev.record()
+
+    def resolve(wait=False):
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return False
+        if int(host):
+            n = int(host)
+            host.zero_()
+            raise IndexError(f"index out of range in self ({n} token ids outside the embedding table in an earlier training step)")
+        return True
+    return resolve
 
 
 def layernorm(x, gamma, beta, out_dtype, eps=1e-12, out=None):

@@ -386,6 +386,7 @@ class FastSpeech2(torch.nn.Module):
         d_used = ds.reshape(-1).to(torch.int64).contiguous()
         d_eff, cum, ol, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=0)
         ol_h = ol.tolist()
+        hip.check_bad_ids(dev)   # out-of-range token ids: IndexError as nn.Embedding, read at the sync above
         if sum(ol_h) == 0:   # the batched call applies the all-zero rule only when the whole batch sums to 0 (:85-94)
             logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
             d_eff, cum, ol, _ = hip.lr_durations(rb, d_used, 1.0, zero_rule=1)

@@ -157,9 +157,10 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     # length-derived device tensors and the one host read-back (output lengths = duration sums) happen here, before GPU work is queued
     kv = hip.h2d(ilens, torch.int32, dev)
     kvo = olens.to(device=dev, dtype=torch.int32).contiguous()
-    ol_h = [int(v) for v in ds.sum(1).tolist()]
     ids = xs.reshape(-1).to(torch.int64).contiguous()
     x = A.Embedding.apply(ids, c.p["encoder.embed.0.weight"], math.sqrt(Ad), model.padding_idx)
+    ol_h = [int(v) for v in ds.sum(1).tolist()]
+    hip.check_bad_ids(dev)     # ids outside the table (zero rows, counted by the kernel) raise here like nn.Embedding: the sync above is needed anyway
     x = c.drop(x, R["enc_pos"])
     hs = _conformer(c, "encoder.", x, rb, kv, model.aheads, dict(pos=R["enc_pos"], layer=R["enc"], ffn=R["enc"], attn=R["enc_attn"]))
     if model.spks is not None:                                       # fastspeech2.py:589-592

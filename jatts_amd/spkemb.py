@@ -12,6 +12,7 @@ Every contraction is a ``jatts_conv1d`` launch in f32 (SpeechBrain's "same" refl
 JATTS_PAD_REFLECT); pooling / squeeze-excitation / normalisation pieces are the kernels of csrc/spkemb.hip.
 No CPU fallback: CPU tensors or a missing libjatts_hip.so raise.
 """
+import logging
 import math
 import wave
 
@@ -160,7 +161,7 @@ class ECAPA_TDNN(torch.nn.Module):
 
 class FbankFrontEnd:
     """SpeechBrain Fbank(n_mels=80) + InputNormalization(sentence, mean only) [recalled]: 16 kHz, 25 ms Hamming window = n_fft 400,
-    10 ms hop, centre reflect padding, power spectrum, triangular mel filters 0..8 kHz, 10 log10 with amin 1e-10 and top_db 80."""
+    10 ms hop, centred frames zero-padded at both ends (SpeechBrain STFT pad_mode "constant"), power spectrum, triangular mel filters 0..8 kHz, 10 log10 with amin 1e-10 and top_db 80."""
 
     def __init__(self, device, n_mels=80, n_fft=400, hop=160, sample_rate=16000, f_min=0.0, f_max=8000.0):
         self.n_mels, self.n_fft, self.hop = n_mels, n_fft, hop
@@ -194,8 +195,8 @@ class FbankFrontEnd:
         """waves: list of 1-D float tensors -> (RaggedBatch over frames, feats f32 (rows, ldo))."""
         dev = self.window.device
         ns = [int(w.numel()) for w in waves]
-        if min(ns) <= self.n_fft // 2:
-            raise ValueError("waveform shorter than the STFT's reflect padding")
+        if min(ns) < 1:
+            raise ValueError("empty waveform")
         x = torch.cat([w.reshape(-1).float() for w in waves]).to(dev).contiguous()
         cu = [0]
         for n in ns:
@@ -212,9 +213,19 @@ def load_wav(path):
     """torchaudio.load's contract for 16-bit PCM: float32 in [-1, 1) (int16 / 32768), channels averaged away never (the
     reference passes the file as is, multi-channel files become a batch there; mono is what the recipes hold)."""
     with wave.open(path, "rb") as w:
-        if w.getsampwidth() != 2:
-            raise NotImplementedError("16-bit PCM wav expected")
-        a = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+        sw, raw = w.getsampwidth(), w.readframes(w.getnframes())
+        if sw == 2:
+            a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        elif sw == 4:
+            a = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif sw == 3:                                          # 24-bit: sign-extend the three little-endian bytes
+            b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            a = ((v ^ 0x800000) - 0x800000).astype(np.float32) / 8388608.0
+        elif sw == 1:                                          # 8-bit wav is unsigned
+            a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        else:
+            raise NotImplementedError(f"PCM wav with {8 * sw}-bit samples")
         if w.getnchannels() > 1:
             a = a.reshape(-1, w.getnchannels())[:, 0]
         return torch.from_numpy(a.copy()), w.getframerate()
@@ -235,6 +246,9 @@ class SpkEmbExtractor:
         self.model = self.model.to(self.device)
         self.front = FbankFrontEnd(self.device, n_mels=self.model.input_size)
         self._cache = {}
+        logging.getLogger(__name__).warning(
+            "SpkEmbExtractor: parity with speechbrain/spkrec-ecapa-voxceleb is UNVERIFIED (SpeechBrain is absent from the build "
+            "environment; features and ECAPA-TDNN are restated from the public recipe) -- prefer precomputed `spkemb_path` columns")
 
     @torch.no_grad()
     def encode_batch(self, waves):

@@ -206,6 +206,7 @@ class FastSpeech2Trainer:
                 o += k
         self.steps = 0
         self.last_lr = None
+        self._bad_ids = None
         self._buckets = None
 
     # -- gradient all-reduce overlapped with backward (what DistributedDataParallel's reducer does for the reference): the flat gradient
@@ -259,9 +260,23 @@ class FastSpeech2Trainer:
             o += p.numel()
         return out
 
+    def _sched_params(self):
+        sp = dict(self.scheduler_params)
+        if (self.scheduler or "").lower() == "warmuplr":
+            sp.setdefault("warmup_steps", self.warmup_steps)
+        return sp
+
+    def _seed(self):
+        """Dropout stream of the micro-batch about to run: a function of (optimiser step, micro-batch index) -- `_Ctx` mixes the rank
+        in -- so a resumed run continues the stream instead of replaying steps 1..N, and eval_step does not consume from it."""
+        return self.steps * self.accumulate + self._micro + 1
+
     def state_dict(self, epochs=0):
         m, v = self._views(self.flat_m), self._views(self.flat_v)
-        opt = {"state": {}, "param_groups": [dict(lr=self.last_lr if self.last_lr is not None else self.base_lr, betas=tuple(self.betas),
+        # torch steps the scheduler AFTER the optimiser: a checkpoint holds the lr of the NEXT step (StepLR is chainable and reads
+        # group["lr"] back, so storing the lr just used would lose a decay at steps % step_size == 0)
+        next_lr = scheduled_lr(self.scheduler, self.base_lr, self.steps + 1, **self._sched_params())
+        opt = {"state": {}, "param_groups": [dict(lr=next_lr, betas=tuple(self.betas),
                                                   eps=self.eps, weight_decay=self.wd, amsgrad=False, maximize=False, foreach=None,
                                                   capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False,
                                                   initial_lr=self.base_lr, params=list(range(len(self.params))))]}
@@ -270,7 +285,7 @@ class FastSpeech2Trainer:
                 opt["state"][i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[i].detach().cpu().clone(),
                                    "exp_avg_sq": v[i].detach().cpu().clone()}
         sch = {"base_lrs": [self.base_lr], "last_epoch": self.steps, "_step_count": self.steps + 1, "_get_lr_called_within_step": False,
-               "_last_lr": [self.last_lr if self.last_lr is not None else self.base_lr], **self.scheduler_params}
+               "_last_lr": [next_lr], **self.scheduler_params}
         if (self.scheduler or "").lower() == "warmuplr":
             sch["warmup_steps"] = self.warmup_steps
         return {"model": {k: t.detach().cpu().clone() for k, t in self.model.state_dict().items()}, "optimizer": opt, "scheduler": sch,
@@ -303,16 +318,23 @@ class FastSpeech2Trainer:
         self.betas, self.eps, self.wd = tuple(g["betas"]), g["eps"], g["weight_decay"]
         self.base_lr = g.get("initial_lr", self.base_lr)
         if "scheduler" in sd and sd["scheduler"]:
-            self.warmup_steps = sd["scheduler"].get("warmup_steps", self.warmup_steps)
+            sch = sd["scheduler"]
+            self.warmup_steps = sch.get("warmup_steps", self.warmup_steps)
+            for k in ("step_size", "gamma"):           # a reference StepLR checkpoint carries its own schedule
+                if k in sch:
+                    self.scheduler_params[k] = sch[k]
+            if "base_lrs" in sch and sch["base_lrs"]:
+                self.base_lr = sch["base_lrs"][0]
+        self._micro = 0
+        self.last_lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **self._sched_params()) if self.steps > 0 else None
 
     def compute_losses(self, batch):
         """forward + criterion of trainers/fastspeech2.py:44-84 -> dict of differentiable scalars incl. "loss"."""
         from .models.fastspeech2_train import criterion, train_forward
         m = self.model
-        m._train_calls += 1
         ret = train_forward(m, batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["durations"], batch["duration_lens"],
                             batch["pitch"], batch["pitch_lens"], batch["energys"], batch["energy_lens"], spembs=batch.get("spkembs"),
-                            sids=batch.get("sids"), seed=m._train_calls)
+                            sids=batch.get("sids"), seed=self._seed())
         return criterion(ret, batch["durations"], batch["pitch"], batch["energys"], batch["ilens"])
 
     @torch.no_grad()
@@ -331,6 +353,8 @@ class FastSpeech2Trainer:
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
         m = self.model
         m.train()
+        if self._bad_ids is not None and self._bad_ids():       # out-of-range token ids of an EARLIER step (zero rows, counted on the
+            self._bad_ids = None                                # device): raised here, one step late, instead of a host sync per step
         if self._micro == 0:
             self.flat_g.zero_()
         o = 0
@@ -355,10 +379,7 @@ class FastSpeech2Trainer:
         elif multi:
             allreduce_flat(self.flat_g, self.group, self.bucket_bytes)
         self.steps += 1
-        sp = dict(self.scheduler_params)
-        if (self.scheduler or "").lower() == "warmuplr":
-            sp.setdefault("warmup_steps", self.warmup_steps)
-        lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **sp)
+        lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **self._sched_params())
         self.last_lr = lr
         ss = None
         if self.grad_norm and self.grad_norm > 0:
@@ -367,6 +388,8 @@ class FastSpeech2Trainer:
         hip.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps,
                       grad_sumsq=ss, max_norm=self.grad_norm or 0.0)
         m._prep = None
+        if self._bad_ids is None:
+            self._bad_ids = hip.bad_ids_async(self.flat_p.device)
         losses = {k: v.detach() for k, v in losses.items()}
         if ss is not None:
             losses["grad_norm"] = ss.sqrt()
@@ -387,10 +410,9 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
         from .models.matchatts_train import criterion, train_forward
         m = self.model
         mas = m._MAS      # tts2 MatchaTTS_MAS: alignment module + MAS; + ForwardSumLoss / binarisation loss by schedule
-        m._train_calls += 1
         ret = train_forward(m, batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch.get("durations"), batch.get("duration_lens"),
                             spembs=batch.get("spkembs"), sids=batch.get("sids"), cfm_t=batch.get("cfm_t"), cfm_noise=batch.get("cfm_noise"),
-                            seed=m._train_calls)
+                            seed=self._seed())
         return criterion(ret, batch.get("durations"), batch["ilens"], duration_loss=self.steps > self.dp_train_start_steps,
                          olens=batch["olens"], forward_sum=mas and self.steps < self.dp_train_start_steps,
                          bin_loss=mas and self.steps > self.bin_loss_start_steps, lambda_align=self.lambda_align)
@@ -410,9 +432,8 @@ class VITSTrainer(FastSpeech2Trainer):
     def compute_losses(self, batch):
         from .models.vits_train import criterion, train_forward
         m = self.model
-        m._train_calls += 1
         ret = train_forward(m, batch["xs"], batch["ilens"], batch["ys"], batch["olens"], batch["spkembs"], post_noise=batch.get("post_noise"),
-                            seed=m._train_calls)
+                            seed=self._seed())
         return criterion(ret, batch["ilens"], batch["olens"], duration_loss=self.steps > self.dp_train_start_steps,
                          forward_sum=self.steps < self.dp_train_start_steps, bin_loss=self.steps > self.bin_loss_start_steps,
                          lambda_align=self.lambda_align, lambda_mel=self.lambda_mel)

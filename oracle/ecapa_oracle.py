@@ -7,7 +7,7 @@ and the reference holds no test or fixture for it -> **PARITY UNPINNED**.  What 
 [recalled: speechbrain.lobes.features.Fbank, speechbrain.processing.features.{STFT, Filterbank, InputNormalization},
 speechbrain.lobes.models.ECAPA_TDNN (Desplanques et al., arXiv 2005.07143), hparams of spkrec-ecapa-voxceleb]:
 
-  compute_features  Fbank(n_mels=80): STFT(16 kHz, win 25 ms = n_fft 400, hop 10 ms, Hamming, center, reflect pad)
+  compute_features  Fbank(n_mels=80): STFT(16 kHz, win 25 ms = n_fft 400, hop 10 ms, Hamming, center, constant (zero) pad = SpeechBrain STFT default)
                     -> power spectrum -> triangular mel filterbank (0..8000 Hz) -> 10 log10(clamp 1e-10), top_db 80
   mean_var_norm     InputNormalization(norm_type="sentence", std_norm=False): subtract the utterance mean per channel
   embedding_model   ECAPA_TDNN(80, channels [1024, 1024, 1024, 1024, 3072], kernels [5, 3, 3, 3, 1], dilations
@@ -40,7 +40,7 @@ def mel_filterbank(n_mels=80, n_fft=400, sample_rate=16000, f_min=0.0, f_max=800
 def fbank_features(wav, n_mels=80, n_fft=400, hop=160):
     """wav (n,) -> (T, n_mels) sentence-mean-normalised log-mel features."""
     window = torch.hamming_window(n_fft)
-    spec = torch.stft(wav.unsqueeze(0), n_fft, hop, n_fft, window, center=True, pad_mode="reflect", normalized=False,
+    spec = torch.stft(wav.unsqueeze(0), n_fft, hop, n_fft, window, center=True, pad_mode="constant", normalized=False,
                       onesided=True, return_complex=True)[0].t()                       # (T, 201)
     power = spec.real ** 2 + spec.imag ** 2
     fb = power @ mel_filterbank(n_mels, n_fft)

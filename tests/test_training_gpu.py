@@ -522,3 +522,122 @@ def test_eval_step_equals_the_reference_eval_losses(cuda, lib):
         assert abs(float(out[k]) - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (k, float(out[k]), float(ref[k]))
     assert m.training and tr.steps == 0 and torch.equal(tr.flat_p, p0)
     assert torch.equal(dict(m.named_buffers())["postnet.postnet.0.1.running_mean"], rm0)
+
+
+def test_steplr_checkpoint_resumes_under_torch_with_the_decay(cuda, lib, tmp_path):
+    """A checkpoint written at steps == step_size must hold the lr of the NEXT step: torch's StepLR is chainable and reads
+    group["lr"] back, so a resumed reference trainer (Adam + StepLR, scheduler.step() after optimizer.step()) applies the decayed
+    lr at step step_size + 1 exactly like this trainer does.  Also: a StepLR checkpoint's step_size / gamma are restored."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer, scheduled_lr
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+
+    def make():
+        m = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+        m.load_state_dict(golden_state(keys, 0))
+        return m.to(cuda)
+    a = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, scheduler="steplr", scheduler_params={"step_size": 2, "gamma": 0.5})
+    for _ in range(2):
+        a.train_step(batch)
+    assert a.last_lr == 1e-3
+    path = str(tmp_path / "checkpoint-2steps.pkl")
+    a.save_checkpoint(path)
+    ck = torch.load(path, map_location="cpu")
+    # the reference's resume: torch Adam + StepLR load the two state_dicts (trainers/base.py:110-124)
+    ref = make()
+    ref.train()
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    tsch = torch.optim.lr_scheduler.StepLR(topt, step_size=2, gamma=0.5)
+    topt.load_state_dict(ck["optimizer"])
+    tsch.load_state_dict(ck["scheduler"])
+    lrs = []
+    for _ in range(3):                      # steps 3, 4, 5 under torch
+        lrs.append(topt.param_groups[0]["lr"])
+        topt.step()
+        tsch.step()
+    ours = [scheduled_lr("steplr", 1e-3, s, step_size=2, gamma=0.5) for s in (3, 4, 5)]
+    assert lrs == pytest.approx(ours, rel=1e-12) and ours[0] == 5e-4 and ours[2] == 2.5e-4
+    a.train_step(batch)
+    assert a.last_lr == 5e-4
+    b = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, scheduler="steplr", scheduler_params={"step_size": 1000, "gamma": 0.9})
+    b.load_checkpoint(path)                 # the checkpoint's own schedule wins
+    assert b.scheduler_params["step_size"] == 2 and b.scheduler_params["gamma"] == 0.5
+    b.train_step(batch)
+    assert b.last_lr == 5e-4 and maxdiff(a.flat_p, b.flat_p) <= 1e-7
+
+
+def test_resume_continues_the_dropout_stream(cuda, lib, tmp_path):
+    """Dropout masks are keyed on (optimiser step, micro-batch, rank), not on a call counter: a resumed run draws the masks of step
+    N + 1 (not those of step 1 again), eval_step in between does not shift them, and so it stays bit-identical to the uninterrupted run."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+
+    def make():           # the recipe's dropout rates (FS2_SMALL's defaults), NOT the golden's zeros
+        m = FastSpeech2(idim=20, **{**FS2_SMALL, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+        m.load_state_dict(golden_state(keys, 0))
+        return m.to(cuda)
+    a = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    l1 = float(a.train_step(batch)["loss"])
+    a.train_step(batch)
+    path = str(tmp_path / "c.pkl")
+    a.save_checkpoint(path)
+    a.eval_step(batch)
+    l3 = float(a.train_step(batch)["loss"])
+    b = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    b.load_checkpoint(path)
+    l3b = float(b.train_step(batch)["loss"])
+    assert abs(l3b - l3) <= 1e-6 * abs(l3) and maxdiff(a.flat_p, b.flat_p) <= 1e-7
+    c = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    assert abs(float(c.train_step(batch)["loss"]) - l1) <= 1e-6 * abs(l1)      # same step number -> same masks
+    c.load_checkpoint(path)
+    c.steps = 0                                           # the old behaviour: masks of step 1 on the step-3 weights
+    assert abs(float(c.train_step(batch)["loss"]) - l3) > 1e-5 * abs(l3)
+
+
+def test_out_of_range_token_ids_raise_like_nn_embedding(cuda, lib):
+    """Every embed_scale launch bounds-checks: an id outside the table gives a zero row, never a read outside the
+    table, and surfaces as IndexError -- at the forward's own host sync for FastSpeech2 (train and eval forward()), one step late
+    through the trainer's stream-ordered snapshot for the sync-free Matcha / VITS steps."""
+    from jatts_amd import hip
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    table = torch.randn(7, 16, device=cuda)
+    ids = torch.tensor([1, 7, -3, 6], device=cuda)
+    out = hip.embed_scale(ids, table, 2.0)
+    assert torch.equal(out[0], table[1] * 2.0) and torch.equal(out[3], table[6] * 2.0) and float(out[1:3].abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        hip.check_bad_ids(cuda)
+    hip.check_bad_ids(cuda)                                  # counter was reset
+    hip.embed_scale(ids, table, 2.0)
+    resolve = hip.bad_ids_async(cuda)
+    with pytest.raises(IndexError):
+        resolve(wait=True)
+    hip.check_bad_ids(cuda)                                  # the snapshot took the count with it
+
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+    m = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+    m.load_state_dict(golden_state(keys, 0))
+    m = m.to(cuda)
+    tr = FastSpeech2Trainer(m, lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    tr.train_step(batch)
+    bad = dict(batch, xs=batch["xs"].clone())
+    bad["xs"][0, 0] = 20                                     # == idim: one past the table
+    with pytest.raises(IndexError):
+        tr.train_step(bad)
+    m.eval()
+    with pytest.raises(IndexError):
+        m(bad["xs"], il, bad["ys"], ol, bad["durations"], il, bad["pitch"], il, bad["energys"], il)
+    tr.train_step(batch)                                     # and the trainer carries on with a good batch
