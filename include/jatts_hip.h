@@ -107,6 +107,11 @@ typedef struct jatts_conv_desc {
                               * instead of its packed row (V^T with 8-aligned sequence starts, see vt_col0) */
   int32_t pad_mode;    /* JATTS_PAD_ZERO (rows outside the sequence read as zero) or JATTS_PAD_REFLECT (torch
                         * padding_mode="reflect", the SpeechBrain Conv1d default used by ECAPA-TDNN; halo < length) */
+  int32_t variant;     /* 0: the library picks the kernel / tile (the product setting).  Non-zero forces one where it applies
+                        * (parity tests reach every kernel; tools/bench_conv.py tunes the heuristic).  f32, n_out > 64:
+                        * 1 = LDS-staged 128n x 64t, 2 = LDS-staged 128n x 128t, 3 = register-streamed ("direct": one plain
+                        * zero-padded input; csrc/conv1d_direct.h) 128n x 128t with a 2-step operand ring, 4 = the same with a
+                        * 4-step ring.  Unknown / inapplicable values fall back to 0. */
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);

@@ -212,7 +212,7 @@ def convtranspose_as_conv(w, stride, padding):
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
            in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
-           y_seq_col0=None, reflect=False):
+           y_seq_col0=None, reflect=False, variant=0):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
@@ -249,6 +249,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     for i, x in enumerate(xs):
         d.x[i] = _ptr(x, cols[i])
     d.pad_mode = _abi.PAD_REFLECT if reflect else _abi.PAD_ZERO
+    d.variant = variant
     d.ldx, d.in_scale = ldx, in_scale
     d.pre_act = _abi.PRE_LRELU if pre_lrelu is not None else _abi.PRE_NONE
     d.pre_slope = pre_lrelu or 0.0

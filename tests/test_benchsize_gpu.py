@@ -1,0 +1,161 @@
+"""Oracle / reference parity AT THE SHAPES bench.py TIMES: the largest comparisons used to be ~50 frames, so the
+128 x 128 f32 conv tile (12.9 % of the profiled step) and the 768-frame vocoder were reached by self-comparisons only.
+
+  * FastSpeech2: utterances 0 / 37 of the bench batch through the REAL reference's B=1 inference() (tests/golden/fs2_bench768.npz, made by
+    tests/golden/make_golden_r3.py) vs f32 inference_batch alone and inside the 64-utterance bench batch;
+  * HiFi-GAN v1 22 kHz full width on that 768-frame mel vs oracle.hifigan_generate (unpinned oracle), alone and inside
+    the batch of 64;
+  * jatts_conv1d f32 vs fp64 F.conv1d at launches of > 600 workgroups with every f32 kernel variant forced (LDS-staged 128 x 64 and
+    128 x 128 tiles, the register-streamed kernel with both ring depths) and under the product heuristic (variant 0 = the register-streamed kernel
+    wherever it applies).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden_state, load_golden, maxdiff, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bench_stack(cuda, lib):
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.synthetic import FS2_JSUT, HIFIGAN_V1_22K, pin_duration_head, synth_hifigan_state, synth_texts
+    from jatts_amd.vocoder import Vocoder
+    z, keys = load_golden("fs2_bench768.npz")
+    m = FastSpeech2(idim=45, **FS2_JSUT)
+    m.load_state_dict(pin_duration_head(golden_state(keys, 0), 6))
+    m = m.to(cuda).set_precision("fp32")
+    ones, zeros = [1.0] * 80, [0.0] * 80
+    vsd = synth_hifigan_state(HIFIGAN_V1_22K, 0)
+    voc = Vocoder(vsd, {"sampling_rate": 22050, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_22K},
+                  {"mean": zeros, "scale": ones}, cuda, trg_stats={"mean": zeros, "scale": ones})
+    voc.set_precision("fp32")
+    texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]      # bench.py's batch (rank 0)
+    return z, m, voc, vsd, texts
+
+
+def test_fs2_bench_utterances_match_the_reference(bench_stack):
+    """f32 mel of a 128-phoneme / 768-frame bench utterance vs the real reference (abs 2e-3 on values up to 4.8), computed alone and
+    as part of the 64-utterance batch bench.py times; integer outputs exact."""
+    z, m, voc, vsd, texts = bench_stack
+    utts = [int(u) for u in z["utts"]]
+    rb = m.inference_batch(texts)
+    assert rb["olens"] == [768] * 64
+    for j, u in enumerate(utts):
+        assert torch.equal(texts[u].cpu(), torch.tensor(z[f"u{j}_text"]))
+        ref = torch.tensor(z[f"u{j}_feat_gen"])
+        r1 = m.inference_batch([texts[u]])
+        assert torch.equal(r1["duration"].cpu(), torch.tensor(z[f"u{j}_duration"]))
+        e1 = maxdiff(r1["feat_gen"], ref)
+        eb = maxdiff(rb["feat_gen"][768 * u:768 * (u + 1)], ref)
+        assert e1 <= 2e-3 and eb <= 2e-3, f"bench utterance {u}: alone {e1:.3e}, in the batch {eb:.3e}"
+        assert maxdiff(r1["pitch"].reshape(-1), z[f"u{j}_pitch"].reshape(-1)) <= 2e-3
+        assert maxdiff(r1["energy"].reshape(-1), z[f"u{j}_energy"].reshape(-1)) <= 2e-3
+        assert torch.equal(rb["duration"][128 * u:128 * (u + 1)].cpu(), torch.tensor(z[f"u{j}_duration"]))
+
+
+def test_hifigan_bench_size_matches_the_oracle(bench_stack):
+    """HiFi-GAN v1 (22.05 kHz, hop 256, 512 channels) on a 768-frame mel: 196 608 samples vs oracle.hifigan_generate (f32, abs 2e-4 on a
+    signal in [-1, 1]), alone and as utterances 0 / 37 inside the batch of 64 the bench times."""
+    from jatts_amd import hip
+    from jatts_amd.synthetic import HIFIGAN_V1_22K
+    from oracle.hifigan_oracle import hifigan_generate
+    z, m, voc, vsd, texts = bench_stack
+    utts = [int(u) for u in z["utts"]]
+    dev = texts[0].device
+    rbatch = m.inference_batch(texts)
+    mel_b = rbatch["feat_gen"].clone()
+    refs = {}
+    for j, u in enumerate(utts):                              # the golden (reference) mel takes the two utterances' places
+        mel_b[768 * u:768 * (u + 1)] = torch.tensor(z[f"u{j}_feat_gen"]).to(dev)
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        with torch.no_grad():
+            refs[u] = hifigan_generate(vsd, torch.tensor(z[f"u{j}_feat_gen"]), HIFIGAN_V1_22K["upsample_scales"],
+                                       HIFIGAN_V1_22K["resblock_dilations"])
+        assert refs[u].numel() == 768 * 256 and float(refs[u].abs().max()) > 1e-3
+    yb = voc.decode_batch(rbatch["feats_rb"], mel_b)
+    assert yb.numel() == 64 * 768 * 256
+    for j, u in enumerate(utts):
+        y1 = voc.decode_batch(hip.RaggedBatch([768], dev), torch.tensor(z[f"u{j}_feat_gen"]).to(dev))
+        e1 = maxdiff(y1.reshape(-1), refs[u].reshape(-1))
+        eb = maxdiff(yb[768 * 256 * u:768 * 256 * (u + 1)].reshape(-1), refs[u].reshape(-1))
+        assert e1 <= 2e-4 and eb <= 2e-4, f"utterance {u}: alone {e1:.3e}, in the batch {eb:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------------------ f32 conv, every variant
+def _ref_conv64(x, w, b, lens, dil, pad, k):
+    outs, o = [], 0
+    for L in lens:
+        xs = F.pad(x[o:o + L].t().unsqueeze(0).double(), (pad, (k - 1) * dil - pad))
+        outs.append(F.conv1d(xs, w.double(), b.double(), dilation=dil)[0].t())
+        o += L
+    return torch.cat(outs)
+
+
+BIG = [  # c_in, n_out, k, dil, lens, act, resid     (128 x 128 tiles: ceil(L / 128) per sequence x ceil(n_out / 128) > 600 workgroups)
+    (384, 1536, 3, 1, [1024] * 8, "relu", False),            # FFN w_1: 8 x 8 x 12 = 768
+    (1536, 384, 3, 1, [1024] * 26, None, True),              # FFN w_2 with the residual stream: 26 x 8 x 3 = 624
+    (384, 384, 1, 1, [768] * 34 + [700], None, True),        # attention / conv-module projections, one ragged sequence: 35 x 6 x 3 = 630
+    (512, 2048, 1, 1, [768] * 7, None, False),               # Matcha U-Net FFN: 7 x 6 x 16 = 672
+    (192, 768, 1, 1, [640, 513, 768, 31] * 5, None, False),  # ragged lengths, c_in = 3 chunks
+    (256, 256, 5, 1, [1500, 77, 2048], "tanh", False),       # postnet-like, small launch (the 128 x 64 tile under the heuristic)
+    (128, 136, 3, 2, [300, 1000], None, False),              # n_out not a multiple of 32, dilation 2
+]
+VARIANTS = [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", BIG, ids=[f"{c[0]}to{c[1]}k{c[2]}" for c in BIG])
+def test_conv1d_f32_every_variant_at_bench_size(cuda, lib, case, variant):
+    from jatts_amd import hip
+    c_in, n_out, k, dil, lens, act, resid = case
+    g = torch.Generator().manual_seed(c_in * 7 + n_out)
+    R = sum(lens)
+    x = torch.randn(R, c_in, generator=g)
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k)
+    b = torch.randn(n_out, generator=g)
+    res = torch.randn(R, n_out, generator=g) if resid else None
+    pad = (k - 1) // 2 * dil
+    ref = _ref_conv64(x, w, b, lens, dil, pad, k)
+    ref = {"relu": torch.relu, "tanh": torch.tanh, None: lambda t: t}[act](ref)
+    alpha = 0.5 if resid else 1.0
+    ref = ref * alpha + (res.double() if resid else 0)
+    rb = hip.RaggedBatch(lens, cuda)
+    wp = hip.pack_conv_weight(w.to(cuda), hip.F32)
+    y = hip.conv1d(rb, x.to(cuda), wp, c_in, n_out, k, dtype=hip.F32, dil=dil, bias=b.to(cuda),
+                   act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], alpha=alpha,
+                   resid=None if res is None else res.to(cuda), out_f32=True, variant=variant)
+    e = relerr(y, ref)
+    assert e <= 3e-6, f"conv1d f32 {case[:4]} variant {variant}: rel err {e:.3e}"
+    assert maxdiff(y, ref) <= 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_conv1d_f32_reflect_padding_and_transposed_output(cuda, lib, variant):
+    """Reflect padding (ECAPA-TDNN convs: the register-streamed kernels hand it to the LDS-staged one) and the transposed V^T output
+    (served by the register-streamed kernels through the generic fragment-order epilogue)."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(variant)
+    lens, c_in, n_out, k, dil = [97, 300, 41], 128, 192, 5, 2
+    R = sum(lens)
+    x = torch.randn(R, c_in, generator=g)
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k)
+    b = torch.randn(n_out, generator=g)
+    pad = (k - 1) // 2 * dil
+    outs, o = [], 0
+    for L in lens:
+        xs = F.pad(x[o:o + L].t().unsqueeze(0).double(), (pad, pad), mode="reflect")
+        outs.append(F.conv1d(xs, w.double(), b.double(), dilation=dil)[0].t())
+        o += L
+    ref = torch.cat(outs)
+    rb = hip.RaggedBatch(lens, cuda)
+    wp = hip.pack_conv_weight(w.to(cuda), hip.F32)
+    y = hip.conv1d(rb, x.to(cuda), wp, c_in, n_out, k, dtype=hip.F32, dil=dil, bias=b.to(cuda), reflect=True, variant=variant)
+    assert relerr(y, ref) <= 3e-6
+    ref0 = _ref_conv64(x, w, b, lens, dil, pad, k)
+    yt = hip.conv1d(rb, x.to(cuda), wp, c_in, n_out, k, dtype=hip.F32, dil=dil, bias=b.to(cuda), transposed=True, variant=variant)
+    assert relerr(yt.t(), ref0) <= 3e-6

@@ -14,6 +14,8 @@ SHAPES = [  # (c_in, n_out, k, frames per utterance, resid f32 out?)
     (384, 384, 1, 768, True), (384, 768, 1, 768, False), (384, 1536, 3, 768, False), (1536, 384, 3, 768, True),
     (512, 512, 1, 768, True), (512, 1536, 1, 768, False), (512, 2048, 1, 768, False), (2048, 512, 1, 768, True),
     (512, 512, 3, 768, False), (512, 512, 1, 384, True), (512, 2048, 1, 384, False), (1024, 512, 3, 384, False),
+    (192, 768, 1, 768, False), (384, 1536, 3, 128, False), (1536, 384, 3, 128, True), (384, 384, 1, 128, True),
+    (256, 256, 5, 768, False), (256, 1024, 3, 6144, False),
 ]
 
 
@@ -23,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
+    ap.add_argument("--variant", type=int, default=0, help="jatts_conv_desc.variant (0 = the product heuristic)")
     a = ap.parse_args()
     dt = hip.F16 if a.dtype == "f16" else hip.F32
     dev = torch.device("cuda:0")
@@ -36,7 +39,7 @@ def main():
         r = torch.zeros(rows, n, device=dev) if res else None
 
         def run():
-            return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res)
+            return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res, variant=a.variant)
         for _ in range(2):
             run()
         torch.cuda.synchronize()
@@ -47,7 +50,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        print(f"{a.dtype} {c:5d} -> {n:5d} k={k} rows={rows:6d} resid={int(res)}  {ms * 1e3:8.1f} us  {2.0 * c * n * k * rows / ms / 1e9:7.1f} TFLOP/s")
+        print(f"{a.dtype} v{a.variant} {c:5d} -> {n:5d} k={k} rows={rows:6d} resid={int(res)}  {ms * 1e3:8.1f} us  {2.0 * c * n * k * rows / ms / 1e9:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
