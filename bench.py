@@ -667,9 +667,15 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from jatts_amd.synthetic import synth_texts
         total = os.cpu_count() or 1
-        threads = min(32, total)   # oversubscribing a 256-thread host makes torch CPU slower
         texts = synth_texts(a.batch, a.cpu_t_text, 45, seed=1)
+        # the CPU side gets its best thread count on THIS box: two utterances per candidate (tools/cpu_threads_sweep.py is the full
+        # sweep, profiles/r03_cpu_threads.json), then the whole batch on the winner
+        cands = [t for t in (16, 32, 64, 128) if t <= total] or [total]
+        cpu_baseline(job_fs2_sd, job_voc_sd, job_vp, texts[:1], 2, 1e9, cands[-1])        # warm-up
+        trial = {t: cpu_baseline(job_fs2_sd, job_voc_sd, job_vp, texts[:2], 2, 1e9, t)["value"] for t in cands}
+        threads = max(trial, key=trial.get)
         cb = cpu_baseline(job_fs2_sd, job_voc_sd, job_vp, texts, 2, a.cpu_budget, threads)
+        cb["thread_calibration"] = {str(t): v for t, v in trial.items()}
         cb["rtf"] = cb["seconds"] / (cb["samples"] / job_sr)
         cb["cpu_model"], cb["host_logical_cores"] = cpu_model(), total
         # SURVEY 8d also asks for the recipe default OMP_NUM_THREADS=1 (path.sh:15): one thread, bounded sample

@@ -1,0 +1,77 @@
+#!/usr/bin/env bash
+# egs/jvs/tts1 (multi-speaker JVS) on the MI355X path: the reference recipe's interface (same variables, same --option syntax, same directory
+# layout: exp/<expname>/{config.yml,stats.h5,tokens.txt,*.pkl} -> exp/<expname>/results/<checkpoint>/<set>/wav/*.wav) with
+# stage 4 (network decoding) running on jatts_amd.  Stages -1..3 (download, data preparation, feature extraction,
+# statistics, training) and 5 (evaluation) are the reference's and are not rebuilt here: run them there, then point
+# --expdir / --checkpoint at the result, or start this script with --stage 4 inside the reference's recipe directory.
+# Multi-speaker: config.yml's feat_list holds `spkemb`; data/<set>.csv carries `ref_wav_path` (the reference extracts an ECAPA-TDNN
+# embedding per row, tts_decode.py:209-212 -- here on the GPU, cached per speaker wav, jatts_amd.spkemb) or a precomputed `spkemb_path`.
+#     ./run.sh --stage 4 --stop_stage 4 --tag mytag [--checkpoint exp/.../checkpoint-100000steps.pkl] [--n_gpus 8]
+
+log() {
+    local fname=${BASH_SOURCE[1]##*/}
+    echo -e "$(date '+%Y-%m-%dT%H:%M:%S') (${fname}:${BASH_LINENO[0]}:${FUNCNAME[1]}) $*"
+}
+
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+REPO_ROOT="$(cd "${HERE}/../../.." && pwd)"
+export PYTHONPATH="${REPO_ROOT}${PYTHONPATH:+:${PYTHONPATH}}"
+export PYTHONIOENCODING=UTF-8
+python=${PYTHON:-python3}
+
+# basic settings (reference egs/jvs/tts1/run.sh:14-62)
+stage=4        # stage to start
+stop_stage=4   # stage to stop
+verbose=1      # verbosity level (lower is less info)
+n_gpus=1       # number of gpus (decoding: one process per GPU, utterances sharded)
+
+conf=conf/fastspeech2.v1.yaml
+
+# text related setting
+token_type="phn"
+token_column="phonemes"
+g2p=julius
+cleaner=none
+
+# training related setting
+tag=""         # tag for directory to save model
+expdir=""      # exp/<expname>; derived from conf / tag like the reference when empty
+
+# decoding related setting
+outdir=
+checkpoint=""  # checkpoint path to be used for decoding; if not provided, the latest one will be used
+precision=fp32        # fp32 = the reference's arithmetic; fp16 = fast mode (f16 MFMA operands, f32 accumulate)
+decode_batch_size=64  # utterances per ragged batch
+master_port=29517
+
+# shellcheck disable=SC1091
+. "${REPO_ROOT}/egs/common/parse_options.sh" || exit 1
+. "${REPO_ROOT}/egs/common/stage4.sh" || exit 1
+
+set -euo pipefail
+
+train_set="train"
+dev_set="dev"
+test_set="test_parallel_with_ref"   # reference egs/jvs/tts*/run.sh: parallel test sentences with a reference wav per row
+
+if [ -z "${expdir}" ]; then
+    if [ -z "${tag}" ]; then
+        expname="${train_set}_${token_type}_${cleaner}_$(basename "${conf%.*}")"
+    else
+        expname="${train_set}_${token_type}_${cleaner}_${tag}"
+    fi
+    expdir=exp/${expname}
+fi
+
+if [ "${stage}" -le 3 ]; then
+    log "Stages <= 3 (data preparation, features, statistics, training) are the reference recipe's own: run them there."
+fi
+
+if [ "${stage}" -le 4 ] && [ "${stop_stage}" -ge 4 ]; then
+    log "Stage 4: Network decoding"
+    stage4_decode
+fi
+
+if [ "${stage}" -le 5 ] && [ "${stop_stage}" -ge 5 ]; then
+    log "Stage 5 (objective evaluation) is the reference recipe's own (evaluate.py on ${expdir}/results/*/${test_set}/wav)."
+fi

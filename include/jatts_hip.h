@@ -111,7 +111,7 @@ typedef struct jatts_conv_desc {
                         * (parity tests reach every kernel; tools/bench_conv.py tunes the heuristic).  f32, n_out > 64:
                         * 1 = LDS-staged 128n x 64t, 2 = LDS-staged 128n x 128t, 3 = register-streamed ("direct": one plain
                         * zero-padded input; csrc/conv1d_direct.h) 128n x 128t with a 2-step operand ring, 4 = the same with a
-                        * 4-step ring.  Unknown / inapplicable values fall back to 0. */
+                        * 4-step ring, 5 = register-streamed 128n x 64t.  Unknown / inapplicable values fall back to 0. */
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);

@@ -13,7 +13,7 @@ int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s) {
   // default: the register-streamed kernel wherever it applies (one plain zero-padded input: every projection / FFN / postnet conv of the
   // acoustic models): 2-20 % faster than the LDS-staged tiles on every shape of tools/bench_conv.py (profiles/r03_notes.md)
   if (tile == 0 || tile >= 3) {
-    const int rc = jatts_conv1d_f32_direct(d, tile ? tile : 3, s);
+    const int rc = jatts_conv1d_f32_direct(d, tile, s);
     if (rc != 1) return rc;
   }
   // The 128 x 128 tile runs two workgroups per CU (512 slots).  A launch of <= ~1.1 x that many workgroups spends its second round

@@ -4,9 +4,19 @@
 // -> JATTS_OK / error, or 1 when the variant does not apply (the caller falls back to the LDS-staged kernel)
 int jatts_conv1d_f32_direct(const jatts_conv_desc& d, int variant, hipStream_t s) {
   if (!conv_direct_ok(d) || d.n_out <= 64) return 1;
+  if (variant == 0) {
+    // 128n x 128t unless the launch would leave most of the 768 workgroup slots (3 per CU) empty or its time tiles half empty
+    // (sequences of <= 64 rows): then 128n x 64t -- tools/bench_conv.py, profiles/r03_notes.md: +40-80 % at 4 096 rows, +5-17 % at
+    // 8 192 rows x n_out <= 768, -13 % at 8 192 rows x 384 -> 1536 k3 (768 workgroups), which therefore stays on the big tile
+    const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
+    const int64_t t128 = (maxL + 127) / 128, t64 = (maxL + 63) / 64;
+    const int64_t wgs = t128 * d.rg.n_seq * ((d.n_out + 127) / 128);
+    variant = (wgs <= 512 || t64 * 64 * 23 <= t128 * 128 * 20) ? 5 : 3;
+  }
   switch (variant) {
     case 3: return launch_conv_direct<2, 2, 2, 2, 2>(d, s);      // 128n x 128t, 256 threads, ring 2: three workgroups per CU
     case 4: return launch_conv_direct<2, 2, 2, 2, 4>(d, s);      // ring 4 (two workgroups per CU)
+    case 5: return launch_conv_direct<2, 1, 2, 2, 2>(d, s);      // 128n x 64t (64n x 32t wave tiles): twice the workgroups for small launches
     case 8: return launch_conv_direct<2, 2, 2, 2, 2, 1>(d, s);   // DIAGNOSIS, wrong results: nothing streamed in the main loop
     default: return 1;
   }

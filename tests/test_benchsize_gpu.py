@@ -105,7 +105,7 @@ BIG = [  # c_in, n_out, k, dil, lens, act, resid     (128 x 128 tiles: ceil(L / 
     (256, 256, 5, 1, [1500, 77, 2048], "tanh", False),       # postnet-like, small launch (the 128 x 64 tile under the heuristic)
     (128, 136, 3, 2, [300, 1000], None, False),              # n_out not a multiple of 32, dilation 2
 ]
-VARIANTS = [0, 1, 2, 3, 4]
+VARIANTS = [0, 1, 2, 3, 4, 5]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -134,7 +134,7 @@ def test_conv1d_f32_every_variant_at_bench_size(cuda, lib, case, variant):
     assert maxdiff(y, ref) <= 5e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("variant", [0, 3, 4, 5])
 def test_conv1d_f32_reflect_padding_and_transposed_output(cuda, lib, variant):
     """Reflect padding (ECAPA-TDNN convs: the register-streamed kernels hand it to the LDS-staged one) and the transposed V^T output
     (served by the register-streamed kernels through the generic fragment-order epilogue)."""

@@ -256,3 +256,67 @@ def test_trained_checkpoint_feeds_stage4(cuda, lib, tmp_path):
             assert w.getframerate() == 24000 and w.getnframes() > 0
             changed += int(w.getnframes() != w0.getnframes() or w.readframes(w.getnframes()) != w0.readframes(w0.getnframes()))
     assert changed == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("recipe,column", [("tts2", "spkemb_path"), ("tts1", "ref_wav_path")])
+def test_jvs_recipe_run_sh_stage4_multispeaker(cuda, lib, tmp_path, recipe, column):
+    """egs/jvs/tts{1,2}/run.sh --stage 4 (reference egs/jvs/tts2/run.sh:192-215): the multi-speaker layout -- test set
+    `test_parallel_with_ref`, feat_list with `spkemb`, one speaker per csv row as a precomputed `spkemb_path` (.npy) or as a
+    `ref_wav_path` the GPU front end embeds -- with the mel-VITS of BASELINE config 5 (192-d speaker embedding) at a small width."""
+    import subprocess
+    from jatts_amd.models import VITS
+    from jatts_amd.spkemb import ECAPA_TDNN
+    from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state, synth_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "recipe"
+    exp = work / "exp" / "train_phn_none_unit"
+    os.makedirs(exp)
+    os.makedirs(work / "data")
+    tokens = ["<blank>", "<unk>"] + [f"p{i}" for i in range(17)] + ["<sos/eos>"]
+    (exp / "tokens.txt").write_text("\n".join(tokens) + "\n")
+    g = torch.Generator().manual_seed(0)
+    spk = []
+    for i in range(2):
+        if column == "spkemb_path":
+            p = work / f"spk{i}.npy"
+            np.save(p, torch.randn(192, generator=g).numpy())
+        else:
+            p = work / f"spk{i}.wav"
+            y = (torch.randn(9600, generator=g) * 0.1).clamp(-1, 1)
+            with wave.open(str(p), "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+                w.writeframes((y * 32767).round().to(torch.int16).numpy().tobytes())
+        spk.append(str(p))
+    with open(work / "data" / "test_parallel_with_ref.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["sample_id", "phonemes", column])
+        w.writeheader()
+        for i, n in enumerate((7, 12, 9, 5)):
+            w.writerow({"sample_id": f"jvs{i % 2 + 1:03d}_utt{i}", "phonemes": " ".join(tokens[int(j)] for j in torch.randint(2, 19, (n,), generator=g)),
+                        column: spk[i % 2]})
+    vcfg = dict(odim=80, adim=64, aheads=2, text_encoder_blocks=2, text_encoder_attention_heads=2, dlayers=2, dunits=128, flow_flows=2,
+                flow_layers=2, posterior_encoder_layers=2, duration_predictor_chans=64, spk_embed_dim=192)
+    torch.save({"model": synth_state_dict(VITS(idim=20, **vcfg).state_dict(), 2)}, exp / "checkpoint-1steps.pkl")
+    ecfg = dict(channels=[256, 256, 256, 256, 768], attention_channels=64, se_channels=64, lin_neurons=192, res2net_scale=4)
+    torch.save(synth_state_dict(ECAPA_TDNN(**ecfg).state_dict(), 5), exp / "ecapa.ckpt")
+    vparams = dict(HIFIGAN_V1_24K, channels=512)
+    v = exp / "hfg"
+    os.makedirs(v)
+    torch.save({"model": {"generator": synth_hifigan_state(vparams, 0)}}, v / "voc.pkl")
+    with open(v / "voc.yml", "w") as f:
+        yaml.safe_dump({"sampling_rate": 24000, "generator_type": "HiFiGANGenerator",
+                        "generator_params": {k: (list(x) if isinstance(x, tuple) else x) for k, x in vparams.items()}}, f)
+    np.savez(exp / "stats.npz", mel_mean=np.zeros(80, np.float32), mel_scale=np.ones(80, np.float32))
+    np.savez(v / "vstats.npz", mean=np.zeros(80, np.float32), scale=np.ones(80, np.float32))
+    with open(exp / "config.yml", "w") as f:
+        yaml.safe_dump({"model_type": "VITS", "model_params": dict(vcfg, idim=20), "out_feat_type": "mel", "feat_list": ["mel", "spkemb"],
+                        "spkemb_checkpoint": str(exp / "ecapa.ckpt"), "spkemb_params": ecfg,
+                        "vocoder": {"checkpoint": str(v / "voc.pkl"), "config": str(v / "voc.yml"), "stats": str(v / "vstats.npz")}}, f)
+    r = subprocess.run(["bash", os.path.join(root, "egs", "jvs", recipe, "run.sh"), "--stage", "4", "--stop_stage", "4", "--tag", "unit",
+                        "--verbose", "0", "--decode_batch_size", "3"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = exp / "results" / "checkpoint-1steps" / "test_parallel_with_ref"
+    assert (out / "decode.log").exists()
+    for i in range(4):
+        with wave.open(str(out / "wav" / f"jvs{i % 2 + 1:03d}_utt{i}.wav")) as w:
+            assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0

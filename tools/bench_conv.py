@@ -16,6 +16,7 @@ SHAPES = [  # (c_in, n_out, k, frames per utterance, resid f32 out?)
     (512, 512, 3, 768, False), (512, 512, 1, 384, True), (512, 2048, 1, 384, False), (1024, 512, 3, 384, False),
     (192, 768, 1, 768, False), (384, 1536, 3, 128, False), (1536, 384, 3, 128, True), (384, 384, 1, 128, True),
     (256, 256, 5, 768, False), (256, 1024, 3, 6144, False),
+    (384, 768, 1, 128, False), (192, 768, 1, 128, False), (768, 384, 1, 64, True), (384, 384, 1, 64, True), (1536, 384, 1, 64, True), (384, 1536, 1, 64, False),
 ]
 
 
