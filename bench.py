@@ -670,7 +670,7 @@ def main():
         texts = synth_texts(a.batch, a.cpu_t_text, 45, seed=1)
         # the CPU side gets its best thread count on THIS box: two utterances per candidate (tools/cpu_threads_sweep.py is the full
         # sweep, profiles/r03_cpu_threads.json), then the whole batch on the winner
-        cands = [t for t in (16, 32, 64, 128) if t <= total] or [total]
+        cands = [t for t in (8, 16, 24, 32, 64) if t <= total] or [total]   # profiles/r03_cpu_threads.json: 16 wins on the EPYC 9575F box, 128 is 5x slower
         cpu_baseline(job_fs2_sd, job_voc_sd, job_vp, texts[:1], 2, 1e9, cands[-1])        # warm-up
         trial = {t: cpu_baseline(job_fs2_sd, job_voc_sd, job_vp, texts[:2], 2, 1e9, t)["value"] for t in cands}
         threads = max(trial, key=trial.get)

@@ -290,6 +290,9 @@ int jatts_ctc_forward_sum(const float* log_p, int32_t n_batch, int32_t t_max, in
 int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim, float* out, void* stream);
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* y[i] = (resid ? resid[i] : 0) + alpha * dropout(x)[i] with jatts_dropout's mask for (seed, i): the residual connections of the
+ * conformer layers (jatts/modules/conformer/encoder_layer.py:100-170) in one launch; p == 0 is a plain scaled add. */
+int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by
  * min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) when grad_sumsq != NULL and max_norm > 0 (clip_grad_norm_).  The hyper-parameters
  * are doubles: bias corrections and step size are computed in double (torch computes them as Python floats) and rounded once. */

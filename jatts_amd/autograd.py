@@ -309,6 +309,21 @@ class Dropout(torch.autograd.Function):
         return hip.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
 
 
+class ResidualDropAdd(torch.autograd.Function):
+    """x + alpha * dropout(h) -- a conformer layer's residual connection (encoder_layer.py:100-170) as one launch forward and one
+    backward (d_x = dy is passed through, d_h = alpha * mask(dy) / (1 - p) regenerates the mask)."""
+
+    @staticmethod
+    def forward(ctx, x, h, alpha, p, seed):
+        ctx.alpha, ctx.p, ctx.seed = alpha, p, seed
+        return hip.dropout_add(h.contiguous(), x.contiguous(), p, alpha, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dh = hip.dropout_add(dy.contiguous(), None, ctx.p, ctx.alpha, ctx.seed) if ctx.needs_input_grad[1] else None
+        return (dy if ctx.needs_input_grad[0] else None), dh, None, None, None
+
+
 class ForwardSum(torch.autograd.Function):
     """ForwardSumLoss.forward after the prior has been added (losses/forward_sum_loss.py:58-78): mean over the batch of the
     per-utterance CTC losses; the gradient is the one torch's ctc_loss backward produces."""

@@ -522,6 +522,20 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     y[i] = mix32(seed * 0x100000001B3ull + (uint64_t)i) >= thr ? x[i] * keep_scale : 0.f;
 }
 
+// y = resid + alpha * dropout(x): the residual connections of the conformer layers (encoder_layer.py:100-170: x + ff_scale * dropout(ffn),
+// x + dropout(attn), x + dropout(conv)) in ONE launch instead of dropout + scale + add; resid may be NULL (the backward of the
+// dropped branch: alpha * mask(dy) / (1 - p)), p may be 0 (a plain scaled add).
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y,
+                                                          int64_t n, float p, float alpha, uint64_t seed) {
+  const float keep_scale = alpha / (1.f - p);
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const bool keep = p <= 0.f || mix32(seed * 0x100000001B3ull + (uint64_t)i) >= thr;
+    const float v = keep ? x[i] * keep_scale : 0.f;
+    y[i] = resid ? resid[i] + v : v;
+  }
+}
+
 // ------------------------------------------------------------------ optimiser
 // sum of squares into a double (gradient-norm clipping: torch.nn.utils.clip_grad_norm_, trainers/fastspeech2.py:90-94)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
@@ -936,6 +950,15 @@ extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint6
   NULLCHK(!(p >= 0.f && p < 1.f), "dropout: 0 <= p < 1");
   if (n <= 0) return JATTS_OK;
   hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, y, n, p, seed);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, void* stream) {
+  NULLCHK(!x || !y, "dropout_add: null pointer");
+  NULLCHK(!(p >= 0.f && p < 1.f), "dropout_add: 0 <= p < 1");
+  if (n <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, resid, y, n, p, alpha, seed);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -64,6 +64,68 @@ def _count(flops):
         _FLOPS += flops
 
 
+# ---- zero pool for the training step: the small accumulators the reduction kernels add into (column sums, LayerNorm / GroupNorm
+# parameter gradients, per-sequence sums ...) used to be one torch.zeros() each = one fill launch each (~550 of a FastSpeech2 step's
+# 2 960 launches).  A trainer opens the pool at the top of a step: ONE fill zeroes the region the previous step used, and every
+# accumulator is a 64-byte-aligned slice of it; slices are never handed out twice within a step, and nothing taken from the pool
+# outlives the step (gradients are accumulated into the flat gradient buffer, saved statistics die with the graph).
+class _ZeroPool:
+    def __init__(self, device, floats=1 << 20):
+        self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
+        self.off, self.high, self.misses = 0, 0, 0
+
+    def begin(self):
+        self.high = max(self.high, self.off)
+        if self.misses:                       # the last step ran out: grow (the next step's accumulators all fit)
+            self.buf = torch.zeros(max(2 * self.buf.numel(), 2 * (self.high + self.misses)), dtype=torch.float32, device=self.buf.device)
+            self.misses = 0
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+    def take(self, numel):
+        n = (numel + 15) & ~15
+        if self.off + n > self.buf.numel():
+            self.misses += n
+            return None
+        t = self.buf[self.off:self.off + numel]
+        self.off += n
+        return t
+
+
+_ZPOOL = None
+
+
+def zero_pool_begin(device):
+    """Open (or re-arm) the device's zero pool: call at the top of a training step.  Pair with zero_pool_end()."""
+    global _ZPOOL
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device(dev.type, torch.cuda.current_device())
+    if _ZPOOL is None or _ZPOOL.buf.device != dev:
+        _ZPOOL = _ZeroPool(dev)
+    _ZPOOL.begin()
+    _ZPOOL.active = True
+
+
+def zero_pool_end():
+    if _ZPOOL is not None:
+        _ZPOOL.active = False
+
+
+def _zeros(shape, device):
+    """Zero-initialised f32 accumulator: a slice of the step's zero pool when one is open on ``device``, else torch.zeros."""
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    if _ZPOOL is not None and getattr(_ZPOOL, "active", False) and _ZPOOL.buf.device == device:
+        n = 1
+        for v in shape:
+            n *= v
+        t = _ZPOOL.take(n)
+        if t is not None:
+            return t.view(shape)
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 class _Timed:
     def __init__(self, tag, meta):
         self.tag, self.meta = tag, meta
@@ -754,7 +816,7 @@ def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1):
 def col_sum(x, dim=None):
     lib = _abi.load()
     dim = dim or x.shape[1]
-    out = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    out = _zeros((dim), x.device)
     _abi.check(lib.jatts_col_sum(_dev(x).data_ptr(), x.shape[1], x.shape[0], dim, out.data_ptr(), _stream()), "jatts_col_sum")
     return out
 
@@ -775,8 +837,8 @@ def layernorm_bwd(x, dy, gamma, eps, need_dx=True, need_dparam=True):
     x, dy = _f32c(x), _f32c(dy)
     rows, dim = x.shape
     dx = torch.empty_like(x) if need_dx else None
-    dg = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
-    db = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
+    dg = _zeros((dim), x.device) if need_dparam else None
+    db = _zeros((dim), x.device) if need_dparam else None
     _abi.check(lib.jatts_layernorm_bwd(x.data_ptr(), dim, dy.data_ptr(), dim, _f32c(gamma).data_ptr(), rows, dim, float(eps), _ptr(dx), dim,
                                        _ptr(dg), _ptr(db), _stream()), "jatts_layernorm_bwd")
     return dx, dg, db
@@ -829,7 +891,7 @@ def dwconv(rb, x, w, bias, pad, flip=False):
 def dwconv_wgrad(rb, x, dy, k_w, pad):
     lib = _abi.load()
     x, dy = _f32c(x), _f32c(dy)
-    dw = torch.zeros(x.shape[1], k_w, dtype=torch.float32, device=x.device)
+    dw = _zeros((x.shape[1], k_w), x.device)
     rg = rb.struct()
     _abi.check(lib.jatts_dwconv_wgrad(C.byref(rg), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[1], k_w, pad, _stream()),
                "jatts_dwconv_wgrad")
@@ -841,8 +903,8 @@ def col_stats(x, y2=None, shift=None, mul=None):
     lib = _abi.load()
     x = _f32c(x)
     rows, dim = x.shape
-    o0 = torch.zeros(dim, dtype=torch.float32, device=x.device)
-    o1 = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    o0 = _zeros((dim), x.device)
+    o1 = _zeros((dim), x.device)
     _abi.check(lib.jatts_col_stats(x.data_ptr(), _ptr(y2), dim, rows, dim, _ptr(shift), _ptr(mul), 0 if y2 is None else 1, o0.data_ptr(),
                                    o1.data_ptr(), _stream()), "jatts_col_stats")
     return o0, o1
@@ -860,7 +922,7 @@ def bn_bwd_apply(x, dy, mean, rstd, gamma, s_dy, s_dyx):
 def index_add_rows(src, idx, n_dst, scale=1.0, skip=-1):
     lib = _abi.load()
     src = _f32c(src)
-    dst = torch.zeros(n_dst, src.shape[1], dtype=torch.float32, device=src.device)
+    dst = _zeros((n_dst, src.shape[1]), src.device)
     _abi.check(lib.jatts_index_add_rows(src.data_ptr(), src.shape[1], _dev(idx).data_ptr(), src.shape[0], src.shape[1], float(scale), int(skip),
                                         n_dst, dst.data_ptr(), _stream()), "jatts_index_add_rows")
     return dst
@@ -921,7 +983,7 @@ def outer_rows(v, w, bias=None, out=None):
 def col_wsum(x, v):
     lib = _abi.load()
     x, v = _f32c(x), _f32c(v)
-    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    out = _zeros((x.shape[1]), x.device)
     _abi.check(lib.jatts_col_wsum(x.data_ptr(), x.shape[1], v.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "jatts_col_wsum")
     return out
 
@@ -952,6 +1014,20 @@ def dropout(x, p, seed):
     x = _f32c(x)
     y = torch.empty_like(x)
     _abi.check(lib.jatts_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "jatts_dropout")
+    return y
+
+
+def dropout_add(x, resid, p, alpha, seed):
+    """resid + alpha * dropout(x) (resid may be None); see jatts_dropout_add."""
+    lib = _abi.load()
+    x = _f32c(x)
+    if resid is not None:
+        resid = _f32c(resid)
+        if resid.shape != x.shape:
+            raise ValueError("dropout_add: shape mismatch")
+    y = torch.empty_like(x)
+    _abi.check(lib.jatts_dropout_add(x.data_ptr(), _ptr(resid), y.data_ptr(), x.numel(), float(p), float(alpha),
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "jatts_dropout_add")
     return y
 
 
@@ -988,8 +1064,8 @@ def groupnorm_bwd(rb, x, dy, groups, gamma, mean, rstd, need_dx=True, need_dpara
     x, dy = _f32c(x), _f32c(dy)
     dim = x.shape[1]
     dx = torch.empty_like(x) if need_dx else None
-    dg = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
-    db = torch.zeros(dim, dtype=torch.float32, device=x.device) if need_dparam else None
+    dg = _zeros((dim), x.device) if need_dparam else None
+    db = _zeros((dim), x.device) if need_dparam else None
     rg = rb.struct()
     _abi.check(lib.jatts_groupnorm_bwd(C.byref(rg), x.data_ptr(), dy.data_ptr(), dim, groups, _f32c(gamma).data_ptr(), mean.data_ptr(),
                                        rstd.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), _stream()), "jatts_groupnorm_bwd")
@@ -1009,8 +1085,8 @@ def snakebeta_bwd(x, dy, alpha, beta):
     lib = _abi.load()
     x, dy = _f32c(x), _f32c(dy)
     dx = torch.empty_like(x)
-    da = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-    db = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    da = _zeros((x.shape[1]), x.device)
+    db = _zeros((x.shape[1]), x.device)
     _abi.check(lib.jatts_snakebeta_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
                                        dx.data_ptr(), da.data_ptr(), db.data_ptr(), _stream()), "jatts_snakebeta_bwd")
     return dx, da, db
@@ -1036,7 +1112,7 @@ def seq_sum(rb, x):
     """-> (n_seq, dim) f32: per-sequence column sums."""
     lib = _abi.load()
     x = _f32c(x)
-    out = torch.zeros(rb.n_seq, x.shape[1], dtype=torch.float32, device=x.device)
+    out = _zeros((rb.n_seq, x.shape[1]), x.device)
     rg = rb.struct()
     _abi.check(lib.jatts_seq_sum(C.byref(rg), x.data_ptr(), x.shape[1], out.data_ptr(), _stream()), "jatts_seq_sum")
     return out

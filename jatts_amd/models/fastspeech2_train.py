@@ -36,6 +36,13 @@ class _Ctx:
         self.n_drop += 1
         return A.Dropout.apply(x, rate, self.seed + self.n_drop)
 
+    def resid_drop(self, x, h, rate, alpha=1.0):
+        """x + alpha * dropout(h): one launch (ResidualDropAdd) instead of dropout, scale and add."""
+        rate = rate if self.train else 0.0
+        if rate > 0.0:
+            self.n_drop += 1
+        return A.ResidualDropAdd.apply(x, h, alpha, max(rate, 0.0), self.seed + self.n_drop)
+
     def conv(self, x, name, rb, dil=1, pad=None, bias=True):
         w = self.p[name + ".weight"]
         if w.dim() == 2:                     # nn.Linear == Conv1d with k = 1
@@ -81,7 +88,7 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
             h = c.ln(x, q + ln)
             h = A.Act.apply(c.conv(h, q + nm + ".w_1", rb), "relu")
             h = c.conv(c.drop(h, rates["ffn"]), q + nm + ".w_2", rb)
-            return x + ff_scale * c.drop(h, rates["layer"])
+            return c.resid_drop(x, h, rates["layer"], ff_scale)
         if macaron:
             x = ffn(x, "feed_forward_macaron", "norm_ff_macaron")
         # legacy relative-position self-attention (attention.py:164-206)
@@ -97,7 +104,7 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
         p_attn = A.ShiftSoftmax.apply(ac, bd, kv, 1.0 / math.sqrt(dk), 2 if rel_style == "new" else 1)
         p_attn = c.drop(p_attn, rates["attn"])
         ctxv = torch.matmul(p_attn, vh).permute(0, 2, 1, 3).reshape(B * T, Ad)
-        x = x + c.drop(c.conv(ctxv, a + "linear_out", rb), rates["layer"])
+        x = c.resid_drop(x, c.conv(ctxv, a + "linear_out", rb), rates["layer"])
         # convolution module (convolution.py:56-79)
         if (q + "conv_module.pointwise_conv1.weight") in c.p:
             m = q + "conv_module."
@@ -105,7 +112,7 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
             h = A.GLU.apply(c.conv(h, m + "pointwise_conv1", rb))
             h = A.DepthwiseConv.apply(h, c.p[m + "depthwise_conv.weight"], c.p[m + "depthwise_conv.bias"], rb)
             h = A.Act.apply(c.bn(h, m + "norm"), "swish")
-            x = x + c.drop(c.conv(h, m + "pointwise_conv2", rb), rates["layer"])
+            x = c.resid_drop(x, c.conv(h, m + "pointwise_conv2", rb), rates["layer"])
         x = ffn(x, "feed_forward", "norm_ff")
         if (q + "norm_final.weight") in c.p:
             x = c.ln(x, q + "norm_final")

@@ -353,6 +353,14 @@ class FastSpeech2Trainer:
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
         m = self.model
         m.train()
+        hip.zero_pool_begin(self.flat_p.device)     # the step's small zero-initialised accumulators: one fill instead of ~550
+        try:
+            return self._train_step(batch)
+        finally:
+            hip.zero_pool_end()
+
+    def _train_step(self, batch):
+        m = self.model
         if self._bad_ids is not None and self._bad_ids():       # out-of-range token ids of an EARLIER step (zero rows, counted on the
             self._bad_ids = None                                # device): raised here, one step late, instead of a host sync per step
         if self._micro == 0:

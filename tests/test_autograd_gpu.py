@@ -347,3 +347,50 @@ def test_add_seq_vector_backward(cuda, lib):
     y = A.AddSeqVector.apply(xd, vd, hip.RaggedBatch(lens, cuda))
     y.backward(gy.to(cuda))
     _check([("y", y, yr), ("dx", xd.grad, xr.grad), ("dv", vd.grad, vr.grad)])
+
+
+def test_residual_drop_add_and_zero_pool(cuda, lib):
+    """ResidualDropAdd == x + alpha * Dropout(h) (same counter-based mask, forward and backward, p = 0 included), and the zero pool
+    (one fill per training step instead of one per accumulator): reductions taken inside a pooled step equal the unpooled ones, a
+    second step never sees the first one's sums, and a pool that runs out falls back to torch.zeros and grows."""
+    from jatts_amd import autograd as A
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(300, 96, generator=g).to(cuda).requires_grad_(True)
+    h = torch.randn(300, 96, generator=g).to(cuda).requires_grad_(True)
+    dy = torch.randn(300, 96, generator=g).to(cuda)
+    for p, alpha, seed in ((0.0, 0.5, 7), (0.2, 1.0, 11), (0.1, 0.5, 12345678901)):
+        y = A.ResidualDropAdd.apply(x, h, alpha, p, seed)
+        ref = x.detach() + alpha * (hip.dropout(h.detach().contiguous(), p, seed) if p > 0 else h.detach())
+        assert torch.equal(y, ref) or float((y - ref).abs().max()) <= 1e-6
+        gx, gh = torch.autograd.grad(y, (x, h), dy)
+        assert torch.equal(gx, dy)
+        refh = alpha * (hip.dropout(dy.contiguous(), p, seed) if p > 0 else dy)
+        assert float((gh - refh).abs().max()) <= 1e-6
+    a = torch.randn(1000, 384, generator=g).to(cuda)
+    want = a.double().sum(0)
+    plain = hip.col_sum(a)
+    for step in range(3):
+        hip.zero_pool_begin(cuda)
+        try:
+            outs = [hip.col_sum(a) for _ in range(5)]
+            assert all(o.data_ptr() != outs[0].data_ptr() for o in outs[1:])
+            for o in outs:
+                assert float((o.double() - want).abs().max()) <= 1e-2 and float((o - plain).abs().max()) <= 2e-3
+        finally:
+            hip.zero_pool_end()
+    assert hip._ZPOOL.off > 0 and not hip._ZPOOL.active
+    small = hip._ZeroPool(cuda, floats=1024)                 # runs out: falls back, then grows at the next begin()
+    hip._ZPOOL, keep = small, hip._ZPOOL
+    try:
+        hip.zero_pool_begin(cuda)
+        outs = [hip.col_sum(a) for _ in range(5)]            # 5 x 384 floats > 1024
+        assert all(float((o - plain).abs().max()) <= 2e-3 for o in outs) and hip._ZPOOL.misses > 0
+        hip.zero_pool_end()
+        hip.zero_pool_begin(cuda)
+        assert hip._ZPOOL.buf.numel() > 1024 and hip._ZPOOL.misses == 0
+        outs = [hip.col_sum(a) for _ in range(5)]
+        assert all(float((o - plain).abs().max()) <= 2e-3 for o in outs)
+        hip.zero_pool_end()
+    finally:
+        hip._ZPOOL = keep

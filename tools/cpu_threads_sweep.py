@@ -48,7 +48,7 @@ def main():
     cores = os.cpu_count() or 1
     run(sd, vsd, HIFIGAN_V1_22K, texts[:1], min(32, cores))      # warm-up (allocator, thread pool)
     rows = []
-    for th in (1, 16, 32, 64, 128, 256):
+    for th in (1, 8, 16, 24, 32, 64, 128):
         if th > cores:
             continue
         n = 3 if th == 1 else a.utts
