@@ -153,18 +153,19 @@ typedef struct jatts_resunit_desc {
 int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------
- * HiFi-GAN ResBlock, all dilation units fused in one launch (f16 operands only):
+ * HiFi-GAN ResBlock, all dilation units fused in one launch (f16 operands; f32 for the small-channel k = 3 blocks):
  *   for u in 0..n_units-1:  x <- x + conv_k,1( lrelu( conv_k,dil[u]( lrelu(x) ) + b1[u] ) ) + b2[u]
  * parallel_wavegan.layers.HiFiGANResidualBlock.forward [third party; call site jatts/vocoder/vocoder.py:64].
  * x is read once and y written once per ResBlock (the per-unit launches move 3x the bytes); the residual stream stays
- * in registers between units, rounded to f16 once per unit (where the per-unit launches round it on its way to HBM).
+ * in registers between units, rounded to f16 once per unit (where the per-unit launches round it on its way to HBM);
+ * at f32 (channels 32 / 64, k_w = 3: round 3) nothing is rounded: the result equals the per-unit launches to f32 summation order.
  * channels in {32, 64, 128}, k_w in {3, 7} (wider receptive fields waste too much of the tile on halo), n_units <= 3;
  * returns JATTS_ERR_UNSUPPORTED otherwise -- callers then issue jatts_hifigan_resunit per unit.
  * add0 / add1 / out_scale: the MRF mean fused into the output pass, as in jatts_resunit_desc.
  * ------------------------------------------------------------------------------- */
 typedef struct jatts_resblock_desc {
   jatts_ragged rg;
-  int32_t dtype;     /* JATTS_F16 */
+  int32_t dtype;     /* JATTS_F16 (channels 32 / 64 / 128), or JATTS_F32 for channels 32 / 64 with a chain halo of <= 16 rows a side (k = 3) */
   int32_t channels;
   int32_t k_w;
   int32_t n_units;

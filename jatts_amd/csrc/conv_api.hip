@@ -13,6 +13,7 @@ int jatts_resunit_f16_narrow(const jatts_resunit_desc& d, hipStream_t s);  // C 
 int jatts_resunit_f16_wide(const jatts_resunit_desc& d, hipStream_t s);    // C = 128, 256, 512
 int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
 int jatts_resblock_f16(const jatts_resblock_desc& d, hipStream_t s);
+int jatts_resblock_f32(const jatts_resblock_desc& d, hipStream_t s);
 
 extern "C" int jatts_debug_trace(void* buf, int64_t n_workgroups) {
   jatts_g_trace = (unsigned long long*)buf;
@@ -63,7 +64,7 @@ extern "C" int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream
   if (d->x == d->y) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: y must not alias x");
   if (d->k_w < 1 || !(d->k_w & 1)) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: odd k_w required");
   if (!(d->slope >= 0.f && d->slope <= 1.f)) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: LeakyReLU slope must be in [0, 1]");
-  if (d->dtype != JATTS_F16) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resblock: f16 operands only (use jatts_hifigan_resunit)");
+  if (d->dtype != JATTS_F16 && d->dtype != JATTS_F32) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: unknown dtype");
   if (d->rg.max_len <= 0) return JATTS_OK;
-  return jatts_resblock_f16(*d, (hipStream_t)stream);
+  return d->dtype == JATTS_F16 ? jatts_resblock_f16(*d, (hipStream_t)stream) : jatts_resblock_f32(*d, (hipStream_t)stream);
 }

@@ -11,6 +11,8 @@
 // stream x stays in REGISTERS (packed f16) from the first unit to the last; LDS holds one tile: lrelu(x), overwritten
 // by h, overwritten by lrelu(x'), ... with M = p2 * max(dil) margin rows a side for the dilated taps.
 #pragma once
+#include <type_traits>
+
 #include "resunit_impl.h"
 
 namespace {
@@ -30,13 +32,15 @@ __device__ __forceinline__ f16x4 lrelu4(f16x4 v, float slope) {   // max(v, f16(
 
 template <typename T, int C, int WGCOLS, int WN, int NT, int KCGMAX = 8, int OCC = 2>
 __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_kernel(jatts_resblock_desc d, unsigned bias_off) {
-  static_assert(sizeof(T) == 2, "the fused ResBlock is an f16-operand kernel (in f32 every unit is MFMA-bound: nothing to fuse for)");
+  // f16: the HBM-bound shapes (x read / written once per ResBlock).  f32 (round 3): every shape is MFMA-bound, but at C = 32 / 64 with k = 3
+  // a conv is only 6 / 12 K-steps and the per-unit launches spend as long in their staging / store phases (instruction-slot bound,
+  // profiles/r03_notes.md) as in their MFMAs: one launch per ResBlock drops two of three staging + store passes.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
   constexpr int NF = C / (WN * 32);
   constexpr int KC16 = C / 16, NFR = C / 32;
   constexpr int pitch = C * (int)sizeof(T) + 16;
-  constexpr int KCG = KC16 < KCGMAX ? KC16 : KCGMAX;
+  constexpr int KCG = sizeof(T) == 4 ? 2 : (KC16 < KCGMAX ? KC16 : KCGMAX);   // f32: a step is 64-cycle MFMAs, two steps of look-ahead suffice
   constexpr int NTHR = WN * WT * 64;
   constexpr int UPR = C / 8;
   static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_ke
     stage_unit<T, (UBX < 8 ? 8 : (UBX < 24 ? UBX : 24)), NTHR>(smem, pitch, rows, UPR, t0 - H - M, L, seq_row0, xg, C, false, d.slope);
   }
   __syncthreads();
-  f16x4 resid[NF][NT][4];   // x of this lane's (column, 4-channel quad) elements: C-fragment layout, packed f16
+  typedef typename std::conditional<sizeof(T) == 2, f16x4, f32x4>::type R4;
+  R4 resid[NF][NT][4];   // x of this lane's (column, 4-channel quad) elements: C-fragment layout (packed f16 / f32)
   uint32_t keep[NT];   // all-ones / zero: ANDed onto packed f16 pairs (exact zeroing, also of an overflowed edge column)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_ke
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        resid[f][t][q] = *reinterpret_cast<const f16x4*>(smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T));
+        resid[f][t][q] = *reinterpret_cast<const R4*>(smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T));
   }
   __syncthreads();
   for (int u = threadIdx.x; u < rows * UPR; u += NTHR) {   // tile <- lrelu(tile), in place
@@ -127,10 +132,17 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_ke
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          // h = lrelu(acc) rounded to f16: round first, then max(h, f16(h * slope)) on packed pairs (the staging form)
-          const f16x4 o = lrelu4(mask4(f16x4{(f16)acc[f][t][4 * q], (f16)acc[f][t][4 * q + 1], (f16)acc[f][t][4 * q + 2],
-                                             (f16)acc[f][t][4 * q + 3]}, keep[t]), d.slope);
-          *reinterpret_cast<f16x4*>(smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T)) = o;
+          char* dst = smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T);
+          if constexpr (sizeof(T) == 2) {
+            // h = lrelu(acc) rounded to f16: round first, then max(h, f16(h * slope)) on packed pairs (the staging form)
+            *reinterpret_cast<f16x4*>(dst) = lrelu4(mask4(f16x4{(f16)acc[f][t][4 * q], (f16)acc[f][t][4 * q + 1], (f16)acc[f][t][4 * q + 2],
+                                                               (f16)acc[f][t][4 * q + 3]}, keep[t]), d.slope);
+          } else {   // f32: h = lrelu(acc), zero outside the sequence
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = keep[t] ? lrelu(acc[f][t][4 * q + e], d.slope) : 0.f;
+            *reinterpret_cast<f32x4*>(dst) = o;
+          }
         }
     }
     lds_barrier();
@@ -147,13 +159,24 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_ke
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f16x4 xn;
+          char* dst = smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T);
+          if constexpr (sizeof(T) == 2) {
+            f16x4 xn;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xn[e] = (f16)(acc[f][t][4 * q + e] + (float)resid[f][t][q][e]);   // x' = x + conv(...) in f32, rounded once
-          xn = mask4(xn, keep[t]);
-          resid[f][t][q] = xn;
-          const f16x4 o = last ? xn : lrelu4(xn, d.slope);   // next unit's operand: lrelu(x'); after the last unit: x' itself
-          *reinterpret_cast<f16x4*>(smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * sizeof(T)) = o;
+            for (int e = 0; e < 4; ++e) xn[e] = (f16)(acc[f][t][4 * q + e] + (float)resid[f][t][q][e]);   // x' = x + conv(...) in f32, rounded once
+            xn = mask4(xn, keep[t]);
+            resid[f][t][q] = xn;
+            *reinterpret_cast<f16x4*>(dst) = last ? xn : lrelu4(xn, d.slope);   // next unit's operand: lrelu(x'); after the last unit: x' itself
+          } else {
+            f32x4 xn, o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              xn[e] = keep[t] ? acc[f][t][4 * q + e] + resid[f][t][q][e] : 0.f;
+              o[e] = last ? xn[e] : lrelu(xn[e], d.slope);
+            }
+            resid[f][t][q] = xn;
+            *reinterpret_cast<f32x4*>(dst) = o;
+          }
         }
     }
     lds_barrier();

@@ -173,6 +173,11 @@ class HiFiGANGenerator(torch.nn.Module):
     # (channels, kernel size) of the ResBlocks issued as ONE fused launch (jatts_hifigan_resblock): the shapes where it
     # measured faster than three unit launches (profiles/r02_notes.md); JATTS_HIFIGAN_FUSE=0 switches it off
     fused_blocks = frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE", "1") == "0" else frozenset({(32, 3), (32, 7), (64, 3)})
+    # f32 (round 3): only the k = 3 block of the 32-channel stage, where a conv is 6 K-steps and the per-unit launches spend as long in their
+    # staging / store phases as in their MFMAs: 4.11 vs 4.42 ms (0.72 vs 0.66 of the f32 MFMA peak).  C = 64 k = 3 measured 4 % SLOWER fused
+    # (7.78 vs 7.48 ms: the 24-row chain halo of a 256-column window) and stays on the per-unit path (tools/bench_unit.py --resblock
+    # --dtype f32); JATTS_HIFIGAN_FUSE_F32=0 switches the fused launch off (A/B runs)
+    fused_blocks_f32 = frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE_F32", "1") == "0" else frozenset({(32, 3)})
 
     # tuning knob (profiles/r01_notes.md): run the independent ResBlock chains of a stage on separate HIP streams
     concurrent = os.environ.get("JATTS_HIFIGAN_STREAMS", "0") == "1"
@@ -222,7 +227,8 @@ class HiFiGANGenerator(torch.nn.Module):
                 cur = up
                 st = side[j] if j < len(side) else None
                 # HBM-bound shapes: the whole ResBlock in one launch (x read once, y written once; residual in registers)
-                if dt == hip.F16 and (c_out, units[0][2]) in self.fused_blocks and len(units) <= 3 and st is None:
+                if (c_out, units[0][2]) in (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32) and len(units) <= 3 and st is None \
+                        and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if dt == hip.F16 else 16):
                     lastb = fuse_mean and j == len(blocks) - 1
                     hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(c1.w, c1.b, c2.w, c2.b, d) for c1, c2, _, d in units],
                                          c_out, units[0][2], self.slope, dt, add=outs if lastb else None,

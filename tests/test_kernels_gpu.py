@@ -204,6 +204,46 @@ def test_hifigan_resblock_fused(cuda, lib, C, k, dils, lens, mrf):
     assert relerr(y.float(), cur.float().double()) <= 2e-3   # same arithmetic up to one f16 rounding of the stream per unit
 
 
+@pytest.mark.parametrize("C,dils,lens,mrf", [(32, (1, 3, 5), [1300, 3, 250, 40], False), (64, (1, 3, 5), [513, 700], False),
+                                              (32, (1, 3, 5), [700, 90], True), (64, (1, 3), [260, 31], True), (32, (2,), [500], False)])
+def test_hifigan_resblock_fused_f32(cuda, lib, C, dils, lens, mrf):
+    """The f32 whole-ResBlock launch (k = 3, C = 32 / 64; round 3) against the fp64 chain of units and against the per-unit f32 launches."""
+    from jatts_amd import hip
+    k = 3
+    g = torch.Generator().manual_seed(C * 10 + len(dils))
+    R = sum(lens)
+    x = torch.randn(R, C, generator=g)
+    ws = [(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), torch.randn(C, generator=g) * 0.1,
+           torch.randn(C, C, k, generator=g) * 0.5 / math.sqrt(C * k), torch.randn(C, generator=g) * 0.1) for _ in dils]
+    adds = [torch.randn(R, C, generator=g) for _ in range(2)] if mrf else None
+    ref = x.double()
+    for (w1, b1, w2, b2), d in zip(ws, dils):
+        ref = _ref_unit(ref, w1, b1, w2, b2, lens, k, d, 0.1, False)
+    if mrf:
+        ref = (ref + adds[0].double() + adds[1].double()) / 3.0
+    rb = _ragged(lens, cuda)
+    xd = x.to(cuda)
+    packed = [(hip.pack_conv_weight(w1.to(cuda), hip.F32, 32), b1.to(cuda), hip.pack_conv_weight(w2.to(cuda), hip.F32, 32), b2.to(cuda), d)
+              for (w1, b1, w2, b2), d in zip(ws, dils)]
+    y = torch.full_like(xd, float("nan"))
+    addd = [a.to(cuda) for a in adds] if mrf else None
+    hip.hifigan_resblock(rb, 1, xd, y, packed, C, k, 0.1, hip.F32, add=addd, out_scale=1.0 / 3.0 if mrf else 1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all(), "unwritten / non-finite outputs"
+    e = relerr(y, ref)
+    assert e <= TOL["fp32"], f"resblock f32 C={C} dils={dils}: rel err {e:.3e}"
+    cur, bufs = xd, [torch.empty_like(xd), torch.empty_like(xd)]
+    for i, (w1, b1, w2, b2, d) in enumerate(packed):
+        lastu = i == len(packed) - 1
+        hip.hifigan_resunit(rb, 1, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, hip.F32,
+                            add=addd if (mrf and lastu) else None, out_scale=1.0 / 3.0 if (mrf and lastu) else 1.0)
+        cur = bufs[i & 1]
+    assert relerr(y, cur.double()) <= 1e-5
+    with pytest.raises(Exception):      # k = 7 chains are not fused at f32 (halo 36 rows a side): UNSUPPORTED, callers issue units
+        w7 = hip.pack_conv_weight(torch.randn(C, C, 7, generator=g).to(cuda), hip.F32, 32)
+        hip.hifigan_resblock(rb, 1, xd, torch.empty_like(xd), [(w7, packed[0][1], w7, packed[0][1], d) for d in (1, 3, 5)], C, 7, 0.1, hip.F32)
+
+
 def test_hifigan_resblock_refuses_wide_receptive_fields(cuda, lib):
     from jatts_amd import hip
     from jatts_amd._abi import JattsHipError

@@ -40,27 +40,27 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     return ms
 
 
-def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5)):
-    """Fused ResBlock launch against the three per-unit launches (f16)."""
+def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5), dt=hip.F16):
+    """Fused ResBlock launch against the three per-unit launches."""
     dev = torch.device("cuda:0")
     rb = hip.RaggedBatch([T] * B, dev)
     rows = B * T * rate
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).half()
+    x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     units = []
     for d in dils:
-        w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), hip.F16, 32)
-        w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) * 0.3 / (C * k) ** 0.5).to(dev), hip.F16, 32)
+        w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dt, 32)
+        w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) * 0.3 / (C * k) ** 0.5).to(dev), dt, 32)
         units.append((w1, torch.zeros(C, device=dev), w2, torch.zeros(C, device=dev), d))
 
     def fused():
-        hip.hifigan_resblock(rb, rate, x, bufs[0], units, C, k, 0.1, hip.F16)
+        hip.hifigan_resblock(rb, rate, x, bufs[0], units, C, k, 0.1, dt)
 
     def unfused():
         cur = x
         for i, (w1, b1, w2, b2, d) in enumerate(units):
-            hip.hifigan_resunit(rb, rate, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, hip.F16)
+            hip.hifigan_resunit(rb, rate, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, dt)
             cur = bufs[i & 1]
 
     res = []
@@ -76,7 +76,7 @@ def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5)):
         torch.cuda.synchronize()
         res.append(a.elapsed_time(b) / iters)
     flops = 4.0 * C * C * k * rows * len(dils)
-    byts = 2.0 * rows * C * 2
+    byts = 2.0 * rows * C * (2 if dt == hip.F16 else 4)
     print(f"ResBlock C={C:4d} k={k:2d} rows={rows:9d}: fused {res[0]:7.3f} ms ({flops / res[0] / 1e9:7.1f} TFLOP/s, {byts / res[0] / 1e6:7.1f} GB/s "
           f"of x-in + y-out)   3 unit launches {res[1]:7.3f} ms   speed-up {res[1] / res[0]:.2f}x")
     return res
@@ -96,9 +96,9 @@ def main():
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
     dt = hip.F16 if a.dtype == "f16" else hip.F32
     if a.resblock:
-        for C in (32, 64, 128):
-            for k in (3, 7):
-                run_block(C, k, rates[C], a.iters)
+        for C in ((32, 64, 128) if dt == hip.F16 else (32, 64)):
+            for k in ((3, 7) if dt == hip.F16 else (3,)):
+                run_block(C, k, rates[C], a.iters, dt=dt)
         return
     if a.all:
         tot = 0.0
