@@ -159,3 +159,43 @@ def test_conv1d_f32_reflect_padding_and_transposed_output(cuda, lib, variant):
     ref0 = _ref_conv64(x, w, b, lens, dil, pad, k)
     yt = hip.conv1d(rb, x.to(cuda), wp, c_in, n_out, k, dtype=hip.F32, dil=dil, bias=b.to(cuda), transposed=True, variant=variant)
     assert relerr(yt.t(), ref0) <= 3e-6
+
+
+EDGE = [  # c_in (window of a wider row), n_out, k, dil, lens, x_col0, ldx, act, resid_ld
+    (64, 72, 3, 1, [1, 2, 5, 129, 64], 0, 64, "relu", None),          # one-row sequences, n_out = 72 (multiple of 8, not of 32)
+    (128, 384, 1, 1, [127, 1, 130], 64, 256, None, 512),               # column window of a wider matrix, residual with its own row stride
+    (192, 200, 5, 3, [33, 400, 7], 0, 192, "tanh", None),              # dilation 3 with sequences shorter than the receptive field
+    (64, 1000, 1, 1, [300], 0, 64, "swish", None),                     # wide output, one sequence
+    (256, 136, 7, 1, [50, 3, 200], 128, 384, None, None),              # n_out % 8 == 0 but % 32 != 0, k = 7, shifted window
+]
+
+
+@pytest.mark.parametrize("variant", [0, 3, 5])
+@pytest.mark.parametrize("case", EDGE, ids=[f"{c[0]}to{c[1]}k{c[2]}d{c[3]}" for c in EDGE])
+def test_conv1d_direct_edge_geometry(cuda, lib, case, variant):
+    """The register-streamed kernel's addressing corners: zero padding by descriptor range check at both sequence ends, sequences
+    shorter than a tile / than the receptive field, column windows of wider rows (x_col0, ldx > c_in), residual rows with their own
+    stride, partial last n-fragments, every fused activation -- against fp64."""
+    from jatts_amd import hip
+    c_in, n_out, k, dil, lens, x_col0, ldx, act, rld = case
+    g = torch.Generator().manual_seed(c_in + n_out + k)
+    R = sum(lens)
+    xw = torch.randn(R, ldx, generator=g)
+    x = xw[:, x_col0:x_col0 + c_in]
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k)
+    b = torch.randn(n_out, generator=g)
+    pad = (k - 1) // 2 * dil
+    ref = _ref_conv64(x, w, b, lens, dil, pad, k)
+    ref = {"relu": torch.relu, "tanh": torch.tanh, "swish": lambda t: t * torch.sigmoid(t), None: lambda t: t}[act](ref)
+    resw = torch.randn(R, rld, generator=g) if rld else None
+    alpha = 0.5 if rld else 1.0
+    if rld:
+        ref = ref * alpha + resw[:, 8:8 + n_out].double()
+    rb = hip.RaggedBatch(lens, cuda)
+    wp = hip.pack_conv_weight(w.to(cuda), hip.F32)
+    resd = resw.to(cuda) if rld else None
+    y = hip.conv1d(rb, xw.to(cuda), wp, c_in, n_out, k, dtype=hip.F32, dil=dil, bias=b.to(cuda), ldx=ldx, x_col0=x_col0,
+                   act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, "swish": hip.ACT_SWISH, None: hip.ACT_NONE}[act], alpha=alpha,
+                   resid=resd, resid_col0=8 if rld else 0, out_f32=True, variant=variant)
+    assert torch.isfinite(y).all()
+    assert relerr(y, ref) <= 5e-6, f"{case} variant {variant}: rel err {relerr(y, ref):.3e}"
