@@ -14,20 +14,30 @@ from helpers import maxdiff
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def stack(cuda, lib):
+def _make_stack(cuda, prec):
     from jatts_amd.models import FastSpeech2
     from jatts_amd.synthetic import FS2_JSUT, HIFIGAN_V1_22K, pin_duration_head, synth_hifigan_state, synth_state_dict
     from jatts_amd.vocoder import Vocoder
     m = FastSpeech2(idim=45, **FS2_JSUT)
     m.load_state_dict(pin_duration_head(synth_state_dict(m.state_dict(), 0), 6))
-    m = m.to(cuda).set_precision("fp16")
+    m = m.to(cuda).set_precision(prec)
     ones, zeros = [1.0] * 80, [0.0] * 80
     voc = Vocoder(synth_hifigan_state(HIFIGAN_V1_22K, 0),
                   {"sampling_rate": 22050, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_22K},
                   {"mean": zeros, "scale": ones}, cuda, trg_stats={"mean": zeros, "scale": ones})
-    voc.set_precision("fp16")
+    voc.set_precision(prec)
     return m, voc
+
+
+@pytest.fixture(scope="module")
+def stack(cuda, lib):
+    return _make_stack(cuda, "fp16")
+
+
+@pytest.fixture(scope="module")
+def stack32(cuda, lib):
+    """The f32 (headline) arithmetic: its own model / vocoder pair, so the fp16 tests of this module never see a precision switch."""
+    return _make_stack(cuda, "fp32")
 
 
 def _synth(stack, texts):
@@ -44,9 +54,13 @@ def _synth(stack, texts):
     return r, outs
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
 @pytest.mark.parametrize("ragged", [False, True], ids=["64x128", "64xU(64..128)"])
-def test_full_batch_properties(cuda, stack, ragged):
+def test_full_batch_properties(cuda, stack, stack32, ragged, prec):
+    """fp32 = the arithmetic bench.py's headline measures (register-streamed f32 convs, f32 fused units): determinism, utterance
+    independence and permutation equivariance hold bit for bit there too."""
     from jatts_amd.synthetic import synth_texts
+    stack = stack32 if prec == "fp32" else stack
     texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
     if ragged:
         g = torch.Generator().manual_seed(5)
