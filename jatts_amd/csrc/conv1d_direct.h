@@ -52,10 +52,27 @@ __device__ __forceinline__ void apply_act_alpha(f32x16 (&acc)[NF][NT], int act, 
 // DIAG (tools/bench_conv.py --variant 8, wrong results, kept for the record of profiles/r03_notes.md): 1 = nothing is streamed in the
 // main loop (the operands of the first D steps are reused) -- the pure-MFMA ceiling of this launch geometry.
 template <int NF, int NT, int WN, int WT, int D, int DIAG = 0>
-__global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap) {
+__global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap, int gx, int n_tiles, int tpx, int gz, int zc) {
+  // XCD-aware work order (1-D grid): the dispatcher places workgroup id on XCD id % 8, each XCD with its own 4 MiB L2.  XCD x takes the
+  // contiguous tile range [x * tpx, (x + 1) * tpx) (tile = (time tile, sequence)) and walks it as  for n-block chunk: for tile: for
+  // n-block in chunk  (zc n-blocks per chunk: their weight slices, <= ~2 MiB, stay in that L2), so a tile's activation rows are fetched
+  // from the fabric once per chunk instead of once per n-block: 512 -> 2048 k1 moved 2.2 GB per launch for a 100 MB input
+  // (profiles/r03_notes.md), and on a power-limited kernel fabric bytes are clock.
+  const unsigned wg_lin = blockIdx.x;
+  int bx, by, bz;
+  {
+    const int xcd = (int)(wg_lin & 7u), m = (int)(wg_lin >> 3);
+    const int per_chunk = tpx * zc;
+    const int c = m / per_chunk, rem = m - c * per_chunk;
+    const int tl = rem / zc;
+    const int tile = xcd * tpx + tl;
+    bz = c * zc + (rem - tl * zc);
+    if (tl >= tpx || tile >= n_tiles || bz >= gz) return;
+    by = tile / gx;
+    bx = tile - by * gx;
+  }
   // Phase trace (profiling hook, jatts_debug_trace; tools/trace_conv.py): thread 0 of the first trace_cap workgroups stamps
   // [hw id, start, main loop entered, main loop done, stored, -, -, -, realtime start, realtime end]
-  const unsigned wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   const bool tracing = trace != nullptr && wg_lin < trace_cap && threadIdx.x == 0;
 #define JATTS_CSTAMP(i) do { if (tracing) trace[(size_t)wg_lin * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   if (tracing) {
@@ -67,10 +84,10 @@ __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_k
   }
   JATTS_CSTAMP(1);
   constexpr int BT = WT * NT * 32;
-  const int b = blockIdx.y;
+  const int b = by;
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
-  const int t0 = blockIdx.x * BT;
+  const int t0 = bx * BT;
   if (t0 >= L) return;
   const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_k
   const int KC16 = d.c_in >> 4;
   const int n_pad = (d.n_out + 31) & ~31;
   const int NFR = n_pad >> 5;
-  const int nf0 = (blockIdx.z * WN + wn) * NF;
+  const int nf0 = (bz * WN + wn) * NF;
   const int col0 = wt * NT * 32;
   const int g = lane >> 5;
 
@@ -179,11 +196,11 @@ __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_k
     }
   } else {   // transposed (V^T) / ragged-width outputs: the generic fragment-order epilogue of the LDS-staged kernel
     switch (d.act) {
-      case JATTS_ACT_RELU: conv_epilogue<float, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-      case JATTS_ACT_TANH: conv_epilogue<float, JATTS_ACT_TANH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-      case JATTS_ACT_SWISH: conv_epilogue<float, JATTS_ACT_SWISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-      case JATTS_ACT_MISH: conv_epilogue<float, JATTS_ACT_MISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-      default: conv_epilogue<float, JATTS_ACT_NONE, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
+      case JATTS_ACT_RELU: conv_epilogue<float, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+      case JATTS_ACT_TANH: conv_epilogue<float, JATTS_ACT_TANH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+      case JATTS_ACT_SWISH: conv_epilogue<float, JATTS_ACT_SWISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+      case JATTS_ACT_MISH: conv_epilogue<float, JATTS_ACT_MISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+      default: conv_epilogue<float, JATTS_ACT_NONE, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
     }
   }
   JATTS_CSTAMP(4);
@@ -206,8 +223,18 @@ template <int NF, int NT, int WN, int WT, int D, int DIAG = 0>
 int launch_conv_direct(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
-  dim3 grid((unsigned)((maxL + BT - 1) / BT), (unsigned)d.rg.n_seq, (unsigned)((d.n_out + BN - 1) / BN));
-  hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG>), grid, dim3(WN * WT * 64), 0, s, d, jatts_g_trace, jatts_g_trace_cap);
+  const int gx = (int)((maxL + BT - 1) / BT), gz = (d.n_out + BN - 1) / BN;
+  const int64_t n_tiles = (int64_t)gx * d.rg.n_seq;
+  const int tpx = (int)((n_tiles + 7) / 8);
+  const int64_t slice = (int64_t)BN * d.c_in * d.k_w * 4;                  // bytes of one n-block's weights
+  int zc = (int)((2 << 20) / (slice > 0 ? slice : 1));
+  zc = zc < 1 ? 1 : (zc > gz ? gz : zc);
+  const int n_chunks = (gz + zc - 1) / zc;
+  zc = (gz + n_chunks - 1) / n_chunks;      // even chunks: workgroups that find no work (and exit) perturb the placement of the others
+  const int64_t total = 8 * (int64_t)tpx * zc * n_chunks;
+  if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
+  hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
+                     jatts_g_trace_cap, gx, (int)n_tiles, tpx, gz, zc);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

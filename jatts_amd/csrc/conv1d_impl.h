@@ -13,7 +13,7 @@ constexpr int KCH = 64;  // channels staged per LDS chunk
 // (n_out % 4 != 0) a scalar loop.
 template <typename T, int ACT, int NF, int NT>
 __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (&acc)[NF][NT], int t0, int col0, int nf0,
-                                              int lane, int L, int64_t seq_row0) {
+                                              int lane, int L, int64_t seq_row0, int seq) {
   const int g = lane >> 5;
   const bool vec_r = d.resid && (d.ldr & 3) == 0, vec_y = (d.ldy & 3) == 0 && !d.y_transposed;
 #pragma unroll
@@ -21,7 +21,7 @@ __device__ __forceinline__ void conv_epilogue(const jatts_conv_desc& d, f32x16 (
     const int pos = t0 + col0 + t * 32 + (lane & 31);
     if (pos >= L) continue;
     const int64_t row = seq_row0 + pos;
-    const int64_t trow = d.y_seq_col0 ? (int64_t)d.y_seq_col0[blockIdx.y] * d.rg.len_mul + pos : row;  // transposed output column
+    const int64_t trow = d.y_seq_col0 ? (int64_t)d.y_seq_col0[seq] * d.rg.len_mul + pos : row;  // transposed output column
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -224,11 +224,11 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
 #undef JATTS_EPI
   }
   switch (d.act) {
-    case JATTS_ACT_RELU: conv_epilogue<T, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-    case JATTS_ACT_TANH: conv_epilogue<T, JATTS_ACT_TANH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-    case JATTS_ACT_SWISH: conv_epilogue<T, JATTS_ACT_SWISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-    case JATTS_ACT_MISH: conv_epilogue<T, JATTS_ACT_MISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
-    default: conv_epilogue<T, JATTS_ACT_NONE, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0); break;
+    case JATTS_ACT_RELU: conv_epilogue<T, JATTS_ACT_RELU, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+    case JATTS_ACT_TANH: conv_epilogue<T, JATTS_ACT_TANH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+    case JATTS_ACT_SWISH: conv_epilogue<T, JATTS_ACT_SWISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+    case JATTS_ACT_MISH: conv_epilogue<T, JATTS_ACT_MISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
+    default: conv_epilogue<T, JATTS_ACT_NONE, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
   }
 }
 
