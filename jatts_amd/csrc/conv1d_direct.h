@@ -52,25 +52,10 @@ __device__ __forceinline__ void apply_act_alpha(f32x16 (&acc)[NF][NT], int act, 
 // DIAG (tools/bench_conv.py --variant 8, wrong results, kept for the record of profiles/r03_notes.md): 1 = nothing is streamed in the
 // main loop (the operands of the first D steps are reused) -- the pure-MFMA ceiling of this launch geometry.
 template <int NF, int NT, int WN, int WT, int D, int DIAG = 0>
-__global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap, int gx, int n_tiles, int tpx, int gz, int zc) {
-  // XCD-aware work order (1-D grid): the dispatcher places workgroup id on XCD id % 8, each XCD with its own 4 MiB L2.  XCD x takes the
-  // contiguous tile range [x * tpx, (x + 1) * tpx) (tile = (time tile, sequence)) and walks it as  for n-block chunk: for tile: for
-  // n-block in chunk  (zc n-blocks per chunk: their weight slices, <= ~2 MiB, stay in that L2), so a tile's activation rows are fetched
-  // from the fabric once per chunk instead of once per n-block: 512 -> 2048 k1 moved 2.2 GB per launch for a 100 MB input
-  // (profiles/r03_notes.md), and on a power-limited kernel fabric bytes are clock.
-  const unsigned wg_lin = blockIdx.x;
+__global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap, XcdOrder xo) {
+  const unsigned wg_lin = blockIdx.x;     // 1-D grid in XCD-aware order (conv1d_impl.h: XcdOrder)
   int bx, by, bz;
-  {
-    const int xcd = (int)(wg_lin & 7u), m = (int)(wg_lin >> 3);
-    const int per_chunk = tpx * zc;
-    const int c = m / per_chunk, rem = m - c * per_chunk;
-    const int tl = rem / zc;
-    const int tile = xcd * tpx + tl;
-    bz = c * zc + (rem - tl * zc);
-    if (tl >= tpx || tile >= n_tiles || bz >= gz) return;
-    by = tile / gx;
-    bx = tile - by * gx;
-  }
+  if (!xo.decode(wg_lin, bx, by, bz)) return;
   // Phase trace (profiling hook, jatts_debug_trace; tools/trace_conv.py): thread 0 of the first trace_cap workgroups stamps
   // [hw id, start, main loop entered, main loop done, stored, -, -, -, realtime start, realtime end]
   const bool tracing = trace != nullptr && wg_lin < trace_cap && threadIdx.x == 0;
@@ -223,18 +208,11 @@ template <int NF, int NT, int WN, int WT, int D, int DIAG = 0>
 int launch_conv_direct(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
-  const int gx = (int)((maxL + BT - 1) / BT), gz = (d.n_out + BN - 1) / BN;
-  const int64_t n_tiles = (int64_t)gx * d.rg.n_seq;
-  const int tpx = (int)((n_tiles + 7) / 8);
-  const int64_t slice = (int64_t)BN * d.c_in * d.k_w * 4;                  // bytes of one n-block's weights
-  int zc = (int)((2 << 20) / (slice > 0 ? slice : 1));
-  zc = zc < 1 ? 1 : (zc > gz ? gz : zc);
-  const int n_chunks = (gz + zc - 1) / zc;
-  zc = (gz + n_chunks - 1) / n_chunks;      // even chunks: workgroups that find no work (and exit) perturb the placement of the others
-  const int64_t total = 8 * (int64_t)tpx * zc * n_chunks;
+  XcdOrder xo;
+  const int64_t total = xo.plan((int)((maxL + BT - 1) / BT), d.rg.n_seq, (d.n_out + BN - 1) / BN, (int64_t)BN * d.c_in * d.k_w * 4);
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
   hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
-                     jatts_g_trace_cap, gx, (int)n_tiles, tpx, gz, zc);
+                     jatts_g_trace_cap, xo);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

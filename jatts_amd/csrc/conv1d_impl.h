@@ -5,6 +5,40 @@
 
 namespace {
 
+// ------------------------------------------------------------------ XCD-aware work order (shared by both conv kernels)
+// The dispatcher places workgroup id on XCD id % 8, each XCD with its own 4 MiB L2.  In the natural (time tile, sequence, n-block) grid
+// the n-blocks that share an activation tile are a whole (tiles x sequences) plane of ids apart, land on every XCD and re-read the
+// tile through L2 misses: 512 -> 2048 k1 moved 2.2 GB from the fabric per launch for a 100 MB input.  Here XCD x owns the contiguous
+// tile range [x * tpx, (x + 1) * tpx) (tile = (time tile, sequence)) and walks it as  for n-block chunk: for tile: for n-block in
+// chunk  with chunks of <= ~2 MiB of weights (they stay in that L2), evened out so that almost no workgroup finds an empty slot
+// (a workgroup that exits at once still perturbs the placement of the others).  4.6x less fabric traffic, +3-12 % on the wide f32
+// shapes -- on a power-limited kernel fabric bytes are clock (profiles/r03_notes.md).
+struct XcdOrder {
+  int gx, n_tiles, tpx, gz, zc;
+  int64_t plan(int gx_, int n_seq, int gz_, int64_t slice_bytes) {
+    gx = gx_; gz = gz_;
+    n_tiles = gx_ * n_seq;
+    tpx = (n_tiles + 7) / 8;
+    zc = (int)((2 << 20) / (slice_bytes > 0 ? slice_bytes : 1));
+    zc = zc < 1 ? 1 : (zc > gz ? gz : zc);
+    const int n_chunks = (gz + zc - 1) / zc;
+    zc = (gz + n_chunks - 1) / n_chunks;
+    return 8 * (int64_t)tpx * zc * n_chunks;     // workgroups of the 1-D grid
+  }
+  __device__ __forceinline__ bool decode(unsigned id, int& bx, int& by, int& bz) const {
+    const int xcd = (int)(id & 7u), m = (int)(id >> 3);
+    const int per_chunk = tpx * zc;
+    const int c = m / per_chunk, rem = m - c * per_chunk;
+    const int tl = rem / zc;
+    const int tile = xcd * tpx + tl;
+    bz = c * zc + (rem - tl * zc);
+    if (tile >= n_tiles || bz >= gz) return false;
+    by = tile / gx;
+    bx = tile - by * gx;
+    return true;
+  }
+};
+
 // ------------------------------------------------------------------ generic conv kernel
 constexpr int KCH = 64;  // channels staged per LDS chunk
 
@@ -113,13 +147,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const jatts_conv_desc& d, f32x
 template <typename T, int NF, int NT, int WN, int WT, int NIN, bool ASYNC, int KCHT = KCH>
 // two workgroups per CU (<= 256 registers) for the single-input pipelines: one workgroup's LDS commits, barriers and epilogue
 // then run under the other's MFMAs (the f32 kernel at 268 registers had the CU to itself and sat at ~55 % MFMA utilisation)
-__global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN == 1 && ASYNC && WT * NT * 32 <= 128)) ? 2 : 1) void conv1d_kernel(jatts_conv_desc d, int f32_tile) {
+__global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN == 1 && ASYNC && WT * NT * 32 <= 128)) ? 2 : 1) void conv1d_kernel(jatts_conv_desc d, int f32_tile, XcdOrder xo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32;
-  const int b = blockIdx.y;
+  int bx, b, bz;
+  if (!xo.decode(blockIdx.x, bx, b, bz)) return;
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
-  const int t0 = blockIdx.x * BT;
+  const int t0 = bx * BT;
   if (t0 >= L) return;
   const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -129,7 +164,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   const int KC16 = d.c_in >> 4;
   const int n_pad = (d.n_out + 31) & ~31;
   const int NFR = n_pad >> 5;
-  const int nf0 = (blockIdx.z * WN + wn) * NF;
+  const int nf0 = (bz * WN + wn) * NF;
   const int col0 = wt * NT * 32;
 
   const T* xin[3] = {(const T*)d.x[0], (const T*)d.x[1], (const T*)d.x[2]};
@@ -198,7 +233,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   {
     // the loop's last barrier has retired every read of the activation buffers: reuse them as the output tile
     constexpr int BN = WN * NF * 32;
-    const int n_base = blockIdx.z * BN;
+    const int n_base = bz * BN;
     const bool rowmajor = !d.y_transposed && (d.n_out & 7) == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0;
 #define JATTS_EPI(TO)                                                                                                  \
   switch (d.act) {                                                                                                     \
@@ -261,7 +296,10 @@ int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, f32_tile);
+  XcdOrder xo;
+  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * (int64_t)sizeof(T));
+  if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WN * WT * 64), lds, s, d, f32_tile, xo);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
