@@ -126,16 +126,10 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
   char* vs = smem + KB * KP;
   float* kus = reinterpret_cast<float*>(smem + KB * KP + DK * VP);
 
-  // XCD-aware 1-D order: the dispatcher puts workgroup id on XCD id % 8; all query tiles of one (sequence, head) go to ONE XCD, so its K / V
-  // (1.2-1.5 MB at T = 768) are fetched into one L2 instead of eight (profiles/r03_notes.md)
-  const int n_qt = d.rg.max_len > 0 ? (d.rg.max_len + QB - 1) / QB : 1;
-  const int xcd = (int)(blockIdx.x & 7u), m = (int)(blockIdx.x >> 3);
-  const int pair = xcd + 8 * (m / n_qt);              // (sequence, head) pair
-  if (pair >= d.rg.n_seq * d.n_heads) return;
-  const int b = pair / d.n_heads, h = pair - b * d.n_heads;
+  const int b = blockIdx.y, h = blockIdx.z;
   const int row0 = d.rg.cu_rows[b];
   const int Tn = d.rg.cu_rows[b + 1] - row0;
-  const int i0 = (m % n_qt) * QB;
+  const int i0 = blockIdx.x * QB;
   if (i0 >= Tn) return;
   // keys >= Tk are masked out of the softmax (a PADDED batch, the reference's training-time forward(): Tn is then the padded
   // length, which the rel-shift geometry keeps using, and Tk the utterance's own length; attention.py:80-88)
@@ -296,10 +290,7 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
 template <typename T, int DK>
 int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
   const size_t lds = (size_t)KB * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KB * sizeof(T) + 16) + KB * sizeof(float);
-  const int64_t n_qt = (d.rg.max_len + QB - 1) / QB, pairs = (int64_t)d.rg.n_seq * d.n_heads;
-  const int64_t total = 8 * ((pairs + 7) / 8) * n_qt;
-  if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "relpos_attention: launch too large");
-  dim3 grid((unsigned)total);
+  dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
   auto kern = relattn_kernel<T, DK>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
