@@ -95,8 +95,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
                                                               float* __restrict__ dw, float* __restrict__ ws) {
   constexpr int TT = 32, P = 68;
   extern __shared__ float sm[];
-  float* dys = sm;
-  float* xs = sm + TT * P;
   const int halo = (KW - 1) * dil;
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, grp = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,47 +106,89 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
   for (int k = 0; k < KW; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-  for (int s = grp; s < rg.n_seq; s += seq_groups) {
+  // Software pipeline over the (sequence, 32-step chunk) pairs of this group (round 3): the global loads of chunk i + 1 are issued into
+  // registers BEFORE the MFMAs of chunk i and committed to the other LDS buffer after them -- one barrier per chunk and no exposed load
+  // latency (the synchronous load -> store -> barrier -> MFMA -> barrier form left a k = 1 chunk of 1 024 MFMA cycles waiting ~2 us
+  // for its operands: 43-67 TFLOP/s).
+  constexpr int NDY = TT * 16 / 256, NXV = (TT + 32) * 16 / 256;      // f32x4 per thread: dy tile, x tile (halo <= 32)
+  f32x4 rdy[NDY], rx[NXV];
+  const int nx_rows = TT + halo;
+  auto issue = [&](int s, int t0) {
     const int64_t row0 = (int64_t)rg.cu_rows[s] * rg.len_mul;
     const int L = (rg.cu_rows[s + 1] - rg.cu_rows[s]) * rg.len_mul;
-    for (int t0 = 0; t0 < L; t0 += TT) {
-      for (int i = threadIdx.x; i < TT * 16; i += 256) {
-        const int r = i >> 4, q = (i & 15) * 4;
-        const int tt = t0 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (tt < L) {
-          const float* src = dy + (row0 + tt) * ldy + n0 + q;
-          if (vec_dy) v = *reinterpret_cast<const f32x4*>(src);
-          else
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (n0 + q + e < n_out) v[e] = src[e];
-        }
-        *reinterpret_cast<f32x4*>(&dys[r * P + q]) = v;
-      }
-      for (int i = threadIdx.x; i < (TT + halo) * 16; i += 256) {
-        const int r = i >> 4, q = (i & 15) * 4;
-        const int p = t0 - pad + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p >= 0 && p < L) {
-          const float* src = x + (row0 + p) * ldx + c0 + q;
-          if (vec_x) v = *reinterpret_cast<const f32x4*>(src);
-          else
+    for (int j = 0; j < NDY; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      const int r = i >> 4, q = (i & 15) * 4;
+      const int tt = t0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (tt < L) {
+        const float* src = dy + (row0 + tt) * ldy + n0 + q;
+        if (vec_dy) v = *reinterpret_cast<const f32x4*>(src);
+        else
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (c0 + q + e < c_in) v[e] = src[e];
-        }
-        *reinterpret_cast<f32x4*>(&xs[r * P + q]) = v;
+          for (int e = 0; e < 4; ++e) if (n0 + q + e < n_out) v[e] = src[e];
       }
-      __syncthreads();
-      const float* ap = dys + hi * P + wn * 32 + lo;
-      const float* bp = xs + hi * P + wc * 32 + lo;
-#pragma unroll 4
-      for (int tp = 0; tp < TT / 2; ++tp) {
-        const float a = ap[2 * tp * P];
-#pragma unroll
-        for (int k = 0; k < KW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(2 * tp + k * dil) * P], acc[k], 0, 0, 0);
-      }
-      __syncthreads();
+      rdy[j] = v;
     }
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      const int r = i >> 4, q = (i & 15) * 4;
+      const int p = t0 - pad + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < nx_rows && p >= 0 && p < L) {
+        const float* src = x + (row0 + p) * ldx + c0 + q;
+        if (vec_x) v = *reinterpret_cast<const f32x4*>(src);
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c0 + q + e < c_in) v[e] = src[e];
+      }
+      rx[j] = v;
+    }
+  };
+  auto commit = [&](float* dst_dy, float* dst_x) {
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      *reinterpret_cast<f32x4*>(&dst_dy[(i >> 4) * P + (i & 15) * 4]) = rdy[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if ((i >> 4) < nx_rows) *reinterpret_cast<f32x4*>(&dst_x[(i >> 4) * P + (i & 15) * 4]) = rx[j];
+    }
+  };
+  const int buf_floats = (2 * TT + halo) * P;       // one buffer: dy tile then x tile
+  int cs = grp, ct0 = 0;                            // current chunk
+  if (cs < rg.n_seq) {
+    // (sequences of length 0 contribute one all-zero chunk: harmless)
+    issue(cs, ct0);
+    commit(sm, sm + TT * P);
+  }
+  __syncthreads();
+  int it = 0;
+  while (cs < rg.n_seq) {
+    const int Lc = (rg.cu_rows[cs + 1] - rg.cu_rows[cs]) * rg.len_mul;
+    int ns = cs, nt0 = ct0 + TT;                    // next chunk
+    if (nt0 >= Lc) { ns = cs + seq_groups; nt0 = 0; }
+    const bool more = ns < rg.n_seq;
+    if (more) issue(ns, nt0);
+    const float* cur = sm + (it & 1) * buf_floats;
+    const float* ap = cur + hi * P + wn * 32 + lo;
+    const float* bp = cur + TT * P + hi * P + wc * 32 + lo;
+#pragma unroll 4
+    for (int tp = 0; tp < TT / 2; ++tp) {
+      const float a = ap[2 * tp * P];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(2 * tp + k * dil) * P], acc[k], 0, 0, 0);
+    }
+    if (more) {
+      float* nxt = sm + ((it + 1) & 1) * buf_floats;
+      commit(nxt, nxt + TT * P);
+    }
+    __syncthreads();
+    cs = ns; ct0 = nt0; ++it;
   }
   // C/D map: column (lane & 31) = c, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = n
   const int c = c0 + wc * 32 + lo;
@@ -263,7 +303,7 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
     if (g > rg->n_seq) g = rg->n_seq;
     if (g < 1) g = 1;
     const dim3 grid((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)g);
-    const size_t lds = (size_t)(64 + (k_w - 1) * dil) * 68 * sizeof(float);
+    const size_t lds = 2 * (size_t)(64 + (k_w - 1) * dil) * 68 * sizeof(float);   // two buffers of (dy tile | x tile + halo)
     if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
     else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
     else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
