@@ -199,3 +199,62 @@ def test_conv1d_direct_edge_geometry(cuda, lib, case, variant):
                    resid=resd, resid_col0=8 if rld else 0, out_f32=True, variant=variant)
     assert torch.isfinite(y).all()
     assert relerr(y, ref) <= 5e-6, f"{case} variant {variant}: rel err {relerr(y, ref):.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ configs 3 and 5 at the bench's length
+def _seeded_noise(z):
+    shape = [int(v) for v in z["noise_shape"]]
+    # the reference drew randn_like(x) with x of shape (1, C, T); the fixture records (T, C) = noise[0].t()
+    return torch.randn(1, shape[1], shape[0], generator=torch.Generator().manual_seed(int(z["noise_seed"])))[0].t().contiguous()
+
+
+@pytest.mark.parametrize("prec,atol", [("fp32", 5e-3), ("fp16", 0.15)])
+def test_matcha_bench_utterance_matches_the_reference(cuda, lib, prec, atol):
+    """BASELINE configs[2] at the bench's utterance length: the config-3 model (U-Net 512/512, head dim 256, 10 Euler steps) on a
+    128-phoneme bench utterance -> 768 frames, against the REAL reference (matcha_bench128.npz; diffusers attention = SDPA stand-in),
+    alone and as one of 8 utterances of a batch."""
+    from jatts_amd.models import MatchaTTS_MAS
+    from jatts_amd.synthetic import MATCHA_MAS_JSUT, matcha_golden_tweaks, pin_duration_head, synth_texts
+    z, keys = load_golden("matcha_bench128.npz")
+    m = MatchaTTS_MAS(idim=45, **MATCHA_MAS_JSUT)
+    m.load_state_dict(pin_duration_head(matcha_golden_tweaks(golden_state(keys, 0)), 6))
+    m = m.to(cuda).set_precision(prec)
+    text = torch.tensor(z["u0_text"]).to(cuda)
+    assert torch.equal(text.cpu(), synth_texts(64, 128, 45, seed=1)[5])
+    noise = _seeded_noise(z)
+    ref = z["u0_feat_gen"]
+    r = m.inference_batch([text], n_timesteps=10, temperature=0.667, noise=[noise])
+    assert torch.equal(r["duration"].cpu(), torch.tensor(z["u0_duration"])) and r["feat_gen"].shape == ref.shape == (768, 80)
+    e1 = maxdiff(r["feat_gen"], ref)
+    others = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)[8:15]]
+    g = torch.Generator().manual_seed(77)
+    rb = m.inference_batch(others[:3] + [text] + others[3:], n_timesteps=10, temperature=0.667,
+                           noise=[torch.randn(768, 80, generator=g) for _ in range(3)] + [noise] + [torch.randn(768, 80, generator=g) for _ in range(4)])
+    eb = maxdiff(rb["feat_gen"][3 * 768:4 * 768], ref)
+    assert e1 <= atol and eb <= atol, f"{prec}: alone {e1:.3e}, in a batch {eb:.3e}"
+
+
+@pytest.mark.parametrize("prec,atol", [("fp32", 3e-3), ("fp16", 8e-2)])
+def test_vits_bench_utterance_matches_the_reference(cuda, lib, prec, atol):
+    """BASELINE configs[4] at the bench's utterance length: mel-VITS with a 192-d speaker embedding on a 128-phoneme bench utterance ->
+    768 frames, against the REAL reference (vits_bench128.npz), alone and inside a batch of 8."""
+    from jatts_amd.models import VITS
+    from jatts_amd.synthetic import VITS_JSUT, pin_duration_head, synth_texts
+    z, keys = load_golden("vits_bench128.npz")
+    m = VITS(idim=45, spk_embed_dim=192, **VITS_JSUT)
+    m.load_state_dict(pin_duration_head(golden_state(keys, 0), 6))
+    m = m.to(cuda).set_precision(prec)
+    text = torch.tensor(z["u0_text"]).to(cuda)
+    spk = torch.tensor(z["u0_spemb"])
+    noise = _seeded_noise(z)
+    ref = z["u0_feat_gen"]
+    r = m.inference_batch([text], spk.unsqueeze(0), noise=[noise])
+    assert torch.equal(r["duration"].cpu(), torch.tensor(z["u0_duration"])) and r["feat_gen"].shape == ref.shape == (768, 80)
+    e1 = maxdiff(r["feat_gen"], ref)
+    others = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)[8:15]]
+    g = torch.Generator().manual_seed(78)
+    spks = torch.cat([torch.randn(3, 192, generator=g), spk.unsqueeze(0), torch.randn(4, 192, generator=g)])
+    rb = m.inference_batch(others[:3] + [text] + others[3:], spks,
+                           noise=[torch.randn(768, 384, generator=g) for _ in range(3)] + [noise] + [torch.randn(768, 384, generator=g) for _ in range(4)])
+    eb = maxdiff(rb["feat_gen"][3 * 768:4 * 768], ref)
+    assert e1 <= atol and eb <= atol, f"{prec}: alone {e1:.3e}, in a batch {eb:.3e}"

@@ -205,3 +205,30 @@ def test_training_lr_schedules_match_torch_and_the_reference_formula():
         want = 0.0008 * 4000 ** 0.5 * min(step ** -0.5, step * 4000 ** -1.5)
         assert abs(scheduled_lr("warmuplr", 0.0008, step, warmup_steps=4000) - want) <= 1e-18
     assert scheduled_lr(None, 3e-4, 17) == 3e-4
+
+
+def test_oracles_match_reference_at_the_bench_length():
+    """Round-3 fixtures (tests/golden/make_golden_r3.py): the REAL reference on 128-phoneme bench utterances -> 768 frames, for the three
+    acoustic models of BASELINE configs[1] / [2] / [4].  The CPU oracles reproduce them (FastSpeech2 and Matcha bit-exactly)."""
+    from jatts_amd.synthetic import matcha_golden_tweaks, pin_duration_head
+    from oracle.matcha_oracle import matcha_inference
+    from oracle.vits_oracle import vits_inference
+    torch.set_num_threads(8)
+
+    def noise_of(z):
+        shape = [int(v) for v in z["noise_shape"]]
+        return torch.randn(1, shape[1], shape[0], generator=torch.Generator().manual_seed(int(z["noise_seed"])))[0].t().contiguous()
+    z, keys = load_golden("fs2_bench768.npz")
+    sd = pin_duration_head(golden_state(keys, 0), 6)
+    o = O.fs2_inference(sd, torch.tensor(z["u1_text"]), 2)
+    assert o["feat_gen"].shape == (768, 80) and maxdiff(o["feat_gen"], z["u1_feat_gen"]) == 0.0
+    assert np.array_equal(o["duration"].numpy(), z["u1_duration"])
+    z, keys = load_golden("vits_bench128.npz")
+    o = vits_inference(pin_duration_head(golden_state(keys, 0), 6), torch.tensor(z["u0_text"]), 2, 2, torch.tensor(z["u0_spemb"]), noise_of(z))
+    assert o["feat_gen"].shape == (768, 80) and maxdiff(o["feat_gen"], z["u0_feat_gen"]) <= 1e-5
+    assert np.array_equal(o["duration"].numpy(), z["u0_duration"])
+    z, keys = load_golden("matcha_bench128.npz")
+    o = matcha_inference(pin_duration_head(matcha_golden_tweaks(golden_state(keys, 0)), 6), torch.tensor(z["u0_text"]), 2, 2, noise_of(z),
+                         n_timesteps=10, temperature=0.667)
+    assert o["feat_gen"].shape == (768, 80) and maxdiff(o["feat_gen"], z["u0_feat_gen"]) <= 1e-5
+    assert np.array_equal(o["duration"].numpy(), z["u0_duration"])
