@@ -343,8 +343,16 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     for (tag, meta), v in fam.items():
         if tag not in ("resunit", "resblock"):
             other[tag] = other.get(tag, 0.0) + sum(v)
+    conv = [(m, v) for (t, m), v in fam.items() if t == "conv1d"]
+    conv_flops = sum(2.0 * m[0] * m[1] * m[2] * m[3] * len(v) for m, v in conv)
+    conv_ms = sum(sum(v) for _, v in conv)
+    roof_conv = None
+    if conv_ms > 0:      # second family: every jatts_conv1d launch of the step (acoustic model + HiFi-GAN input / upsampling convs)
+        roof_conv = dict(bound="mfma", achieved=conv_flops / conv_ms / 1e9, peak=peak_tf, unit="TFLOP/s", frac=conv_flops / conv_ms / 1e9 / peak_tf,
+                         ms_per_step=conv_ms / steps, launches_per_step=sum(len(v) for _, v in conv) / steps)
     return dict(
         roofline=roof,
+        roofline_conv1d=roof_conv,
         resunit_ms_per_step=sum(u["total_ms"] for u in units) / steps,
         other_kernel_ms_per_step={k: v / steps for k, v in other.items()},
         resunit_by_shape=sorted(units, key=lambda u: -u["total_ms"]),
