@@ -109,8 +109,8 @@ typedef struct jatts_conv_desc {
                         * padding_mode="reflect", the SpeechBrain Conv1d default used by ECAPA-TDNN; halo < length) */
   int32_t variant;     /* 0: the library picks the kernel / tile (the product setting).  Non-zero forces one where it applies
                         * (parity tests reach every kernel; tools/bench_conv.py tunes the heuristic).  f32, n_out > 64:
-                        * 1 = LDS-staged 128n x 64t, 2 = LDS-staged 128n x 128t, 3 = register-streamed ("direct": one plain
-                        * zero-padded input; csrc/conv1d_direct.h) 128n x 128t with a 2-step operand ring, 4 = the same with a
+                        * 1 = LDS-staged 128n x 64t, 2 = LDS-staged 128n x 128t, 3 = register-streamed ("direct": one zero-padded input, optionally with the
+                        * LeakyReLU prologue; csrc/conv1d_direct.h) 128n x 128t with a 2-step operand ring, 4 = the same with a
                         * 4-step ring, 5 = register-streamed 128n x 64t.  Unknown / inapplicable values fall back to 0. */
 } jatts_conv_desc;
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ void apply_act_alpha(f32x16 (&acc)[NF][NT], int act, 
 
 // DIAG (tools/bench_conv.py --variant 8, wrong results, kept for the record of profiles/r03_notes.md): 1 = nothing is streamed in the
 // main loop (the operands of the first D steps are reused) -- the pure-MFMA ceiling of this launch geometry.
-template <int NF, int NT, int WN, int WT, int D, int DIAG = 0>
+template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false>
 __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap, XcdOrder xo) {
   const unsigned wg_lin = blockIdx.x;     // 1-D grid in XCD-aware order (conv1d_impl.h: XcdOrder)
   int bx, by, bz;
@@ -139,6 +139,12 @@ __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_k
   for (int s0 = 0; s0 < n_steps; s0 += D) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
+      if (PRE) {   // LeakyReLU prologue (HiFi-GAN upsampling convs): max(v, slope v), 0 <= slope <= 1, on the fragment about to be consumed
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rb[j][t][e] = fmaxf(rb[j][t][e], rb[j][t][e] * d.pre_slope);
+      }
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -199,19 +205,20 @@ inline bool conv_direct_ok(const jatts_conv_desc& d) {
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   const int64_t n_pad = (d.n_out + 31) & ~31;
   const int64_t ld = d.ldx > d.ldy ? (d.ldx > d.ldr ? d.ldx : d.ldr) : (d.ldy > d.ldr ? d.ldy : d.ldr);
-  return d.n_in == 1 && d.in_scale == 1.f && d.pre_act == JATTS_PRE_NONE && d.pad_mode == JATTS_PAD_ZERO && (d.ldx & 3) == 0 &&
+  return d.n_in == 1 && d.in_scale == 1.f && (d.pre_act == JATTS_PRE_NONE || (d.pre_act == JATTS_PRE_LRELU && d.pre_slope >= 0.f && d.pre_slope <= 1.f)) &&
+         d.pad_mode == JATTS_PAD_ZERO && (d.ldx & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(d.x[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 &&
          (maxL + 256 + (int64_t)d.k_w * d.dil) * ld * 4 < (int64_t)1 << 31 && (int64_t)d.k_w * d.c_in * n_pad * 4 < (int64_t)1 << 31;
 }
 
-template <int NF, int NT, int WN, int WT, int D, int DIAG = 0>
+template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false>
 int launch_conv_direct(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   XcdOrder xo;
   const int64_t total = xo.plan((int)((maxL + BT - 1) / BT), d.rg.n_seq, (d.n_out + BN - 1) / BN, (int64_t)BN * d.c_in * d.k_w * 4);
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
-  hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
+  hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG, PRE>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
                      jatts_g_trace_cap, xo);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;

@@ -13,6 +13,14 @@ int jatts_conv1d_f32_direct(const jatts_conv_desc& d, int variant, hipStream_t s
     const int64_t wgs = t128 * d.rg.n_seq * ((d.n_out + 127) / 128);
     variant = (wgs <= 512 || t64 * 64 * 23 <= t128 * 128 * 20) ? 5 : 3;
   }
+  if (d.pre_act != JATTS_PRE_NONE) {
+    // LeakyReLU prologue (the HiFi-GAN upsampling convs): max(v, slope v) on the activation fragment about to be consumed -- 32 VALU per
+    // 32-MFMA step, and still 5-8 % faster than the LDS-staged kernel on the large launches (256 -> 1024 k3 at 393 216 rows: 134.0 vs 126.9
+    // TFLOP/s, 512 -> 2048 k1: 111.9 vs 104.1).  Both tiles: an utterance must take the same kernel family (same summation order) alone
+    // and inside a batch -- results are bit-identical wherever a sequence sits (tests/test_fullsize_gpu.py).
+    if (variant == 5) return launch_conv_direct<2, 1, 2, 2, 2, 0, true>(d, s);
+    return launch_conv_direct<2, 2, 2, 2, 2, 0, true>(d, s);
+  }
   switch (variant) {
     case 3: return launch_conv_direct<2, 2, 2, 2, 2>(d, s);      // 128n x 128t, 256 threads, ring 2: three workgroups per CU
     case 4: return launch_conv_direct<2, 2, 2, 2, 4>(d, s);      // ring 4 (two workgroups per CU)

@@ -161,6 +161,25 @@ def test_conv1d_f32_reflect_padding_and_transposed_output(cuda, lib, variant):
     assert relerr(yt.t(), ref0) <= 3e-6
 
 
+@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("shape", [(256, 1024, 3, [2048] * 6 + [1000]), (128, 128, 3, [4096, 777]), (512, 2048, 1, [768] * 7)])
+def test_conv1d_f32_lrelu_prologue_at_bench_size(cuda, lib, shape, variant):
+    """The HiFi-GAN upsampling convs' form (LeakyReLU(0.1) on the input, polyphase ConvTranspose as a stride-1 conv): register-streamed kernel with
+    the prologue on the B fragments (variant 3 / the product heuristic at these sizes) and the LDS-staged kernel (variant 2) vs fp64."""
+    from jatts_amd import hip
+    c_in, n_out, k, lens = shape
+    g = torch.Generator().manual_seed(c_in + n_out)
+    R = sum(lens)
+    x = torch.randn(R, c_in, generator=g)
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k)
+    b = torch.randn(n_out, generator=g)
+    ref = _ref_conv64(F.leaky_relu(x.double(), 0.1), w, b, lens, 1, (k - 1) // 2, k)
+    rb = hip.RaggedBatch(lens, cuda)
+    y = hip.conv1d(rb, x.to(cuda), hip.pack_conv_weight(w.to(cuda), hip.F32), c_in, n_out, k, dtype=hip.F32, bias=b.to(cuda), pre_lrelu=0.1,
+                   out_f32=True, variant=variant)
+    assert relerr(y, ref) <= 3e-6, f"{shape[:3]} variant {variant}: {relerr(y, ref):.3e}"
+
+
 EDGE = [  # c_in (window of a wider row), n_out, k, dil, lens, x_col0, ldx, act, resid_ld
     (64, 72, 3, 1, [1, 2, 5, 129, 64], 0, 64, "relu", None),          # one-row sequences, n_out = 72 (multiple of 8, not of 32)
     (128, 384, 1, 1, [127, 1, 130], 64, 256, None, 512),               # column window of a wider matrix, residual with its own row stride

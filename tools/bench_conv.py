@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     ap.add_argument("--variant", type=int, default=0, help="jatts_conv_desc.variant (0 = the product heuristic)")
+    ap.add_argument("--pre-lrelu", type=float, default=None, help="LeakyReLU prologue slope (the HiFi-GAN upsampling convs)")
     a = ap.parse_args()
     dt = hip.F16 if a.dtype == "f16" else hip.F32
     dev = torch.device("cuda:0")
@@ -40,7 +41,7 @@ def main():
         r = torch.zeros(rows, n, device=dev) if res else None
 
         def run():
-            return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res, variant=a.variant)
+            return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res, variant=a.variant, pre_lrelu=a.pre_lrelu)
         for _ in range(2):
             run()
         torch.cuda.synchronize()
