@@ -9,13 +9,13 @@ int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s) {
   // JATTS_CONV_F32_TILE (process-wide tuning override) / jatts_conv_desc.variant (per call): see include/jatts_hip.h
   static const int env_tile = [] { const char* e = getenv("JATTS_CONV_F32_TILE"); return e ? atoi(e) : 0; }();
   const int tile = d.variant ? d.variant : env_tile;
-  if (d.n_out <= 64) return launch_conv<float, 2, 2, 1, 4>(d, s);
   // default: the register-streamed kernel wherever it applies (one plain zero-padded input: every projection / FFN / postnet conv of the
   // acoustic models): 2-20 % faster than the LDS-staged tiles on every shape of tools/bench_conv.py (profiles/r03_notes.md)
   if (tile == 0 || tile >= 3) {
     const int rc = jatts_conv1d_f32_direct(d, tile, s);
     if (rc != 1) return rc;
   }
+  if (d.n_out <= 64) return launch_conv<float, 2, 2, 1, 4>(d, s);
   // The 128 x 128 tile runs two workgroups per CU (512 slots).  A launch of <= ~1.1 x that many workgroups spends its second round
   // nearly empty; the 64-step tile (half the work per workgroup, 5-10 % less efficient per FLOP) fills the chip better there:
   // 4-14 % faster on the training-size and half-rate shapes (384->384, 1536->384 k3 at 24 576 rows; 512->512, 1024->512 at 12 288),

@@ -3,7 +3,11 @@
 
 // -> JATTS_OK / error, or 1 when the variant does not apply (the caller falls back to the LDS-staged kernel)
 int jatts_conv1d_f32_direct(const jatts_conv_desc& d, int variant, hipStream_t s) {
-  if (!conv_direct_ok(d) || d.n_out <= 64) return 1;
+  if (!conv_direct_ok(d)) return 1;
+  if (d.n_out <= 64) {   // narrow outputs (HiFi-GAN's last upsampling conv: 64 -> 2 x 32 channels at 6.3 M rows): 64n x 256t, four waves along time
+    if (variant != 0 && variant != 3) return 1;
+    return d.pre_act != JATTS_PRE_NONE ? launch_conv_direct<2, 2, 1, 4, 2, 0, true>(d, s) : launch_conv_direct<2, 2, 1, 4, 2>(d, s);
+  }
   if (variant == 0) {
     // 128n x 128t unless the launch would leave most of the 768 workgroup slots (3 per CU) empty or its time tiles half empty
     // (sequences of <= 64 rows): then 128n x 64t -- tools/bench_conv.py, profiles/r03_notes.md: +40-80 % at 4 096 rows, +5-17 % at
