@@ -400,12 +400,18 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
              energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il,
              spkembs=torch.randn(batch, 192, generator=g).to(dev) if kind == "vits" else None)
     cls = {"fs2": FastSpeech2Trainer, "matcha": MatchaTTSTrainer, "matcha_mas": MatchaTTSTrainer, "vits": VITSTrainer}[kind]
-    tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, **extra)
+    # FastSpeech2: the whole step replayed as ONE captured hipGraph per batch signature (the other trainers' steps still talk to the host:
+    # MAS durations, scipy prior, CFM draws); the first call runs eagerly, the second captures, the timed ones replay
+    graph = kind == "fs2"
+    tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=graph, **extra)
     from jatts_amd import hip
     hip.flops_begin()            # dense work of ONE step as launched: 2 c_in n_out k rows per conv forward / dgrad / wgrad launch
     first = float(tr.train_step(b)["loss"])
     torch.cuda.synchronize()
     dense_tflop = hip.flops_end() / 1e12
+    if graph:
+        tr.train_step(b)         # capture + first replay
+        torch.cuda.synchronize()
     per = []
     for _ in range(steps):       # every step timed on its own (a step ends in the optimiser kernels: nothing to overlap with the next one);
         t0 = time.perf_counter()  # the MEDIAN is reported: these steps launch 2 300-6 200 kernels each and a busy host shows up as outliers
@@ -416,6 +422,7 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     n_frames = int(ol.sum())
     mean = sum(per) / len(per)
     line = {"kind": kind, "workload": f"{name} _train_step, batch {batch} x {t_text} phonemes x {frames} frames", "dtype": "f32",
+            "executor": "hipGraph replay (one graph per batch signature)" if graph and tr.capture_graph else "eager (one Python launch per kernel)",
             "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_mean": mean * 1e3, "ms_per_step_all": [round(v * 1e3, 2) for v in per],
             "frames_per_s": n_frames / dt, "loss_first": first, "loss_last": float(o["loss"]),
             "dense_tflops_per_step": dense_tflop, "achieved_tflops": dense_tflop / dt,

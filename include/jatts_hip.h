@@ -290,16 +290,21 @@ int jatts_ctc_forward_sum(const float* log_p, int32_t n_batch, int32_t t_max, in
  * per-sequence vector added to every row (speaker / time embeddings, WaveNet global conditioning). */
 int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim, float* out, void* stream);
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the backward is the same call on dy. */
-int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* seed_dev (may be NULL): the mask seed is *seed_dev + seed -- a captured graph replays with a new base seed per step (device memory) and
+ * `seed` as the call site's offset. */
+int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* y[i] = (resid ? resid[i] : 0) + alpha * dropout(x)[i] with jatts_dropout's mask for (seed, i): the residual connections of the
  * conformer layers (jatts/modules/conformer/encoder_layer.py:100-170) in one launch; p == 0 is a plain scaled add. */
-int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, void* stream);
+int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, const uint64_t* seed_dev,
+                      void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by
  * min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) when grad_sumsq != NULL and max_norm > 0 (clip_grad_norm_).  The hyper-parameters
  * are doubles: bias corrections and step size are computed in double (torch computes them as Python floats) and rounded once. */
 int jatts_sumsq(const float* x, int64_t n, double* out, void* stream);
 int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                    double weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream);
+                    double weight_decay, int64_t step, const double* grad_sumsq, float max_norm, const float* hyper_dev, void* stream);
+/* hyper_dev (may be NULL): 7 device floats [lr / bc1, 1 - beta1, beta2, 1 - beta2, eps, weight_decay, sqrt(bc2)] that REPLACE the host
+ * scalars -- a captured training step replays with the scalars of the current optimiser step (jatts_amd.training: graph mode). */
 
 /* Profiling hook (not part of the reference interface): while `buf` is non-NULL, thread 0 of the first n_workgroups
  * workgroups of every jatts_hifigan_resunit launch writes 16 uint64 to buf[16*wg ..]: {XCC_ID<<32 | HW_ID, s_memtime

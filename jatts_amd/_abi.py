@@ -154,10 +154,10 @@ PROTOTYPES = {
     "jatts_snakebeta_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_ctc_forward_sum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "jatts_seq_sum": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "jatts_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
-    "jatts_dropout_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
+    "jatts_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "jatts_dropout_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "jatts_sumsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "jatts_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]),
+    "jatts_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "jatts_zero_pad_rows": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "jatts_cfm_mix": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),

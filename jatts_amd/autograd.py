@@ -300,13 +300,13 @@ class Dropout(torch.autograd.Function):
     """Inverted dropout with a counter-based mask (seed, element index): the backward regenerates the mask."""
 
     @staticmethod
-    def forward(ctx, x, p, seed):
-        ctx.p, ctx.seed = p, seed
-        return hip.dropout(x.contiguous(), p, seed)
+    def forward(ctx, x, p, seed, seed_dev=None):
+        ctx.p, ctx.seed, ctx.seed_dev = p, seed, seed_dev
+        return hip.dropout(x.contiguous(), p, seed, seed_dev)
 
     @staticmethod
     def backward(ctx, dy):
-        return hip.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+        return hip.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.seed_dev), None, None, None
 
 
 class ResidualDropAdd(torch.autograd.Function):
@@ -314,14 +314,14 @@ class ResidualDropAdd(torch.autograd.Function):
     backward (d_x = dy is passed through, d_h = alpha * mask(dy) / (1 - p) regenerates the mask)."""
 
     @staticmethod
-    def forward(ctx, x, h, alpha, p, seed):
-        ctx.alpha, ctx.p, ctx.seed = alpha, p, seed
-        return hip.dropout_add(h.contiguous(), x.contiguous(), p, alpha, seed)
+    def forward(ctx, x, h, alpha, p, seed, seed_dev=None):
+        ctx.alpha, ctx.p, ctx.seed, ctx.seed_dev = alpha, p, seed, seed_dev
+        return hip.dropout_add(h.contiguous(), x.contiguous(), p, alpha, seed, seed_dev)
 
     @staticmethod
     def backward(ctx, dy):
-        dh = hip.dropout_add(dy.contiguous(), None, ctx.p, ctx.alpha, ctx.seed) if ctx.needs_input_grad[1] else None
-        return (dy if ctx.needs_input_grad[0] else None), dh, None, None, None
+        dh = hip.dropout_add(dy.contiguous(), None, ctx.p, ctx.alpha, ctx.seed, ctx.seed_dev) if ctx.needs_input_grad[1] else None
+        return (dy if ctx.needs_input_grad[0] else None), dh, None, None, None, None
 
 
 class ForwardSum(torch.autograd.Function):

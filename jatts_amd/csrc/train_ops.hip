@@ -515,7 +515,9 @@ __device__ __forceinline__ uint32_t mix32(uint64_t k) {   // splitmix64 finalise
   k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
   return (uint32_t)((k ^ (k >> 31)) >> 32);
 }
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, uint64_t seed) {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, uint64_t seed,
+                                                      const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // captured graphs: the per-step base seed lives in device memory, `seed` is the site offset
   const float keep_scale = 1.f / (1.f - p);
   const uint32_t thr = (uint32_t)(p * 4294967296.0);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -526,7 +528,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 // x + dropout(attn), x + dropout(conv)) in ONE launch instead of dropout + scale + add; resid may be NULL (the backward of the
 // dropped branch: alpha * mask(dy) / (1 - p)), p may be 0 (a plain scaled add).
 __global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y,
-                                                          int64_t n, float p, float alpha, uint64_t seed) {
+                                                          int64_t n, float p, float alpha, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;
   const float keep_scale = alpha / (1.f - p);
   const uint32_t thr = (uint32_t)(p * 4294967296.0);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -555,7 +558,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // host like torch's Python floats and rounded to f32 once.  gscale = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float step_size, float w1, float b2, float w2, float eps, float wd, float bc2_sqrt,
-                                                   const double* __restrict__ sumsq, float max_norm) {
+                                                   const double* __restrict__ sumsq, float max_norm, const float* __restrict__ hyper) {
+  if (hyper) {   // captured graphs: the per-step scalars [step_size, 1 - beta1, beta2, 1 - beta2, eps, weight_decay, sqrt(bc2)] live in device memory
+    step_size = hyper[0]; w1 = hyper[1]; b2 = hyper[2]; w2 = hyper[3]; eps = hyper[4]; wd = hyper[5]; bc2_sqrt = hyper[6];
+  }
   float gs = 1.f;
   if (sumsq && max_norm > 0.f) {
     const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
@@ -945,20 +951,21 @@ extern "C" int jatts_masked_loss_bwd(const jatts_ragged* rg, const float* a, int
   return JATTS_OK;
 }
 
-extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   NULLCHK(!x || !y, "dropout: null pointer");
   NULLCHK(!(p >= 0.f && p < 1.f), "dropout: 0 <= p < 1");
   if (n <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, y, n, p, seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, y, n, p, seed, seed_dev);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
 
-extern "C" int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, void* stream) {
+extern "C" int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed,
+                                 const uint64_t* seed_dev, void* stream) {
   NULLCHK(!x || !y, "dropout_add: null pointer");
   NULLCHK(!(p >= 0.f && p < 1.f), "dropout_add: 0 <= p < 1");
   if (n <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, resid, y, n, p, alpha, seed);
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_, x, resid, y, n, p, alpha, seed, seed_dev);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -971,13 +978,13 @@ extern "C" int jatts_sumsq(const float* x, int64_t n, double* out, void* stream)
   return JATTS_OK;
 }
 extern "C" int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                               double weight_decay, int64_t step, const double* grad_sumsq, float max_norm, void* stream) {
+                               double weight_decay, int64_t step, const double* grad_sumsq, float max_norm, const float* hyper_dev, void* stream) {
   NULLCHK(!p || !g || !m || !v, "adam_step: null pointer");
   NULLCHK(step < 1, "adam_step: step counts from 1");
   if (n <= 0) return JATTS_OK;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 4096)), dim3(256), 0, S_, p, g, m, v, n, (float)(lr / bc1), (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), grad_sumsq, max_norm);
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), grad_sumsq, max_norm, hyper_dev);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

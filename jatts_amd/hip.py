@@ -73,15 +73,23 @@ class _ZeroPool:
     def __init__(self, device, floats=1 << 20):
         self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
         self.off, self.high, self.misses = 0, 0, 0
+        self.active = False
+        self._retired = []        # outgrown buffers stay alive: captured graphs may still write into them
 
     def begin(self):
+        """Zero everything any step has used so far (the high-water mark: a few hundred KB) and start handing out from the front.  Never
+        allocates: safe inside a graph capture."""
         self.high = max(self.high, self.off)
-        if self.misses:                       # the last step ran out: grow (the next step's accumulators all fit)
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.off = 0
+
+    def end(self):
+        self.high = max(self.high, self.off)
+        if self.misses:           # the step ran out (its overflow used torch.zeros): grow now, outside any capture
+            self._retired.append(self.buf)
             self.buf = torch.zeros(max(2 * self.buf.numel(), 2 * (self.high + self.misses)), dtype=torch.float32, device=self.buf.device)
             self.misses = 0
-        elif self.off:
-            self.buf[:self.off].zero_()
-        self.off = 0
 
     def take(self, numel):
         n = (numel + 15) & ~15
@@ -111,6 +119,8 @@ def zero_pool_begin(device):
 def zero_pool_end():
     if _ZPOOL is not None:
         _ZPOOL.active = False
+        if not torch.cuda.is_current_stream_capturing():
+            _ZPOOL.end()
 
 
 def _zeros(shape, device):
@@ -162,12 +172,32 @@ def h2d(values, dtype, device):
     """Small host list -> device tensor WITHOUT stalling the host: staged through pinned memory and copied asynchronously on the
     current stream.  torch.tensor(values, device=...) copies from pageable memory, which blocks the host until everything already
     queued on the stream has run -- one pipeline drain per call in the middle of a forward pass."""
-    t = torch.tensor(values, dtype=dtype)
-    if torch.device(device).type == "cuda":
-        return t.pin_memory().to(device, non_blocking=True)
-    return t.to(device)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return torch.tensor(values, dtype=dtype, device=dev)
+    # small length-derived arrays repeat from step to step (same bucket of lengths): cached per (values, dtype, device), which also makes
+    # a training step capturable -- a cache hit issues no copy, so a captured graph never holds a memcpy from a host buffer that is gone
+    key = None
+    if isinstance(values, (list, tuple)) and len(values) <= 65536 and (not values or isinstance(values[0], (int, float, bool))):
+        key = (tuple(values), dtype, dev.index if dev.index is not None else torch.cuda.current_device())
+        hit = _H2D_CACHE.get(key)
+        if hit is not None:
+            if hit[2] != torch.cuda.current_stream().cuda_stream and not torch.cuda.is_current_stream_capturing() and not hit[1].query():
+                torch.cuda.current_stream().wait_event(hit[1])
+            return hit[0]
+    if torch.cuda.is_current_stream_capturing():
+        raise _abi.JattsHipError("h2d of new values while a graph is being captured: run the step once outside the capture first")
+    t = torch.tensor(values, dtype=dtype).pin_memory().to(dev, non_blocking=True)
+    if key is not None:
+        ev = torch.cuda.Event()
+        ev.record()
+        if len(_H2D_CACHE) >= 4096:
+            _H2D_CACHE.pop(next(iter(_H2D_CACHE)))
+        _H2D_CACHE[key] = (t, ev, torch.cuda.current_stream().cuda_stream)
+    return t
 
 
+_H2D_CACHE = {}       # (values, dtype, device) -> (tensor, upload-complete event, stream)
 _GEOM_CACHE = {}      # (lens, device) -> (cu tensor, upload-complete event); insertion-ordered, oldest evicted
 _GEOM_CACHE_MAX = 512
 
@@ -201,7 +231,7 @@ class RaggedBatch:
             if len(_GEOM_CACHE) >= _GEOM_CACHE_MAX:
                 _GEOM_CACHE.pop(next(iter(_GEOM_CACHE)))
             _GEOM_CACHE[key] = hit = (t, ev, torch.cuda.current_stream().cuda_stream)
-        elif hit[2] != torch.cuda.current_stream().cuda_stream and not hit[1].query():
+        elif hit[2] != torch.cuda.current_stream().cuda_stream and not torch.cuda.is_current_stream_capturing() and not hit[1].query():
             torch.cuda.current_stream().wait_event(hit[1])     # uploaded on another stream and still in flight
         self.cu = hit[0]
 
@@ -1009,15 +1039,17 @@ def masked_loss_bwd(rb, a, b, valid_len, kind, scale, upstream=None, log_offset=
     return da.view_as(a)
 
 
-def dropout(x, p, seed):
+def dropout(x, p, seed, seed_dev=None):
+    """seed_dev: optional int64 (1,) device tensor -- the mask seed is then *seed_dev + seed (graph mode: per-step base on the device)."""
     lib = _abi.load()
     x = _f32c(x)
     y = torch.empty_like(x)
-    _abi.check(lib.jatts_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "jatts_dropout")
+    _abi.check(lib.jatts_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(seed_dev), _stream()),
+               "jatts_dropout")
     return y
 
 
-def dropout_add(x, resid, p, alpha, seed):
+def dropout_add(x, resid, p, alpha, seed, seed_dev=None):
     """resid + alpha * dropout(x) (resid may be None); see jatts_dropout_add."""
     lib = _abi.load()
     x = _f32c(x)
@@ -1027,7 +1059,7 @@ def dropout_add(x, resid, p, alpha, seed):
             raise ValueError("dropout_add: shape mismatch")
     y = torch.empty_like(x)
     _abi.check(lib.jatts_dropout_add(x.data_ptr(), _ptr(resid), y.data_ptr(), x.numel(), float(p), float(alpha),
-                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "jatts_dropout_add")
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(seed_dev), _stream()), "jatts_dropout_add")
     return y
 
 
@@ -1039,11 +1071,17 @@ def sumsq(x, out):
     return out
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq=None, max_norm=0.0):
+def adam_hyper(lr, beta1, beta2, eps, weight_decay, step):
+    """The 7 per-step scalars of jatts_adam_step's hyper_dev, computed in double like torch: [lr / bc1, 1 - b1, b2, 1 - b2, eps, wd, sqrt(bc2)]."""
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    return [lr / bc1, 1.0 - beta1, beta2, 1.0 - beta2, eps, weight_decay, bc2 ** 0.5]
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq=None, max_norm=0.0, hyper_dev=None):
     lib = _abi.load()
     _abi.check(lib.jatts_adam_step(_f32c(p).data_ptr(), _f32c(g).data_ptr(), _f32c(m).data_ptr(), _f32c(v).data_ptr(), p.numel(), float(lr),
                                    float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _ptr(grad_sumsq), float(max_norm),
-                                   _stream()), "jatts_adam_step")
+                                   _ptr(hyper_dev), _stream()), "jatts_adam_step")
 
 
 def groupnorm_fwd(rb, x, groups, gamma, beta, eps):

@@ -28,20 +28,25 @@ class _Ctx:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()          # data-parallel replicas draw different dropout masks
         self.seed = (int(seed) * 4099 + rank) * 1000003
+        # graph mode (training.py): the per-step base seed lives in a device tensor the trainer rewrites before every replay; the call
+        # sites then pass only their offset
+        self.seed_dev = getattr(model, "_seed_dev", None)
+        if self.seed_dev is not None:
+            self.seed = 0
         self.n_drop = 0
 
     def drop(self, x, rate):
         if not self.train or rate <= 0.0:
             return x
         self.n_drop += 1
-        return A.Dropout.apply(x, rate, self.seed + self.n_drop)
+        return A.Dropout.apply(x, rate, self.seed + self.n_drop, self.seed_dev)
 
     def resid_drop(self, x, h, rate, alpha=1.0):
         """x + alpha * dropout(h): one launch (ResidualDropAdd) instead of dropout, scale and add."""
         rate = rate if self.train else 0.0
         if rate > 0.0:
             self.n_drop += 1
-        return A.ResidualDropAdd.apply(x, h, alpha, max(rate, 0.0), self.seed + self.n_drop)
+        return A.ResidualDropAdd.apply(x, h, alpha, max(rate, 0.0), self.seed + self.n_drop, self.seed_dev)
 
     def conv(self, x, name, rb, dil=1, pad=None, bias=True):
         w = self.p[name + ".weight"]
@@ -64,6 +69,22 @@ class _Ctx:
         return x * s + (self.p[name + ".bias"] - self.b[name + ".running_mean"] * s)
 
 
+_POS_TABLES = {}
+
+
+def _pos_table(rel_style, T, Ad, device):
+    """rel_style "new": RelPositionalEncoding's (2T-1, A) table (positional_encoding.py:265-309); "legacy": pe[:, :T] of the reversed table
+    (positional_encoding.py:221-235).  Constant per (style, T, A): kept on the device (also what makes the step capturable)."""
+    key = (rel_style, T, Ad, str(device))
+    t = _POS_TABLES.get(key)
+    if t is None:
+        t = (rel_pos_table_new(T, Ad) if rel_style == "new" else legacy_rel_pos_table(T, Ad, max(PE_TABLE_LEN, T))).to(device)
+        if len(_POS_TABLES) >= 64:
+            _POS_TABLES.pop(next(iter(_POS_TABLES)))
+        _POS_TABLES[key] = t
+    return t
+
+
 def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
     """conformer/encoder.py:233-289 after the input layer: x (rows, A) is already x * sqrt(A) (+ positional dropout).
     rel_style "legacy": LegacyRelPositionalEncoding / LegacyRelPositionMultiHeadedAttention (FastSpeech2, Matcha-TTS);
@@ -71,10 +92,7 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
     B, T = rb.n_seq, rb.max_len
     Ad = x.shape[1]
     dk = Ad // H
-    if rel_style == "new":
-        pos = rel_pos_table_new(T, Ad).to(x.device)                                # (2T-1, A) (positional_encoding.py:265-309)
-    else:
-        pos = legacy_rel_pos_table(T, Ad, max(PE_TABLE_LEN, T)).to(x.device)      # pe[:, :T] (positional_encoding.py:221-235)
+    pos = _pos_table(rel_style, T, Ad, x.device)       # device copy cached per (style, T, A): rebuilt on the host + uploaded once, not per layer stack per step
     n_pos = pos.shape[0]
     pos = c.drop(pos, rates["pos"])
     rbp = hip.RaggedBatch([n_pos], x.device)
@@ -163,11 +181,14 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     rb = hip.RaggedBatch([Tm] * B, dev)
     # length-derived device tensors and the one host read-back (output lengths = duration sums) happen here, before GPU work is queued
     kv = hip.h2d(ilens, torch.int32, dev)
-    kvo = olens.to(device=dev, dtype=torch.int32).contiguous()
+    kvo = hip.h2d([int(v) for v in olens.tolist()], torch.int32, dev) if not olens.is_cuda else olens.to(torch.int32).contiguous()
     ids = xs.reshape(-1).to(torch.int64).contiguous()
     x = A.Embedding.apply(ids, c.p["encoder.embed.0.weight"], math.sqrt(Ad), model.padding_idx)
-    ol_h = [int(v) for v in ds.sum(1).tolist()]
-    hip.check_bad_ids(dev)     # ids outside the table (zero rows, counted by the kernel) raise here like nn.Embedding: the sync above is needed anyway
+    if getattr(model, "_static_olens", None) is not None:      # graph mode: the trainer checked once that sum(durations) == these lengths
+        ol_h = list(model._static_olens)
+    else:
+        ol_h = [int(v) for v in ds.sum(1).tolist()]
+        hip.check_bad_ids(dev)     # ids outside the table (zero rows, counted by the kernel) raise here like nn.Embedding: the sync above is needed anyway
     x = c.drop(x, R["enc_pos"])
     hs = _conformer(c, "encoder.", x, rb, kv, model.aheads, dict(pos=R["enc_pos"], layer=R["enc"], ffn=R["enc"], attn=R["enc_attn"]))
     if model.spks is not None:                                       # fastspeech2.py:589-592
@@ -230,8 +251,9 @@ def criterion(ret, durations, pitch, energy, ilens, use_masking=True):
     B, To, od = before.shape
     Tm = ret["d_outs"].shape[1]
     rbo, rbt = hip.RaggedBatch([To] * B, dev), hip.RaggedBatch([Tm] * B, dev)
-    vo = olens.to(device=dev, dtype=torch.int32) if use_masking else None
-    vi = ilens.to(device=dev, dtype=torch.int32) if use_masking else None
+    _len32 = lambda t: t.to(torch.int32) if t.is_cuda else hip.h2d([int(v) for v in t.tolist()], torch.int32, dev)  # noqa: E731  (cached: no copy under capture)
+    vo = _len32(olens) if use_masking else None
+    vi = _len32(ilens) if use_masking else None
     n_o = float(int(olens.sum()) if use_masking else B * To) * od
     n_i = float(int(ilens.sum()) if use_masking else B * Tm)
     ys2 = ys.to(dev).float().reshape(B * To, od).contiguous()

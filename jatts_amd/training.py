@@ -175,7 +175,7 @@ class FastSpeech2Trainer:
     the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
 
     def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
-                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1, scheduler="warmuplr", scheduler_params=None):
+                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1, scheduler="warmuplr", scheduler_params=None, capture_graph=False):
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
         self.overlap = overlap
@@ -207,6 +207,11 @@ class FastSpeech2Trainer:
         self.steps = 0
         self.last_lr = None
         self._bad_ids = None
+        # graph mode: the whole step (forward, losses, backward, clip + Adam) of a batch SIGNATURE (shapes + length tuples: a length bucket)
+        # captured once as a hipGraph and replayed; the first step of a signature runs eagerly (it fills every per-lengths cache), the
+        # second is captured.  See _graph_step.
+        self.capture_graph = bool(capture_graph) and self._graph_capable
+        self._graphs = {}
         self._buckets = None
 
     # -- gradient all-reduce overlapped with backward (what DistributedDataParallel's reducer does for the reference): the flat gradient
@@ -348,11 +353,96 @@ class FastSpeech2Trainer:
         finally:
             self.model.train(was)
 
+    _graph_capable = True      # subclasses whose step still synchronises with the host (MAS durations, scipy priors) switch it off
+
+    def _signature(self, batch):
+        sig = []
+        for k in sorted(batch):
+            v = batch[k]
+            if v is None:
+                continue
+            if torch.is_tensor(v) and not v.is_cuda and v.dim() == 1 and v.dtype in (torch.int64, torch.int32):
+                sig.append((k, tuple(int(x) for x in v.tolist())))          # length vectors: part of the bucket
+            elif torch.is_tensor(v):
+                sig.append((k, tuple(v.shape), str(v.dtype)))
+            else:
+                sig.append((k, repr(v)))
+        return tuple(sig)
+
+    def _graph_step(self, batch):
+        """One optimiser step by graph replay.  Preconditions (checked where they can be): world size 1, no gradient accumulation, the
+        length vectors (ilens / olens / *_lens) are CPU tensors, sum(durations) == olens per utterance."""
+        dev = self.flat_p.device
+        sig = self._signature(batch)
+        st = self._graphs.get(sig)
+        if st is None:                       # first sight of this bucket: eager step, remember the verified frame counts
+            if "durations" in batch and batch["durations"] is not None:
+                dsum = [int(v) for v in batch["durations"].sum(1).tolist()]
+                if dsum != [int(v) for v in batch["olens"].tolist()]:
+                    raise ValueError("graph mode needs sum(durations) == olens for every utterance")
+            self._graphs[sig] = {"graph": None}
+            return self._train_step(batch)
+        if st["graph"] is None:              # second sight: capture
+            st["in"] = {k: (v.to(dev).clone() if torch.is_tensor(v) and (v.is_cuda or v.dim() != 1 or v.dtype not in (torch.int64, torch.int32)) else v)
+                        for k, v in batch.items()}
+            st["seed"] = torch.zeros(1, dtype=torch.int64, device=dev)
+            st["hyper"] = torch.zeros(7, dtype=torch.float32, device=dev)
+            st["seed_host"] = torch.zeros(1, dtype=torch.int64).pin_memory()
+            st["hyper_host"] = torch.zeros(7, dtype=torch.float32).pin_memory()
+            m = self.model
+            m._seed_dev, m._static_olens = st["seed"], [int(v) for v in batch["olens"].tolist()]
+            g = torch.cuda.CUDAGraph()
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    hip.zero_pool_begin(dev)
+                    self.flat_g.zero_()
+                    losses = self.compute_losses(st["in"])
+                    losses["loss"].backward()
+                    ss = None
+                    if self.grad_norm and self.grad_norm > 0:
+                        ss = torch.zeros((), dtype=torch.float64, device=dev)
+                        hip.sumsq(self.flat_g, ss)
+                    hip.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, self.betas[0], self.betas[1], self.eps, self.wd, 1,
+                                  grad_sumsq=ss, max_norm=self.grad_norm or 0.0, hyper_dev=st["hyper"])
+                    st["out"] = {k: v.detach() for k, v in losses.items()}
+                    if ss is not None:
+                        st["out"]["grad_norm"] = ss.sqrt()
+            finally:
+                hip.zero_pool_end()
+                m._seed_dev, m._static_olens = None, None
+            st["graph"] = g
+        # replay: refresh the static inputs and the per-step scalars (all stream-ordered copies; no host wait)
+        for k, v in batch.items():
+            if torch.is_tensor(v) and torch.is_tensor(st["in"].get(k)) and st["in"][k].is_cuda:
+                st["in"][k].copy_(v, non_blocking=True)
+        self.steps += 1
+        lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **self._sched_params())
+        self.last_lr = lr
+        rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        st["seed_host"][0] = ((self.steps - 1) * self.accumulate + 1) * 4099 * 1000003 + rank * 1000003   # == _Ctx's (seed * 4099 + rank) * 1000003
+        st["hyper_host"].copy_(torch.tensor(hip.adam_hyper(lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps), dtype=torch.float32))
+        st["seed"].copy_(st["seed_host"], non_blocking=True)
+        st["hyper"].copy_(st["hyper_host"], non_blocking=True)
+        st["graph"].replay()
+        self.model._prep = None
+        return dict(st["out"])
+
     def train_step(self, batch):
         """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
         m = self.model
         m.train()
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if self.capture_graph and not multi and self.accumulate == 1:
+            sig_seen = self._graphs.get(self._signature(batch))
+            if sig_seen is not None:
+                return self._graph_step(batch)          # capture / replay
+            hip.zero_pool_begin(self.flat_p.device)
+            try:
+                return self._graph_step(batch)          # first sight: eager (inside an open zero pool, like every eager step)
+            finally:
+                hip.zero_pool_end()
         hip.zero_pool_begin(self.flat_p.device)     # the step's small zero-initialised accumulators: one fill instead of ~550
         try:
             return self._train_step(batch)
@@ -410,6 +500,8 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
     all-reduce and checkpoint layout as FastSpeech2Trainer; the duration loss joins once `steps > dp_train_start_steps`
     (trainers/matchatts.py:66-75).  ``cfm_t`` / ``cfm_noise`` in the batch inject the two random draws of CFM.compute_loss."""
 
+    _graph_capable = False     # CFM draws / MAS durations / the scipy prior are still host-driven here
+
     def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, **kw):
         super().__init__(model, **kw)
         self.dp_train_start_steps, self.bin_loss_start_steps, self.lambda_align = dp_train_start_steps, bin_loss_start_steps, lambda_align
@@ -431,6 +523,8 @@ class VITSTrainer(FastSpeech2Trainer):
     duration loss after `dp_train_start_steps`, lambda_align x ForwardSumLoss before it, lambda_align x the binarisation loss
     after `bin_loss_start_steps`; same flat-buffer optimiser / all-reduce / checkpoint layout.  ``post_noise`` in the batch
     injects the posterior encoder's random draw.  (gradient_accumulate_steps = 1.)"""
+
+    _graph_capable = False
 
     def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, lambda_mel=1.0, **kw):
         super().__init__(model, **kw)

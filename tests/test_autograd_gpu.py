@@ -386,9 +386,9 @@ def test_residual_drop_add_and_zero_pool(cuda, lib):
         hip.zero_pool_begin(cuda)
         outs = [hip.col_sum(a) for _ in range(5)]            # 5 x 384 floats > 1024
         assert all(float((o - plain).abs().max()) <= 2e-3 for o in outs) and hip._ZPOOL.misses > 0
-        hip.zero_pool_end()
-        hip.zero_pool_begin(cuda)
+        hip.zero_pool_end()                                  # grows here (never inside begin(): a capture must not allocate)
         assert hip._ZPOOL.buf.numel() > 1024 and hip._ZPOOL.misses == 0
+        hip.zero_pool_begin(cuda)
         outs = [hip.col_sum(a) for _ in range(5)]
         assert all(float((o - plain).abs().max()) <= 2e-3 for o in outs)
         hip.zero_pool_end()

@@ -238,7 +238,7 @@ def test_trainer_checkpoint_is_the_reference_format_and_resumes(cuda, lib, tmp_p
     assert b.steps == 2
     la, lb = a.train_step(batch), b.train_step(batch)
     assert abs(float(la["loss"]) - float(lb["loss"])) <= 1e-6 * abs(float(la["loss"]))
-    assert maxdiff(a.flat_p, b.flat_p) <= 1e-7 and abs(a.last_lr - b.last_lr) == 0.0
+    assert maxdiff(a.flat_p, b.flat_p) <= 5e-7 and abs(a.last_lr - b.last_lr) == 0.0      # (one f32 ulp at |p| ~ 1 is 1.2e-7: the atomics-based reductions)
 
 
 def test_fastspeech2_speaker_conditioned_train_step_matches_reference(cuda, lib):
@@ -641,3 +641,49 @@ def test_out_of_range_token_ids_raise_like_nn_embedding(cuda, lib):
     with pytest.raises(IndexError):
         m(bad["xs"], il, bad["ys"], ol, bad["durations"], il, bad["pitch"], il, bad["energys"], il)
     tr.train_step(batch)                                     # and the trainer carries on with a good batch
+
+
+def test_graph_mode_replays_the_same_training(cuda, lib):
+    """FastSpeech2Trainer(capture_graph=True): the first step of a batch signature (shapes + length tuples) runs eagerly, the second is
+    captured as ONE graph (forward, losses, backward, clip + Adam), later ones replay it with the inputs, the dropout base seed and the
+    Adam / lr scalars refreshed on the device.  Against an eager trainer on the same data, dropout ON: same losses and parameters step
+    by step (to the rounding of the atomics-based reductions), also when the DATA changes under the same signature."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+
+    def make():           # the recipe's dropout rates (FS2_SMALL's defaults)
+        m = FastSpeech2(idim=20, **{**FS2_SMALL, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+        m.load_state_dict(golden_state(keys, 0))
+        return m.to(cuda)
+    a = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=10)
+    b = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=10, capture_graph=True)
+    g = torch.Generator().manual_seed(0)
+    for step in range(6):
+        cur = dict(batch)
+        if step >= 3:                                        # new data, same signature: the static inputs must be refreshed
+            cur["ys"] = batch["ys"] + 0.1 * torch.randn(batch["ys"].shape, generator=g)
+            cur["pitch"] = batch["pitch"] + 0.1 * torch.randn(batch["pitch"].shape, generator=g)
+        la, lb = a.train_step(cur), b.train_step(cur)
+        for k in ("loss", "mel_loss", "duration_loss", "pitch_loss", "energy_loss", "grad_norm"):
+            assert abs(float(la[k]) - float(lb[k])) <= 2e-5 * max(1.0, abs(float(la[k]))), (step, k, float(la[k]), float(lb[k]))
+        assert a.steps == b.steps == step + 1 and a.last_lr == b.last_lr
+        assert maxdiff(a.flat_g, b.flat_g) <= 2e-5, (step, maxdiff(a.flat_g, b.flat_g))      # same gradients (to the atomics' rounding)
+        # parameters: Adam turns a gradient that is pure rounding noise (the depthwise-conv bias in front of BatchNorm: exactly zero in
+        # exact arithmetic) into +-lr steps, in eager mode from run to run as well -- compare where the gradient carries signal
+        o = 0
+        for p_ in a.params:
+            k = p_.numel()
+            if float(a.flat_g[o:o + k].abs().max()) > 1e-4:
+                assert maxdiff(a.flat_p[o:o + k], b.flat_p[o:o + k]) <= 5e-6, (step, o)
+            o += k
+    (st,) = b._graphs.values()
+    assert st["graph"] is not None                           # steps 2.. were replays of one captured graph
+    # running BatchNorm statistics follow too (buffers are updated inside the graph)
+    for (n1, b1), (_, b2) in zip(a.model.named_buffers(), b.model.named_buffers()):
+        if b1.dtype.is_floating_point:
+            assert maxdiff(b1, b2) <= 2e-4 * max(1.0, float(b1.abs().max())), n1
