@@ -58,9 +58,9 @@ def _tblock(c, p, x, rb, heads, key_bias, rate):
 
 
 def sinusoidal_time_embedding(t, od):
-    """SinusoidalPosEmb(2 odim) of decoder.py:48-63 on the host: (B,) -> (B, 2 odim)."""
-    freq = torch.exp(torch.arange(od).float() * -(math.log(10000) / (od - 1)))
-    emb = 1000.0 * t.reshape(-1, 1).float().cpu() * freq.unsqueeze(0)
+    """SinusoidalPosEmb(2 odim) of decoder.py:48-63, on t's device: (B,) -> (B, 2 odim)."""
+    freq = torch.exp(torch.arange(od, device=t.device).float() * -(math.log(10000) / (od - 1)))
+    emb = 1000.0 * t.reshape(-1, 1).float() * freq.unsqueeze(0)
     return torch.cat((emb.sin(), emb.cos()), dim=-1).contiguous()
 
 
@@ -133,14 +133,15 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
     Te = max(olens_in)
     v1 = hip.h2d(olens_in, torch.int32, dev)
     v2 = hip.h2d([n // 2 for n in olens_in], torch.int32, dev)
-    t = (torch.rand(B) if cfm_t is None else cfm_t.reshape(B).float().cpu())
-    t_dev = t.to(dev).contiguous()
-    temb = sinusoidal_time_embedding(t, od).to(dev)
-    z = (torch.randn(B, Te, od) if cfm_noise is None else cfm_noise[:, :Te].float()).to(dev).reshape(B * Te, od).contiguous()
+    # the two CFM draws (flow_matching.py:104-110: rand / randn_like on the model's device) are generated ON the device: a host randn of
+    # B x Te x odim elements plus its upload was ~10 ms of every step
+    t_dev = (torch.rand(B, device=dev) if cfm_t is None else cfm_t.reshape(B).float().to(dev)).contiguous()
+    temb = sinusoidal_time_embedding(t_dev, od)
+    z = (torch.randn(B, Te, od, device=dev) if cfm_noise is None else cfm_noise[:, :Te].float().to(dev)).reshape(B * Te, od).contiguous()
     extra = {}
     if model._MAS:
         from ..alignments import frame_token_indices
-        extra["_prior"] = beta_binomial_prior(ilens, olens).to(dev)                         # ForwardSumLoss's static prior (host scipy)
+        extra["_prior"] = beta_binomial_prior_dev(ilens, olens, dev)                         # ForwardSumLoss's static prior (host scipy)
         kvo = hip.h2d(olens, torch.int32, dev)
         tsel, fsel = frame_token_indices(ilens, olens, Tm, To, dev)
         tm_ = torch.arange(Tm, device=dev).unsqueeze(0) < kv.unsqueeze(1)                   # (B, Tm) valid tokens
@@ -212,6 +213,22 @@ def beta_binomial_prior(ilens, olens, w=1.0):
     return out
 
 
+_PRIOR_DEV = {}
+
+
+def beta_binomial_prior_dev(ilens, olens, device):
+    """beta_binomial_prior on the device, cached per (ilens, olens, device): the (B, To, Tm) tensor is 12.6 MB at the recipes' batch -- assembling
+    it on the host and uploading it from pageable memory cost ~10 ms of every MAS-phase step."""
+    key = (tuple(ilens), tuple(olens), str(device))
+    t = _PRIOR_DEV.get(key)
+    if t is None:
+        t = beta_binomial_prior(list(ilens), list(olens)).to(device)
+        if len(_PRIOR_DEV) >= 16:
+            _PRIOR_DEV.pop(next(iter(_PRIOR_DEV)))
+        _PRIOR_DEV[key] = t
+    return t
+
+
 def criterion(ret, durations, ilens, duration_loss=True, olens=None, forward_sum=False, bin_loss=False, lambda_align=2.0):
     """The loss block of MatchaTTSTrainer._train_step (trainers/matchatts.py:47-103): CFMLoss + EncoderPriorLoss, the duration loss
     once `steps > dp_train_start_steps` (``duration_loss``); for the MAS model also lambda_align x ForwardSumLoss while
@@ -227,7 +244,7 @@ def criterion(ret, durations, ilens, duration_loss=True, olens=None, forward_sum
     total = ret["cfm_loss"] + prior
     if forward_sum:
         il, ol = [int(v) for v in ilens.tolist()], [int(v) for v in olens.tolist()]
-        lp = ret["log_p_attn"] + (ret["_prior"] if "_prior" in ret else beta_binomial_prior(il, ol).to(dev))
+        lp = ret["log_p_attn"] + (ret["_prior"] if "_prior" in ret else beta_binomial_prior_dev(il, ol, dev))
         out["forward_sum_loss"] = A.ForwardSum.apply(lp, ilens, olens, -1.0)                # blank_prob = e^-1
         total = total + lambda_align * out["forward_sum_loss"]
     if bin_loss:

@@ -63,10 +63,12 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, spembs, post_
     kv = hip.h2d(ilens, torch.int32, dev)
     kvo = hip.h2d(olens, torch.int32, dev)
     from ..alignments import frame_token_indices
-    from .matchatts_train import beta_binomial_prior
+    from .matchatts_train import beta_binomial_prior_dev
     tsel, fsel = frame_token_indices(ilens, olens, Tm, To, dev)
-    prior = beta_binomial_prior(ilens, olens).to(dev)                                          # ForwardSumLoss's static prior
-    nz_all = (torch.randn(B, To, Ad) if post_noise is None else post_noise[:, :To].float()).to(dev).reshape(B * To, Ad)
+    prior = beta_binomial_prior_dev(ilens, olens, dev)                                         # ForwardSumLoss's static prior (cached on the device)
+    # the posterior draw (vits.py:479 randn_like on the model's device): generated ON the device -- a host randn of B x To x A elements (9.4 M at
+    # the recipe's batch) plus its upload cost ~50 ms of a 210 ms step
+    nz_all = (torch.randn(B, To, Ad, device=dev) if post_noise is None else post_noise[:, :To].float().to(dev)).reshape(B * To, Ad)
     spk = spembs.to(dev).float().reshape(B, -1).contiguous()
     tmk = torch.arange(Tm, device=dev).unsqueeze(0) < kv.unsqueeze(1)
     fm = (torch.arange(To, device=dev).unsqueeze(0) < kvo.unsqueeze(1)).float()
@@ -134,7 +136,7 @@ def criterion(ret, ilens, olens, duration_loss=True, forward_sum=False, bin_loss
     """The loss block of VITSTrainer._train_step (trainers/vits.py:47-110): lambda_mel x MelLoss (L1 on `outs`) + KLDivergenceLoss
     (losses/kldivergence_loss.py:17-49), the duration loss once `steps > dp_train_start_steps`, lambda_align x ForwardSumLoss while
     `steps < dp_train_start_steps`, lambda_align x the binarisation loss once `steps > bin_loss_start_steps`."""
-    from .matchatts_train import beta_binomial_prior
+    from .matchatts_train import beta_binomial_prior_dev
     outs = ret["outs"]
     dev = outs.device
     B, To, od = outs.shape
@@ -155,7 +157,7 @@ def criterion(ret, ilens, olens, duration_loss=True, forward_sum=False, bin_loss
         total = total + out["duration_loss"]
     if forward_sum:
         il, ol = [int(v) for v in ilens.tolist()], [int(v) for v in olens.tolist()]
-        prior = ret["_prior"] if "_prior" in ret else beta_binomial_prior(il, ol).to(dev)
+        prior = ret["_prior"] if "_prior" in ret else beta_binomial_prior_dev(il, ol, dev)
         out["forward_sum_loss"] = A.ForwardSum.apply(ret["log_p_attn"] + prior, ilens, olens, -1.0)
         total = total + lambda_align * out["forward_sum_loss"]
     if bin_loss:
