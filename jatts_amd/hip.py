@@ -1139,8 +1139,10 @@ def ctc_forward_sum(log_p, ilens, olens, log_blank, want_grad=True, grad_scale=1
     ws = torch.empty(2 * B * T * (2 * max_i + 1), dtype=torch.float32, device=log_p.device)
     nll = torch.empty(B, dtype=torch.float32, device=log_p.device)
     grad = torch.empty_like(log_p) if want_grad else None
-    il = ilens.to(device=log_p.device, dtype=torch.int32).contiguous()
-    ol = olens.to(device=log_p.device, dtype=torch.int32).contiguous()
+    # (cached pinned uploads: .to(device) of a pageable CPU tensor blocks the host until everything queued so far -- the whole forward --
+    # has run: 50 ms per VITS step)
+    _up = lambda t: t.to(torch.int32).contiguous() if t.is_cuda else h2d([int(v) for v in t.tolist()], torch.int32, log_p.device)  # noqa: E731
+    il, ol = _up(ilens), _up(olens)
     _abi.check(lib.jatts_ctc_forward_sum(log_p.data_ptr(), B, T, ld, il.data_ptr(), ol.data_ptr(), max_i, float(log_blank), ws.data_ptr(),
                                          nll.data_ptr(), _ptr(grad), float(grad_scale), _stream()), "jatts_ctc_forward_sum")
     return nll, grad

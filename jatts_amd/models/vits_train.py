@@ -142,8 +142,9 @@ def criterion(ret, ilens, olens, duration_loss=True, forward_sum=False, bin_loss
     B, To, od = outs.shape
     Tm = ret["d_outs"].shape[1]
     rbf, rbt = hip.RaggedBatch([To] * B, dev), hip.RaggedBatch([Tm] * B, dev)
-    vo = olens.to(device=dev, dtype=torch.int32)
-    vi = ilens.to(device=dev, dtype=torch.int32)
+    # (cached pinned uploads: a .to(device) of a pageable CPU tensor here blocks the host until the whole queued forward has run)
+    vo = olens.to(torch.int32) if olens.is_cuda else hip.h2d([int(v) for v in olens.tolist()], torch.int32, dev)
+    vi = ilens.to(torch.int32) if ilens.is_cuda else hip.h2d([int(v) for v in ilens.tolist()], torch.int32, dev)
     n_o = float(int(olens.sum())) * od
     mel = A.MaskedLoss.apply(outs.reshape(B * To, od), ret["ys"].reshape(B * To, od).contiguous(), rbf, vo, 0, 1.0 / n_o, -1.0)
     zm = ret["y_mask"]
