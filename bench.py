@@ -400,9 +400,10 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
              energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il,
              spkembs=torch.randn(batch, 192, generator=g).to(dev) if kind == "vits" else None)
     cls = {"fs2": FastSpeech2Trainer, "matcha": MatchaTTSTrainer, "matcha_mas": MatchaTTSTrainer, "vits": VITSTrainer}[kind]
-    # FastSpeech2: the whole step replayed as ONE captured hipGraph per batch signature (the other trainers' steps still talk to the host:
-    # MAS durations, scipy prior, CFM draws); the first call runs eagerly, the second captures, the timed ones replay
-    graph = kind == "fs2"
+    # FastSpeech2 / tts1 Matcha: the whole step replayed as ONE captured hipGraph per batch signature (the MAS models' steps still talk to
+    # the host: the search's durations come back mid-step); a signature's first call runs eagerly, its second captures, the timed ones
+    # replay (Matcha's signature changes once after step 1, when the duration loss joins)
+    graph = kind in ("fs2", "matcha")
     tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=graph, **extra)
     from jatts_amd import hip
     hip.flops_begin()            # dense work of ONE step as launched: 2 c_in n_out k rows per conv forward / dgrad / wgrad launch
@@ -410,8 +411,10 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     torch.cuda.synchronize()
     dense_tflop = hip.flops_end() / 1e12
     if graph:
-        tr.train_step(b)         # capture + first replay
+        for _ in range(3):       # (eager first sight of the steady-state signature,) capture + first replay, one more replay
+            tr.train_step(b)
         torch.cuda.synchronize()
+        assert any(st.get("graph") is not None for st in tr._graphs.values()), "graph mode did not capture"
     per = []
     for _ in range(steps):       # every step timed on its own (a step ends in the optimiser kernels: nothing to overlap with the next one);
         t0 = time.perf_counter()  # the MEDIAN is reported: these steps launch 2 300-6 200 kernels each and a busy host shows up as outliers

@@ -45,6 +45,10 @@ __global__ void fold_loss_kernel(const double* part, int n, double scale, float*
 // One workgroup = a 64(n) x 64(c) tile of one tap over a slice of the sequences; a thread owns 4 x 4 outputs; dy / x tiles of
 // 32 time steps go through LDS; partial sums are added with f32 atomics (f32 FMA at the f32-MFMA rate on gfx950).
 constexpr int WG_TT = 32;
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const float* x, int ldx, const float* dy, int ldy, int c_in,
                                                          int n_out, int k_w, int dil, int pad, int seq_groups, float* dw) {
   __shared__ float dys[WG_TT][64 + 4];
@@ -315,9 +319,10 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
     JATTS_CHECK_LAUNCH();
     return JATTS_OK;
   }
-  if (workspace) {   // the VALU fallback accumulates with atomics: it needs a zeroed dw
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)n_out * c_in * k_w * sizeof(float), S_);
-    if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
+  if (workspace) {   // the VALU fallback accumulates with atomics: it needs a zeroed dw (a kernel, not hipMemsetAsync: under stream
+                     // capture the memset did not reliably replay with the graph -- tests/test_training_gpu.py, Matcha graph mode)
+    const int64_t total = (int64_t)n_out * c_in * k_w;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, S_, dw, total);
   }
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)(k_w * groups)), dim3(256), 0, S_,
                      *rg, x, ldx, dy, ldy, c_in, n_out, k_w, dil, pad, groups, dw);

@@ -500,11 +500,17 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
     all-reduce and checkpoint layout as FastSpeech2Trainer; the duration loss joins once `steps > dp_train_start_steps`
     (trainers/matchatts.py:66-75).  ``cfm_t`` / ``cfm_noise`` in the batch inject the two random draws of CFM.compute_loss."""
 
-    _graph_capable = False     # CFM draws / MAS durations / the scipy prior are still host-driven here
+    # graph mode: the tts1 model only (ground-truth durations; the CFM draws are device draws, graph-safe through torch's generator).
+    # The MAS model's durations still make a host round trip inside the step.
 
     def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, **kw):
         super().__init__(model, **kw)
         self.dp_train_start_steps, self.bin_loss_start_steps, self.lambda_align = dp_train_start_steps, bin_loss_start_steps, lambda_align
+        if model._MAS:
+            self.capture_graph = False
+
+    def _signature(self, batch):      # the loss schedule is part of the graph
+        return super()._signature(batch) + (("duration_loss", self.steps > self.dp_train_start_steps),)
 
     def compute_losses(self, batch):
         from .models.matchatts_train import criterion, train_forward

@@ -326,6 +326,50 @@ def test_matcha_tts1_training_reduces_the_loss(cuda, lib):
     assert all(math.isfinite(v) for v in cfm) and min(cfm[-3:]) < 0.9 * cfm[0], cfm
 
 
+def test_matcha_tts1_graph_mode_replays_the_same_training(cuda, lib):
+    """MatchaTTSTrainer(capture_graph=True) on the tts1 model: step 1 eager (no duration loss), step 2 eager again (the loss schedule
+    is part of the signature: the duration loss joined), step 3 captured, later steps replayed -- same losses and gradients as an eager
+    trainer on the same data and injected CFM draws, dropout on.  Without injected draws the graph draws them on the device each
+    replay (torch's generator is graph-safe): losses differ from replay to replay and stay finite."""
+    import json
+    from jatts_amd.models import MatchaTTS
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    from jatts_amd.training import MatchaTTSTrainer
+    z, keys = load_golden("matcha_tts1_train_small.npz")
+    zi, _ = load_golden("matcha_tts1_forward_small.npz")
+    cfg = {**json.loads(str(z["config"])), "transformer_enc_dropout_rate": 0.1, "decoder_dropout": 0.05}
+
+    def make():
+        m = MatchaTTS(idim=20, **cfg)
+        m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 4)))
+        return m.to(cuda)
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il = t("text_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=t("feats_lengths"), durations=t("durations"), duration_lens=il,
+                 cfm_t=t("t"), cfm_noise=t("z"))
+    a = MatchaTTSTrainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0)
+    b = MatchaTTSTrainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0, capture_graph=True)
+    g = torch.Generator().manual_seed(1)
+    for step in range(6):
+        cur = dict(batch)
+        if step >= 4:
+            cur["cfm_noise"] = torch.randn(batch["cfm_noise"].shape, generator=g)
+        la, lb = a.train_step(cur), b.train_step(cur)
+        assert set(la) == set(lb)
+        for k in la:
+            tol = 2e-5 * (1 + 5 * step)
+            assert abs(float(la[k]) - float(lb[k])) <= tol * max(1.0, abs(float(la[k]))), (step, k, float(la[k]), float(lb[k]))
+        assert a.steps == b.steps == step + 1 and a.last_lr == b.last_lr
+        assert maxdiff(a.flat_g, b.flat_g) <= 2e-5 * (1 + 5 * step) * max(1.0, float(a.flat_g.abs().max())), (step, maxdiff(a.flat_g, b.flat_g))
+    assert len(b._graphs) == 2                                 # (no duration loss) eager only; (duration loss) captured
+    assert sum(st["graph"] is not None for st in b._graphs.values()) == 1
+    # device draws inside the graph
+    free = {k: v for k, v in batch.items() if not k.startswith("cfm_")}
+    c = MatchaTTSTrainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=0, capture_graph=True)
+    vals = [float(c.train_step(free)["cfm_loss"]) for _ in range(6)]
+    assert all(math.isfinite(v) for v in vals) and len({round(v, 6) for v in vals[3:]}) == 3, vals
+
+
 def test_matcha_mas_train_step_matches_reference(cuda, lib):
     """MatchaTTS_MAS (tts2 recipe) with every loss term of jatts/trainers/matchatts.py:47-103 switched on at once -- CFM + prior +
     duration + 2 x ForwardSumLoss (beta-binomial prior, CTC) + 2 x binarisation -- against the REAL reference on the CPU
