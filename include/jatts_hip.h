@@ -196,11 +196,14 @@ int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const
                       const int32_t* valid_len, int32_t kind, float log_offset, double scale, float* out, double* workspace,
                       void* stream);
 /* dw[n][c][tap] = sum_t dy[t][n] * x[t + tap*dil - pad][c] over all sequences (torch weight layout (n_out, c_in, k_w), f32).
- * workspace != NULL (n_seq * k_w * pad64(n_out) * pad64(c_in) floats): split-K partials are written there and summed by a second
- * launch, dw is OVERWRITTEN (deterministic, no atomics).  workspace == NULL: dw += with f32 atomics (caller zeroes dw; order not
- * fixed). */
+ * workspace != NULL (n_seq * (k_w * pad64(n_out) * pad64(c_in) + pad64(n_out)) floats): split-K partials are written there and summed
+ * by a second launch, dw is OVERWRITTEN (deterministic, no atomics).  workspace == NULL: dw += with f32 atomics (caller zeroes dw; order
+ * not fixed).
+ * db (nullable, n_out floats, OVERWRITTEN): the bias gradient sum_t dy[t][n] of the same convolution (torch.nn.Conv1d's bias.grad).  On
+ * the MFMA path with a workspace it falls out of the dy tiles the kernel stages anyway (no second pass over dy); otherwise a column-sum
+ * launch (f32 atomics). */
 int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
-                       int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* workspace, void* stream);
+                       int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* db, float* workspace, void* stream);
 /* Pack a torch-layout f32 weight (n_out, c_in, k_w) into jatts_conv1d's fragment order (zero padded: n to 32, c to c_mult) as
  * `dtype`, in one launch.  mode 0: the weight itself; mode 1: the data-gradient operand W'[c][n][k'] = W[n][c][k_w-1-k'] (a conv from
  * n_out to c_in channels; padded sizes follow the swapped roles).  out: k_w * pad32(n) * pad(c, c_mult) elements. */
@@ -256,6 +259,16 @@ int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t n_batch, in
  * bd [T][2T-1], shifted[i][j] = bd[i][j - i + T - 1]. */
 /* WaveNet gate backward (vits/wavenet/residual_block.py:150-156): y = tanh(a) sigmoid(b), x = [a | b] [rows][2 dim]. */
 int jatts_gate_bwd(const float* x, const float* dy, float* dx, int64_t rows, int32_t dim, void* stream);
+/* torch.nn.utils.weight_norm (dim 0; the WaveNet convolutions of jatts/modules/vits/wavenet/residual_block.py:60-103 are wrapped by
+ * apply_weight_norm, vits.py:403-411): w [n_out][row_len] = g[o] v[o][:] / ||v[o][:]||, inv_norm[o] = 1 / ||v[o]|| kept for the backward
+ * (dv [n_out][row_len], dg [n_out]). */
+int jatts_weight_norm_fwd(const float* v, const float* g, int32_t n_out, int32_t row_len, float* w, float* inv_norm, void* stream);
+int jatts_weight_norm_bwd(const float* v, const float* g, const float* inv_norm, const float* dw, int32_t n_out, int32_t row_len,
+                          float* dv, float* dg, void* stream);
+/* WaveNet residual / skip split (residual_block.py:158-167): o [rows][2 dim] = [res | skip]; h_out = h + res, skip_out = skip (nullable) +
+ * skip part.  jatts_concat2 is its backward: out [rows][2 dim] = [a | b] (either nullable = zeros). */
+int jatts_split_add(const float* o, const float* h, const float* skip, int64_t rows, int32_t dim, float* h_out, float* skip_out, void* stream);
+int jatts_concat2(const float* a, const float* b, int64_t rows, int32_t dim, float* out, void* stream);
 /* Rank-1 pieces of Linear(dim -> 1) heads and Conv1d(1 -> dim, k=1) embeddings:
  * out[r][c] (+)= v[r] w[c] + bias[c];  out[c] += sum_r v[r] x[r][c];  y[r] = bias[0] + sum_c x[r][c] w[c]. */
 int jatts_outer_rows(const float* v, const float* w, const float* bias, int64_t rows, int32_t dim, int32_t accumulate, float* out,
@@ -297,6 +310,12 @@ int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, c
  * conformer layers (jatts/modules/conformer/encoder_layer.py:100-170) in one launch; p == 0 is a plain scaled add. */
 int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, const uint64_t* seed_dev,
                       void* stream);
+/* Gradient gather for the flat-buffer optimiser: n separately allocated f32 gradient tensors (HOST arrays of device pointers, element
+ * counts and destination offsets in elements) -> flat[dst_off[i] .. + numel[i]), = or += (accumulate).  ceil(n / 64) launches, the tensor
+ * list passed by value (graph-capturable, no table upload).  Replaces torch's one `param.grad += g` kernel per parameter
+ * (AccumulateGrad, 260-650 launches per step of the reference's loss.backward(), jatts/trainers/fastspeech2.py:86). */
+int jatts_gather_grads(const float* const* src, const int64_t* numel, const int64_t* dst_off, int32_t n, float* flat, int32_t accumulate,
+                       void* stream);
 /* *out += sum x^2 (double); Adam step (torch.optim.Adam semantics, step counts from 1) with the gradient scaled by
  * min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) when grad_sumsq != NULL and max_norm > 0 (clip_grad_norm_).  The hyper-parameters
  * are doubles: bias corrections and step size are computed in double (torch computes them as Python floats) and rounded once. */

@@ -384,6 +384,41 @@ class AlignLogProb(torch.autograd.Function):
         return dF.reshape(B * To, A_).float(), dT.reshape(B * Tm, A_).float(), None, None, None, None
 
 
+class WeightNorm(torch.autograd.Function):
+    """torch.nn.utils.weight_norm (dim 0): w = g v / ||v||, one launch each way (torch spells it as norm, div, mul and ~10 kernels back;
+    a VITS step has ~100 weight-normalised convolutions)."""
+
+    @staticmethod
+    def forward(ctx, g, v):
+        g, v = g.contiguous(), v.contiguous()
+        w, inv = hip.weight_norm_fwd(v, g)
+        ctx.save_for_backward(g, v, inv)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        g, v, inv = ctx.saved_tensors
+        dv, dg = hip.weight_norm_bwd(v, g, inv, dw.contiguous())
+        return dg, dv
+
+
+class SplitAdd(torch.autograd.Function):
+    """WaveNet ResidualBlock tail (vits/wavenet/residual_block.py:158-167): (o = [res | skip part], h, skip) -> (h + res, skip + skip
+    part) in one pass; the backward is one concat instead of two zero-filled slice gradients and their sum."""
+
+    @staticmethod
+    def forward(ctx, o, h, skip):
+        ctx.has_skip = skip is not None
+        return hip.split_add(o.contiguous(), h.contiguous(), skip.contiguous() if skip is not None else None)
+
+    @staticmethod
+    def backward(ctx, dh, ds):
+        ref = dh if dh is not None else ds
+        rows, dim = ref.shape
+        do = hip.concat2(dh.contiguous() if dh is not None else None, ds.contiguous() if ds is not None else None, rows, dim, ref.device)
+        return do, dh, (ds if ctx.has_skip else None)
+
+
 class Gate(torch.autograd.Function):
     """WaveNet gated activation tanh(a) * sigmoid(b) on [a | b] (vits/wavenet/residual_block.py:150-156)."""
 

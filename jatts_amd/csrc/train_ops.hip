@@ -447,6 +447,65 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   }
 }
 
+// torch.nn.utils.weight_norm (dim 0) as one launch each way: w[o][:] = g[o] v[o][:] / ||v[o][:]||.  One workgroup per output channel
+// (row_len = c_in * k <= a few thousand); the norm is accumulated in double like the rest of the step's reductions.
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, int row_len,
+                                                              float* __restrict__ w, float* __restrict__ inv_norm) {
+  __shared__ double part[4];
+  const int o = blockIdx.x;
+  const float* vr = v + (int64_t)o * row_len;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < row_len; i += 256) s += (double)vr[i] * vr[i];
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float inv = (float)(1.0 / sqrt(part[0] + part[1] + part[2] + part[3]));
+  const float sc = g[o] * inv;
+  for (int i = threadIdx.x; i < row_len; i += 256) w[(int64_t)o * row_len + i] = vr[i] * sc;
+  if (threadIdx.x == 0) inv_norm[o] = inv;
+}
+// dg[o] = <dw, v> / ||v||;  dv = g / ||v|| (dw - v <dw, v> / ||v||^2)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                              const float* __restrict__ inv_norm, const float* __restrict__ dw, int row_len,
+                                                              float* __restrict__ dv, float* __restrict__ dg) {
+  __shared__ double part[4];
+  const int o = blockIdx.x;
+  const float* vr = v + (int64_t)o * row_len;
+  const float* dr = dw + (int64_t)o * row_len;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < row_len; i += 256) s += (double)vr[i] * dr[i];
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float dot = (float)(part[0] + part[1] + part[2] + part[3]);
+  const float inv = inv_norm[o], sc = g[o] * inv, k = dot * inv * inv;
+  for (int i = threadIdx.x; i < row_len; i += 256) dv[(int64_t)o * row_len + i] = sc * (dr[i] - vr[i] * k);
+  if (threadIdx.x == 0) dg[o] = dot * inv;
+}
+
+// WaveNet residual / skip bookkeeping (residual_block.py:158-167) in one pass: o = [res | skip] [rows][2 dim];
+// h_out = h + res, skip_out = skip + o's second half (skip nullable: first layer).  Backward is a plain concat: do = [dh | dskip].
+__global__ __launch_bounds__(256) void split_add_kernel(const float* __restrict__ o, const float* __restrict__ h, const float* __restrict__ skip,
+                                                        int64_t rows, int C, float* __restrict__ h_out, float* __restrict__ skip_out) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    h_out[i] = h[i] + o[r * 2 * C + c];
+    skip_out[i] = (skip ? skip[i] : 0.f) + o[r * 2 * C + C + c];
+  }
+}
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t rows, int C,
+                                                      float* __restrict__ out) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    out[r * 2 * C + c] = a ? a[i] : 0.f;
+    out[r * 2 * C + C + c] = b ? b[i] : 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ rank-1 helpers (Linear(C -> 1) heads, Conv1d(1 -> C, k=1) embeddings)
 // out[r][c] (+)= v[r] * w[c] + bias[c]
 __global__ __launch_bounds__(256) void outer_rows_kernel(const float* __restrict__ v, const float* __restrict__ w, const float* __restrict__ bias,
@@ -556,6 +615,32 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // torch.optim.Adam (no amsgrad): g' = g * gscale (+ wd * p); m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
 // p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps); the scalars (bias corrections, step size, 1 - beta) are computed in double on the
 // host like torch's Python floats and rounded to f32 once.  gscale = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given.
+// Gradient gather: up to 64 separately allocated gradient tensors -> their slots in the flat gradient buffer, one launch.  The tensor list
+// travels BY VALUE in the kernel arguments (no pointer-table upload, nothing to keep alive; a captured graph bakes it in).  One workgroup =
+// one 4 096-element chunk of one tensor; chunk0[] = prefix sum of the tensors' chunk counts.
+constexpr int GATHER_MAX = 64, GATHER_CHUNK = 4096;
+struct GatherBatch {
+  const float* src[GATHER_MAX];
+  int64_t dst[GATHER_MAX];
+  int64_t numel[GATHER_MAX];
+  int32_t chunk0[GATHER_MAX + 1];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void gather_grads_kernel(GatherBatch b, float* __restrict__ flat, int accumulate) {
+  const int blk = blockIdx.x;
+  int lo = 0, hi = b.n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b.chunk0[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const int64_t s = (int64_t)(blk - b.chunk0[lo]) * GATHER_CHUNK;
+  const int64_t n = b.numel[lo] - s < GATHER_CHUNK ? b.numel[lo] - s : GATHER_CHUNK;
+  const float* __restrict__ src = b.src[lo] + s;
+  float* __restrict__ dst = flat + b.dst[lo] + s;
+  if (accumulate) for (int i = threadIdx.x; i < n; i += 256) dst[i] += src[i];
+  else for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float step_size, float w1, float b2, float w2, float eps, float wd, float bc2_sqrt,
                                                    const double* __restrict__ sumsq, float max_norm, const float* __restrict__ hyper) {
@@ -891,6 +976,37 @@ extern "C" int jatts_gate_bwd(const float* x, const float* dy, float* dx, int64_
   return JATTS_OK;
 }
 
+extern "C" int jatts_weight_norm_fwd(const float* v, const float* g, int32_t n_out, int32_t row_len, float* w, float* inv_norm, void* stream) {
+  NULLCHK(!v || !g || !w || !inv_norm, "weight_norm_fwd: null pointer");
+  NULLCHK(n_out < 1 || row_len < 1, "weight_norm_fwd: bad geometry");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((unsigned)n_out), dim3(256), 0, S_, v, g, row_len, w, inv_norm);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_weight_norm_bwd(const float* v, const float* g, const float* inv_norm, const float* dw, int32_t n_out, int32_t row_len,
+                                     float* dv, float* dg, void* stream) {
+  NULLCHK(!v || !g || !inv_norm || !dw || !dv || !dg, "weight_norm_bwd: null pointer");
+  NULLCHK(n_out < 1 || row_len < 1, "weight_norm_bwd: bad geometry");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)n_out), dim3(256), 0, S_, v, g, inv_norm, dw, row_len, dv, dg);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_split_add(const float* o, const float* h, const float* skip, int64_t rows, int32_t dim, float* h_out, float* skip_out,
+                               void* stream) {
+  NULLCHK(!o || !h || !h_out || !skip_out, "split_add: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(split_add_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, o, h, skip, rows, dim, h_out, skip_out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_concat2(const float* a, const float* b, int64_t rows, int32_t dim, float* out, void* stream) {
+  NULLCHK(!out, "concat2: null pointer");
+  if (rows <= 0 || dim <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(concat2_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, a, b, rows, dim, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
 extern "C" int jatts_shift_softmax_fwd(const float* ac, const float* bd, int32_t n_batch, int32_t n_heads, int32_t t_len, const int32_t* lens,
                                        float scale, int32_t shift_mode, float* p, void* stream) {
   NULLCHK(!ac || !p, "shift_softmax_fwd: null pointer");
@@ -974,6 +1090,29 @@ extern "C" int jatts_sumsq(const float* x, int64_t n, double* out, void* stream)
   NULLCHK(!x || !out, "sumsq: null pointer");
   if (n <= 0) return JATTS_OK;
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n, 4096, 1024)), dim3(256), 0, S_, x, n, out);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_gather_grads(const float* const* src, const int64_t* numel, const int64_t* dst_off, int32_t n, float* flat,
+                                  int32_t accumulate, void* stream) {
+  NULLCHK(n < 0 || (n > 0 && (!src || !numel || !dst_off || !flat)), "gather_grads: null pointer");
+  for (int i0 = 0; i0 < n; i0 += GATHER_MAX) {
+    GatherBatch b;
+    b.n = n - i0 < GATHER_MAX ? n - i0 : GATHER_MAX;
+    int32_t chunks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      NULLCHK(!src[i0 + i] || numel[i0 + i] < 0 || dst_off[i0 + i] < 0, "gather_grads: bad entry");
+      b.src[i] = src[i0 + i];
+      b.dst[i] = dst_off[i0 + i];
+      b.numel[i] = numel[i0 + i];
+      b.chunk0[i] = chunks;
+      chunks += (int32_t)((numel[i0 + i] + GATHER_CHUNK - 1) / GATHER_CHUNK);
+    }
+    for (int i = b.n; i < GATHER_MAX; ++i) { b.src[i] = nullptr; b.dst[i] = 0; b.numel[i] = 0; b.chunk0[i] = chunks; }
+    b.chunk0[GATHER_MAX] = chunks;
+    if (chunks == 0) continue;
+    hipLaunchKernelGGL(gather_grads_kernel, dim3((unsigned)chunks), dim3(256), 0, S_, b, flat, accumulate);
+  }
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
 template <int KW>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, const float* __restrict__ x, int ldx, const float* __restrict__ dy,
                                                               int ldy, int c_in, int n_out, int dil, int pad, int seq_groups,
-                                                              float* __restrict__ dw, float* __restrict__ ws) {
+                                                              float* __restrict__ dw, float* __restrict__ ws, float* __restrict__ bws) {
   constexpr int TT = 32, P = 68;
   extern __shared__ float sm[];
   const int halo = (KW - 1) * dil;
@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
   constexpr int NDY = TT * 16 / 256, NXV = (TT + 32) * 16 / 256;      // f32x4 per thread: dy tile, x tile (halo <= 32)
   f32x4 rdy[NDY], rx[NXV];
   const int nx_rows = TT + halo;
+  // bias gradient (column sums of dy) for free: the c-tile-0 workgroups already hold every dy tile of their n-tile in registers on its
+  // way to LDS; a thread's NDY vectors share one 4-column group, so it keeps a running f32x4 and the group's 16 threads are folded at
+  // the end.  Per-group partials go to bws[grp][n], summed with the weight partials by wgrad_reduce_kernel (deterministic, no atomics).
+  const bool do_b = bws != nullptr && blockIdx.y == 0;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto issue = [&](int s, int t0) {
     const int64_t row0 = (int64_t)rg.cu_rows[s] * rg.len_mul;
     const int L = (rg.cu_rows[s + 1] - rg.cu_rows[s]) * rg.len_mul;
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
     for (int j = 0; j < NDY; ++j) {
       const int i = threadIdx.x + 256 * j;
       *reinterpret_cast<f32x4*>(&dst_dy[(i >> 4) * P + (i & 15) * 4]) = rdy[j];
+      if (do_b) bsum += rdy[j];
     }
 #pragma unroll
     for (int j = 0; j < NXV; ++j) {
@@ -194,6 +200,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
     __syncthreads();
     cs = ns; ct0 = nt0; ++it;
   }
+  if (do_b) {   // (uniform per workgroup; the loop above ended on a barrier, LDS is free)
+    *reinterpret_cast<f32x4*>(&sm[(threadIdx.x >> 4) * 64 + (threadIdx.x & 15) * 4]) = bsum;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += sm[r * 64 + threadIdx.x];
+      bws[(int64_t)grp * gridDim.x * 64 + n0 + threadIdx.x] = a;
+    }
+  }
   // C/D map: column (lane & 31) = c, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = n
   const int c = c0 + wc * 32 + lo;
   if (ws) {   // split-K partial of this sequence group: ws[grp][tap][n][c] (c fastest: 128-byte row stores), summed by wgrad_reduce_kernel
@@ -220,9 +236,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
 // dw[n][c][k] = sum over groups of ws[g][k][n][c]  (overwrites dw: no zero fill, no atomics -- 32-way contended f32 atomics on a
 // 368 k-element gradient were 85 % of the k = 5 launches' time)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int groups, int K, int n64, int c64, int n_out, int c_in,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, const float* __restrict__ bws, float* __restrict__ db) {
   const int64_t total = (int64_t)n_out * c_in * K;
   const int64_t gstride = (int64_t)K * n64 * c64;
+  if (db)
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < n_out; n += gridDim.x * 256) {
+      float a = 0.f;
+      for (int g = 0; g < groups; ++g) a += bws[(int64_t)g * n64 + n];
+      db[n] = a;
+    }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int k = (int)(i % K);
     const int64_t nc = i / K;
@@ -273,9 +295,29 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, in
   if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// the same over all rows of a ragged batch (row count read from the device-side offsets), into a zero-filled out: the bias gradient of
+// the convolutions whose weight gradient takes the VALU path
+__global__ __launch_bounds__(256) void col_sum_ragged_kernel(jatts_ragged rg, const float* x, int ld, int dim, float* out) {
+  const int64_t rows = (int64_t)rg.cu_rows[rg.n_seq] * rg.len_mul;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < dim)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
+
+static void bias_grad_plain(const jatts_ragged* rg, const float* dy, int ldy, int n_out, float* db, void* stream) {
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, S_, db, (int64_t)n_out);
+  hipLaunchKernelGGL(col_sum_ragged_kernel, dim3((unsigned)((n_out + 63) / 64), 128), dim3(256), 0, S_, *rg, dy, ldy, n_out, db);
+}
 
 extern "C" int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
                                  const int32_t* valid_len, int32_t kind, float log_offset, double scale, float* out, double* workspace,
@@ -292,7 +334,7 @@ extern "C" int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t
 }
 
 extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
-                                  int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* workspace, void* stream) {
+                                  int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* db, float* workspace, void* stream) {
   if (!rg || !x || !dy || !dw) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: null pointer");
   if (c_in < 1 || n_out < 1 || k_w < 1 || dil < 1) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: bad geometry");
   if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
@@ -308,17 +350,21 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
     if (g < 1) g = 1;
     const dim3 grid((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)g);
     const size_t lds = 2 * (size_t)(64 + (k_w - 1) * dil) * 68 * sizeof(float);   // two buffers of (dy tile | x tile + halo)
-    if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
-    else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
-    else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace);
+    // bias partials live behind the weight partials: workspace[g k n64 c64 ..][g][n64]
+    float* bws = (db && workspace) ? workspace + (int64_t)g * k_w * grid.x * 64 * grid.y * 64 : nullptr;
+    if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace, bws);
+    else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace, bws);
+    else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace, bws);
     if (workspace) {
       const int64_t total = (int64_t)n_out * c_in * k_w;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, S_, workspace, g, k_w,
-                         (int)grid.x * 64, (int)grid.y * 64, n_out, c_in, dw);
+                         (int)grid.x * 64, (int)grid.y * 64, n_out, c_in, dw, bws, bws ? db : nullptr);
     }
+    if (db && !bws) bias_grad_plain(rg, dy, ldy, n_out, db, stream);
     JATTS_CHECK_LAUNCH();
     return JATTS_OK;
   }
+  if (db) bias_grad_plain(rg, dy, ldy, n_out, db, stream);
   if (workspace) {   // the VALU fallback accumulates with atomics: it needs a zeroed dw (a kernel, not hipMemsetAsync: under stream
                      // capture the memset did not reliably replay with the graph -- tests/test_training_gpu.py, Matcha graph mode)
     const int64_t total = (int64_t)n_out * c_in * k_w;

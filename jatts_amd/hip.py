@@ -832,15 +832,18 @@ def masked_loss(rb, a, b, valid_len, kind, scale, log_offset=-1.0):
     return out
 
 
-def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1):
+def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1, want_db=False):
+    """-> dw (n_out, c_in, k_w); with want_db -> (dw, db): the bias gradient comes out of the same launch (the kernel's dy tiles)."""
     lib = _abi.load()
     dw = torch.empty(n_out, c_in, k_w, dtype=torch.float32, device=x.device)
-    ws = torch.empty(rb.n_seq * k_w * round_up(n_out, 64) * round_up(c_in, 64), dtype=torch.float32, device=x.device)   # split-K partials
+    db = torch.empty(n_out, dtype=torch.float32, device=x.device) if want_db else None
+    ws = torch.empty(rb.n_seq * (k_w * round_up(n_out, 64) * round_up(c_in, 64) + round_up(n_out, 64)), dtype=torch.float32,
+                     device=x.device)                                                                                   # split-K partials
     rg = rb.struct(len_mul)
     _count(2.0 * c_in * n_out * k_w * rb.total * len_mul)
     _abi.check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
-                                      pad, dw.data_ptr(), ws.data_ptr(), _stream()), "jatts_conv1d_wgrad")
-    return dw
+                                      pad, dw.data_ptr(), _ptr(db), ws.data_ptr(), _stream()), "jatts_conv1d_wgrad")
+    return (dw, db) if want_db else dw
 
 
 def col_sum(x, dim=None):
@@ -999,6 +1002,50 @@ def gate_bwd(x, dy):
     return dx
 
 
+def weight_norm_fwd(v, g):
+    """-> (w, inv_norm): w = g v / ||v|| per output channel (v (n_out, ...), g (n_out, 1, ...))."""
+    lib = _abi.load()
+    v, g = _f32c(v), _f32c(g)
+    n_out = v.shape[0]
+    w = torch.empty_like(v)
+    inv = torch.empty(n_out, dtype=torch.float32, device=v.device)
+    _abi.check(lib.jatts_weight_norm_fwd(v.data_ptr(), g.data_ptr(), n_out, v.numel() // n_out, w.data_ptr(), inv.data_ptr(), _stream()),
+               "jatts_weight_norm_fwd")
+    return w, inv
+
+
+def weight_norm_bwd(v, g, inv, dw):
+    lib = _abi.load()
+    v, g, dw = _f32c(v), _f32c(g), _f32c(dw)
+    n_out = v.shape[0]
+    dv, dg = torch.empty_like(v), torch.empty_like(g)
+    _abi.check(lib.jatts_weight_norm_bwd(v.data_ptr(), g.data_ptr(), inv.data_ptr(), dw.data_ptr(), n_out, v.numel() // n_out,
+                                         dv.data_ptr(), dg.data_ptr(), _stream()), "jatts_weight_norm_bwd")
+    return dv, dg
+
+
+def split_add(o, h, skip=None):
+    """o (rows, 2 dim) = [res | skip part]; -> (h + res, skip + skip part)."""
+    lib = _abi.load()
+    o, h = _f32c(o), _f32c(h)
+    rows, dim = h.shape
+    if o.shape != (rows, 2 * dim):
+        raise ValueError("split_add: o must be (rows, 2 dim)")
+    h_out, s_out = torch.empty_like(h), torch.empty_like(h)
+    _abi.check(lib.jatts_split_add(o.data_ptr(), h.data_ptr(), _ptr(_f32c(skip) if skip is not None else None), rows, dim,
+                                   h_out.data_ptr(), s_out.data_ptr(), _stream()), "jatts_split_add")
+    return h_out, s_out
+
+
+def concat2(a, b, rows, dim, device):
+    """-> (rows, 2 dim) = [a | b]; None = zeros."""
+    lib = _abi.load()
+    out = torch.empty(rows, 2 * dim, dtype=torch.float32, device=device)
+    _abi.check(lib.jatts_concat2(_ptr(_f32c(a) if a is not None else None), _ptr(_f32c(b) if b is not None else None), rows, dim,
+                                 out.data_ptr(), _stream()), "jatts_concat2")
+    return out
+
+
 def outer_rows(v, w, bias=None, out=None):
     lib = _abi.load()
     v, w = _f32c(v), _f32c(w)
@@ -1069,6 +1116,21 @@ def sumsq(x, out):
     x = _f32c(x)
     _abi.check(lib.jatts_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "jatts_sumsq")
     return out
+
+
+def gather_grads(grads, offsets, flat, accumulate=False):
+    """grads: list of contiguous f32 device tensors, offsets: their element offsets in ``flat``; flat[off : off + numel] (+)= grad."""
+    lib = _abi.load()
+    n = len(grads)
+    if n == 0:
+        return
+    for g in grads:
+        if g.dtype != torch.float32 or not g.is_contiguous() or g.device != flat.device:
+            raise ValueError("gather_grads takes contiguous f32 tensors on the flat buffer's device")
+    src = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+    num = (C.c_int64 * n)(*[g.numel() for g in grads])
+    off = (C.c_int64 * n)(*[int(o) for o in offsets])
+    _abi.check(lib.jatts_gather_grads(src, num, off, n, flat.data_ptr(), 1 if accumulate else 0, _stream()), "jatts_gather_grads")
 
 
 def adam_hyper(lr, beta1, beta2, eps, weight_decay, step):

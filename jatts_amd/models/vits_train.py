@@ -20,8 +20,7 @@ def _wn_weight(c, stem):
     """torch.nn.utils.weight_norm: w = g * v / ||v|| (norm over each output channel), or the plain weight."""
     if (stem + ".weight") in c.p:
         return c.p[stem + ".weight"]
-    g, v = c.p[stem + ".weight_g"], c.p[stem + ".weight_v"]
-    return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+    return A.WeightNorm.apply(c.p[stem + ".weight_g"], c.p[stem + ".weight_v"])
 
 
 def _wavenet(c, prefix, h, g_spk, rb, rbs, n_layers, rate):
@@ -36,8 +35,7 @@ def _wavenet(c, prefix, h, g_spk, rb, rbs, n_layers, rate):
         y = A.Conv1dFunction.apply(c.drop(h, rate), w, c.p[q + "conv.bias"], rb, 1, (k - 1) // 2)
         y = A.AddSeqVector.apply(y, A.Conv1dFunction.apply(g_spk, _wn_weight(c, q + "conv1x1_glo"), None, rbs, 1, 0), rb)
         o = A.Conv1dFunction.apply(A.Gate.apply(y, rb), _wn_weight(c, q + "conv1x1_out"), c.p[q + "conv1x1_out.bias"], rb, 1, 0)
-        h = h + o[:, :Ad]
-        skips = o[:, Ad:] if skips is None else skips + o[:, Ad:]
+        h, skips = A.SplitAdd.apply(o, h, skips)
     return skips * math.sqrt(1.0 / n_layers)
 
 

@@ -335,6 +335,37 @@ def test_wavenet_gate_backward(cuda, lib):
     _check([("y", y, yr), ("dx", xd.grad, xr.grad)])
 
 
+def test_weight_norm_and_wavenet_split_add_backward(cuda, lib):
+    """WeightNorm == torch.nn.utils.weight_norm's g * v / ||v|| (dim 0) and SplitAdd == (h + o[:, :C], skip + o[:, C:]) (skip None on
+    the first layer), forward and backward vs fp64 torch."""
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(23)
+    for shape in [(384, 192, 5), (48, 7, 1), (3, 1, 3)]:
+        v, gg, gy = torch.randn(shape, generator=g), torch.rand(shape[0], 1, 1, generator=g) + 0.5, torch.randn(shape, generator=g)
+        (vr, vd), (gr, gd) = _leaf(v, cuda), _leaf(gg, cuda)
+        wr = gr * vr / vr.reshape(shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+        wr.backward(gy.double())
+        w = A.WeightNorm.apply(gd, vd)
+        w.backward(gy.to(cuda))
+        _check([("w", w, wr), ("dv", vd.grad, vr.grad), ("dg", gd.grad, gr.grad)])
+    rows, C = 333, 96
+    o, h, sk = torch.randn(rows, 2 * C, generator=g), torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g)
+    g1, g2 = torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g)
+    for with_skip in (True, False):
+        (orf, od), (hr, hd), (sr, sd) = _leaf(o, cuda), _leaf(h, cuda), _leaf(sk, cuda)
+        h2r = hr + orf[:, :C]
+        s2r = (sr + orf[:, C:]) if with_skip else orf[:, C:]
+        ((h2r * g1.double()).sum() + (s2r * g2.double()).sum() + (h2r * h2r).sum()).backward()
+        h2, s2 = A.SplitAdd.apply(od, hd, sd if with_skip else None)
+        ((h2 * g1.to(cuda)).sum() + (s2 * g2.to(cuda)).sum() + (h2 * h2).sum()).backward()
+        pairs = [("h", h2, h2r), ("s", s2, s2r), ("do", od.grad, orf.grad), ("dh", hd.grad, hr.grad)]
+        if with_skip:
+            pairs.append(("ds", sd.grad, sr.grad))
+        else:
+            assert sd.grad is None
+        _check(pairs)
+
+
 def test_add_seq_vector_backward(cuda, lib):
     from jatts_amd import autograd as A, hip
     g = torch.Generator().manual_seed(18)

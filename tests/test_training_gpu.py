@@ -33,7 +33,7 @@ def test_fastspeech2_losses_match_reference(cuda, lib):
 
 
 @pytest.mark.parametrize("c_in,n_out,k,dil,lens", [(64, 96, 3, 1, [70, 5, 33]), (80, 64, 5, 2, [40, 41]), (128, 128, 1, 1, [129]),
-                                                   (48, 20, 7, 3, [64, 30])])
+                                                   (48, 20, 7, 3, [64, 30]), (192, 320, 5, 1, [300, 257, 64, 1]), (384, 200, 3, 1, [768, 500])])
 def test_conv1d_backward_matches_autograd(cuda, lib, c_in, n_out, k, dil, lens):
     from jatts_amd import hip
     from jatts_amd.training import Conv1dFunction
