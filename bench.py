@@ -363,10 +363,9 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     )
 
 
-def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
-    """One `_train_step` of the reference trainers on the recipes' models (jatts/trainers/fastspeech2.py:24-100 on
-    conf/fastspeech2.v1.yaml; jatts/trainers/matchatts.py:23-120 on the tts1 conf/matcha_tts.v1.prior.steplr.large.yaml): forward in
-    train mode, the losses, backward, clip + Adam -- f32, synthetic weights / targets, batch 32."""
+def train_setup(dev, kind="fs2", batch=32, t_text=128, frames=6):
+    """The recipes' model (synthetic weights), one synthetic batch and the trainer class for a training leg
+    -> (model, batch dict, trainer class, trainer kwargs, name, model TFLOP per utterance or None)."""
     import torch
     from jatts_amd.models import VITS, FastSpeech2, MatchaTTS, MatchaTTS_MAS
     from jatts_amd.synthetic import FS2_JSUT, MATCHA_MAS_JSUT, VITS_JSUT, matcha_golden_tweaks, synth_state_dict
@@ -400,10 +399,19 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
              energys=torch.randn(batch, t_text, 1, generator=g).to(dev), energy_lens=il,
              spkembs=torch.randn(batch, 192, generator=g).to(dev) if kind == "vits" else None)
     cls = {"fs2": FastSpeech2Trainer, "matcha": MatchaTTSTrainer, "matcha_mas": MatchaTTSTrainer, "vits": VITSTrainer}[kind]
-    # FastSpeech2 / tts1 Matcha: the whole step replayed as ONE captured hipGraph per batch signature (the MAS models' steps still talk to
-    # the host: the search's durations come back mid-step); a signature's first call runs eagerly, its second captures, the timed ones
-    # replay (Matcha's signature changes once after step 1, when the duration loss joins)
-    graph = kind in ("fs2", "matcha")
+    return m, b, cls, extra, name, flop_per_utt
+
+
+def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
+    """One `_train_step` of the reference trainers on the recipes' models (jatts/trainers/fastspeech2.py:24-100 on
+    conf/fastspeech2.v1.yaml; jatts/trainers/matchatts.py:23-120 on the tts1 conf/matcha_tts.v1.prior.steplr.large.yaml): forward in
+    train mode, the losses, backward, clip + Adam -- f32, synthetic weights / targets, batch 32."""
+    import torch
+    m, b, cls, extra, name, flop_per_utt = train_setup(dev, kind, batch, t_text, frames)
+    ol = b["olens"]
+    # the whole step replayed as ONE captured hipGraph per batch signature (lengths + loss-schedule phase); a signature's first call runs
+    # eagerly, its second captures, the timed ones replay (tts1 Matcha's signature changes once after step 1, when the duration loss joins)
+    graph = True
     tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=graph, **extra)
     from jatts_amd import hip
     hip.flops_begin()            # dense work of ONE step as launched: 2 c_in n_out k rows per conv forward / dgrad / wgrad launch

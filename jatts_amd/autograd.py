@@ -220,8 +220,39 @@ class RowDot(torch.autograd.Function):
         dy = dy.contiguous()
         dx = hip.outer_rows(dy, weight.detach().reshape(-1).contiguous()) if ctx.needs_input_grad[0] else None
         dw = hip.col_wsum(x, dy).view_as(weight) if ctx.needs_input_grad[1] else None
-        db = dy.sum().reshape(1) if ctx.needs_input_grad[2] else None
+        db = hip.col_sum(dy.view(-1, 1)).reshape(1) if ctx.needs_input_grad[2] else None     # (own reduction: see AddBias)
         return dx, dw, db
+
+
+class AddBias(torch.autograd.Function):
+    """x (rows, C) + b (C,) -- pos_bias_u / pos_bias_v on the query rows (attention.py:190-195) -- with the bias gradient taken by
+    jatts_col_sum.  As a broadcast torch add, autograd reduces the (B, H, T, d_k) gradient with at::reduce_kernel's multi-block form,
+    whose block semaphores are zeroed by a memset; inside a captured step on this stack that memset does not replay reliably and the
+    bias gradients came back as garbage (1e38) at the recipes' batch size.  SumAll is the same for a full sum."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        return x + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        C_ = dy.shape[-1]
+        db = hip.col_sum(dy.reshape(-1, C_).contiguous()) if ctx.needs_input_grad[1] else None
+        return dy, db
+
+
+class SumAll(torch.autograd.Function):
+    """x.sum() through jatts_col_sum (see AddBias)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        return hip.col_sum(x2).sum()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.expand(ctx.shape)
 
 
 class OuterRows(torch.autograd.Function):
@@ -380,7 +411,10 @@ class AlignLogProb(torch.autograd.Function):
         d2 = (F_ * F_).sum(-1).unsqueeze(2) + (T_ * T_).sum(-1).unsqueeze(1) - 2.0 * torch.matmul(F_, T_.transpose(1, 2))
         w = (-dscore / torch.sqrt(d2.clamp_min(1e-24))).masked_fill(~vm, 0.0)
         dF = w.sum(-1, keepdim=True) * F_ - torch.matmul(w, T_)
-        dT = w.sum(1).unsqueeze(-1) * T_ - torch.matmul(w.transpose(1, 2), F_)
+        # sum_i w_ij rides along as one more GEMM column: torch's strided multi-block reduction keeps its block semaphores zero with a
+        # memset, which did not replay reliably inside a captured step on this stack (garbage text-side gradients at B 32 x 768 frames)
+        wF = torch.matmul(w.transpose(1, 2), torch.cat([F_, torch.ones(B, To, 1, dtype=F_.dtype, device=F_.device)], dim=-1))
+        dT = wF[..., A_:] * T_ - wF[..., :A_]
         return dF.reshape(B * To, A_).float(), dT.reshape(B * Tm, A_).float(), None, None, None, None
 
 

@@ -114,11 +114,14 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
         a = q + "self_attn."
         wqkv = torch.cat([c.p[a + "linear_q.weight"], c.p[a + "linear_k.weight"], c.p[a + "linear_v.weight"]], 0).unsqueeze(-1)
         bqkv = torch.cat([c.p[a + "linear_q.bias"], c.p[a + "linear_k.bias"], c.p[a + "linear_v.bias"]], 0)
-        qkv = A.Conv1dFunction.apply(h, wqkv, bqkv, rb, 1, 0).view(B, T, 3, H, dk)
-        qh, kh, vh = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))                   # (B, H, T, dk)
+        qkv2 = A.Conv1dFunction.apply(h, wqkv, bqkv, rb, 1, 0)                               # (rows, 3 A)
+        qkv = qkv2.view(B, T, 3, H, dk)
+        kh, vh = (qkv[:, :, j].permute(0, 2, 1, 3) for j in (1, 2))                         # (B, H, T, dk)
         ph = A.Conv1dFunction.apply(pos, c.p[a + "linear_pos.weight"].unsqueeze(-1), None, rbp, 1, 0).view(n_pos, H, dk).permute(1, 0, 2)
-        ac = torch.matmul(qh + c.p[a + "pos_bias_u"][None, :, None, :], kh.transpose(-2, -1))        # rocBLAS batched GEMMs
-        bd = torch.matmul(qh + c.p[a + "pos_bias_v"][None, :, None, :], ph.transpose(-2, -1)[None])
+        qu, qv = (A.AddBias.apply(qkv2[:, :Ad], c.p[a + nm].reshape(-1)).view(B, T, H, dk).permute(0, 2, 1, 3)
+                  for nm in ("pos_bias_u", "pos_bias_v"))
+        ac = torch.matmul(qu, kh.transpose(-2, -1))                                         # rocBLAS batched GEMMs
+        bd = torch.matmul(qv, ph.transpose(-2, -1)[None])
         p_attn = A.ShiftSoftmax.apply(ac, bd, kv, 1.0 / math.sqrt(dk), 2 if rel_style == "new" else 1)
         p_attn = c.drop(p_attn, rates["attn"])
         ctxv = torch.matmul(p_attn, vh).permute(0, 2, 1, 3).reshape(B * T, Ad)

@@ -147,7 +147,7 @@ def criterion(ret, ilens, olens, duration_loss=True, forward_sum=False, bin_loss
     mel = A.MaskedLoss.apply(outs.reshape(B * To, od), ret["ys"].reshape(B * To, od).contiguous(), rbf, vo, 0, 1.0 / n_o, -1.0)
     zm = ret["y_mask"]
     kl = ret["logs_p"] - ret["logs_q"] - 0.5 + 0.5 * (ret["z_p"] - ret["m_p"]) ** 2 * torch.exp(-2.0 * ret["logs_p"])
-    kl = torch.sum(kl * zm) / torch.sum(zm)
+    kl = A.SumAll.apply(kl * zm) / A.SumAll.apply(zm)                  # (own full reductions: capture-safe, see autograd.AddBias)
     out = dict(mel_loss=mel, kl_loss=kl)
     total = lambda_mel * mel + kl
     if duration_loss:

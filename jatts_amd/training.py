@@ -383,7 +383,7 @@ class FastSpeech2Trainer:
         finally:
             self.model.train(was)
 
-    _graph_capable = True      # subclasses whose step still synchronises with the host (MAS durations, scipy priors) switch it off
+    _graph_capable = True      # a subclass whose step synchronises with the host switches it off
 
     def _signature(self, batch):
         sig = []
@@ -534,17 +534,16 @@ class MatchaTTSTrainer(FastSpeech2Trainer):
     all-reduce and checkpoint layout as FastSpeech2Trainer; the duration loss joins once `steps > dp_train_start_steps`
     (trainers/matchatts.py:66-75).  ``cfm_t`` / ``cfm_noise`` in the batch inject the two random draws of CFM.compute_loss."""
 
-    # graph mode: the tts1 model only (ground-truth durations; the CFM draws are device draws, graph-safe through torch's generator).
-    # The MAS model's durations still make a host round trip inside the step.
+    # graph mode: the CFM draws are device draws (graph-safe through torch's generator); the MAS model's search, its durations and the
+    # Gaussian upsampling they drive all stay on the device, so its step captures too.  The loss schedule is part of the signature.
 
     def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, **kw):
         super().__init__(model, **kw)
         self.dp_train_start_steps, self.bin_loss_start_steps, self.lambda_align = dp_train_start_steps, bin_loss_start_steps, lambda_align
-        if model._MAS:
-            self.capture_graph = False
 
     def _signature(self, batch):      # the loss schedule is part of the graph
-        return super()._signature(batch) + (("duration_loss", self.steps > self.dp_train_start_steps),)
+        return super()._signature(batch) + (("schedule", self.steps > self.dp_train_start_steps, self.steps < self.dp_train_start_steps,
+                                             self.steps > self.bin_loss_start_steps),)
 
     def compute_losses(self, batch):
         from .models.matchatts_train import criterion, train_forward
@@ -564,12 +563,14 @@ class VITSTrainer(FastSpeech2Trainer):
     after `bin_loss_start_steps`; same flat-buffer optimiser / all-reduce / checkpoint layout.  ``post_noise`` in the batch
     injects the posterior encoder's random draw.  (gradient_accumulate_steps = 1.)"""
 
-    _graph_capable = False
-
     def __init__(self, model, dp_train_start_steps=0, bin_loss_start_steps=0, lambda_align=2.0, lambda_mel=1.0, **kw):
         super().__init__(model, **kw)
         self.dp_train_start_steps, self.bin_loss_start_steps = dp_train_start_steps, bin_loss_start_steps
         self.lambda_align, self.lambda_mel = lambda_align, lambda_mel
+
+    def _signature(self, batch):      # the loss schedule is part of the graph
+        return super()._signature(batch) + (("schedule", self.steps > self.dp_train_start_steps, self.steps < self.dp_train_start_steps,
+                                             self.steps > self.bin_loss_start_steps),)
 
     def compute_losses(self, batch):
         from .models.vits_train import criterion, train_forward

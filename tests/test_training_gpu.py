@@ -426,6 +426,48 @@ def test_matcha_mas_trainer_schedule(cuda, lib):
     assert float(out[2]["forward_sum_loss"]) < float(out[0]["forward_sum_loss"])
 
 
+def test_mas_trainers_graph_mode(cuda, lib):
+    """capture_graph=True on the two MAS trainers (MatchaTTS_MAS, VITS): the alignment search, its durations and everything downstream
+    stay on the device, so the step captures; the loss schedule (forward-sum -> duration -> binarisation) changes the signature, each
+    phase is captured on its second step.  Same losses as the eager trainer on injected draws, dropout off in these small configs."""
+    import json
+    from jatts_amd.models import VITS, MatchaTTS_MAS
+    from jatts_amd.synthetic import matcha_golden_tweaks
+    from jatts_amd.training import MatchaTTSTrainer, VITSTrainer
+    t_ = lambda z, k: torch.tensor(z[k])  # noqa: E731
+    z, keys = load_golden("matcha_mas_train_small.npz")
+    zi, _ = load_golden("matcha_forward_small.npz")
+
+    def make_m():
+        m = MatchaTTS_MAS(idim=20, **json.loads(str(z["config"])))
+        m.load_state_dict(matcha_golden_tweaks(golden_state(keys, 3)))
+        return m.to(cuda)
+    mb = dict(xs=t_(zi, "text"), ilens=t_(zi, "text_lengths"), ys=t_(zi, "feats"), olens=t_(zi, "feats_lengths"), cfm_t=t_(zi, "t"),
+              cfm_noise=t_(zi, "z"))
+    zv, keys_v = load_golden("vits_train_small.npz")
+    zvi, _ = load_golden("vits_forward_small.npz")
+
+    def make_v():
+        m = VITS(idim=20, **json.loads(str(zv["config"])))
+        m.load_state_dict(golden_state(keys_v, 2))
+        return m.to(cuda)
+    vb = dict(xs=t_(zvi, "text"), ilens=t_(zvi, "text_lengths"), ys=t_(zvi, "feats"), olens=t_(zvi, "feats_lengths"), spkembs=t_(zvi, "spembs"),
+              post_noise=t_(zvi, "noise"))
+    for cls, make, batch in ((MatchaTTSTrainer, make_m, mb), (VITSTrainer, make_v, vb)):
+        kw = dict(dp_train_start_steps=3, bin_loss_start_steps=6, lr=2e-4, grad_norm=1.0, warmup_steps=0)
+        a, b = cls(make(), **kw), cls(make(), capture_graph=True, **kw)
+        assert b.capture_graph
+        for step in range(11):
+            la, lb = a.train_step(batch), b.train_step(batch)
+            assert set(la) == set(lb), (step, sorted(la), sorted(lb))
+            for k in la:
+                tol = 5e-5 * (1 + 5 * step)
+                assert abs(float(la[k]) - float(lb[k])) <= tol * max(1.0, abs(float(la[k]))), (cls.__name__, step, k, float(la[k]), float(lb[k]))
+        # phases: steps 0-2 (forward-sum), 3 (none of the three), 4-6 (duration), 7.. (duration + binarisation)
+        assert len(b._graphs) == 4
+        assert sum(st["graph"] is not None for st in b._graphs.values()) == 3      # the one-step phase never reaches its capture
+
+
 def test_vits_train_step_matches_reference(cuda, lib):
     """mel-VITS with every loss term of jatts/trainers/vits.py:47-110 on at once -- mel + KL + duration + 2 x ForwardSumLoss + 2 x
     binarisation -- against the REAL reference on the CPU (vits_train_small.npz): MAS durations, the five losses, every parameter's
