@@ -445,6 +445,8 @@ class FastSpeech2Trainer:
                 m._seed_dev, m._static_olens = None, None
             st["graph"] = g
         # replay: refresh the static inputs and the per-step scalars (all stream-ordered copies; no host wait)
+        if self._bad_ids is not None and self._bad_ids():       # out-of-range token ids of an EARLIER replay (zero rows, counted on the
+            self._bad_ids = None                                # device by the embedding kernel inside the graph): IndexError, one step late
         for k, v in batch.items():
             if torch.is_tensor(v) and torch.is_tensor(st["in"].get(k)) and st["in"][k].is_cuda:
                 st["in"][k].copy_(v, non_blocking=True)
@@ -458,6 +460,8 @@ class FastSpeech2Trainer:
         st["hyper"].copy_(st["hyper_host"], non_blocking=True)
         st["graph"].replay()
         self.model._prep = None
+        if self._bad_ids is None:
+            self._bad_ids = hip.bad_ids_async(dev)
         return dict(st["out"])
 
     def train_step(self, batch):

@@ -727,6 +727,20 @@ def test_out_of_range_token_ids_raise_like_nn_embedding(cuda, lib):
     with pytest.raises(IndexError):
         m(bad["xs"], il, bad["ys"], ol, bad["durations"], il, bad["pitch"], il, bad["energys"], il)
     tr.train_step(batch)                                     # and the trainer carries on with a good batch
+    # graph mode: the replayed embedding kernel counts on the device, the trainer's stream-ordered snapshot raises one step late
+    m2 = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
+    m2.load_state_dict(golden_state(keys, 0))
+    tg = FastSpeech2Trainer(m2.to(cuda), lr=1e-3, grad_norm=1.0, warmup_steps=0, capture_graph=True)
+    for _ in range(3):
+        tg.train_step(batch)                                 # eager, capture + replay, replay
+    tg.train_step(bad)                                       # replay with a bad id: zero row, counted
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        tg.train_step(batch)
+        torch.cuda.synchronize()
+        tg.train_step(batch)
+    torch.cuda.synchronize()
+    tg.train_step(batch)
 
 
 def test_graph_mode_replays_the_same_training(cuda, lib):
