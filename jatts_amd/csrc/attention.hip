@@ -51,20 +51,20 @@ __device__ __forceinline__ void load4u(const T* p, float (&o)[4]) {
 // One K / V^T tile in flight in registers: the global loads of tile t+1 are issued before the MFMAs of tile t
 // and land in LDS after them, so no wave ever waits on a tile load (the first version staged V^T with one
 // 2-byte load per element, each a serialized round trip: 1.1 ms per decoder layer, profiles/r01_notes.md).
-template <typename T, int DK>
+template <typename T, int DK, int KBT>
 struct TileRegs {
-  static constexpr int N = DK / 32;  // 16-byte (8-element) chunks per thread for K and for V^T
+  static constexpr int N = KBT * DK / 2048;  // 8-element chunks per thread for K and for V^T (KBT x DK elements over 256 threads)
   typename Elem<T>::vec8 k[N], v[N];
   float ku;
 };
 
-template <typename T, int DK>
-__device__ __forceinline__ void tile_load(TileRegs<T, DK>& tr, const jatts_relattn_desc& d, const T* kg, const T* vtg,
+template <typename T, int DK, int KBT>
+__device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_relattn_desc& d, const T* kg, const T* vtg,
                                           int row0, int h, int j0, int Tn, bool vt_vec) {
   typedef typename Elem<T>::vec8 Vec;
   constexpr int UPR = DK / 8;
 #pragma unroll
-  for (int i = 0; i < TileRegs<T, DK>::N; ++i) {
+  for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
     const int u = threadIdx.x + 256 * i;
     {  // K rows: keys, 8 channels per chunk
       const int r = u / UPR, cu = u - r * UPR, j = j0 + r;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK>& tr, const jatts_relat
       tr.k[i] = (j >= 0 && j < Tn) ? load8<T>(kg + (int64_t)j * d.ldk + cu * 8) : z;
     }
     {  // V^T rows: channels, 8 keys per chunk
-      const int r = u >> 3, jc = j0 + 8 * (u & 7);
+      const int r = u / (KBT / 8), jc = j0 + 8 * (u % (KBT / 8));
       Vec z;
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
@@ -93,38 +93,41 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK>& tr, const jatts_relat
     }
   }
   tr.ku = 0.f;
-  if (d.ku && threadIdx.x < KB) {
+  if (d.ku && threadIdx.x < KBT) {
     const int j = j0 + (int)threadIdx.x;
     if (j >= 0 && j < Tn) tr.ku = d.ku[(int64_t)(row0 + j) * d.n_heads + h];
   }
 }
 
-template <typename T, int DK>
-__device__ __forceinline__ void tile_store(const TileRegs<T, DK>& tr, char* ks, char* vs, float* kus, int KP, int VP) {
+template <typename T, int DK, int KBT>
+__device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char* ks, char* vs, float* kus, int KP, int VP) {
   constexpr int UPR = DK / 8;
 #pragma unroll
-  for (int i = 0; i < TileRegs<T, DK>::N; ++i) {
+  for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
     const int u = threadIdx.x + 256 * i;
     const int r = u / UPR, cu = u - r * UPR;
     store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i]);
-    store8<T>(vs + (size_t)(u >> 3) * VP + (size_t)(u & 7) * 8 * sizeof(T), tr.v[i]);
+    store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i]);
   }
-  if (threadIdx.x < KB) kus[threadIdx.x] = tr.ku;
+  if (threadIdx.x < KBT) kus[threadIdx.x] = tr.ku;
 }
 
-template <typename T, int DK>
-__global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
+// KBT = keys per tile: 64, or 32 for f32 at d_k >= 128 -- there a 64-key tile pair is 102-136 KB of LDS, ONE workgroup (one wave per SIMD)
+// per CU, and every softmax / rescale instruction stalls the matrix pipe (0.33 of the f32 MFMA peak); half tiles fit two workgroups.
+template <typename T, int DK, int KBT>
+__global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<T>::vec8 Vec;
   // K tile pitch: the score MFMAs read 16 key rows x 4 channel groups per ds_read_b128; with the pitch = 2 (mod 4)
   // 16-byte units the hardware's 16-lane groups hit 16 distinct slots (+16 left 41 % of the LDS cycles in conflict)
   constexpr int KP = DK * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
-  constexpr int VP = KB * (int)sizeof(T) + 16;  // V^T tile pitch
+  constexpr int VP = KBT * (int)sizeof(T) + 16;  // V^T tile pitch
+  constexpr int NF = KBT / 16;                   // 16-key score fragments per tile
   constexpr int NKS = DK / 32;                  // contraction steps for S
   constexpr int NDF = DK / 16;                  // output d fragments
   char* ks = smem;
-  char* vs = smem + KB * KP;
-  float* kus = reinterpret_cast<float*>(smem + KB * KP + DK * VP);
+  char* vs = smem + KBT * KP;
+  float* kus = reinterpret_cast<float*>(smem + KBT * KP + DK * VP);
 
   const int b = blockIdx.y, h = blockIdx.z;
   const int row0 = d.rg.cu_rows[b];
@@ -165,19 +168,19 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
   // d_k <= 192: the next tile is prefetched into registers during the current tile's MFMAs.  d_k = 256 does not
   // have the registers for that at 2 waves/SIMD: it loads and stores the tile back to back (still 16-byte batched)
   // and relies on the second resident workgroup to cover the round trip.
-  constexpr bool PREFETCH = DK <= 192 || sizeof(T) != 2;
-  TileRegs<T, DK> tr;
-  if (PREFETCH) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
-  for (int j0 = j_start; j0 < Tk; j0 += KB) {
-    if (!PREFETCH) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec);
-    tile_store<T, DK>(tr, ks, vs, kus, KP, VP);
+  constexpr bool PREFETCH = (DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192);   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
+  TileRegs<T, DK, KBT> tr;
+  if (PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
+  for (int j0 = j_start; j0 < Tk; j0 += KBT) {
+    if (!PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec);
+    tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP);
     __syncthreads();
-    if (PREFETCH && j0 + KB < Tk) tile_load<T, DK>(tr, d, kg, vtg, row0, h, j0 + KB, Tn, vt_vec);
+    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec);
 
     // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
-    float bd[4][4];
+    float bd[NF][4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NF; ++f) {
       const int jq = j0 + 16 * f + 4 * g;  // this lane's 4 consecutive keys jq .. jq+3 of fragment f
 #pragma unroll
       for (int r = 0; r < 4; ++r) bd[f][r] = 0.f;
@@ -208,13 +211,13 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
     }
 
     // ---- S^T fragments: st[f][r] = key (j0 + 16 f + 4 g + r)  x  query qc ----
-    f32x4 st[4];
+    f32x4 st[NF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) st[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < NF; ++f) st[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {   // 4 independent accumulator chains per contraction step
+    for (int s = 0; s < NKS; ++s) {   // NF independent accumulator chains per contraction step
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+      for (int f = 0; f < NF; ++f) {
         const T* ap = reinterpret_cast<const T*>(ks + (size_t)(16 * f + qc) * KP) + 32 * s + 8 * g;
         Vec a = load8<T>(ap);
         mma16(a, qf[s], st[f]);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
     // ---- bias terms, scale, mask, online softmax ----
     float mx = -INFINITY;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NF; ++f) {
       const f32x4 kq = *reinterpret_cast<const f32x4*>(kus + 16 * f + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = __expf(st[f][r] - m_new);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
     // ---- O^T += V^T P^T over two 32-key blocks.  Contraction slots of k-group g in block kb:
     //      keys {32kb + 4g + r} (from st[2kb]) then {32kb + 16 + 4g + r} (from st[2kb+1]) ----
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < KBT / 32; ++kb) {
       Vec pb;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -287,11 +290,11 @@ __global__ __launch_bounds__(256, (DK <= 256 && sizeof(T) == 2) ? 2 : 1) void re
   }
 }
 
-template <typename T, int DK>
-int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
-  const size_t lds = (size_t)KB * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KB * sizeof(T) + 16) + KB * sizeof(float);
+template <typename T, int DK, int KBT = KB>
+int launch_attn_kb(const jatts_relattn_desc& d, hipStream_t s) {
+  const size_t lds = (size_t)KBT * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KBT * sizeof(T) + 16) + KBT * sizeof(float);
   dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
-  auto kern = relattn_kernel<T, DK>;
+  auto kern = relattn_kernel<T, DK, KBT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
@@ -299,6 +302,14 @@ int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
+}
+template <typename T, int DK>
+int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
+  if constexpr (sizeof(T) == 4 && DK >= 128 && DK % 64 == 0) {
+    static const int half = [] { const char* e = getenv("JATTS_ATTN_KB32"); return e ? atoi(e) : 1; }();
+    if (half) return launch_attn_kb<T, DK, 32>(d, s);
+  }
+  return launch_attn_kb<T, DK, KB>(d, s);
 }
 
 template <typename T>
