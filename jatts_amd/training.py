@@ -178,7 +178,8 @@ class FastSpeech2Trainer:
     the clip coefficient is read on the device (no host sync in the step besides the loss values the caller asks for)."""
 
     def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
-                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1, scheduler="warmuplr", scheduler_params=None, capture_graph=False):
+                 bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1, scheduler="warmuplr", scheduler_params=None, capture_graph=False,
+                 max_graphs=8):
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
         self.overlap = overlap
@@ -218,6 +219,7 @@ class FastSpeech2Trainer:
         # second is captured.  See _graph_step.
         self.capture_graph = bool(capture_graph) and self._graph_capable
         self._graphs = {}
+        self.max_graphs = max(1, int(max_graphs))     # captured graphs kept (each owns the activations of one step: GBs); least recently used evicted
         self._buckets = None
 
     # -- gradients into the flat buffer.  With .grad pre-set to views of flat_g, autograd's AccumulateGrad runs one `view += g` kernel per
@@ -413,6 +415,11 @@ class FastSpeech2Trainer:
             self._graphs[sig] = {"graph": None}
             return self._train_step(batch)
         if st["graph"] is None:              # second sight: capture
+            live = [(v.get("used", 0), k) for k, v in self._graphs.items() if v.get("graph") is not None]
+            while len(live) >= self.max_graphs:               # a bucketed sampler can produce many signatures: bound the graphs' memory
+                live.sort()
+                _, k = live.pop(0)
+                self._graphs[k] = {"graph": None}             # (its next sight captures again)
             st["in"] = {k: (v.to(dev).clone() if torch.is_tensor(v) and (v.is_cuda or v.dim() != 1 or v.dtype not in (torch.int64, torch.int32)) else v)
                         for k, v in batch.items()}
             st["seed"] = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -459,6 +466,7 @@ class FastSpeech2Trainer:
         st["seed"].copy_(st["seed_host"], non_blocking=True)
         st["hyper"].copy_(st["hyper_host"], non_blocking=True)
         st["graph"].replay()
+        st["used"] = self.steps
         self.model._prep = None
         if self._bad_ids is None:
             self._bad_ids = hip.bad_ids_async(dev)

@@ -789,3 +789,12 @@ def test_graph_mode_replays_the_same_training(cuda, lib):
     for (n1, b1), (_, b2) in zip(a.model.named_buffers(), b.model.named_buffers()):
         if b1.dtype.is_floating_point:
             assert maxdiff(b1, b2) <= 2e-4 * max(1.0, float(b1.abs().max())), n1
+    # a second signature (one utterance fewer) with max_graphs = 1: capturing it evicts the first graph, which is re-captured on demand
+    b.max_graphs = 1
+    small = {k: (v[:-1] if torch.is_tensor(v) else v) for k, v in batch.items()}
+    for _ in range(3):
+        out = b.train_step(small)
+    assert sum(v.get("graph") is not None for v in b._graphs.values()) == 1 and math.isfinite(float(out["loss"]))
+    for _ in range(2):
+        out = b.train_step(batch)
+    assert sum(v.get("graph") is not None for v in b._graphs.values()) == 1 and math.isfinite(float(out["loss"]))
