@@ -425,3 +425,29 @@ def test_residual_drop_add_and_zero_pool(cuda, lib):
         hip.zero_pool_end()
     finally:
         hip._ZPOOL = keep
+
+
+def test_gather_grads_into_the_flat_buffer(cuda, lib):
+    """jatts_gather_grads: 150 tensors of odd sizes (three launches of <= 64, chunks of 4 096 elements) copied / accumulated into their
+    slots of a flat buffer; untouched slots keep their content."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(31)
+    sizes = [int(v) for v in torch.randint(1, 9000, (150,), generator=g)] + [1, 4096, 4097, 70000]
+    offs, o = [], 0
+    for i, n in enumerate(sizes):
+        offs.append(o)
+        o += n + (3 if i % 7 == 0 else 0)          # gaps between some slots
+    flat = torch.full((o + 5,), -7.0, device=cuda)
+    grads = [torch.randn(n, generator=g).to(cuda) for n in sizes]
+    hip.gather_grads(grads, offs, flat)
+    want = torch.full((o + 5,), -7.0)
+    for t, off in zip(grads, offs):
+        want[off:off + t.numel()] = t.cpu()
+    assert torch.equal(flat.cpu(), want)
+    hip.gather_grads(grads[:70], offs[:70], flat, accumulate=True)
+    for t, off in zip(grads[:70], offs[:70]):
+        want[off:off + t.numel()] += t.cpu()
+    assert torch.equal(flat.cpu(), want)
+    hip.gather_grads([], [], flat)
+    with pytest.raises(ValueError):
+        hip.gather_grads([grads[0].double()], [0], flat)
