@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak run of FastSpeech2Trainer at recipe size on one fixed synthetic batch (memorisation): the loss must fall steadily and stay
-finite over a few hundred steps (dropout on, WarmupLR, gradient clipping).  python tools/soak_train.py [--steps 200]"""
+finite over a few hundred steps (dropout on, WarmupLR, gradient clipping).  python tools/soak_train.py [--steps 200] [--graph]"""
 import argparse
 import json
 import math
@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--graph", action="store_true", help="FastSpeech2Trainer(capture_graph=True): the ragged batch replayed as one hipGraph")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m = FastSpeech2(idim=45, **{**FS2_JSUT, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
@@ -41,7 +42,7 @@ def main():
     batch = dict(xs=(torch.randint(1, 45, (B, T), generator=g) * mask.squeeze(-1).long()).to(dev), ilens=il, ys=ys.to(dev), olens=ol, durations=ds.to(dev),
                  duration_lens=il, pitch=(torch.randn(B, T, 1, generator=g) * mask).to(dev), pitch_lens=il,
                  energys=(torch.randn(B, T, 1, generator=g) * mask).to(dev), energy_lens=il)
-    tr = FastSpeech2Trainer(m, lr=1.0e-3, grad_norm=1.0, warmup_steps=50)
+    tr = FastSpeech2Trainer(m, lr=1.0e-3, grad_norm=1.0, warmup_steps=50, capture_graph=a.graph)
     hist, t0 = [], time.perf_counter()
     for s in range(a.steps):
         out = tr.train_step(batch)
