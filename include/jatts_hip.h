@@ -306,6 +306,10 @@ int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim, float* ou
 /* seed_dev (may be NULL): the mask seed is *seed_dev + seed -- a captured graph replays with a new base seed per step (device memory) and
  * `seed` as the call site's offset. */
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* stream);
+/* dropout(act(x)) in one pass (the FFN's ReLU -> Dropout, modules/transformer/multi_layer_conv.py:52-63; modes as jatts_act_fwd, mask as
+ * jatts_dropout: bit-identical to the two launches).  dy == NULL: out = keep ? act(x) / (1 - p) : 0; else out = keep ? dy act'(x) / (1 - p) : 0. */
+int jatts_act_dropout(int32_t mode, const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev,
+                      void* stream);
 /* y[i] = (resid ? resid[i] : 0) + alpha * dropout(x)[i] with jatts_dropout's mask for (seed, i): the residual connections of the
  * conformer layers (jatts/modules/conformer/encoder_layer.py:100-170) in one launch; p == 0 is a plain scaled add. */
 int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed, const uint64_t* seed_dev,

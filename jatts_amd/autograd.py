@@ -340,6 +340,24 @@ class Dropout(torch.autograd.Function):
         return hip.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.seed_dev), None, None, None
 
 
+class ActDropout(torch.autograd.Function):
+    """dropout(act(x)) -- the feed-forward module's ReLU -> Dropout (multi_layer_conv.py:52-63) -- as one launch each way; the same
+    counter-based mask as Dropout (bit-identical to Act followed by Dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, p, seed, seed_dev=None):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.cfg = (mode, p, seed, seed_dev)
+        return hip.act_dropout(x, mode, p, seed, seed_dev)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mode, p, seed, seed_dev = ctx.cfg
+        return hip.act_dropout(x, mode, p, seed, seed_dev, dy=dy.contiguous()), None, None, None, None
+
+
 class ResidualDropAdd(torch.autograd.Function):
     """x + alpha * dropout(h) -- a conformer layer's residual connection (encoder_layer.py:100-170) as one launch forward and one
     backward (d_x = dy is passed through, d_h = alpha * mask(dy) / (1 - p) regenerates the mask)."""

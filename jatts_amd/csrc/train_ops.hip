@@ -583,6 +583,35 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     y[i] = mix32(seed * 0x100000001B3ull + (uint64_t)i) >= thr ? x[i] * keep_scale : 0.f;
 }
 
+// dropout(act(x)) in one pass each way (the FFN's ReLU -> dropout, multi_layer_conv.py:52-63): same counter-based mask as dropout_kernel
+// (element index i), so it is bit-identical to act_fwd + dropout; dy == nullptr: forward (y = keep ? act(x) / (1 - p) : 0), else
+// backward (dx = keep ? dy act'(x) / (1 - p) : 0).
+__global__ __launch_bounds__(256) void act_dropout_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
+                                                          int64_t n, int mode, float p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;
+  const float keep_scale = 1.f / (1.f - p);
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  const uint64_t base = seed * 0x100000001B3ull;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+      f32x4 d = {1.f, 1.f, 1.f, 1.f}, o;
+      if (dy) d = *reinterpret_cast<const f32x4*>(dy + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool keep = mix32(base + (uint64_t)(i + e)) >= thr;
+        o[e] = keep ? (dy ? d[e] * act_grad(v[e], mode) : act_val(v[e], mode)) * keep_scale : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(out + i) = o;
+    } else {
+      for (int64_t k = i; k < n; ++k) {
+        const bool keep = mix32(base + (uint64_t)k) >= thr;
+        out[k] = keep ? (dy ? dy[k] * act_grad(x[k], mode) : act_val(x[k], mode)) * keep_scale : 0.f;
+      }
+    }
+  }
+}
+
 // y = resid + alpha * dropout(x): the residual connections of the conformer layers (encoder_layer.py:100-170: x + ff_scale * dropout(ffn),
 // x + dropout(attn), x + dropout(conv)) in ONE launch instead of dropout + scale + add; resid may be NULL (the backward of the
 // dropped branch: alpha * mask(dy) / (1 - p)), p may be 0 (a plain scaled add).
@@ -1076,6 +1105,16 @@ extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint6
   return JATTS_OK;
 }
 
+extern "C" int jatts_act_dropout(int32_t mode, const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed,
+                                 const uint64_t* seed_dev, void* stream) {
+  NULLCHK(!x || !out, "act_dropout: null pointer");
+  NULLCHK(mode < 1 || mode > 4, "act_dropout: mode 1 ReLU, 2 tanh, 3 Swish, 4 Mish");
+  NULLCHK(!(p >= 0.f && p < 1.f), "act_dropout: 0 <= p < 1");
+  if (n <= 0) return JATTS_OK;
+  hipLaunchKernelGGL(act_dropout_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, S_, x, dy, out, n, mode, p, seed, seed_dev);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
 extern "C" int jatts_dropout_add(const float* x, const float* resid, float* y, int64_t n, float p, float alpha, uint64_t seed,
                                  const uint64_t* seed_dev, void* stream) {
   NULLCHK(!x || !y, "dropout_add: null pointer");

@@ -1096,6 +1096,16 @@ def dropout(x, p, seed, seed_dev=None):
     return y
 
 
+def act_dropout(x, mode, p, seed, seed_dev=None, dy=None):
+    """dropout(act(x)) in one pass; with dy: its backward dy * act'(x) * mask / (1 - p).  Same mask as dropout()."""
+    lib = _abi.load()
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    _abi.check(lib.jatts_act_dropout(ACT_MODE[mode], x.data_ptr(), _ptr(_f32c(dy) if dy is not None else None), out.data_ptr(), x.numel(),
+                                     float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(seed_dev), _stream()), "jatts_act_dropout")
+    return out
+
+
 def dropout_add(x, resid, p, alpha, seed, seed_dev=None):
     """resid + alpha * dropout(x) (resid may be None); see jatts_dropout_add."""
     lib = _abi.load()

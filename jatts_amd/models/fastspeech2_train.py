@@ -41,6 +41,13 @@ class _Ctx:
         self.n_drop += 1
         return A.Dropout.apply(x, rate, self.seed + self.n_drop, self.seed_dev)
 
+    def act_drop(self, x, mode, rate):
+        """dropout(act(x)): one launch (ActDropout); the dropout site keeps its place in the seed sequence."""
+        if not self.train or rate <= 0.0:
+            return A.Act.apply(x, mode)
+        self.n_drop += 1
+        return A.ActDropout.apply(x, mode, rate, self.seed + self.n_drop, self.seed_dev)
+
     def resid_drop(self, x, h, rate, alpha=1.0):
         """x + alpha * dropout(h): one launch (ResidualDropAdd) instead of dropout, scale and add."""
         rate = rate if self.train else 0.0
@@ -104,8 +111,8 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
 
         def ffn(x, nm, ln):
             h = c.ln(x, q + ln)
-            h = A.Act.apply(c.conv(h, q + nm + ".w_1", rb), "relu")
-            h = c.conv(c.drop(h, rates["ffn"]), q + nm + ".w_2", rb)
+            h = c.act_drop(c.conv(h, q + nm + ".w_1", rb), "relu", rates["ffn"])
+            h = c.conv(h, q + nm + ".w_2", rb)
             return c.resid_drop(x, h, rates["layer"], ff_scale)
         if macaron:
             x = ffn(x, "feed_forward_macaron", "norm_ff_macaron")

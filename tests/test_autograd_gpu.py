@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import relerr
+from helpers import maxdiff, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 3e-5
@@ -451,3 +451,24 @@ def test_gather_grads_into_the_flat_buffer(cuda, lib):
     hip.gather_grads([], [], flat)
     with pytest.raises(ValueError):
         hip.gather_grads([grads[0].double()], [0], flat)
+
+
+@pytest.mark.parametrize("mode", ["relu", "swish"])
+def test_act_dropout_equals_act_then_dropout(cuda, lib, mode):
+    """ActDropout == Dropout(Act(x)) (same counter-based mask; bit for bit for ReLU), forward and backward, odd sizes, seed on the device too."""
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(41)
+    for n in (4099, 64, 3):
+        x, gy = torch.randn(n, 7, generator=g), torch.randn(n, 7, generator=g)
+        for seed_dev in (None, torch.tensor([12345], dtype=torch.int64, device=cuda)):
+            x1, x2 = x.clone().to(cuda).requires_grad_(), x.clone().to(cuda).requires_grad_()
+            y1 = A.Dropout.apply(A.Act.apply(x1, mode), 0.3, 77, seed_dev)
+            y2 = A.ActDropout.apply(x2, mode, 0.3, 77, seed_dev)
+            y1.backward(gy.to(cuda))
+            y2.backward(gy.to(cuda))
+            if mode == "relu":                       # (the FFN's case) bit for bit
+                assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+            else:                                    # same mask; the fused expression may contract its multiplies differently
+                assert torch.equal(y1 == 0, y2 == 0) and maxdiff(y1, y2) <= 1e-6 and maxdiff(x1.grad, x2.grad) <= 1e-6
+            if n > 1000:
+                assert 0.2 < float((y2 == 0).float().mean()) < (0.75 if mode == "relu" else 0.4)
