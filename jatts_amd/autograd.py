@@ -241,6 +241,22 @@ class AddBias(torch.autograd.Function):
         return dy, db
 
 
+class QKVSplit(torch.autograd.Function):
+    """The fused Q|K|V projection (rows, 3 A) -> (q + pos_bias_u, q + pos_bias_v, k, v), each (B, H, T, d_k) contiguous, in one launch
+    each way (jatts_qkv_split / _bwd; the bias gradients are column sums taken in the same backward pass).  Replaces two broadcast adds
+    and three permute copies forward, four zero-filled slice gradients and three adds backward, per attention layer."""
+
+    @staticmethod
+    def forward(ctx, qkv, u, v, B, T, H):
+        ctx.shapes = (u.shape, v.shape)
+        return tuple(hip.qkv_split(qkv.contiguous(), u.reshape(-1).contiguous(), v.reshape(-1).contiguous(), B, T, H))
+
+    @staticmethod
+    def backward(ctx, dqu, dqv, dk_, dvv):
+        dqkv, du, dv = hip.qkv_split_bwd(dqu.contiguous(), dqv.contiguous(), dk_.contiguous(), dvv.contiguous())
+        return dqkv, du.view(ctx.shapes[0]), dv.view(ctx.shapes[1]), None, None, None
+
+
 class SumAll(torch.autograd.Function):
     """x.sum() through jatts_col_sum (see AddBias)."""
 

@@ -612,6 +612,52 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(const float* __restric
   }
 }
 
+// Head split of the fused Q|K|V projection (attention.py:81-88,190-195): qkv [rows = B T][3 A] -> q + pos_bias_u, q + pos_bias_v, k, v,
+// each [B][H][T][d_k] contiguous (what the batched GEMMs want), one pass.  The backward gathers the four gradients back into d qkv
+// [rows][3 A] and adds the column sums of d(q + u), d(q + v) -- the bias gradients -- to du / dv (zero-initialised, f32 atomics: one per
+// thread and 32 rows).  As torch ops this was 2 broadcast adds + 3 permute copies forward and 4 zero-filled slice gradients + 3 adds back.
+__global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, const float* __restrict__ u, const float* __restrict__ v,
+                                                        int B, int T, int H, int dk, float* __restrict__ qu, float* __restrict__ qv,
+                                                        float* __restrict__ k, float* __restrict__ vv) {
+  const int A = H * dk;
+  const int64_t n = (int64_t)B * T * A;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / A;
+    const int c = (int)(i - row * A), h = c / dk, d = c - h * dk;
+    const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+    const int64_t o = (((int64_t)b * H + h) * T + t) * dk + d;
+    const float* src = qkv + row * 3 * A + c;
+    const float q = src[0];
+    qu[o] = q + u[c];
+    qv[o] = q + v[c];
+    k[o] = src[A];
+    vv[o] = src[2 * A];
+  }
+}
+__global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restrict__ dqu, const float* __restrict__ dqv, const float* __restrict__ dk_,
+                                                            const float* __restrict__ dvv, int B, int T, int H, int dk, float* __restrict__ dqkv,
+                                                            float* __restrict__ du, float* __restrict__ dv) {
+  const int A = H * dk;
+  const int64_t rows = (int64_t)B * T, r0 = (int64_t)blockIdx.x * 32;
+  for (int c = threadIdx.x; c < A; c += 256) {
+    const int h = c / dk, d = c - h * dk;
+    float su = 0.f, sv = 0.f;
+    for (int64_t row = r0; row < r0 + 32 && row < rows; ++row) {
+      const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+      const int64_t o = (((int64_t)b * H + h) * T + t) * dk + d;
+      const float a = dqu[o], e = dqv[o];
+      float* dst = dqkv + row * 3 * A + c;
+      dst[0] = a + e;
+      dst[A] = dk_[o];
+      dst[2 * A] = dvv[o];
+      su += a;
+      sv += e;
+    }
+    atomicAdd(&du[c], su);
+    atomicAdd(&dv[c], sv);
+  }
+}
+
 // y = resid + alpha * dropout(x): the residual connections of the conformer layers (encoder_layer.py:100-170: x + ff_scale * dropout(ffn),
 // x + dropout(attn), x + dropout(conv)) in ONE launch instead of dropout + scale + add; resid may be NULL (the backward of the
 // dropped branch: alpha * mask(dy) / (1 - p)), p may be 0 (a plain scaled add).
@@ -1105,6 +1151,25 @@ extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint6
   return JATTS_OK;
 }
 
+extern "C" int jatts_qkv_split(const float* qkv, const float* u, const float* v, int32_t n_batch, int32_t t_len, int32_t n_heads, int32_t d_k,
+                               float* qu, float* qv, float* k, float* vv, void* stream) {
+  NULLCHK(!qkv || !u || !v || !qu || !qv || !k || !vv, "qkv_split: null pointer");
+  NULLCHK(n_batch < 1 || t_len < 1 || n_heads < 1 || d_k < 1, "qkv_split: bad geometry");
+  hipLaunchKernelGGL(qkv_split_kernel, dim3(blocks_for((int64_t)n_batch * t_len * n_heads * d_k, 1024)), dim3(256), 0, S_, qkv, u, v, n_batch, t_len,
+                     n_heads, d_k, qu, qv, k, vv);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+extern "C" int jatts_qkv_split_bwd(const float* dqu, const float* dqv, const float* dk, const float* dvv, int32_t n_batch, int32_t t_len,
+                                   int32_t n_heads, int32_t d_k, float* dqkv, float* du, float* dv, void* stream) {
+  NULLCHK(!dqu || !dqv || !dk || !dvv || !dqkv || !du || !dv, "qkv_split_bwd: null pointer");
+  NULLCHK(n_batch < 1 || t_len < 1 || n_heads < 1 || d_k < 1, "qkv_split_bwd: bad geometry");
+  const int64_t rows = (int64_t)n_batch * t_len;
+  hipLaunchKernelGGL(qkv_split_bwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, S_, dqu, dqv, dk, dvv, n_batch, t_len, n_heads, d_k, dqkv,
+                     du, dv);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
 extern "C" int jatts_act_dropout(int32_t mode, const float* x, const float* dy, float* out, int64_t n, float p, uint64_t seed,
                                  const uint64_t* seed_dev, void* stream) {
   NULLCHK(!x || !out, "act_dropout: null pointer");

@@ -1096,6 +1096,32 @@ def dropout(x, p, seed, seed_dev=None):
     return y
 
 
+def qkv_split(qkv, u, v, B, T, H):
+    """qkv (B T, 3 A) -> (q + u, q + v, k, v) each (B, H, T, d_k) contiguous."""
+    lib = _abi.load()
+    qkv, u, v = _f32c(qkv), _f32c(u), _f32c(v)
+    A3 = qkv.shape[1]
+    dk = A3 // 3 // H
+    if qkv.shape[0] != B * T or dk * H * 3 != A3 or u.numel() != H * dk or v.numel() != H * dk:
+        raise ValueError("qkv_split: shapes")
+    outs = [torch.empty(B, H, T, dk, dtype=torch.float32, device=qkv.device) for _ in range(4)]
+    _abi.check(lib.jatts_qkv_split(qkv.data_ptr(), u.data_ptr(), v.data_ptr(), B, T, H, dk, *[o.data_ptr() for o in outs], _stream()),
+               "jatts_qkv_split")
+    return outs
+
+
+def qkv_split_bwd(dqu, dqv, dk_, dvv):
+    """-> (dqkv (B T, 3 A), du (A,), dv (A,))."""
+    lib = _abi.load()
+    dqu, dqv, dk_, dvv = _f32c(dqu), _f32c(dqv), _f32c(dk_), _f32c(dvv)
+    B, H, T, dk = dqu.shape
+    dqkv = torch.empty(B * T, 3 * H * dk, dtype=torch.float32, device=dqu.device)
+    du, dv = _zeros((H * dk), dqu.device), _zeros((H * dk), dqu.device)
+    _abi.check(lib.jatts_qkv_split_bwd(dqu.data_ptr(), dqv.data_ptr(), dk_.data_ptr(), dvv.data_ptr(), B, T, H, dk, dqkv.data_ptr(),
+                                       du.data_ptr(), dv.data_ptr(), _stream()), "jatts_qkv_split_bwd")
+    return dqkv, du, dv
+
+
 def act_dropout(x, mode, p, seed, seed_dev=None, dy=None):
     """dropout(act(x)) in one pass; with dy: its backward dy * act'(x) * mask / (1 - p).  Same mask as dropout()."""
     lib = _abi.load()

@@ -122,11 +122,8 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
         wqkv = torch.cat([c.p[a + "linear_q.weight"], c.p[a + "linear_k.weight"], c.p[a + "linear_v.weight"]], 0).unsqueeze(-1)
         bqkv = torch.cat([c.p[a + "linear_q.bias"], c.p[a + "linear_k.bias"], c.p[a + "linear_v.bias"]], 0)
         qkv2 = A.Conv1dFunction.apply(h, wqkv, bqkv, rb, 1, 0)                               # (rows, 3 A)
-        qkv = qkv2.view(B, T, 3, H, dk)
-        kh, vh = (qkv[:, :, j].permute(0, 2, 1, 3) for j in (1, 2))                         # (B, H, T, dk)
+        qu, qv, kh, vh = A.QKVSplit.apply(qkv2, c.p[a + "pos_bias_u"], c.p[a + "pos_bias_v"], B, T, H)      # each (B, H, T, dk), one launch
         ph = A.Conv1dFunction.apply(pos, c.p[a + "linear_pos.weight"].unsqueeze(-1), None, rbp, 1, 0).view(n_pos, H, dk).permute(1, 0, 2)
-        qu, qv = (A.AddBias.apply(qkv2[:, :Ad], c.p[a + nm].reshape(-1)).view(B, T, H, dk).permute(0, 2, 1, 3)
-                  for nm in ("pos_bias_u", "pos_bias_v"))
         ac = torch.matmul(qu, kh.transpose(-2, -1))                                         # rocBLAS batched GEMMs
         bd = torch.matmul(qv, ph.transpose(-2, -1)[None])
         p_attn = A.ShiftSoftmax.apply(ac, bd, kv, 1.0 / math.sqrt(dk), 2 if rel_style == "new" else 1)

@@ -472,3 +472,23 @@ def test_act_dropout_equals_act_then_dropout(cuda, lib, mode):
                 assert torch.equal(y1 == 0, y2 == 0) and maxdiff(y1, y2) <= 1e-6 and maxdiff(x1.grad, x2.grad) <= 1e-6
             if n > 1000:
                 assert 0.2 < float((y2 == 0).float().mean()) < (0.75 if mode == "relu" else 0.4)
+
+
+def test_qkv_split_backward(cuda, lib):
+    """QKVSplit == the reference's view / transpose of linear_q/k/v outputs plus the two position biases (attention.py:81-88,190-195),
+    forward and backward (d qkv, d pos_bias_u, d pos_bias_v) vs fp64 torch."""
+    from jatts_amd import autograd as A
+    g = torch.Generator().manual_seed(43)
+    for B, T, H, dk in [(3, 37, 2, 24), (2, 5, 4, 8), (1, 129, 2, 192)]:
+        Ad = H * dk
+        qkv, u, v = torch.randn(B * T, 3 * Ad, generator=g), torch.randn(H, dk, generator=g), torch.randn(H, dk, generator=g)
+        gs = [torch.randn(B, H, T, dk, generator=g) for _ in range(4)]
+        (qr, qd), (ur, ud), (vr, vd) = _leaf(qkv, cuda), _leaf(u, cuda), _leaf(v, cuda)
+        x = qr.view(B, T, 3, H, dk)
+        q_, k_, v_ = (x[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        ref = (q_ + ur[None, :, None, :], q_ + vr[None, :, None, :], k_, v_)
+        sum((r * g_.double()).sum() for r, g_ in zip(ref, gs)).backward()
+        outs = A.QKVSplit.apply(qd, ud, vd, B, T, H)
+        sum((o * g_.to(cuda)).sum() for o, g_ in zip(outs, gs)).backward()
+        assert all(o.is_contiguous() for o in outs)
+        _check([(f"out{i}", o, r) for i, (o, r) in enumerate(zip(outs, ref))] + [("dqkv", qd.grad, qr.grad), ("du", ud.grad, ur.grad), ("dv", vd.grad, vr.grad)])
