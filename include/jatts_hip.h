@@ -308,7 +308,8 @@ int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim, float* ou
 int jatts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* Head split of the fused Q|K|V projection for the training-time attention (modules/transformer/attention.py:81-88,190-195):
  * qkv [n_batch t_len][3 A] (A = n_heads d_k) -> qu = q + pos_bias_u, qv = q + pos_bias_v, k, vv, each [n_batch][n_heads][t_len][d_k]
- * contiguous.  _bwd: the four gradients -> dqkv [rows][3 A] (overwritten) and du / dv [A] += column sums (caller zeroes them). */
+ * contiguous.  _bwd: the four gradients -> dqkv [rows][3 A] (overwritten) and du / dv [A] += column sums (caller zeroes them).
+ * u == v == NULL (with qv / dqv / du / dv NULL): the plain head split of an attention without position biases (matchatts/transformer.py:16-25). */
 int jatts_qkv_split(const float* qkv, const float* u, const float* v, int32_t n_batch, int32_t t_len, int32_t n_heads, int32_t d_k, float* qu,
                     float* qv, float* k, float* vv, void* stream);
 int jatts_qkv_split_bwd(const float* dqu, const float* dqv, const float* dk, const float* dvv, int32_t n_batch, int32_t t_len, int32_t n_heads,

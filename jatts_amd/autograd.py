@@ -248,11 +248,19 @@ class QKVSplit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, u, v, B, T, H):
-        ctx.shapes = (u.shape, v.shape)
+        """u = v = None: plain head split -> (q, k, v)."""
+        ctx.shapes = None if u is None else (u.shape, v.shape)
+        if u is None:
+            return tuple(hip.qkv_split(qkv.contiguous(), None, None, B, T, H))
         return tuple(hip.qkv_split(qkv.contiguous(), u.reshape(-1).contiguous(), v.reshape(-1).contiguous(), B, T, H))
 
     @staticmethod
-    def backward(ctx, dqu, dqv, dk_, dvv):
+    def backward(ctx, *grads):
+        if ctx.shapes is None:
+            dq, dk_, dvv = grads
+            dqkv, _, _ = hip.qkv_split_bwd(dq.contiguous(), None, dk_.contiguous(), dvv.contiguous())
+            return dqkv, None, None, None, None, None
+        dqu, dqv, dk_, dvv = grads
         dqkv, du, dv = hip.qkv_split_bwd(dqu.contiguous(), dqv.contiguous(), dk_.contiguous(), dvv.contiguous())
         return dqkv, du.view(ctx.shapes[0]), dv.view(ctx.shapes[1]), None, None, None
 

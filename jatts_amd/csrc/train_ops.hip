@@ -628,8 +628,8 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
     const int64_t o = (((int64_t)b * H + h) * T + t) * dk + d;
     const float* src = qkv + row * 3 * A + c;
     const float q = src[0];
-    qu[o] = q + u[c];
-    qv[o] = q + v[c];
+    qu[o] = u ? q + u[c] : q;          // (u == v == nullptr: a plain head split, qv unused)
+    if (v) qv[o] = q + v[c];
     k[o] = src[A];
     vv[o] = src[2 * A];
   }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restr
     for (int64_t row = r0; row < r0 + 32 && row < rows; ++row) {
       const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
       const int64_t o = (((int64_t)b * H + h) * T + t) * dk + d;
-      const float a = dqu[o], e = dqv[o];
+      const float a = dqu[o], e = dqv ? dqv[o] : 0.f;
       float* dst = dqkv + row * 3 * A + c;
       dst[0] = a + e;
       dst[A] = dk_[o];
@@ -653,8 +653,8 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restr
       su += a;
       sv += e;
     }
-    atomicAdd(&du[c], su);
-    atomicAdd(&dv[c], sv);
+    if (du) atomicAdd(&du[c], su);
+    if (dv) atomicAdd(&dv[c], sv);
   }
 }
 
@@ -1153,7 +1153,7 @@ extern "C" int jatts_dropout(const float* x, float* y, int64_t n, float p, uint6
 
 extern "C" int jatts_qkv_split(const float* qkv, const float* u, const float* v, int32_t n_batch, int32_t t_len, int32_t n_heads, int32_t d_k,
                                float* qu, float* qv, float* k, float* vv, void* stream) {
-  NULLCHK(!qkv || !u || !v || !qu || !qv || !k || !vv, "qkv_split: null pointer");
+  NULLCHK(!qkv || !qu || !k || !vv || (v && !qv) || (!u != !v), "qkv_split: null pointer");
   NULLCHK(n_batch < 1 || t_len < 1 || n_heads < 1 || d_k < 1, "qkv_split: bad geometry");
   hipLaunchKernelGGL(qkv_split_kernel, dim3(blocks_for((int64_t)n_batch * t_len * n_heads * d_k, 1024)), dim3(256), 0, S_, qkv, u, v, n_batch, t_len,
                      n_heads, d_k, qu, qv, k, vv);
@@ -1162,7 +1162,7 @@ extern "C" int jatts_qkv_split(const float* qkv, const float* u, const float* v,
 }
 extern "C" int jatts_qkv_split_bwd(const float* dqu, const float* dqv, const float* dk, const float* dvv, int32_t n_batch, int32_t t_len,
                                    int32_t n_heads, int32_t d_k, float* dqkv, float* du, float* dv, void* stream) {
-  NULLCHK(!dqu || !dqv || !dk || !dvv || !dqkv || !du || !dv, "qkv_split_bwd: null pointer");
+  NULLCHK(!dqu || !dk || !dvv || !dqkv || (!dqv != !dv) || (!du != !dv), "qkv_split_bwd: null pointer");
   NULLCHK(n_batch < 1 || t_len < 1 || n_heads < 1 || d_k < 1, "qkv_split_bwd: bad geometry");
   const int64_t rows = (int64_t)n_batch * t_len;
   hipLaunchKernelGGL(qkv_split_bwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, S_, dqu, dqv, dk, dvv, n_batch, t_len, n_heads, d_k, dqkv,

@@ -1097,28 +1097,36 @@ def dropout(x, p, seed, seed_dev=None):
 
 
 def qkv_split(qkv, u, v, B, T, H):
-    """qkv (B T, 3 A) -> (q + u, q + v, k, v) each (B, H, T, d_k) contiguous."""
+    """qkv (B T, 3 A) -> (q + u, q + v, k, v) each (B, H, T, d_k) contiguous; u = v = None: (q, k, v)."""
     lib = _abi.load()
-    qkv, u, v = _f32c(qkv), _f32c(u), _f32c(v)
+    qkv = _f32c(qkv)
     A3 = qkv.shape[1]
     dk = A3 // 3 // H
-    if qkv.shape[0] != B * T or dk * H * 3 != A3 or u.numel() != H * dk or v.numel() != H * dk:
+    if qkv.shape[0] != B * T or dk * H * 3 != A3 or (u is None) != (v is None):
         raise ValueError("qkv_split: shapes")
-    outs = [torch.empty(B, H, T, dk, dtype=torch.float32, device=qkv.device) for _ in range(4)]
-    _abi.check(lib.jatts_qkv_split(qkv.data_ptr(), u.data_ptr(), v.data_ptr(), B, T, H, dk, *[o.data_ptr() for o in outs], _stream()),
+    if u is not None:
+        u, v = _f32c(u), _f32c(v)
+        if u.numel() != H * dk or v.numel() != H * dk:
+            raise ValueError("qkv_split: bias shapes")
+    outs = [torch.empty(B, H, T, dk, dtype=torch.float32, device=qkv.device) for _ in range(4 if u is not None else 3)]
+    qu, qv, k, vv = outs if u is not None else (outs[0], None, outs[1], outs[2])
+    _abi.check(lib.jatts_qkv_split(qkv.data_ptr(), _ptr(u), _ptr(v), B, T, H, dk, qu.data_ptr(), _ptr(qv), k.data_ptr(), vv.data_ptr(), _stream()),
                "jatts_qkv_split")
     return outs
 
 
 def qkv_split_bwd(dqu, dqv, dk_, dvv):
-    """-> (dqkv (B T, 3 A), du (A,), dv (A,))."""
+    """-> (dqkv (B T, 3 A), du (A,), dv (A,)); dqv None (no position biases): du = dv = None."""
     lib = _abi.load()
-    dqu, dqv, dk_, dvv = _f32c(dqu), _f32c(dqv), _f32c(dk_), _f32c(dvv)
+    dqu, dk_, dvv = _f32c(dqu), _f32c(dk_), _f32c(dvv)
     B, H, T, dk = dqu.shape
     dqkv = torch.empty(B * T, 3 * H * dk, dtype=torch.float32, device=dqu.device)
-    du, dv = _zeros((H * dk), dqu.device), _zeros((H * dk), dqu.device)
-    _abi.check(lib.jatts_qkv_split_bwd(dqu.data_ptr(), dqv.data_ptr(), dk_.data_ptr(), dvv.data_ptr(), B, T, H, dk, dqkv.data_ptr(),
-                                       du.data_ptr(), dv.data_ptr(), _stream()), "jatts_qkv_split_bwd")
+    du = dv = None
+    if dqv is not None:
+        dqv = _f32c(dqv)
+        du, dv = _zeros((H * dk), dqu.device), _zeros((H * dk), dqu.device)
+    _abi.check(lib.jatts_qkv_split_bwd(dqu.data_ptr(), _ptr(dqv), dk_.data_ptr(), dvv.data_ptr(), B, T, H, dk, dqkv.data_ptr(), _ptr(du), _ptr(dv),
+                                       _stream()), "jatts_qkv_split_bwd")
     return dqkv, du, dv
 
 

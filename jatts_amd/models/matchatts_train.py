@@ -45,8 +45,7 @@ def _tblock(c, p, x, rb, heads, key_bias, rate):
     wqkv = torch.cat([c.p[p + "attn1.to_q.weight"], c.p[p + "attn1.to_k.weight"], c.p[p + "attn1.to_v.weight"]], 0).unsqueeze(-1)
     inner = wqkv.shape[0] // 3
     dh = inner // heads
-    qkv = A.Conv1dFunction.apply(n, wqkv, None, rb, 1, 0).view(B, T, 3, heads, dh)
-    qh, kh, vh = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+    qh, kh, vh = A.QKVSplit.apply(A.Conv1dFunction.apply(n, wqkv, None, rb, 1, 0), None, None, B, T, heads)       # each (B, heads, T, dh)
     scale = dh ** -0.5
     sc = torch.matmul(qh, kh.transpose(-2, -1)) + (key_bias / scale)[:, None, None, :]                 # rocBLAS batched GEMM
     pa = A.ShiftSoftmax.apply(sc, None, None, scale)

@@ -492,3 +492,12 @@ def test_qkv_split_backward(cuda, lib):
         sum((o * g_.to(cuda)).sum() for o, g_ in zip(outs, gs)).backward()
         assert all(o.is_contiguous() for o in outs)
         _check([(f"out{i}", o, r) for i, (o, r) in enumerate(zip(outs, ref))] + [("dqkv", qd.grad, qr.grad), ("du", ud.grad, ur.grad), ("dv", vd.grad, vr.grad)])
+        # without position biases (Matcha's transformer blocks): (q, k, v)
+        qr, qd = _leaf(qkv, cuda)
+        x = qr.view(B, T, 3, H, dk)
+        ref = tuple(x[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        sum((r * g_.double()).sum() for r, g_ in zip(ref, gs)).backward()
+        outs = A.QKVSplit.apply(qd, None, None, B, T, H)
+        sum((o * g_.to(cuda)).sum() for o, g_ in zip(outs, gs)).backward()
+        assert len(outs) == 3
+        _check([(f"p{i}", o, r) for i, (o, r) in enumerate(zip(outs, ref))] + [("dqkv", qd.grad, qr.grad)])
