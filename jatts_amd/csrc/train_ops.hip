@@ -403,8 +403,12 @@ __global__ __launch_bounds__(256) void shift_softmax_fwd_kernel(const float* __r
   }
 }
 // ds = p * (dp - sum_j dp p) * scale  (written over dp's row into ds)
+// dbd != nullptr: the same value also goes to its place in the UN-shifted gradient of the position term (the inverse of shifted_bd), so
+// that no second pass over ds is needed: every dbd entry is written exactly once -- row i of ds owns, in the legacy view trick
+// ((i + 1) T + j = r (T + 1) + c + 1), a run of row i and the head of row i + 1 of dbd (row 0 also zero-fills the T - 1 entries of dbd
+// row 0 that no output reads); in the new style (mode 2: bd [T][2T-1], shifted[i][j] = bd[i][j - i + T - 1]) its own row, zeros outside.
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, int T, float scale,
-                                                          float* __restrict__ ds, int64_t n_rows) {
+                                                          float* __restrict__ ds, int64_t n_rows, float* __restrict__ dbd, int mode) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= n_rows) return;
@@ -414,24 +418,31 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int j = lane; j < T; j += 64) s += pr[j] * dr[j];
   s = wave_sum(s);
   float* o = ds + row * T;
-  for (int j = lane; j < T; j += 64) o[j] = pr[j] * (dr[j] - s) * scale;
-}
-// d_bd[r][c] = ds[i][j] with (i + 1) T + j = r (T + 1) + c + 1 (the inverse of shifted_bd; entries that no output reads get 0)
-__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ ds, int T, int64_t n_mats, float* __restrict__ dbd, int mode) {
-  const int W = mode == 2 ? 2 * T - 1 : T;
-  const int64_t n = n_mats * T * W;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int64_t mtx = e / ((int64_t)T * W);
-    const int rc = (int)(e - mtx * T * W);
-    const int r = rc / W, c = rc - r * W;
-    if (mode == 2) {
-      const int j = c - T + 1 + r;
-      dbd[e] = (j >= 0 && j < T) ? ds[mtx * T * T + (int64_t)r * T + j] : 0.f;
-      continue;
+  if (!dbd) {
+    for (int j = lane; j < T; j += 64) o[j] = pr[j] * (dr[j] - s) * scale;
+    return;
+  }
+  const int64_t mtx = row / T;
+  const int i = (int)(row - mtx * T);
+  if (mode == 2) {
+    const int W = 2 * T - 1, c0 = T - 1 - i;                 // ds[i][j] -> dbd[i][c0 + j]
+    float* q = dbd + (mtx * T + i) * (int64_t)W;
+    for (int c = lane; c < W; c += 64) {
+      const int j = c - c0;
+      float v = 0.f;
+      if (j >= 0 && j < T) { v = pr[j] * (dr[j] - s) * scale; o[j] = v; }
+      q[c] = v;
     }
-    const int f = r * (T + 1) + c + 1;
-    const int i = f / T - 1, j = f % T;
-    dbd[e] = (i >= 0 && i < T) ? ds[mtx * T * T + (int64_t)i * T + j] : 0.f;
+    return;
+  }
+  float* q = dbd + mtx * T * (int64_t)T;
+  if (i == 0)
+    for (int c = lane; c < T - 1; c += 64) q[c] = 0.f;      // f = c + 1 < T: read by no output
+  for (int j = lane; j < T; j += 64) {
+    const float v = pr[j] * (dr[j] - s) * scale;
+    o[j] = v;
+    const int f = (i + 1) * T + j, r = f / (T + 1), cc = f - r * (T + 1);
+    if (cc != 0 && r < T) q[(int64_t)r * T + cc - 1] = v;    // (cc == 0: the zero column of the padded view)
   }
 }
 // WaveNet gate (residual_block.py:150-156): y = tanh(a) sigmoid(b) on x = [a | b]; dx = [dy sigmoid(b) (1 - tanh^2 a) | dy tanh(a) s (1 - s)]
@@ -1098,10 +1109,8 @@ extern "C" int jatts_shift_softmax_bwd(const float* p, const float* dp, int32_t 
   NULLCHK(!p || !dp || !ds, "shift_softmax_bwd: null pointer");
   NULLCHK(n_batch < 1 || n_heads < 1 || t_len < 1, "shift_softmax_bwd: bad geometry");
   const int64_t n_rows = (int64_t)n_batch * n_heads * t_len;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, p, dp, t_len, scale, ds, n_rows);
-  if (dbd)
-    hipLaunchKernelGGL(unshift_kernel, dim3(blocks_for(n_rows * (shift_mode == 2 ? 2 * t_len - 1 : t_len), 256)), dim3(256), 0, S_, ds, t_len,
-                       (int64_t)n_batch * n_heads, dbd, shift_mode);
+  NULLCHK(dbd && shift_mode != 1 && shift_mode != 2, "shift_softmax_bwd: shift_mode 1 (legacy) or 2 (new)");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, S_, p, dp, t_len, scale, ds, n_rows, dbd, shift_mode);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
