@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TF = 2500.0   # dense f16/bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 (= the f32 vector rate)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def parse():
@@ -150,7 +150,7 @@ def pmc_passes(argv_tail, timeout_s=240):
 
 
 def committed_traffic():
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
         if os.path.exists(path):
             return json.load(open(path))["kernels"], f"profiles/{rnd}_traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run)"
@@ -465,6 +465,8 @@ def _roof(rf):
         return None
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")
     o = {k: rf.get(k) for k in keep}
+    src = rf.get("traffic_source") or ""
+    o["traffic_source"] = None if rf.get("traffic") is None else ("committed" if src.startswith("profiles/") or "committed" in src else "live")
     o["alg_bytes"] = rf.get("algorithmic_bytes_per_launch")
     o["alg_flops"] = rf.get("algorithmic_flops_per_launch")
     return o
@@ -474,8 +476,8 @@ def compact_line(out, detail_path=None):
     """The ONE line the driver parses: the graded keys only, numbers rounded to 5 significant digits, < LINE_LIMIT
     bytes.  Everything else (`resunit_by_shape`, `conv1d_by_shape`, per-step lists, long sample descriptions) lives
     in the detail file written next to it."""
-    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "config", "rtf", "executor")
+    keys = ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "backend", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "rtf", "executor")
     c = {k: out[k] for k in keys if k in out}
     if out.get("stage_ms_per_step"):
         c["stage_ms"] = out["stage_ms_per_step"]
@@ -493,6 +495,8 @@ def compact_line(out, detail_path=None):
         c["speedup_vs_cpu_rtf"] = out.get("speedup_vs_cpu_rtf")
     else:
         c["cpu_baseline"] = None
+        if out.get("cpu_baseline_note"):
+            c["cpu_baseline_note"] = out["cpu_baseline_note"]
     fm = out.get("fast_mode") or out.get("f32_mode")
     if fm:
         c["fast_mode" if "fast_mode" in out else "f32_mode"] = {
@@ -545,14 +549,43 @@ def write_detail(out):
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate"}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: run the driver's own launch line
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`) as a
+    CHILD process -- never an exec, and before this process has touched the GPU -- relay everything the ranks print to
+    stderr, print rank 0's JSON line as the LAST stdout line and return the child's exit code."""
+    from jatts_amd.distributed import self_launch as launch
+    found = []
+
+    def relay(ln):
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                json.loads(t)
+            except ValueError:
+                return False
+            found[:] = [t]
+            return True
+        return False
+    rc = launch(n, os.path.abspath(__file__), argv, relay=relay)
+    if found:
+        print(found[0], flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (child processes; nothing here has touched the GPU yet)
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py --gpus {a.gpus} launched with WORLD_SIZE={world}: --nproc-per-node must equal --gpus")
 
     # roofline.traffic: PMC passes run as children BEFORE this process touches the GPU
     traffic_table = traffic_source = None
@@ -613,6 +646,8 @@ def main():
                    "hop": job.hop, "sampling_rate": job.sr,
                    "parallelism": f"dp{world} (utterance sharding, int16 PCM all-gather)"
                                   + (" [shared-GPU test mode: all ranks on cuda:0, gloo]" if shared else "")},
+        "n_ranks_seen": dist.get_world_size() if dist else 1,
+        "backend": (("gloo [shared-GPU test mode]" if shared else "nccl (RCCL)") if dist else None),
         "rtf": head["rtf"], "stage_ms_per_step": head["stages"], "rank_ms_per_step": head["rank_ms"],
         "executor": "two-stream pipeline (jatts_amd.pipeline)" if a.pipeline else "sequential",
     }
@@ -714,6 +749,8 @@ def main():
             out["fast_mode"]["speedup_vs_cpu_rtf"] = cb["rtf"] / out["fast_mode"]["rtf"]
     else:
         out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = ("N=1 only (rank 0 at N=1 times the CPU leg; the N>1 line also carries no live PMC traffic: "
+                                    "roofline.traffic is the committed table)" if world > 1 else "--no-cpu-baseline")
     if rank == 0:
         sys.stdout.flush()
         sys.stderr.flush()

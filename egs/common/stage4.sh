@@ -33,6 +33,7 @@ stage4_decode() {
             --outdir "${outdir}/${name}" \
             --precision "${precision}" \
             --batch-size "${decode_batch_size}" \
+            --n_gpus "${n_gpus}" \
             --verbose "${verbose}" > "${outdir}/${name}/decode.log" 2>&1 || { tail -20 "${outdir}/${name}/decode.log"; exit 1; }
         log "Successfully finished decoding of ${name} set."
     done

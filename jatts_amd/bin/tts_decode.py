@@ -161,11 +161,19 @@ def get_parser():
     p.add_argument("--precision", default="fp32", choices=["fp16", "fp32"],
                    help="fp32 = the reference's arithmetic (default); fp16 = fast mode: f16 MFMA operands, f32 accumulate (extension)")
     p.add_argument("--plot", action="store_true", help="also write <outdir>/outs/<id>.png like the reference")
+    p.add_argument("--n_gpus", "--n-gpus", dest="n_gpus", type=int, default=1,
+                   help="one process per GPU, every rank decodes its own shard of the csv (extension; the recipes' n_gpus). "
+                        "Without a launcher in the environment the ranks are started here as child processes")
     return p
 
 
 def main(argv=None):
     args = get_parser().parse_args(argv)
+    if args.n_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python -m jatts_amd.bin.tts_decode --n_gpus N`: start the N ranks as children before anything touches the GPU
+        import sys
+        from jatts_amd.distributed import self_launch
+        raise SystemExit(self_launch(args.n_gpus, "jatts_amd.bin.tts_decode", sys.argv[1:] if argv is None else list(argv), module=True))
     level = logging.DEBUG if args.verbose > 1 else logging.INFO if args.verbose > 0 else logging.WARN
     logging.basicConfig(level=level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
     os.makedirs(os.path.join(args.outdir, "wav"), exist_ok=True)
@@ -176,9 +184,13 @@ def main(argv=None):
     config.update(vars(args))
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if args.n_gpus > 1 and world != args.n_gpus:
+        raise RuntimeError(f"--n_gpus {args.n_gpus} under a launcher with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise RuntimeError("jatts_amd needs an MI355X: there is no CPU fallback")
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    # JATTS_SHARED_GPU=1 (tests only): every rank on cuda:0, to run the world > 1 branch on a one-GPU box
+    shared = os.environ.get("JATTS_SHARED_GPU") == "1"
+    device = torch.device("cuda", 0 if shared else int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(device)
 
     converter = TokenIDConverter(args.token_list)

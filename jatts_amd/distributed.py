@@ -88,3 +88,30 @@ def unshard(waves, lens_per_rank, parts):
             out[i] = waves[r][o:o + m]
             o += m
     return out
+
+
+def self_launch(n, target, argv, module=False, relay=None):
+    """Start `n` ranks of `target` (a script path, or a module name with module=True) the way the recipes / the driver do --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> ...` -- as a CHILD
+    process and return its exit code.  To be called BEFORE the calling process touches the GPU (a process that has initialised HIP
+    must never be replaced by an exec on this pool, and does not need to be: the parent only waits).  `relay(line) -> bool` may claim
+    stdout lines (they are then not echoed to stderr)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += (["-m", target] if module else [target]) + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL across processes)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for ln in proc.stdout:
+        if relay is None or not relay(ln):
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    sys.stderr.flush()
+    return rc

@@ -103,3 +103,29 @@ def test_bucketed_gradient_allreduce_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res) and all(n == 3 for _, _, n in res), res
+
+
+def test_self_launch_starts_the_ranks_as_children(tmp_path):
+    """jatts_amd.distributed.self_launch (what `python bench.py --gpus N` and `tts_decode --n_gpus N` do without a launcher): the
+    driver's own torch.distributed.run line as a CHILD process; every rank sees RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1, stdout lines
+    can be claimed by the caller, the child's exit code comes back."""
+    import sys
+    from jatts_amd.distributed import self_launch
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\n"
+                      "print('rank', os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], sys.argv[1], flush=True)\n"
+                      "sys.exit(3 if sys.argv[1] == 'fail' and os.environ['RANK'] == '1' else 0)\n")
+    seen = []
+    rc = self_launch(2, str(script), ["ok"], relay=lambda ln: seen.append(ln.strip()) or True)
+    assert rc == 0 and sorted(seen) == ["rank 0 2 127.0.0.1 ok", "rank 1 2 127.0.0.1 ok"]
+    assert self_launch(2, str(script), ["fail"], relay=lambda ln: True) != 0
+
+
+def test_bench_refuses_a_mismatched_launch(tmp_path):
+    """bench.py --gpus 4 under a 2-rank launcher is an error, not a silent 2-rank run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--no-pmc"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--nproc-per-node must equal --gpus" in r.stderr

@@ -72,7 +72,8 @@ def test_data_parallel_training_world2(cuda, lib):
     assert abs(a["checksum"] - b["checksum"]) <= 1e-6 * b["checksum"]
 
 
-def test_bench_two_ranks_on_the_shared_gpu(cuda, lib):
+@pytest.mark.parametrize("plain", [False, True], ids=["torchrun", "plain-python"])
+def test_bench_two_ranks_on_the_shared_gpu(cuda, lib, plain):
     """bench.py's N > 1 path (the driver's `torch.distributed.run --nproc-per-node N bench.py --gpus N` launch: sharding by rank,
     barrier-bracketed timing, max over ranks, int16 PCM all-gather inside the step) with two ranks on this box's one GPU
     (JATTS_BENCH_SHARED_GPU=1: gloo instead of RCCL).  The line must report the whole job: n_gpus 2, twice one rank's samples."""
@@ -85,14 +86,21 @@ def test_bench_two_ranks_on_the_shared_gpu(cuda, lib):
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, JATTS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-fast-mode"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-fast-mode"]
+    if plain:    # `python bench.py --gpus 2` with no launcher in the environment: bench.py starts its own two ranks as children
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable] + tail
+    else:        # the driver's launch line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 1 and j["cpu_baseline"] is None
+    assert j["n_ranks_seen"] == 2 and j["backend"].startswith("gloo") and "N=1 only" in j["cpu_baseline_note"]
     per_rank = 8 * 128 * 6 * j["config"]["hop"]
     assert abs(j["value"] * j["ms_per_step"] / 1e3 - 2 * per_rank) <= 1e-4 * per_rank      # the line rounds to 5 significant digits
     assert j["stage_ms"]["audio_all_gather"] > 0.0 and "shared-GPU test mode" in j["config"]["parallelism"]
@@ -102,3 +110,38 @@ def test_bench_two_ranks_on_the_shared_gpu(cuda, lib):
     assert r.stdout.rstrip().endswith(lines[0])                      # nothing printed after it
     detail = json.load(open(os.path.join(root, "bench_detail.json")))
     assert detail["n_gpus"] == 2 and "resunit_by_shape" in detail
+
+
+def test_cli_two_ranks_equal_one_rank(cuda, lib, tmp_path):
+    """`python -m jatts_amd.bin.tts_decode --n_gpus 2` with no launcher: the CLI starts its two ranks itself (children), each decodes
+    its shard of a RAGGED csv (JATTS_SHARED_GPU=1: both on this box's one GPU; there is no collective, the outputs are files) --
+    every wav exists exactly once and is bit-identical to the one-process run."""
+    import subprocess
+    import sys
+    from test_cli import _make_expdir
+    import csv as _csv
+    d = tmp_path
+    _make_expdir(d)
+    tokens = (d / "tokens.txt").read_text().split("\n")[:-1]
+    g = torch.Generator().manual_seed(5)
+    lens = (7, 15, 11, 3, 22, 9, 1)
+    with open(d / "ragged.csv", "w", newline="") as f:
+        w = _csv.DictWriter(f, fieldnames=["sample_id", "phonemes"])
+        w.writeheader()
+        for i, n in enumerate(lens):
+            w.writerow({"sample_id": f"r{i}", "phonemes": " ".join(tokens[int(j)] for j in torch.randint(2, 19, (n,), generator=g))})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "jatts_amd.bin.tts_decode", "--csv", str(d / "ragged.csv"), "--stats", str(d / "stats.npz"),
+            "--token-list", str(d / "tokens.txt"), "--token-column", "phonemes", "--checkpoint", str(d / "checkpoint-1steps.pkl"),
+            "--verbose", "0", "--batch-size", "3"]
+    env = dict(os.environ, JATTS_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for n, out in ((1, "out1"), (2, "out2")):
+        r = subprocess.run(base + ["--outdir", str(d / out), "--n_gpus", str(n)], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    names = sorted(os.listdir(d / "out1" / "wav"))
+    assert names == sorted(f"r{i}.wav" for i in range(len(lens))) == sorted(os.listdir(d / "out2" / "wav"))
+    for nm in names:
+        a, b = (d / "out1" / "wav" / nm).read_bytes(), (d / "out2" / "wav" / nm).read_bytes()
+        assert len(a) > 44 and a == b, nm
