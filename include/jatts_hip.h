@@ -31,6 +31,12 @@ extern "C" {
 
 #define JATTS_F32 0
 #define JATTS_F16 1
+/* f32 activations in HBM, error-corrected split-precision MFMA operands (round 4): every operand value, scaled by a
+ * power of two, travels as hi = f16(v), lo = f16(v - hi) and a product is hi.hi + hi.lo + lo.hi on
+ * v_mfma_f32_32x32x16_f16 with f32 accumulate (3/16 of the matrix-pipe cycles of the exact-f32 chain, ~22 significand
+ * bits per operand).  Accepted by jatts_hifigan_resunit only; weights packed by the host as [hi x8 | lo x8] per lane
+ * (jatts_amd.hip.pack_conv_weight_split) with the inverse per-output-channel scales in ws1 / ws2. */
+#define JATTS_F32S 2
 
 #define JATTS_ACT_NONE 0
 #define JATTS_ACT_RELU 1
@@ -148,6 +154,9 @@ typedef struct jatts_resunit_desc {
   const void* add0;
   const void* add1;
   float out_scale;
+  /* JATTS_F32S only: channels floats each, 2^-s[n] where w1 / w2 were packed as hi/lo of w[n] * 2^s[n] (NULL otherwise) */
+  const float* ws1;
+  const float* ws2;
 } jatts_resunit_desc;
 
 int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);

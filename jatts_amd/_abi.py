@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
-F32, F16 = 0, 1
+F32, F16, F32S = 0, 1, 2      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH = 0, 1, 2, 3, 4
 PRE_NONE, PRE_LRELU = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -39,6 +39,7 @@ class ResUnitDesc(C.Structure):
         ("dil", C.c_int32), ("slope", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
         ("add0", C.c_void_p), ("add1", C.c_void_p), ("out_scale", C.c_float),
+        ("ws1", C.c_void_p), ("ws2", C.c_void_p),
     ]
 
 

@@ -36,6 +36,17 @@ template <> struct Elem<float> {
   static constexpr int kBytes = 4;
 };
 
+// Split-precision operand (round 4): an f32 value v (pre-scaled by a power of two into f16's range) carried as
+// hi = f16(v), lo = f16(v - hi) -- 22 significand bits.  The element TAG is 4 bytes wide like f32, so every address
+// computation of the f32 tiles carries over; 8 consecutive elements are stored PLANAR (16 B of hi, then 16 B of lo)
+// so that each half is directly an MFMA operand.
+struct f16s { f16 hi, lo; };
+struct f16sx8 { f16x8 hi, lo; };
+template <> struct Elem<f16s> {
+  typedef f16sx8 vec8;
+  static constexpr int kBytes = 4;
+};
+
 // One "K=16" step of a 32x32 output fragment.  Lane l supplies row/col (l&31) and
 // contraction elements 8*(l>>5) .. 8*(l>>5)+7 of both operands.
 //  f16 : v_mfma_f32_32x32x16_f16 (dense f16 MFMA rate, f32 accumulate)
@@ -48,6 +59,13 @@ __device__ __forceinline__ void mma32(const f16x8& a, const f16x8& b, f32x16& c)
 __device__ __forceinline__ void mma32(const f32x8& a, const f32x8& b, f32x16& c) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+}
+//  f16s: hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 into ONE f32 accumulator (lo.lo is below f32 resolution);
+//        the caller un-scales the sum by an exact power of two
+__device__ __forceinline__ void mma32(const f16sx8& a, const f16sx8& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
 }
 // 16x16 output fragment, "K=32" step: lane supplies row/col (l&15) and contraction
 // elements 8*(l>>4) .. +7.

@@ -12,6 +12,7 @@ int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s);
 int jatts_resunit_f16_narrow(const jatts_resunit_desc& d, hipStream_t s);  // C = 32, 64
 int jatts_resunit_f16_wide(const jatts_resunit_desc& d, hipStream_t s);    // C = 128, 256, 512
 int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
+int jatts_resunit_split(const jatts_resunit_desc& d, hipStream_t s);       // JATTS_F32S
 int jatts_resblock_f16(const jatts_resblock_desc& d, hipStream_t s);
 int jatts_resblock_f32(const jatts_resblock_desc& d, hipStream_t s);
 
@@ -51,6 +52,10 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return d->channels <= 64 ? jatts_resunit_f16_narrow(*d, s) : jatts_resunit_f16_wide(*d, s);
   if (d->dtype == JATTS_F32) return jatts_resunit_f32(*d, s);
+  if (d->dtype == JATTS_F32S) {
+    if (!d->ws1 || !d->ws2) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: JATTS_F32S needs ws1 / ws2");
+    return jatts_resunit_split(*d, s);
+  }
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels/dtype (use jatts_conv1d)");
 }
 

@@ -43,6 +43,20 @@ template <> struct Vec8IO<float> {
   }
 };
 
+template <> struct Vec8IO<f16s> {   // 32 bytes per 8 elements: [hi x8 | lo x8]
+  static __device__ __forceinline__ f16sx8 ldg(const f16s* p) {
+    const f16x8* q = reinterpret_cast<const f16x8*>(p);
+    return f16sx8{q[0], q[1]};
+  }
+  static __device__ __forceinline__ f16sx8 lds(const char* p) {
+    return f16sx8{*reinterpret_cast<const f16x8*>(p), *reinterpret_cast<const f16x8*>(p + 16)};
+  }
+  static __device__ __forceinline__ void sts(char* p, const f16sx8& v) {
+    *reinterpret_cast<f16x8*>(p) = v.hi;
+    *reinterpret_cast<f16x8*>(p + 16) = v.lo;
+  }
+};
+
 // Stage `rows` x `nch` (multiple of 8) activations into LDS rows of `pitch` bytes.
 // Source row for LDS row r is local position pos0 + r of a sequence of length L starting at
 // global row seq_row0; positions outside [0, L) give zeros.  Up to 3 inputs are summed,

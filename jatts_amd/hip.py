@@ -9,9 +9,9 @@ import ctypes as C
 import torch
 
 from . import _abi
-from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32  # noqa: F401
+from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32, F32S  # noqa: F401
 
-_TORCH = {F32: torch.float32, F16: torch.float16}
+_TORCH = {F32: torch.float32, F16: torch.float16, F32S: torch.float32}
 
 
 def torch_dtype(code):
@@ -270,6 +270,28 @@ def pack_conv_weight(w, dtype_code, c_mult=64):
     return wp.to(torch_dtype(dtype_code))
 
 
+def pack_conv_weight_split(w, c_mult=32):
+    """(n_out, c_in, k) f32 -> the JATTS_F32S operand of the fused HiFi-GAN unit: per output channel n a power-of-two scale
+    2^s[n] puts max |w[n]| in [2^14, 2^15) (so that the lo halves stay normal f16 numbers over 18 binary orders of magnitude
+    below the channel's largest weight); ws = w * 2^s[n] travels as hi = f16(ws), lo = f16(ws - hi) in the fragment order of
+    pack_conv_weight with the two halves of a lane's 8 elements side by side: [tap][c/16][n/32][lane][hi x8 | lo x8].
+    -> (packed f16 tensor, inverse scales 2^-s[n] as f32 (n_pad,)).  Pure scaling by powers of two, one rounding per half."""
+    n, c, k = w.shape
+    w = w.detach().float()
+    n_pad = round_up(n, 32)
+    amax = w.abs().reshape(n, -1).amax(dim=1)
+    e = torch.frexp(amax)[1]                               # amax = m 2^e, m in [0.5, 1)
+    s = torch.where(amax > 0, 15 - e, torch.zeros_like(e)).clamp(-60, 60)
+    ws = torch.ldexp(w, s.view(-1, 1, 1).expand_as(w).to(torch.int32))
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    ph = pack_conv_weight(hi.float(), F16, c_mult).view(-1, 8)
+    pl = pack_conv_weight(lo.float(), F16, c_mult).view(-1, 8)
+    inv = torch.ones(n_pad, dtype=torch.float32, device=w.device)
+    inv[:n] = torch.ldexp(torch.ones_like(amax), (-s).to(torch.int32))
+    return torch.stack([ph, pl], dim=1).reshape(-1).contiguous(), inv.contiguous()
+
+
 def pack_conv_weight_dev(w, dtype_code, c_mult=64, dgrad=False):
     """pack_conv_weight as ONE HIP launch on a device f32 weight (n_out, c_in, k); dgrad=True packs the data-gradient operand
     W'[c][n][k-1-tap] directly (no permute / flip copies).  -> (packed, padded c_in of the packed conv)."""
@@ -361,7 +383,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     return out
 
 
-def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype, add=None, out_scale=1.0):
+def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype, add=None, out_scale=1.0, ws=None):
     lib = _abi.load()
     d = _abi.ResUnitDesc()
     d.rg = rb.struct(len_mul)
@@ -371,6 +393,10 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
         raise ValueError("hifigan_resunit: bad buffer size/dtype")
     d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
     d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    if dtype == F32S:
+        if ws is None or ws[0].numel() < channels or ws[1].numel() < channels or ws[0].dtype != torch.float32:
+            raise ValueError("hifigan_resunit: F32S needs the inverse weight scales (pack_conv_weight_split)")
+        d.ws1, d.ws2 = ws[0].data_ptr(), ws[1].data_ptr()
     if add:
         for a in add:
             if a.numel() != rows * channels or a.dtype != x.dtype:

@@ -162,6 +162,83 @@ def test_hifigan_resunit(cuda, lib, prec, C, k, d, lens):
     assert e <= TOL[prec], f"resunit C={C} k={k} d={d} {prec}: rel err {e:.3e}"
 
 
+def _maxerr(y, ref):
+    return float((y.double().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("xkind", ["unit", "tiny", "large", "wide"])
+@pytest.mark.parametrize("C,k,d,lens", [
+    (32, 3, 1, [700, 3, 250]), (32, 11, 5, [600, 31]), (64, 7, 3, [513]), (64, 11, 5, [260, 9]), (128, 3, 5, [300, 40]),
+    (128, 11, 1, [129]), (128, 11, 5, [300]), (128, 7, 3, [140, 139]), (256, 7, 5, [150, 64]), (256, 11, 5, [70]), (256, 3, 1, [200]),
+])
+def test_hifigan_resunit_split(cuda, lib, C, k, d, lens, xkind):
+    """JATTS_F32S (round 4): f32 activations, split-precision f16 hi/lo MFMA operands with power-of-two tile / channel scales.
+    Held to the SAME tolerance as the exact-f32 kernel (relative L2 <= 2e-5 against fp64), and its maximum error against fp64 must
+    not exceed twice the exact-f32 kernel's on the same inputs -- at unit, tiny (1e-6), large (3e3) and mixed (8 orders of magnitude
+    between rows) activation magnitudes, i.e. wherever f16's narrow exponent range would bite a naive split."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + d)
+    R = sum(lens)
+    x = torch.randn(R, C, generator=g)
+    if xkind == "tiny":
+        x = x * 1e-6
+    elif xkind == "large":
+        x = x * 3e3
+    elif xkind == "wide":
+        x = x * torch.pow(10.0, torch.rand(R, 1, generator=g) * 8 - 6)
+    w1 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k) * torch.pow(10.0, torch.rand(C, 1, 1, generator=g) * 2 - 1)   # per-channel spread
+    w2 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    sb = {"unit": 0.1, "tiny": 1e-7, "large": 300.0, "wide": 0.1}[xkind]
+    b1, b2 = torch.randn(C, generator=g) * sb, torch.randn(C, generator=g) * sb
+    ref = _ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, False)
+    rb = _ragged(lens, cuda)
+    xd = x.to(cuda)
+    ws1, is1 = hip.pack_conv_weight_split(w1.to(cuda), 32)
+    ws2, is2 = hip.pack_conv_weight_split(w2.to(cuda), 32)
+    y = torch.full_like(xd, float("nan"))
+    hip.hifigan_resunit(rb, 1, xd, y, ws1, b1.to(cuda), ws2, b2.to(cuda), C, k, d, 0.1, hip.F32S, ws=(is1, is2))
+    y32 = torch.full_like(xd, float("nan"))
+    hip.hifigan_resunit(rb, 1, xd, y32, hip.pack_conv_weight(w1.to(cuda), hip.F32, 32), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), hip.F32, 32), b2.to(cuda), C, k, d, 0.1, hip.F32)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all(), "unwritten / non-finite outputs"
+    e, e32 = relerr(y, ref), relerr(y32, ref)
+    assert e <= TOL["fp32"], f"split resunit C={C} k={k} d={d} {xkind}: rel err {e:.3e} (exact f32: {e32:.3e})"
+    m, m32 = _maxerr(y, ref), _maxerr(y32, ref)
+    assert m <= 2.0 * m32 + 1e-30, f"split resunit C={C} k={k} d={d} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
+    # an utterance alone == the same utterance inside the batch, bit for bit (tile scales are per utterance tile)
+    if len(lens) > 1:
+        L0 = lens[0]
+        y0 = torch.empty(L0, C, device=cuda)
+        hip.hifigan_resunit(_ragged([L0], cuda), 1, xd[:L0].contiguous(), y0, ws1, b1.to(cuda), ws2, b2.to(cuda), C, k, d, 0.1, hip.F32S, ws=(is1, is2))
+        assert torch.equal(y0, y[:L0])
+
+
+def test_hifigan_resunit_split_mrf_and_errors(cuda, lib):
+    """The fused MRF mean of the split unit's output pass; zero input (tile maximum 0) stays exact; missing scales are refused."""
+    from jatts_amd import hip
+    from jatts_amd._abi import JattsHipError
+    g = torch.Generator().manual_seed(12)
+    lens, C, k, d = [300, 77], 64, 7, 3
+    R = sum(lens)
+    x, a0, a1 = (torch.randn(R, C, generator=g) for _ in range(3))
+    w1, w2 = (torch.randn(C, C, k, generator=g) / math.sqrt(C * k) for _ in range(2))
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    ref = (_ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, False) + a0.double() + a1.double()) / 3.0
+    rb = _ragged(lens, cuda)
+    ws1, is1 = hip.pack_conv_weight_split(w1.to(cuda), 32)
+    ws2, is2 = hip.pack_conv_weight_split(w2.to(cuda), 32)
+    y = torch.empty(R, C, device=cuda)
+    hip.hifigan_resunit(rb, 1, x.to(cuda), y, ws1, b1.to(cuda), ws2, b2.to(cuda), C, k, d, 0.1, hip.F32S,
+                        add=[a0.to(cuda), a1.to(cuda)], out_scale=1.0 / 3.0, ws=(is1, is2))
+    assert relerr(y, ref) <= TOL["fp32"]
+    z = torch.zeros(R, C, device=cuda)
+    hip.hifigan_resunit(rb, 1, z, y, ws1, torch.zeros(C, device=cuda), ws2, b2.to(cuda), C, k, d, 0.1, hip.F32S, ws=(is1, is2))
+    assert torch.equal(y, b2.to(cuda).expand(R, C))          # conv1(0) = 0 -> h = 0 -> y = 0 + b2
+    with pytest.raises((JattsHipError, ValueError)):
+        hip.hifigan_resunit(rb, 1, z, y, ws1, b1.to(cuda), ws2, b2.to(cuda), C, k, d, 0.1, hip.F32S)
+
+
 @pytest.mark.parametrize("C,k,dils,lens,mrf", [
     (32, 3, (1, 3, 5), [1300, 3, 250, 40], False), (32, 7, (1, 3, 5), [900, 31], False), (64, 3, (1, 3, 5), [513, 700], False),
     (64, 7, (1, 3, 5), [600, 64], False), (128, 3, (1, 3, 5), [300, 40], False), (64, 3, (1, 3), [260], False),

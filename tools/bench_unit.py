@@ -20,17 +20,22 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     g = torch.Generator(device="cpu").manual_seed(0)
     x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).to(tdt)
     y = torch.empty_like(x)
-    w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype, 32)
-    w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dtype, 32)
+    wa, wb = (torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), (torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev)
+    kw = {}
+    if dtype == hip.F32S:
+        (w1, i1), (w2, i2) = hip.pack_conv_weight_split(wa, 32), hip.pack_conv_weight_split(wb, 32)
+        kw["ws"] = (i1, i2)
+    else:
+        w1, w2 = hip.pack_conv_weight(wa, dtype, 32), hip.pack_conv_weight(wb, dtype, 32)
     b1 = torch.zeros(C, device=dev)
     b2 = torch.zeros(C, device=dev)
     for _ in range(2):
-        hip.hifigan_resunit(rb, rate, x, y, w1, b1, w2, b2, C, k, d, 0.1, dtype)
+        hip.hifigan_resunit(rb, rate, x, y, w1, b1, w2, b2, C, k, d, 0.1, dtype, **kw)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        hip.hifigan_resunit(rb, rate, x, y, w1, b1, w2, b2, C, k, d, 0.1, dtype)
+        hip.hifigan_resunit(rb, rate, x, y, w1, b1, w2, b2, C, k, d, 0.1, dtype, **kw)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
@@ -90,11 +95,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split"])
     ap.add_argument("--resblock", action="store_true", help="fused ResBlock launches vs per-unit launches (f16)")
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
-    dt = hip.F16 if a.dtype == "f16" else hip.F32
+    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S}[a.dtype]
     if a.resblock:
         for C in ((32, 64, 128) if dt == hip.F16 else (32, 64)):
             for k in ((3, 7) if dt == hip.F16 else (3,)):
