@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--t-text", type=int, default=128)
     ap.add_argument("--frames-per-token", type=int, default=6)
-    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32"],
+    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split"],
                     help="arithmetic of the headline numbers (the reference computes in f32)")
     ap.add_argument("--vocoder", default="22k", choices=["22k", "24k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,11 +157,14 @@ def committed_traffic():
     return None, None
 
 
-def lookup_traffic(table, esz, c):
+def lookup_traffic(table, prec, c):
     if not table:
         return None
-    key = f"resunit_kernelI{'DF16_' if esz == 2 else 'f'}Li{c}E"
-    alt = f"resunit_kernel<{'_Float16' if esz == 2 else 'float'}, {c},"
+    if prec == "fp32_split":
+        key, alt = f"resunit_split_kernelILi{c}E", f"resunit_split_kernel<{c},"
+    else:
+        key = f"resunit_kernelI{'DF16_' if prec == 'fp16' else 'f'}Li{c}E"
+        alt = f"resunit_kernel<{'_Float16' if prec == 'fp16' else 'float'}, {c},"
     hits = [v for k, v in table.items() if key in k or alt in k]
     if not hits:
         return None
@@ -216,7 +219,7 @@ class Job:
             self.noise = [torch.randn(frames, 384, generator=g).to(dev) for _ in self.texts]
 
     def set_precision(self, p):
-        self.m.set_precision(p)
+        self.m.set_precision("fp32" if p == "fp32_split" else p)      # the split mode is the vocoder's (its ResBlock units): text2mel stays exact f32
         self.voc.set_precision(p)
 
     def text2mel(self):
@@ -290,11 +293,15 @@ def run_timed(job, a, world, dist, pipeline=False, record=True):
                 stages=stages, recs=recs, rank_ms=rank_ms, mel=r["feat_gen"], wave=y, frames=sum(r["olens"]), samples_per_step=sum(lens) * world)
 
 
-def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
+def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     """Per-kernel live timings (HIP events on the launch stream inside the timed region) -> roofline of the dominant
     fused-unit family + per-shape tables.  Algorithmic work per dilation unit: 4 C^2 k FLOP and
     2 C sizeof bytes per row (x in, y out); the last unit of a stage also reads the other ResBlocks' outputs for the
     MRF mean its epilogue carries (n_add more reads of C sizeof bytes per row)."""
+    esz = 2 if prec == "fp16" else 4                      # bytes per activation element in HBM
+    # matrix-pipe peak per ALGORITHMIC FLOP: the split mode spends three dense f16 MFMAs per product
+    unit_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
+    conv_peak = MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF      # jatts_conv1d stays exact f32 in the split mode
     fam = {}
     for tag, meta, ms in recs:
         fam.setdefault((tag, meta), []).append(ms)
@@ -306,7 +313,7 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
         nu = len(d) if tag == "resblock" else 1     # a fused ResBlock launch = nu dilation units; x in + y out ONCE
         avg = sum(v) / len(v)
         flops, byts = 4.0 * C * C * k * rows * nu, (2.0 + n_add) * rows * C * esz
-        peak_tf = MFMA_F16_PEAK_TF if esz == 2 else MFMA_F32_PEAK_TF
+        peak_tf = unit_peak
         ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         u = dict(C=C, k=k, dil=d, rows=rows, launches=len(v), avg_ms=avg, total_ms=sum(v),
                  tflops=flops / avg / 1e9, gbs=byts / avg / 1e6, ai=flops / byts, units_per_launch=nu, mrf_addends=n_add)
@@ -325,17 +332,19 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     dom_flops = sum(4.0 * u["C"] ** 2 * u["k"] * u["rows"] * u["launches"] * u["units_per_launch"] for u in dom)
     dom_bytes = sum((2.0 + u["mrf_addends"]) * u["rows"] * u["C"] * esz * u["launches"] for u in dom)
     ai = dom_flops / dom_bytes
-    peak_tf = MFMA_F16_PEAK_TF if esz == 2 else MFMA_F32_PEAK_TF
+    peak_tf = unit_peak
     if ai >= peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
         roof = dict(bound="mfma", achieved=dom_flops / dom_ms / 1e9, peak=peak_tf, unit="TFLOP/s")
     else:
         roof = dict(bound="hbm", achieved=dom_bytes / dom_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s")
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = lookup_traffic(traffic_table, esz, dom_c)
+    roof["traffic"] = lookup_traffic(traffic_table, prec, dom_c)
     roof["traffic_source"] = traffic_source if roof["traffic"] is not None else None
     roof["algorithmic_bytes_per_launch"] = dom_bytes / n_launch
     roof["algorithmic_flops_per_launch"] = dom_flops / n_launch
-    roof["kernel"] = f"resunit_kernel<{'f16' if esz == 2 else 'float'}, C={dom_c}> (fused HiFi-GAN dilation unit, 9 launches per step)"
+    roof["kernel"] = (f"resunit_split_kernel<C={dom_c}> (fused HiFi-GAN dilation unit, f32 I/O, split f16 hi/lo MFMA operands: 3 MFMAs per product, "
+                      f"peak = dense f16 / 3; 9 launches per step)" if prec == "fp32_split" else
+                      f"resunit_kernel<{'f16' if esz == 2 else 'float'}, C={dom_c}> (fused HiFi-GAN dilation unit, 9 launches per step)")
     roof["avg_launch_ms"] = dom_ms / n_launch
     roof["arith_intensity_flop_per_byte"] = ai
     roof["share_of_step"] = dom_ms / (dt * 1e3)
@@ -348,7 +357,7 @@ def kernel_report(recs, steps, esz, dt, traffic_table, traffic_source):
     conv_ms = sum(sum(v) for _, v in conv)
     roof_conv = None
     if conv_ms > 0:      # second family: every jatts_conv1d launch of the step (acoustic model + HiFi-GAN input / upsampling convs)
-        roof_conv = dict(bound="mfma", achieved=conv_flops / conv_ms / 1e9, peak=peak_tf, unit="TFLOP/s", frac=conv_flops / conv_ms / 1e9 / peak_tf,
+        roof_conv = dict(bound="mfma", achieved=conv_flops / conv_ms / 1e9, peak=conv_peak, unit="TFLOP/s", frac=conv_flops / conv_ms / 1e9 / conv_peak,
                          ms_per_step=conv_ms / steps, launches_per_step=sum(len(v) for _, v in conv) / steps)
     return dict(
         roofline=roof,
@@ -497,13 +506,14 @@ def compact_line(out, detail_path=None):
         c["cpu_baseline"] = None
         if out.get("cpu_baseline_note"):
             c["cpu_baseline_note"] = out["cpu_baseline_note"]
-    fm = out.get("fast_mode") or out.get("f32_mode")
-    if fm:
-        c["fast_mode" if "fast_mode" in out else "f32_mode"] = {
-            "dtype": "f16" if "fast_mode" in out else "f32", "value": fm["value"], "ms_per_step": fm["ms_per_step"],
-            "max_abs_err_mel": fm.get("max_abs_err_mel"), "max_abs_err_wave": fm.get("max_abs_err_wave"),
-            "roofline_frac": (fm.get("roofline") or {}).get("frac"), "roofline_bound": (fm.get("roofline") or {}).get("bound"),
-            "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
+    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 io, split f16 hi/lo MFMA in the ResBlock units")):
+        fm = out.get(key)
+        if fm:
+            c[key] = {"dtype": short, "value": fm["value"], "ms_per_step": fm["ms_per_step"],
+                      "vocoder_ms": (fm.get("stage_ms_per_step") or {}).get("vocoder"),
+                      "max_abs_err_mel": fm.get("max_abs_err_mel"), "max_abs_err_wave": fm.get("max_abs_err_wave"),
+                      "roofline_frac": (fm.get("roofline") or {}).get("frac"), "roofline_bound": (fm.get("roofline") or {}).get("bound"),
+                      "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
     if out.get("configs"):
         c["configs"] = {("matcha_mas_b64" if "Matcha" in e["config"] else "vits_spk192_b32"):
                         {"f32_ms": e["ms_per_step"], "f32_value": e["value"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
@@ -518,7 +528,7 @@ def compact_line(out, detail_path=None):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_LIMIT:      # never let the line outgrow the driver's tail again: drop the optional blocks
-        for k in ("training", "configs", "fast_mode", "f32_mode", "stage_ms", "roofline_conv1d", "executor"):
+        for k in ("training", "configs", "fast_mode", "f32_mode", "f32_split_mode", "stage_ms", "roofline_conv1d", "executor"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
@@ -546,7 +556,9 @@ def write_detail(out):
     return rel
 
 
-DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate"}
+MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode"}
+DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate",
+              "fp32_split": "f32 activations; HiFi-GAN ResBlock units on split f16 hi/lo MFMA operands (3 MFMAs per product), f32 accumulate"}
 
 
 def self_launch(n, argv):
@@ -621,18 +633,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     job = Job("fs2", a, dev, rank, a.batch)
-    if a.pmc_child:   # profiled child: one f32 and one f16 step, nothing printed
+    if a.pmc_child:   # profiled child: one step of each arithmetic, nothing printed
         a.steps, a.warmup = 1, 1
-        for p in ("fp32", "fp16"):
+        for p in ("fp32", "fp32_split", "fp16"):
             job.set_precision(p)
             run_timed(job, a, 1, None)
         return
 
-    other = "fp16" if a.precision == "fp32" else "fp32"
     job.set_precision(a.precision)
     head = run_timed(job, a, world, dist, a.pipeline)
-    esz = 4 if a.precision == "fp32" else 2
-    rep = kernel_report(head["recs"], a.steps, esz, head["dt"], traffic_table, traffic_source)
+    rep = kernel_report(head["recs"], a.steps, a.precision, head["dt"], traffic_table, traffic_source)
 
     out = {
         "metric": f"audio samples/sec ({'22.05' if a.vocoder == '22k' else '24'} kHz) + RTF, FastSpeech2+HiFi-GAN",
@@ -653,29 +663,32 @@ def main():
     }
     out.update(rep)
 
-    # ---- the other arithmetic on the same batch, and how far apart the two outputs are
+    # ---- the other arithmetics on the same batch, and how far apart their outputs are from the headline's
     if not a.no_fast_mode:
         mel0, wav0 = head["mel"].float().clone(), head["wave"].float().clone()
-        job.set_precision(other)
-        alt = run_timed(job, a, world, dist, a.pipeline)
-        arep = kernel_report(alt["recs"], a.steps, 2 if other == "fp16" else 4, alt["dt"], traffic_table, traffic_source)
-        same = alt["mel"].shape == mel0.shape and alt["wave"].shape == wav0.shape
-        dm = (alt["mel"].float() - mel0) if same else None
-        dw = (alt["wave"].float() - wav0) if same else None
-        blk = {"dtype": DTYPE_NAME[other], "value": alt["value"], "unit": "samples/s", "ms_per_step": alt["ms_per_step"],
-               "rtf": alt["rtf"], "stage_ms_per_step": alt["stages"],
-               "max_abs_err_mel": float(dm.abs().max()) if same else None,
-               "rms_err_mel": float(dm.pow(2).mean().sqrt()) if same else None,
-               "mel_abs_max": float(mel0.abs().max()),
-               "max_abs_err_wave": float(dw.abs().max()) if same else None,
-               "rms_err_wave": float(dw.pow(2).mean().sqrt()) if same else None,
-               "wave_abs_max": float(wav0.abs().max()), "wave_rms": float(wav0.pow(2).mean().sqrt()),
-               "error_reference": f"the {DTYPE_NAME[a.precision]} run of this process on the same {a.batch} x "
-                                  f"{a.t_text * a.frames_per_token}-frame batch (same durations: {same})",
-               "speedup_vs_headline": head["ms_per_step"] / alt["ms_per_step"]}
-        blk.update(arep)
-        out["fast_mode" if other == "fp16" else "f32_mode"] = blk
-        del mel0, wav0, dm, dw, alt
+        others = [p for p in ("fp32", "fp32_split", "fp16") if p != a.precision]
+        for other in others:
+            job.set_precision(other)
+            alt = run_timed(job, a, world, dist, a.pipeline)
+            arep = kernel_report(alt["recs"], a.steps, other, alt["dt"], traffic_table, traffic_source)
+            same = alt["mel"].shape == mel0.shape and alt["wave"].shape == wav0.shape
+            dm = (alt["mel"].float() - mel0) if same else None
+            dw = (alt["wave"].float() - wav0) if same else None
+            blk = {"dtype": DTYPE_NAME[other], "value": alt["value"], "unit": "samples/s", "ms_per_step": alt["ms_per_step"],
+                   "rtf": alt["rtf"], "stage_ms_per_step": alt["stages"],
+                   "max_abs_err_mel": float(dm.abs().max()) if same else None,
+                   "rms_err_mel": float(dm.pow(2).mean().sqrt()) if same else None,
+                   "mel_abs_max": float(mel0.abs().max()),
+                   "max_abs_err_wave": float(dw.abs().max()) if same else None,
+                   "rms_err_wave": float(dw.pow(2).mean().sqrt()) if same else None,
+                   "wave_abs_max": float(wav0.abs().max()), "wave_rms": float(wav0.pow(2).mean().sqrt()),
+                   "error_reference": f"the {DTYPE_NAME[a.precision]} run of this process on the same {a.batch} x "
+                                      f"{a.t_text * a.frames_per_token}-frame batch (same durations: {same})",
+                   "speedup_vs_headline": head["ms_per_step"] / alt["ms_per_step"]}
+            blk.update(arep)
+            out[MODE_KEY[other]] = blk
+            del dm, dw, alt
+        del mel0, wav0
     del head
     job_fs2_sd, job_voc_sd, job_vp, job_sr = job.sd, job.voc_sd, job.vp, job.sr
     del job
@@ -745,8 +758,9 @@ def main():
         cb["single_thread"]["rtf"] = c1["seconds"] / (c1["samples"] / job_sr)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_rtf"] = cb["rtf"] / out["rtf"]
-        if "fast_mode" in out:
-            out["fast_mode"]["speedup_vs_cpu_rtf"] = cb["rtf"] / out["fast_mode"]["rtf"]
+        for k in ("fast_mode", "f32_split_mode", "f32_mode"):
+            if k in out:
+                out[k]["speedup_vs_cpu_rtf"] = cb["rtf"] / out[k]["rtf"]
     else:
         out["cpu_baseline"] = None
         out["cpu_baseline_note"] = ("N=1 only (rank 0 at N=1 times the CPU leg; the N>1 line also carries no live PMC traffic: "

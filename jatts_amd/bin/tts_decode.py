@@ -158,8 +158,9 @@ def get_parser():
     p.add_argument("--config", default=None, type=str)
     p.add_argument("--verbose", type=int, default=1)
     p.add_argument("--batch-size", type=int, default=64, help="utterances per ragged batch (extension)")
-    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32"],
-                   help="fp32 = the reference's arithmetic (default); fp16 = fast mode: f16 MFMA operands, f32 accumulate (extension)")
+    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split"],
+                   help="fp32 = the reference's arithmetic (default); fp16 = fast mode: f16 MFMA operands, f32 accumulate; fp32_split = f32 "
+                        "everywhere except the vocoder's ResBlock units, which run on error-corrected split f16 hi/lo MFMA operands (extensions)")
     p.add_argument("--plot", action="store_true", help="also write <outdir>/outs/<id>.png like the reference")
     p.add_argument("--n_gpus", "--n-gpus", dest="n_gpus", type=int, default=1,
                    help="one process per GPU, every rank decodes its own shard of the csv (extension; the recipes' n_gpus). "
@@ -205,7 +206,7 @@ def main(argv=None):
     model_class = getattr(jatts_amd.models, config["model_type"])          # tts_decode.py:139
     model = model_class(**config["model_params"])
     model.load_state_dict(torch.load(args.checkpoint, map_location="cpu")["model"])
-    model = model.eval().to(device).set_precision(args.precision)
+    model = model.eval().to(device).set_precision("fp32" if args.precision == "fp32_split" else args.precision)
     logging.info(f"Loaded model parameters from {args.checkpoint}.")
 
     stats = read_stats(args.stats, config["out_feat_type"])                # tts_decode.py:160-164

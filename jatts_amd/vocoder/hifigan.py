@@ -21,6 +21,15 @@ from ..models._conformer import PackedConv
 from ..models import _schema as S
 
 
+class PackedSplitConv:
+    """A ResBlock conv packed for the JATTS_F32S unit: hi/lo f16 halves of w[n] * 2^s[n] + the inverse scales (hip.pack_conv_weight_split)."""
+
+    def __init__(self, w, b):
+        self.n_out, self.c_in, self.k = w.shape
+        self.w, self.inv = hip.pack_conv_weight_split(w, 32)
+        self.b = b.detach().float().contiguous()
+
+
 class HiFiGANGenerator(torch.nn.Module):
     def __init__(self, in_channels=80, out_channels=1, channels=512, kernel_size=7,
                  upsample_scales=(8, 8, 2, 2), upsample_kernel_sizes=(16, 16, 4, 4),
@@ -91,7 +100,11 @@ class HiFiGANGenerator(torch.nn.Module):
         return None
 
     def set_precision(self, precision):
-        if precision not in ("fp16", "fp32"):
+        """"fp32": exact-f32 MFMA (the reference's arithmetic, the default); "fp16": f16 operands and activations (fast mode);
+        "fp32_split" (round 4): f32 activations everywhere, the ResBlock dilation units (97 % of the generator's FLOPs) on
+        error-corrected split-precision MFMA operands (JATTS_F32S: hi/lo f16 halves, f32 accumulate, power-of-two scales) -- measured
+        at or below the exact-f32 path's error against fp64 (tests/test_kernels_gpu.py::test_hifigan_resunit_split)."""
+        if precision not in ("fp16", "fp32", "fp32_split"):
             raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None
@@ -110,9 +123,10 @@ class HiFiGANGenerator(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
+        split = self.precision == "fp32_split"
         sd = self.state_dict()
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
-        P = {"key": key, "dtype": dt, "dev": dev}
+        P = {"key": key, "dtype": dt, "dev": dev, "unit_dtype": hip.F32S if split else dt}
         nb = len(self.resblock_kernel_sizes)
         P["ups"], P["blocks"] = [], []
         supported = {hip.F16: (32, 64, 128, 256, 512), hip.F32: (32, 64, 128, 256)}[dt]
@@ -156,10 +170,9 @@ class HiFiGANGenerator(torch.nn.Module):
                 units = []
                 for di, d in enumerate(self.resblock_dilations[j]):
                     q = f"blocks.{i * nb + j}."
-                    c1 = PackedConv(padw(sd[q + f"convs1.{di}.1.weight"], c_out, c_out), padb(sd[q + f"convs1.{di}.1.bias"], c_out),
-                                    dt, dev, c_mult=32)   # fused unit takes c_in == channels
-                    c2 = PackedConv(padw(sd[q + f"convs2.{di}.1.weight"], c_out, c_out), padb(sd[q + f"convs2.{di}.1.bias"], c_out),
-                                    dt, dev, c_mult=32)
+                    mk = PackedSplitConv if split else (lambda w, b: PackedConv(w, b, dt, dev, c_mult=32))   # fused unit takes c_in == channels
+                    c1 = mk(padw(sd[q + f"convs1.{di}.1.weight"], c_out, c_out).to(dev), padb(sd[q + f"convs1.{di}.1.bias"], c_out).to(dev))
+                    c2 = mk(padw(sd[q + f"convs2.{di}.1.weight"], c_out, c_out).to(dev), padb(sd[q + f"convs2.{di}.1.bias"], c_out).to(dev))
                     units.append((c1, c2, rk, d))
                 stage.append(units)
             P["blocks"].append(stage)
@@ -194,7 +207,7 @@ class HiFiGANGenerator(torch.nn.Module):
         scale/shift: optional per-channel affine applied first (Vocoder.decode normalisation).
         Returns f32 (rows * hop,) packed waveforms (utterance b owns samples cu[b]*hop ...)."""
         P = self._prepare()
-        dt = P["dtype"]
+        dt, udt = P["dtype"], P["unit_dtype"]
         pin = P["in"]
         x = hip.affine_cast(mel, dt, scale=scale, shift=shift, ldy=pin.c_in)
         x = hip.conv1d(rb, x, pin.w, pin.c_in, pin.n_out, pin.k, dtype=dt, bias=pin.b)
@@ -227,7 +240,7 @@ class HiFiGANGenerator(torch.nn.Module):
                 cur = up
                 st = side[j] if j < len(side) else None
                 # HBM-bound shapes: the whole ResBlock in one launch (x read once, y written once; residual in registers)
-                if (c_out, units[0][2]) in (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32) and len(units) <= 3 and st is None \
+                if udt != hip.F32S and (c_out, units[0][2]) in (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32) and len(units) <= 3 and st is None \
                         and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if dt == hip.F16 else 16):
                     lastb = fuse_mean and j == len(blocks) - 1
                     hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(c1.w, c1.b, c2.w, c2.b, d) for c1, c2, _, d in units],
@@ -246,8 +259,9 @@ class HiFiGANGenerator(torch.nn.Module):
                             for ev in done:
                                 torch.cuda.current_stream().wait_event(ev)
                         # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
-                        hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, dt,
-                                            add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0)
+                        hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, udt,
+                                            add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0,
+                                            ws=(c1.inv, c2.inv) if udt == hip.F32S else None)
                         cur = nxt
                     if st is not None:
                         ev = torch.cuda.Event()

@@ -86,6 +86,56 @@ def test_hifigan_bench_size_matches_the_oracle(bench_stack):
         assert e1 <= 2e-4 and eb <= 2e-4, f"utterance {u}: alone {e1:.3e}, in the batch {eb:.3e}"
 
 
+def test_hifigan_split_mode_at_bench_size(bench_stack):
+    """The fp32_split vocoder (round 4: ResBlock units on split f16 hi/lo MFMA operands) on the same 768-frame mels: the SAME tolerance as
+    the exact-f32 path against the f32 oracle (abs 2e-4), and against the oracle run in FP64 its maximum error must not exceed twice the
+    exact-f32 path's -- the condition under which it is not a narrower arithmetic than the reference's.  Alone and inside the batch of 64,
+    bit-identical to each other.  The measured errors go to gpurun_out/r04_split_errors.json (profiles/r04_notes.md quotes them)."""
+    import json
+    import os
+    from jatts_amd import hip
+    from jatts_amd.synthetic import HIFIGAN_V1_22K
+    from oracle.hifigan_oracle import hifigan_generate
+    z, m, voc, vsd, texts = bench_stack
+    utts = [int(u) for u in z["utts"]]
+    dev = texts[0].device
+    rbatch = m.inference_batch(texts)
+    mel_b = rbatch["feat_gen"].clone()
+    for j, u in enumerate(utts):
+        mel_b[768 * u:768 * (u + 1)] = torch.tensor(z[f"u{j}_feat_gen"]).to(dev)
+    vsd64 = {k: v.double() for k, v in vsd.items()}
+    rec = {}
+    try:
+        voc.set_precision("fp32_split")
+        yb = voc.decode_batch(rbatch["feats_rb"], mel_b)
+        for j, u in enumerate(utts):
+            mel = torch.tensor(z[f"u{j}_feat_gen"])
+            torch.set_num_threads(min(32, torch.get_num_threads()))
+            with torch.no_grad():
+                ref32 = hifigan_generate(vsd, mel, HIFIGAN_V1_22K["upsample_scales"], HIFIGAN_V1_22K["resblock_dilations"]).reshape(-1)
+                ref64 = hifigan_generate(vsd64, mel.double(), HIFIGAN_V1_22K["upsample_scales"], HIFIGAN_V1_22K["resblock_dilations"]).reshape(-1)
+            voc.set_precision("fp32_split")
+            ys = voc.decode_batch(hip.RaggedBatch([768], dev), mel.to(dev)).reshape(-1)
+            voc.set_precision("fp32")
+            yf = voc.decode_batch(hip.RaggedBatch([768], dev), mel.to(dev)).reshape(-1)
+            assert torch.equal(ys, yb[768 * 256 * u:768 * 256 * (u + 1)].reshape(-1)), "split mode: utterance alone != inside the batch"
+            e32 = maxdiff(ys, ref32)
+            es64, ef64 = float((ys.double().cpu() - ref64).abs().max()), float((yf.double().cpu() - ref64).abs().max())
+            rs64 = float((ys.double().cpu() - ref64).pow(2).mean().sqrt())
+            rf64 = float((yf.double().cpu() - ref64).pow(2).mean().sqrt())
+            rec[f"utt{u}"] = {"split_vs_f32_oracle_max": e32, "split_vs_fp64_max": es64, "exact_f32_vs_fp64_max": ef64,
+                              "split_vs_fp64_rms": rs64, "exact_f32_vs_fp64_rms": rf64, "f32_oracle_vs_fp64_max": float((ref32.double() - ref64).abs().max()),
+                              "wave_abs_max": float(ref64.abs().max())}
+            assert e32 <= 2e-4, f"utterance {u}: split vs the f32 oracle {e32:.3e}"
+            assert es64 <= 2.0 * ef64 + 1e-7, f"utterance {u}: split {es64:.3e} vs exact f32 {ef64:.3e} against fp64"
+    finally:
+        voc.set_precision("fp32")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r04_split_errors.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+
+
 # ------------------------------------------------------------------------------------------------------------ f32 conv, every variant
 def _ref_conv64(x, w, b, lens, dil, pad, k):
     outs, o = [], 0

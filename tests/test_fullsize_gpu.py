@@ -20,7 +20,7 @@ def _make_stack(cuda, prec):
     from jatts_amd.vocoder import Vocoder
     m = FastSpeech2(idim=45, **FS2_JSUT)
     m.load_state_dict(pin_duration_head(synth_state_dict(m.state_dict(), 0), 6))
-    m = m.to(cuda).set_precision(prec)
+    m = m.to(cuda).set_precision("fp32" if prec == "fp32_split" else prec)
     ones, zeros = [1.0] * 80, [0.0] * 80
     voc = Vocoder(synth_hifigan_state(HIFIGAN_V1_22K, 0),
                   {"sampling_rate": 22050, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_22K},
@@ -54,13 +54,19 @@ def _synth(stack, texts):
     return r, outs
 
 
-@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+@pytest.fixture(scope="module")
+def stack_split(cuda, lib):
+    """f32 text2mel + the fp32_split vocoder (round 4)."""
+    return _make_stack(cuda, "fp32_split")
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32", "fp32_split"])
 @pytest.mark.parametrize("ragged", [False, True], ids=["64x128", "64xU(64..128)"])
-def test_full_batch_properties(cuda, stack, stack32, ragged, prec):
+def test_full_batch_properties(cuda, stack, stack32, stack_split, ragged, prec):
     """fp32 = the arithmetic bench.py's headline measures (register-streamed f32 convs, f32 fused units): determinism, utterance
     independence and permutation equivariance hold bit for bit there too."""
     from jatts_amd.synthetic import synth_texts
-    stack = stack32 if prec == "fp32" else stack
+    stack = {"fp32": stack32, "fp32_split": stack_split, "fp16": stack}[prec]
     texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
     if ragged:
         g = torch.Generator().manual_seed(5)
