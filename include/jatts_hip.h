@@ -352,6 +352,16 @@ int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, dou
  * and end, 6 unused}.  buf: device memory of n_workgroups*128 bytes.  Pass NULL to switch tracing off (the default). */
 int jatts_debug_trace(void* buf, int64_t n_workgroups);
 
+/* Scratch of the DETERMINISTIC reductions of the training kernels (round 4): jatts_layernorm_bwd, jatts_groupnorm_bwd,
+ * jatts_snakebeta_bwd, jatts_dwconv_wgrad, jatts_col_stats, jatts_col_sum, jatts_col_wsum, jatts_seq_sum, jatts_qkv_split_bwd,
+ * jatts_sumsq and the VALU path / bias sums of jatts_conv1d_wgrad reduce across workgroups through per-workgroup slabs that the
+ * last-arriving workgroup adds up in a fixed order (no f32 atomics: results are bit-identical from run to run, like the
+ * reference's).  buf: device memory, 16-byte aligned, ZERO-filled by the caller once, owned by the caller and kept
+ * alive until replaced (a captured graph bakes its address in); the first 64 KiB hold tickets, the rest slabs.  A launch that needs
+ * more fails with JATTS_ERR_ARG naming the size.  Launches of one stream serialise on it; two streams must not run these kernels
+ * concurrently.  buf = NULL unregisters. */
+int jatts_set_workspace(void* buf, int64_t bytes);
+
 /* Output stage: y[t] = tanh( b + sum_{tap,c} w[tap][c] * lrelu( in_scale * sum_i x_i[t+tap-pad][c] ) )
  * (HiFiGANGenerator.output_conv: LeakyReLU(0.01) -> Conv1d(C,1,k) -> Tanh).  w: f32 [k_w][c_in]. */
 int jatts_hifigan_output(const jatts_ragged* rg, int32_t dtype, const void* const* x, int32_t n_in,

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "jatts_hifigan_resunit": (C.c_int, [C.POINTER(ResUnitDesc), C.c_void_p]),
     "jatts_hifigan_resblock": (C.c_int, [C.POINTER(ResBlockDesc), C.c_void_p]),
     "jatts_debug_trace": (C.c_int, [C.c_void_p, C.c_int64]),
+    "jatts_set_workspace": (C.c_int, [C.c_void_p, C.c_int64]),
     "jatts_pcm16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "jatts_alignment_logp": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_int32, C.c_void_p]),

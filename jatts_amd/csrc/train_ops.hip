@@ -6,6 +6,7 @@
 // Reference: torch autograd of jatts/modules/conformer/{encoder_layer,convolution}.py, modules/transformer/{attention,layer_norm}.py,
 // modules/{duration_predictor,variance_predictor,length_regulator,pre_postnets}.py, jatts/losses/*.py, jatts/trainers/fastspeech2.py:24-100.
 #include "common.h"
+#include "det_reduce.h"
 
 namespace {
 
@@ -18,7 +19,8 @@ constexpr int LN_MAXPL = 24;   // LayerNorm backward: channels per lane (C <= 15
 // folded through LDS into one atomicAdd per channel per workgroup.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                             const float* __restrict__ g, int64_t rows, int C, float eps,
-                                                            float* __restrict__ dx, int lddx, float* __restrict__ dg, float* __restrict__ db) {
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ dg, float* __restrict__ db,
+                                                            float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pg[LN_MAXPL], pb[LN_MAXPL], gv[LN_MAXPL];
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
   }
   if (!dg) return;
+  float* slab = slabs + (int64_t)blockIdx.x * 2 * C;     // this workgroup's partial [dg | db]
   for (int j = 0; j < LN_MAXPL; ++j) {
     if (64 * j >= C) break;
     red[0][wave][lane] = pg[j];
@@ -81,12 +84,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if (wave == 0) {
       const int c = lane + 64 * j;
       if (c < C) {
-        atomicAdd(&dg[c], red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
-        atomicAdd(&db[c], red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+        slab[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        slab[C + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
       }
     }
     __syncthreads();
   }
+  if (det_arrive(tickets, gridDim.x, reinterpret_cast<unsigned*>(&red[0][0][0])))
+    det_sum_slabs<4>(slabs, (int)gridDim.x, 2 * C, &red[0][0][0], [&](int i, float t) { if (i < C) dg[i] += t; else db[i - C] += t; });
 }
 
 // ------------------------------------------------------------------ activations
@@ -206,7 +211,8 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(jatts_ragged rg, cons
 }
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 float* __restrict__ dw, int C, int pad, int tiles_per_block) {
+                                                                 float* __restrict__ dw, int C, int pad, int tiles_per_block,
+                                                                 float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float xs[DWT + K - 1][64];
   __shared__ float red[4][64];
   const int s = blockIdx.y, c0 = blockIdx.z * 64;
@@ -235,19 +241,28 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(jatts_ragged rg
       for (int k = 0; k < K; ++k) acc[k] += d * win[i + k];
     }
   }
+  // group = channel tile z; parts = the (time block, sequence) workgroups of that tile; slab = [k][64 channels]
+  const int n_parts = gridDim.x * gridDim.y, part = blockIdx.y * gridDim.x + blockIdx.x;
+  float* gslab = slabs + (int64_t)blockIdx.z * n_parts * (64 * K);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     __syncthreads();
     red[tq][cl] = acc[k];
     __syncthreads();
-    if (tq == 0 && c < C) atomicAdd(&dw[c * K + k], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    if (tq == 0) gslab[(int64_t)part * (64 * K) + k * 64 + cl] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
   }
+  if (det_arrive(tickets + blockIdx.z, n_parts, reinterpret_cast<unsigned*>(&red[0][0])))
+    det_sum_slabs<4>(gslab, n_parts, 64 * K, &red[0][0], [&](int i, float t) {
+      const int k = i >> 6, cc = c0 + (i & 63);
+      if (cc < C) dw[cc * K + k] += t;
+    });
 }
 
 // dw[c][k] += sum_t dy[t][c] x[t + k - pad][c]; a workgroup = 64 channels x a slice of (sequence, time); wave w takes rows t = w mod 4
 constexpr int DW_KMAX = 32;
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dw, int C, int K, int pad) {
+                                                           float* __restrict__ dw, int C, int K, int pad,
+                                                           float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   const int s = blockIdx.y;
@@ -264,15 +279,23 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, cons
         if (k < K && p >= 0 && p < L) acc[k] += d * x[(int64_t)(row0 + p) * C + c];
       }
     }
+  // group = channel tile x; parts = its (sequence, time split) workgroups; slab = [k][64 channels]
+  const int n_parts = gridDim.y * gridDim.z, wg = blockIdx.z * gridDim.y + blockIdx.y;
+  float* gslab = slabs + (int64_t)blockIdx.x * n_parts * (64 * K);
   for (int k = 0; k < K; ++k) {
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < DW_KMAX; ++q) v = q == k ? acc[q] : v;
     red[part][threadIdx.x & 63] = v;
     __syncthreads();
-    if (part == 0 && c < C) atomicAdd(&dw[c * K + k], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part == 0) gslab[(int64_t)wg * (64 * K) + k * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     __syncthreads();
   }
+  if (det_arrive(tickets + blockIdx.x, n_parts, reinterpret_cast<unsigned*>(&red[0][0])))
+    det_sum_slabs<4>(gslab, n_parts, 64 * K, &red[0][0], [&](int i, float t) {
+      const int k = i >> 6, cc = blockIdx.x * 64 + (i & 63);
+      if (cc < C) dw[cc * K + k] += t;
+    });
 }
 
 // ------------------------------------------------------------------ column statistics (BatchNorm with batch statistics)
@@ -280,7 +303,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, cons
 // out0[c] += sum_r dy,          out1[c] += sum_r dy * (x - mean) * rstd  (mode 1: x = x, y2 = dy, shift = mean, mul = rstd)
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, const float* __restrict__ y2, int ld, int64_t rows, int dim,
                                                         const float* __restrict__ shift, const float* __restrict__ mul, int mode,
-                                                        float* __restrict__ out0, float* __restrict__ out1) {
+                                                        float* __restrict__ out0, float* __restrict__ out1,
+                                                        float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   __shared__ float red[2][4][64];
@@ -296,10 +320,16 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   red[0][part][threadIdx.x & 63] = s0;
   red[1][part][threadIdx.x & 63] = s1;
   __syncthreads();
-  if (part == 0 && c < dim) {
-    atomicAdd(&out0[c], red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-    atomicAdd(&out1[c], red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 128;      // group = channel tile; slab = [out0 x 64 | out1 x 64]
+  if (part == 0) {
+    gslab[blockIdx.y * 128 + threadIdx.x] = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+    gslab[blockIdx.y * 128 + 64 + threadIdx.x] = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
   }
+  if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0][0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 128, &red[0][0][0], [&](int i, float t) {
+      const int cc = blockIdx.x * 64 + (i & 63);
+      if (cc < dim) (i < 64 ? out0 : out1)[cc] += t;
+    });
 }
 // BatchNorm backward apply: dx = g * rstd * (dy - s_dy / N - xhat * s_dyxhat / N)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t rows, int C,
@@ -317,7 +347,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ------------------------------------------------------------------ per-sequence column sums (backward of "add a vector per sequence")
 // out[s][c] += sum over the rows of sequence s of x[row][c]; grid (channel tiles, sequences, time splits): the per-sequence statistics
 // kernel of the speaker-embedding path (one workgroup per sequence) left 7/8 of the chip idle on a 32-utterance batch.
-__global__ __launch_bounds__(256) void seq_sum_kernel(jatts_ragged rg, const float* __restrict__ x, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void seq_sum_kernel(jatts_ragged rg, const float* __restrict__ x, int C, float* __restrict__ out,
+                                                      float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, s = blockIdx.y;
   const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
@@ -326,21 +357,46 @@ __global__ __launch_bounds__(256) void seq_sum_kernel(jatts_ragged rg, const flo
     for (int t = blockIdx.z * 4 + part; t < L; t += gridDim.z * 4) a += x[(int64_t)(row0 + t) * C + c];
   red[part][threadIdx.x & 63] = a;
   __syncthreads();
-  if (part == 0 && c < C) atomicAdd(&out[(int64_t)s * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  const int grp = blockIdx.y * gridDim.x + blockIdx.x;                // group = (sequence, channel tile); parts = the time splits
+  float* gslab = slabs + (int64_t)grp * gridDim.z * 64;
+  if (part == 0) gslab[blockIdx.z * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (det_arrive(tickets + grp, gridDim.z, reinterpret_cast<unsigned*>(&red[0][0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.z, 64, &red[0][0], [&](int i, float t) {
+      const int cc = blockIdx.x * 64 + i;
+      if (cc < C) out[(int64_t)s * C + cc] += t;
+    });
 }
 
 // ------------------------------------------------------------------ row-indexed accumulation (embedding backward)
-// dst[idx[r]][c] += scale * src[r][c], rows with idx == skip (padding_idx) or outside [0, n_dst) are dropped
+// dst[idx[r]][c] += scale * src[r][c], rows with idx == skip (padding_idx) or outside [0, n_dst) are dropped.
+// Deterministic: one workgroup per (destination row j, 256-channel tile) walks the source rows IN ORDER -- the index list goes through
+// LDS 1 024 entries at a time, a thread owns one channel and adds the matching rows as they come (an atomic scatter added them in
+// arrival order).  n_dst x rows index reads in total: meant for embedding tables of a TTS vocabulary (tens of symbols).
 __global__ __launch_bounds__(256) void index_add_rows_kernel(const float* __restrict__ src, int ld, const int64_t* __restrict__ idx, int64_t rows,
                                                              int C, float scale, int64_t skip, int64_t n_dst, float* __restrict__ dst) {
-  const int64_t n = rows * C;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / C;
-    const int c = (int)(i - r * C);
-    const int64_t j = idx[r];
-    if (j == skip || j < 0 || j >= n_dst) continue;
-    atomicAdd(&dst[j * C + c], scale * src[r * ld + c]);
+  __shared__ int hit[256];
+  __shared__ int cnt[4];
+  const int64_t j = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (j == skip) return;                     // (uniform per workgroup)
+  float a = 0.f;
+  for (int64_t r0 = 0; r0 < rows; r0 += 256) {
+    const int64_t r = r0 + threadIdx.x;
+    const bool m = r < rows && idx[r] == j;
+    const unsigned long long bal = __ballot(m);
+    __syncthreads();                         // the previous chunk's hit list is consumed
+    if (lane == 0) cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += cnt[w];
+    if (m) hit[base + __popcll(bal & ((1ull << lane) - 1ull))] = threadIdx.x;      // ordered compaction: row order is kept
+    const int nh = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    __syncthreads();
+    if (c < C)
+      for (int h = 0; h < nh; ++h) a += scale * src[(r0 + hit[h]) * ld + c];
   }
+  if (c < C) dst[j * C + c] += a;
 }
 
 // ------------------------------------------------------------------ length-regulator backward (segment sums, deterministic)
@@ -531,7 +587,7 @@ __global__ __launch_bounds__(256) void outer_rows_kernel(const float* __restrict
 }
 // out[c] += sum_r v[r] * x[r][c]
 __global__ __launch_bounds__(256) void col_wsum_kernel(const float* __restrict__ x, int ld, const float* __restrict__ v, int64_t rows, int dim,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   __shared__ float red[4][64];
@@ -540,7 +596,13 @@ __global__ __launch_bounds__(256) void col_wsum_kernel(const float* __restrict__
     for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += v[r] * x[r * ld + c];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 64;
+  if (part == 0) gslab[blockIdx.y * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], [&](int i, float t) {
+      const int cc = blockIdx.x * 64 + i;
+      if (cc < dim) out[cc] += t;
+    });
 }
 // y[r] = bias + sum_c x[r][c] w[c]   (one wave per row)
 __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w, const float* __restrict__ bias,
@@ -647,13 +709,16 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restrict__ dqu, const float* __restrict__ dqv, const float* __restrict__ dk_,
                                                             const float* __restrict__ dvv, int B, int T, int H, int dk, float* __restrict__ dqkv,
-                                                            float* __restrict__ du, float* __restrict__ dv) {
+                                                            float* __restrict__ du, float* __restrict__ dv, int rows_per_block,
+                                                            float* __restrict__ slabs, unsigned* __restrict__ tickets) {
+  __shared__ float red[4 * 64];
   const int A = H * dk;
-  const int64_t rows = (int64_t)B * T, r0 = (int64_t)blockIdx.x * 32;
+  const int64_t rows = (int64_t)B * T, r0 = (int64_t)blockIdx.x * rows_per_block;
+  float* slab = slabs + (int64_t)blockIdx.x * 2 * A;        // this workgroup's partial [du | dv]
   for (int c = threadIdx.x; c < A; c += 256) {
     const int h = c / dk, d = c - h * dk;
     float su = 0.f, sv = 0.f;
-    for (int64_t row = r0; row < r0 + 32 && row < rows; ++row) {
+    for (int64_t row = r0; row < r0 + rows_per_block && row < rows; ++row) {
       const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
       const int64_t o = (((int64_t)b * H + h) * T + t) * dk + d;
       const float a = dqu[o], e = dqv ? dqv[o] : 0.f;
@@ -664,9 +729,17 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restr
       su += a;
       sv += e;
     }
-    if (du) atomicAdd(&du[c], su);
-    if (dv) atomicAdd(&dv[c], sv);
+    if (du || dv) {
+      slab[c] = su;
+      slab[A + c] = sv;
+    }
   }
+  if (!du && !dv) return;
+  if (det_arrive(tickets, gridDim.x, reinterpret_cast<unsigned*>(red)))
+    det_sum_slabs<4>(slabs, (int)gridDim.x, 2 * A, red, [&](int i, float t) {
+      if (i < A) { if (du) du[i] += t; }
+      else if (dv) dv[i - A] += t;
+    });
 }
 
 // y = resid + alpha * dropout(x): the residual connections of the conformer layers (encoder_layer.py:100-170: x + ff_scale * dropout(ffn),
@@ -686,7 +759,8 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restric
 
 // ------------------------------------------------------------------ optimiser
 // sum of squares into a double (gradient-norm clipping: torch.nn.utils.clip_grad_norm_, trainers/fastspeech2.py:90-94)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ out,
+                                                    double* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ double red[256];
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)x[i] * (double)x[i];
@@ -696,7 +770,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+  if (threadIdx.x == 0) slabs[blockIdx.x] = red[0];
+  if (det_arrive(tickets, gridDim.x, reinterpret_cast<unsigned*>(&red[1])))
+    det_sum_slabs<4>(slabs, (int)gridDim.x, 1, red, [&](int, double t) { *out += t; });
 }
 // torch.optim.Adam (no amsgrad): g' = g * gscale (+ wd * p); m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
 // p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps); the scalars (bias corrections, step size, 1 - beta) are computed in double on the
@@ -783,7 +859,7 @@ __global__ __launch_bounds__(256) void groupnorm_fwd_kernel(jatts_ragged rg, con
 __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy, int C, int G,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            float* __restrict__ dbeta, float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float red[4];
   __shared__ float cred[2][256];
   const int s = blockIdx.y, g = blockIdx.x, cg = C / G;
@@ -812,12 +888,17 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(jatts_ragged rg, con
   cred[0][threadIdx.x] = pg;
   cred[1][threadIdx.x] = pb;
   __syncthreads();
+  float* gslab = slabs + (int64_t)g * gridDim.y * 2 * cg;        // group = GroupNorm group; parts = the sequences; slab = [dgamma x cg | dbeta x cg]
   if (threadIdx.x < cg) {
     float a = 0.f, b = 0.f;
     for (int j = threadIdx.x; j < 256; j += cg) { a += cred[0][j]; b += cred[1][j]; }
-    atomicAdd(&dgamma[c], a);
-    atomicAdd(&dbeta[c], b);
+    gslab[(int64_t)s * 2 * cg + threadIdx.x] = a;
+    gslab[(int64_t)s * 2 * cg + cg + threadIdx.x] = b;
   }
+  if (det_arrive(tickets + g, gridDim.y, reinterpret_cast<unsigned*>(&red[0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 2 * cg, &cred[0][0], [&](int i, float t) {
+      if (i < cg) dgamma[g * cg + i] += t; else dbeta[g * cg + i - cg] += t;
+    });
 }
 
 // ------------------------------------------------------------------ SnakeBeta (matchatts/transformer.py:84-102, log-scale alpha / beta)
@@ -834,7 +915,8 @@ __global__ __launch_bounds__(256) void snakebeta_fwd_kernel(const float* __restr
 // dx = dy (1 + a sin(2 a x) / (b + e)); dalpha[c] += sum dy x a sin(2 a x) / (b + e); dbeta[c] += sum dy (-b sin^2(a x) / (b + e)^2)
 __global__ __launch_bounds__(256) void snakebeta_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t rows, int C,
                                                             const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                            float* __restrict__ dx, float* __restrict__ dalpha, float* __restrict__ dbeta) {
+                                                            float* __restrict__ dx, float* __restrict__ dalpha, float* __restrict__ dbeta,
+                                                            float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   __shared__ float red[2][4][64];
@@ -852,10 +934,16 @@ __global__ __launch_bounds__(256) void snakebeta_bwd_kernel(const float* __restr
   red[0][part][threadIdx.x & 63] = sa;
   red[1][part][threadIdx.x & 63] = sb;
   __syncthreads();
-  if (part == 0 && c < C) {
-    atomicAdd(&dalpha[c], red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-    atomicAdd(&dbeta[c], red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 128;
+  if (part == 0) {
+    gslab[blockIdx.y * 128 + threadIdx.x] = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+    gslab[blockIdx.y * 128 + 64 + threadIdx.x] = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
   }
+  if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0][0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 128, &red[0][0][0], [&](int i, float t) {
+      const int cc = blockIdx.x * 64 + (i & 63);
+      if (cc < C) (i < 64 ? dalpha : dbeta)[cc] += t;
+    });
 }
 
 // ------------------------------------------------------------------ forward-sum (CTC) loss of the alignment framework
@@ -936,6 +1024,13 @@ inline unsigned blocks_for(int64_t n, int per_block, unsigned cap = 8192) {
 #define S_ ((hipStream_t)stream)
 #define NULLCHK(cond, msg) \
   if (cond) return jatts_set_error_msg(JATTS_ERR_ARG, msg)
+// scratch of the deterministic reductions (det_reduce.h): `groups` tickets, `floats` f32 of slabs
+#define WS_NEED(groups, floats)                                        \
+  do {                                                                 \
+    const int rc_ = jatts_ws_need((int64_t)(groups), (int64_t)(floats)); \
+    if (rc_ != JATTS_OK) return rc_;                                   \
+  } while (0)
+#define WS_ jatts_g_ws.slabs, jatts_g_ws.tickets
 
 extern "C" int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* gamma, int64_t rows, int32_t dim,
                                    float eps, float* dx, int32_t lddx, float* dgamma, float* dbeta, void* stream) {
@@ -943,8 +1038,10 @@ extern "C" int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy,
   NULLCHK((dgamma == nullptr) != (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
   if (dim < 1 || dim > 64 * LN_MAXPL) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "layernorm_bwd: 1 <= dim <= 1536");
   if (rows <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks_for(rows, 16, 2048)), dim3(256), 0, S_, x, ldx, dy, lddy, gamma, rows, dim, eps, dx, lddx,
-                     dgamma, dbeta);
+  // <= 512 workgroups (8 waves per CU over the chip): the last arriver adds up one [dgamma | dbeta] slab per workgroup
+  const unsigned nb = blocks_for(rows, 16, 512);
+  if (dgamma) WS_NEED(1, (int64_t)nb * 2 * dim);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, S_, x, ldx, dy, lddy, gamma, rows, dim, eps, dx, lddx, dgamma, dbeta, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1003,14 +1100,16 @@ extern "C" int jatts_dwconv_wgrad(const jatts_ragged* rg, const float* x, const 
     const int tiles = (rg->max_len + DWT - 1) / DWT;
     const int tpb = tiles > 8 ? 4 : 1;     // a few tiles per workgroup: 4x fewer atomics on long sequences
     const dim3 tgrid((unsigned)((tiles + tpb - 1) / tpb), (unsigned)rg->n_seq, (unsigned)((dim + 63) / 64));
-    if (k_w == 7) hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<7>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb);
-    else hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<31>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb);
+    WS_NEED(tgrid.z, (int64_t)tgrid.x * tgrid.y * tgrid.z * 64 * k_w);
+    if (k_w == 7) hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<7>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb, WS_);
+    else hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<31>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb, WS_);
     JATTS_CHECK_LAUNCH();
     return JATTS_OK;
   }
   unsigned gz = (unsigned)((rg->max_len + 63) / 64);
   if (gz > 64) gz = 64;
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)rg->n_seq, gz), dim3(256), 0, S_, *rg, x, dy, dw, dim, k_w, pad);
+  WS_NEED((dim + 63) / 64, (int64_t)((dim + 63) / 64) * rg->n_seq * gz * 64 * k_w);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)rg->n_seq, gz), dim3(256), 0, S_, *rg, x, dy, dw, dim, k_w, pad, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1020,9 +1119,10 @@ extern "C" int jatts_col_stats(const float* x, const float* y2, int32_t ld, int6
   NULLCHK(!x || !out0 || !out1 || (mode == 1 && !y2), "col_stats: null pointer");
   NULLCHK(mode != 0 && mode != 1, "col_stats: mode 0 (moments) or 1 (dy sums)");
   if (rows <= 0 || dim <= 0) return JATTS_OK;
-  const int64_t gy = (rows + 255) / 256;
-  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, y2, ld, rows, dim, shift,
-                     mul, mode, out0, out1);
+  const int64_t gy0 = (rows + 255) / 256;
+  const unsigned gx = (unsigned)((dim + 63) / 64), gy = (unsigned)(gy0 < 256 ? gy0 : 256);
+  WS_NEED(gx, (int64_t)gx * gy * 128);
+  hipLaunchKernelGGL(col_stats_kernel, dim3(gx, gy), dim3(256), 0, S_, x, y2, ld, rows, dim, shift, mul, mode, out0, out1, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1040,7 +1140,9 @@ extern "C" int jatts_index_add_rows(const float* src, int32_t ld, const int64_t*
                                     int64_t n_dst, float* dst, void* stream) {
   NULLCHK(!src || !idx || !dst, "index_add_rows: null pointer");
   if (rows <= 0 || dim <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(index_add_rows_kernel, dim3(blocks_for(rows * dim, 256)), dim3(256), 0, S_, src, ld, idx, rows, dim, scale, skip, n_dst, dst);
+  NULLCHK(n_dst < 1 || n_dst > 0x7fffffff, "index_add_rows: 1 <= n_dst < 2^31");
+  hipLaunchKernelGGL(index_add_rows_kernel, dim3((unsigned)n_dst, (unsigned)((dim + 255) / 256)), dim3(256), 0, S_, src, ld, idx, rows, dim, scale, skip,
+                     n_dst, dst);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1126,8 +1228,10 @@ extern "C" int jatts_outer_rows(const float* v, const float* w, const float* bia
 extern "C" int jatts_col_wsum(const float* x, int32_t ld, const float* v, int64_t rows, int32_t dim, float* out, void* stream) {
   NULLCHK(!x || !v || !out, "col_wsum: null pointer");
   if (rows <= 0 || dim <= 0) return JATTS_OK;
-  const int64_t gy = (rows + 255) / 256;
-  hipLaunchKernelGGL(col_wsum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, ld, v, rows, dim, out);
+  const int64_t gy0 = (rows + 255) / 256;
+  const unsigned gx = (unsigned)((dim + 63) / 64), gy = (unsigned)(gy0 < 256 ? gy0 : 256);
+  WS_NEED(gx, (int64_t)gx * gy * 64);
+  hipLaunchKernelGGL(col_wsum_kernel, dim3(gx, gy), dim3(256), 0, S_, x, ld, v, rows, dim, out, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1174,8 +1278,12 @@ extern "C" int jatts_qkv_split_bwd(const float* dqu, const float* dqv, const flo
   NULLCHK(!dqu || !dk || !dvv || !dqkv || (!dqv != !dv) || (!du != !dv), "qkv_split_bwd: null pointer");
   NULLCHK(n_batch < 1 || t_len < 1 || n_heads < 1 || d_k < 1, "qkv_split_bwd: bad geometry");
   const int64_t rows = (int64_t)n_batch * t_len;
-  hipLaunchKernelGGL(qkv_split_bwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, S_, dqu, dqv, dk, dvv, n_batch, t_len, n_heads, d_k, dqkv,
-                     du, dv);
+  // 32 rows per workgroup, more when that would exceed 512 workgroups (= slabs the last arriver adds up for du / dv)
+  int rpb = 32;
+  while ((rows + rpb - 1) / rpb > 512) rpb += 32;
+  const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+  if (du || dv) WS_NEED(1, (int64_t)nb * 2 * n_heads * d_k);
+  hipLaunchKernelGGL(qkv_split_bwd_kernel, dim3(nb), dim3(256), 0, S_, dqu, dqv, dk, dvv, n_batch, t_len, n_heads, d_k, dqkv, du, dv, rpb, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1202,7 +1310,9 @@ extern "C" int jatts_dropout_add(const float* x, const float* resid, float* y, i
 extern "C" int jatts_sumsq(const float* x, int64_t n, double* out, void* stream) {
   NULLCHK(!x || !out, "sumsq: null pointer");
   if (n <= 0) return JATTS_OK;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n, 4096, 1024)), dim3(256), 0, S_, x, n, out);
+  const unsigned nb = blocks_for(n, 4096, 1024);
+  WS_NEED(1, (int64_t)nb * 2);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, S_, x, n, out, (double*)jatts_g_ws.slabs, jatts_g_ws.tickets);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1259,8 +1369,9 @@ extern "C" int jatts_groupnorm_bwd(const jatts_ragged* rg, const float* x, const
   NULLCHK(groups < 1 || dim % groups != 0 || dim / groups > 256 || 256 % (dim / groups) != 0,
           "groupnorm_bwd: channels per group must divide 256");
   if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
+  if (dgamma) WS_NEED(groups, (int64_t)rg->n_seq * 2 * dim);
   hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)groups, (unsigned)rg->n_seq), dim3(256), 0, S_, *rg, x, dy, dim, groups, gamma, mean, rstd, dx,
-                     dgamma, dbeta);
+                     dgamma, dbeta, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1275,9 +1386,10 @@ extern "C" int jatts_snakebeta_bwd(const float* x, const float* dy, int64_t rows
                                    float* dalpha, float* dbeta, void* stream) {
   NULLCHK(!x || !dy || !alpha || !beta || !dx || !dalpha || !dbeta, "snakebeta_bwd: null pointer");
   if (rows <= 0 || dim <= 0) return JATTS_OK;
-  const int64_t gy = (rows + 255) / 256;
-  hipLaunchKernelGGL(snakebeta_bwd_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, dy, rows, dim, alpha,
-                     beta, dx, dalpha, dbeta);
+  const int64_t gy0 = (rows + 255) / 256;
+  const unsigned gx = (unsigned)((dim + 63) / 64), gy = (unsigned)(gy0 < 256 ? gy0 : 256);
+  WS_NEED(gx, (int64_t)gx * gy * 128);
+  hipLaunchKernelGGL(snakebeta_bwd_kernel, dim3(gx, gy), dim3(256), 0, S_, x, dy, rows, dim, alpha, beta, dx, dalpha, dbeta, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -1300,7 +1412,8 @@ extern "C" int jatts_seq_sum(const jatts_ragged* rg, const float* x, int32_t dim
   if (rg->n_seq <= 0 || rg->max_len <= 0 || dim <= 0) return JATTS_OK;
   unsigned gz = (unsigned)((rg->max_len + 63) / 64);
   if (gz > 16) gz = 16;
-  hipLaunchKernelGGL(seq_sum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)rg->n_seq, gz), dim3(256), 0, S_, *rg, x, dim, out);
+  WS_NEED((int64_t)((dim + 63) / 64) * rg->n_seq, (int64_t)((dim + 63) / 64) * rg->n_seq * gz * 64);
+  hipLaunchKernelGGL(seq_sum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)rg->n_seq, gz), dim3(256), 0, S_, *rg, x, dim, out, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "det_reduce.h"
 
 namespace {
 
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, i
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const float* x, int ldx, const float* dy, int ldy, int c_in,
-                                                         int n_out, int k_w, int dil, int pad, int seq_groups, float* dw) {
+                                                         int n_out, int k_w, int dil, int pad, int seq_groups, float* dw, int overwrite,
+                                                         float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float dys[WG_TT][64 + 4];
   __shared__ float xs[WG_TT][64 + 4];
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -79,13 +81,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
       __syncthreads();
     }
   }
+  // deterministic split-K (det_reduce.h): group = (n tile, c tile, tap), parts = the sequence groups, slab = the 64 x 64 partial tile
+  const int tile = (tap * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* gslab = slabs + (int64_t)tile * seq_groups * 4096;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 4 * tn + i, c = c0 + 4 * tc + j;
-      if (n < n_out && c < c_in) atomicAdd(&dw[((int64_t)n * c_in + c) * k_w + tap], acc[i][j]);
-    }
+    *reinterpret_cast<f32x4*>(gslab + (int64_t)grp * 4096 + (4 * tn + i) * 64 + 4 * tc) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+  if (det_arrive(tickets + tile, seq_groups, reinterpret_cast<unsigned*>(&dys[0][0])))
+    det_sum_slabs<4>(gslab, seq_groups, 4096, &xs[0][0], [&](int e, float t) {
+      const int n = n0 + (e >> 6), c = c0 + (e & 63);
+      if (n < n_out && c < c_in) {
+        float* o = &dw[((int64_t)n * c_in + c) * k_w + tap];
+        *o = overwrite ? t : *o + t;
+      }
+    });
 }
 
 // The same reduction on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: A = dy^T fragment [32 n][2 t], B = x fragment [2 t][32 c], the
@@ -224,14 +233,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
       }
     return;
   }
-  if (c < c_in)
-#pragma unroll
-    for (int k = 0; k < KW; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (n < n_out) atomicAdd(&dw[((int64_t)n * c_in + c) * KW + k], acc[k][r]);
-      }
+  // (no workspace: refused by the launcher -- the f32-atomic accumulation this kernel once had was not reproducible run to run)
 }
 // dw[n][c][k] = sum over groups of ws[g][k][n][c]  (overwrites dw: no zero fill, no atomics -- 32-way contended f32 atomics on a
 // 368 k-element gradient were 85 % of the k = 5 launches' time)
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
 }
 
 // out[c] += sum over rows of x[row][c]
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, int64_t rows, int dim, float* out) {
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, int64_t rows, int dim, float* out, int overwrite,
+                                                      float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   __shared__ float red[4][64];
@@ -292,12 +295,19 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, in
     for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 64;      // group = channel tile, parts = the row splits
+  if (part == 0) gslab[blockIdx.y * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], [&](int i, float t) {
+      const int cc = blockIdx.x * 64 + i;
+      if (cc < dim) out[cc] = overwrite ? t : out[cc] + t;
+    });
 }
 
 // the same over all rows of a ragged batch (row count read from the device-side offsets), into a zero-filled out: the bias gradient of
 // the convolutions whose weight gradient takes the VALU path
-__global__ __launch_bounds__(256) void col_sum_ragged_kernel(jatts_ragged rg, const float* x, int ld, int dim, float* out) {
+__global__ __launch_bounds__(256) void col_sum_ragged_kernel(jatts_ragged rg, const float* x, int ld, int dim, float* out, int overwrite,
+                                                             float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int64_t rows = (int64_t)rg.cu_rows[rg.n_seq] * rg.len_mul;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
@@ -307,16 +317,25 @@ __global__ __launch_bounds__(256) void col_sum_ragged_kernel(jatts_ragged rg, co
     for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && c < dim) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 64;      // group = channel tile, parts = the row splits
+  if (part == 0) gslab[blockIdx.y * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0])))
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], [&](int i, float t) {
+      const int cc = blockIdx.x * 64 + i;
+      if (cc < dim) out[cc] = overwrite ? t : out[cc] + t;
+    });
 }
 
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
 
-static void bias_grad_plain(const jatts_ragged* rg, const float* dy, int ldy, int n_out, float* db, void* stream) {
-  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, S_, db, (int64_t)n_out);
-  hipLaunchKernelGGL(col_sum_ragged_kernel, dim3((unsigned)((n_out + 63) / 64), 128), dim3(256), 0, S_, *rg, dy, ldy, n_out, db);
+static int bias_grad_plain(const jatts_ragged* rg, const float* dy, int ldy, int n_out, float* db, void* stream) {
+  const unsigned gx = (unsigned)((n_out + 63) / 64);
+  const int rc = jatts_ws_need(gx, (int64_t)gx * 128 * 64);
+  if (rc != JATTS_OK) return rc;
+  hipLaunchKernelGGL(col_sum_ragged_kernel, dim3(gx, 128), dim3(256), 0, S_, *rg, dy, ldy, n_out, db, 1, jatts_g_ws.slabs, jatts_g_ws.tickets);
+  return JATTS_OK;
 }
 
 extern "C" int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const float* b, int32_t ldb, int32_t dim,
@@ -351,27 +370,31 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
     const dim3 grid((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)g);
     const size_t lds = 2 * (size_t)(64 + (k_w - 1) * dil) * 68 * sizeof(float);   // two buffers of (dy tile | x tile + halo)
     // bias partials live behind the weight partials: workspace[g k n64 c64 ..][g][n64]
-    float* bws = (db && workspace) ? workspace + (int64_t)g * k_w * grid.x * 64 * grid.y * 64 : nullptr;
+    if (!workspace) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d_wgrad: the MFMA path needs its split-K workspace (see include/jatts_hip.h)");
+    float* bws = db ? workspace + (int64_t)g * k_w * grid.x * 64 * grid.y * 64 : nullptr;
     if (k_w == 1) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace, bws);
     else if (k_w == 3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<3>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace, bws);
     else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<5>, grid, dim3(256), lds, S_, *rg, x, ldx, dy, ldy, c_in, n_out, dil, pad, g, dw, workspace, bws);
-    if (workspace) {
+    {
       const int64_t total = (int64_t)n_out * c_in * k_w;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, S_, workspace, g, k_w,
                          (int)grid.x * 64, (int)grid.y * 64, n_out, c_in, dw, bws, bws ? db : nullptr);
     }
-    if (db && !bws) bias_grad_plain(rg, dy, ldy, n_out, db, stream);
     JATTS_CHECK_LAUNCH();
     return JATTS_OK;
   }
-  if (db) bias_grad_plain(rg, dy, ldy, n_out, db, stream);
-  if (workspace) {   // the VALU fallback accumulates with atomics: it needs a zeroed dw (a kernel, not hipMemsetAsync: under stream
-                     // capture the memset did not reliably replay with the graph -- tests/test_training_gpu.py, Matcha graph mode)
-    const int64_t total = (int64_t)n_out * c_in * k_w;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, S_, dw, total);
+  if (db) {
+    const int rc = bias_grad_plain(rg, dy, ldy, n_out, db, stream);
+    if (rc != JATTS_OK) return rc;
+  }
+  // VALU fallback (other kernel widths): deterministic split-K through the library scratch (det_reduce.h); with a workspace argument dw is
+  // OVERWRITTEN (the contract of the MFMA path), without one the result is accumulated into dw
+  {
+    const int rc = jatts_ws_need((int64_t)tiles, (int64_t)tiles * groups * 4096);
+    if (rc != JATTS_OK) return rc;
   }
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)(k_w * groups)), dim3(256), 0, S_,
-                     *rg, x, ldx, dy, ldy, c_in, n_out, k_w, dil, pad, groups, dw);
+                     *rg, x, ldx, dy, ldy, c_in, n_out, k_w, dil, pad, groups, dw, workspace ? 1 : 0, jatts_g_ws.slabs, jatts_g_ws.tickets);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -379,8 +402,13 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
 extern "C" int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* out, void* stream) {
   if (!x || !out) return jatts_set_error_msg(JATTS_ERR_ARG, "col_sum: null pointer");
   if (rows <= 0 || dim <= 0) return JATTS_OK;
-  const int64_t gy = (rows + 255) / 256;
-  hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)(gy < 256 ? gy : 256)), dim3(256), 0, S_, x, ld, rows, dim, out);
+  const int64_t gy0 = (rows + 255) / 256;
+  const unsigned gx = (unsigned)((dim + 63) / 64), gy = (unsigned)(gy0 < 256 ? gy0 : 256);
+  {
+    const int rc = jatts_ws_need(gx, (int64_t)gx * gy * 64);
+    if (rc != JATTS_OK) return rc;
+  }
+  hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(256), 0, S_, x, ld, rows, dim, out, 0, jatts_g_ws.slabs, jatts_g_ws.tickets);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -156,6 +156,28 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_WS = {}               # device -> the zero-initialised scratch of the deterministic reductions (include/jatts_hip.h: jatts_set_workspace)
+_WS_CURRENT = [None]
+WS_BYTES = 64 * 1024 + 96 * 1024 * 1024
+
+
+def _ws(device):
+    """Register this device's scratch with the library before a kernel that reduces across workgroups (LayerNorm / GroupNorm / SnakeBeta
+    parameter gradients, column sums, depthwise-conv weights, the gradient norm): allocated once, outside any graph capture (the trainers'
+    first step of a signature runs eagerly), kept alive for the life of the process -- a captured step bakes its address in."""
+    key = str(device)
+    if _WS_CURRENT[0] == key:
+        return
+    buf = _WS.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _abi.JattsHipError("the reduction scratch must exist before a graph capture: run one eager step first")
+        buf = _WS[key] = torch.zeros(WS_BYTES, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()
+    _abi.check(_abi.load().jatts_set_workspace(buf.data_ptr(), buf.numel()), "jatts_set_workspace")
+    _WS_CURRENT[0] = key
+
+
 def _ptr(t, col0=0):
     if t is None:
         return None
@@ -867,6 +889,7 @@ def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1, want_db=False
                      device=x.device)                                                                                   # split-K partials
     rg = rb.struct(len_mul)
     _count(2.0 * c_in * n_out * k_w * rb.total * len_mul)
+    _ws(x.device)
     _abi.check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
                                       pad, dw.data_ptr(), _ptr(db), ws.data_ptr(), _stream()), "jatts_conv1d_wgrad")
     return (dw, db) if want_db else dw
@@ -876,6 +899,7 @@ def col_sum(x, dim=None):
     lib = _abi.load()
     dim = dim or x.shape[1]
     out = _zeros((dim), x.device)
+    _ws(x.device)
     _abi.check(lib.jatts_col_sum(_dev(x).data_ptr(), x.shape[1], x.shape[0], dim, out.data_ptr(), _stream()), "jatts_col_sum")
     return out
 
@@ -898,6 +922,7 @@ def layernorm_bwd(x, dy, gamma, eps, need_dx=True, need_dparam=True):
     dx = torch.empty_like(x) if need_dx else None
     dg = _zeros((dim), x.device) if need_dparam else None
     db = _zeros((dim), x.device) if need_dparam else None
+    _ws(x.device)
     _abi.check(lib.jatts_layernorm_bwd(x.data_ptr(), dim, dy.data_ptr(), dim, _f32c(gamma).data_ptr(), rows, dim, float(eps), _ptr(dx), dim,
                                        _ptr(dg), _ptr(db), _stream()), "jatts_layernorm_bwd")
     return dx, dg, db
@@ -952,6 +977,7 @@ def dwconv_wgrad(rb, x, dy, k_w, pad):
     x, dy = _f32c(x), _f32c(dy)
     dw = _zeros((x.shape[1], k_w), x.device)
     rg = rb.struct()
+    _ws(x.device)
     _abi.check(lib.jatts_dwconv_wgrad(C.byref(rg), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[1], k_w, pad, _stream()),
                "jatts_dwconv_wgrad")
     return dw
@@ -964,6 +990,7 @@ def col_stats(x, y2=None, shift=None, mul=None):
     rows, dim = x.shape
     o0 = _zeros((dim), x.device)
     o1 = _zeros((dim), x.device)
+    _ws(x.device)
     _abi.check(lib.jatts_col_stats(x.data_ptr(), _ptr(y2), dim, rows, dim, _ptr(shift), _ptr(mul), 0 if y2 is None else 1, o0.data_ptr(),
                                    o1.data_ptr(), _stream()), "jatts_col_stats")
     return o0, o1
@@ -1087,6 +1114,7 @@ def col_wsum(x, v):
     lib = _abi.load()
     x, v = _f32c(x), _f32c(v)
     out = _zeros((x.shape[1]), x.device)
+    _ws(x.device)
     _abi.check(lib.jatts_col_wsum(x.data_ptr(), x.shape[1], v.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "jatts_col_wsum")
     return out
 
@@ -1151,6 +1179,7 @@ def qkv_split_bwd(dqu, dqv, dk_, dvv):
     if dqv is not None:
         dqv = _f32c(dqv)
         du, dv = _zeros((H * dk), dqu.device), _zeros((H * dk), dqu.device)
+    _ws(dqu.device)
     _abi.check(lib.jatts_qkv_split_bwd(dqu.data_ptr(), _ptr(dqv), dk_.data_ptr(), dvv.data_ptr(), B, T, H, dk, dqkv.data_ptr(), _ptr(du), _ptr(dv),
                                        _stream()), "jatts_qkv_split_bwd")
     return dqkv, du, dv
@@ -1184,6 +1213,7 @@ def sumsq(x, out):
     """out (f64 scalar tensor on the device) += sum x^2"""
     lib = _abi.load()
     x = _f32c(x)
+    _ws(x.device)
     _abi.check(lib.jatts_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "jatts_sumsq")
     return out
 
@@ -1237,6 +1267,7 @@ def groupnorm_bwd(rb, x, dy, groups, gamma, mean, rstd, need_dx=True, need_dpara
     dg = _zeros((dim), x.device) if need_dparam else None
     db = _zeros((dim), x.device) if need_dparam else None
     rg = rb.struct()
+    _ws(x.device)
     _abi.check(lib.jatts_groupnorm_bwd(C.byref(rg), x.data_ptr(), dy.data_ptr(), dim, groups, _f32c(gamma).data_ptr(), mean.data_ptr(),
                                        rstd.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), _stream()), "jatts_groupnorm_bwd")
     return dx, dg, db
@@ -1257,6 +1288,7 @@ def snakebeta_bwd(x, dy, alpha, beta):
     dx = torch.empty_like(x)
     da = _zeros((x.shape[1]), x.device)
     db = _zeros((x.shape[1]), x.device)
+    _ws(x.device)
     _abi.check(lib.jatts_snakebeta_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
                                        dx.data_ptr(), da.data_ptr(), db.data_ptr(), _stream()), "jatts_snakebeta_bwd")
     return dx, da, db
@@ -1286,5 +1318,6 @@ def seq_sum(rb, x):
     x = _f32c(x)
     out = _zeros((rb.n_seq, x.shape[1]), x.device)
     rg = rb.struct()
+    _ws(x.device)
     _abi.check(lib.jatts_seq_sum(C.byref(rg), x.data_ptr(), x.shape[1], out.data_ptr(), _stream()), "jatts_seq_sum")
     return out
