@@ -159,6 +159,8 @@ def frame_token_indices(text_lengths, feats_lengths, Tt, Tf, device):
         if len(_SEL_CACHE) >= 64:
             _SEL_CACHE.pop(next(iter(_SEL_CACHE)))
         _SEL_CACHE[key] = hit = (tsel, fsel)
+    hip.keep(hit[0])          # (a graph being captured pins them: the cache evicts)
+    hip.keep(hit[1])
     return hit
 
 

@@ -4,6 +4,7 @@ PyTorch is used here only as plumbing: device memory (torch tensors), the curren
 HIP stream and dtype bookkeeping.  Every wrapper validates shapes, fills the POD
 descriptor and launches asynchronously on ``torch.cuda.current_stream()``.
 """
+import collections
 import ctypes as C
 
 import torch
@@ -190,6 +191,28 @@ def _dev(t):
     return t
 
 
+_KEEP = [None]        # while a training step is being captured: every cached device tensor handed out (the graph bakes their addresses in)
+
+
+def keep_begin():
+    """Start recording the cached device tensors handed out from here on (hip.h2d, RaggedBatch geometry, the models' per-length tables):
+    a captured graph reads them at their addresses for as long as it is replayed, while the caches are bounded and evict -- the capture's
+    owner keeps the returned list alive next to the graph (jatts_amd.training)."""
+    _KEEP[0] = []
+    return _KEEP[0]
+
+
+def keep_end():
+    _KEEP[0] = None
+
+
+def keep(t):
+    """Called by every cache that hands out a device tensor (hit or miss); returns t."""
+    if _KEEP[0] is not None and t is not None:
+        _KEEP[0].append(t)
+    return t
+
+
 def h2d(values, dtype, device):
     """Small host list -> device tensor WITHOUT stalling the host: staged through pinned memory and copied asynchronously on the
     current stream.  torch.tensor(values, device=...) copies from pageable memory, which blocks the host until everything already
@@ -198,28 +221,34 @@ def h2d(values, dtype, device):
     if dev.type != "cuda":
         return torch.tensor(values, dtype=dtype, device=dev)
     # small length-derived arrays repeat from step to step (same bucket of lengths): cached per (values, dtype, device), which also makes
-    # a training step capturable -- a cache hit issues no copy, so a captured graph never holds a memcpy from a host buffer that is gone
+    # a training step capturable -- a cache hit issues no copy, so a captured graph never holds a memcpy from a host buffer that is gone.
+    # LRU, bounded by BYTES (device bytes + the key tuple's ~8 x that on the host): a long decode run produces a new key per batch.
     key = None
-    if isinstance(values, (list, tuple)) and len(values) <= 65536 and (not values or isinstance(values[0], (int, float, bool))):
+    if isinstance(values, (list, tuple)) and len(values) <= 65536 and all(isinstance(v, (int, float, bool)) for v in values[:1] + values[-1:]):
         key = (tuple(values), dtype, dev.index if dev.index is not None else torch.cuda.current_device())
         hit = _H2D_CACHE.get(key)
         if hit is not None:
+            _H2D_CACHE.move_to_end(key)
             if hit[2] != torch.cuda.current_stream().cuda_stream and not torch.cuda.is_current_stream_capturing() and not hit[1].query():
                 torch.cuda.current_stream().wait_event(hit[1])
-            return hit[0]
+            return keep(hit[0])
     if torch.cuda.is_current_stream_capturing():
         raise _abi.JattsHipError("h2d of new values while a graph is being captured: run the step once outside the capture first")
     t = torch.tensor(values, dtype=dtype).pin_memory().to(dev, non_blocking=True)
     if key is not None:
         ev = torch.cuda.Event()
         ev.record()
-        if len(_H2D_CACHE) >= 4096:
-            _H2D_CACHE.pop(next(iter(_H2D_CACHE)))
         _H2D_CACHE[key] = (t, ev, torch.cuda.current_stream().cuda_stream)
-    return t
+        _H2D_BYTES[0] += t.numel() * t.element_size()
+        while _H2D_BYTES[0] > _H2D_CACHE_MAX_BYTES and len(_H2D_CACHE) > 1:
+            _, old = _H2D_CACHE.popitem(last=False)
+            _H2D_BYTES[0] -= old[0].numel() * old[0].element_size()
+    return keep(t)
 
 
-_H2D_CACHE = {}       # (values, dtype, device) -> (tensor, upload-complete event, stream)
+_H2D_CACHE = collections.OrderedDict()       # (values, dtype, device) -> (tensor, upload-complete event, stream); least recently used first
+_H2D_BYTES = [0]
+_H2D_CACHE_MAX_BYTES = 8 << 20               # device bytes; the host-side key tuples cost about 8x that
 _GEOM_CACHE = {}      # (lens, device) -> (cu tensor, upload-complete event); insertion-ordered, oldest evicted
 _GEOM_CACHE_MAX = 512
 
@@ -255,7 +284,7 @@ class RaggedBatch:
             _GEOM_CACHE[key] = hit = (t, ev, torch.cuda.current_stream().cuda_stream)
         elif hit[2] != torch.cuda.current_stream().cuda_stream and not torch.cuda.is_current_stream_capturing() and not hit[1].query():
             torch.cuda.current_stream().wait_event(hit[1])     # uploaded on another stream and still in flight
-        self.cu = hit[0]
+        self.cu = keep(hit[0])
 
     def struct(self, len_mul=1):
         return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul)

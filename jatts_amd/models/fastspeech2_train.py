@@ -89,7 +89,7 @@ def _pos_table(rel_style, T, Ad, device):
         if len(_POS_TABLES) >= 64:
             _POS_TABLES.pop(next(iter(_POS_TABLES)))
         _POS_TABLES[key] = t
-    return t
+    return hip.keep(t)        # (a graph being captured pins it: the cache evicts)
 
 
 def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):

@@ -225,7 +225,7 @@ def beta_binomial_prior_dev(ilens, olens, device):
         if len(_PRIOR_DEV) >= 16:
             _PRIOR_DEV.pop(next(iter(_PRIOR_DEV)))
         _PRIOR_DEV[key] = t
-    return t
+    return hip.keep(t)        # (a graph being captured pins it: the cache evicts)
 
 
 def criterion(ret, durations, ilens, duration_loss=True, olens=None, forward_sum=False, bin_loss=False, lambda_align=2.0):

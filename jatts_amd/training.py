@@ -386,6 +386,7 @@ class FastSpeech2Trainer:
             self.model.train(was)
 
     _graph_capable = True      # a subclass whose step synchronises with the host switches it off
+    SCALAR_RING = 8            # pinned staging slots for the per-step scalars of a replayed graph
 
     def _signature(self, batch):
         sig = []
@@ -407,11 +408,16 @@ class FastSpeech2Trainer:
         dev = self.flat_p.device
         sig = self._signature(batch)
         st = self._graphs.get(sig)
+        if st is not None and st.get("eager_only"):
+            return self._train_step(batch)
         if st is None:                       # first sight of this bucket: eager step, remember the verified frame counts
             if "durations" in batch and batch["durations"] is not None:
                 dsum = [int(v) for v in batch["durations"].sum(1).tolist()]
                 if dsum != [int(v) for v in batch["olens"].tolist()]:
                     raise ValueError("graph mode needs sum(durations) == olens for every utterance")
+            if len(self._graphs) >= 16 * max(1, self.max_graphs):      # signatures seen once and never again (unbucketed data): bounded
+                for k in [k for k, v in self._graphs.items() if v.get("graph") is None][: len(self._graphs) // 2]:
+                    del self._graphs[k]
             self._graphs[sig] = {"graph": None}
             return self._train_step(batch)
         if st["graph"] is None:              # second sight: capture
@@ -424,11 +430,19 @@ class FastSpeech2Trainer:
                         for k, v in batch.items()}
             st["seed"] = torch.zeros(1, dtype=torch.int64, device=dev)
             st["hyper"] = torch.zeros(7, dtype=torch.float32, device=dev)
-            st["seed_host"] = torch.zeros(1, dtype=torch.int64).pin_memory()
-            st["hyper_host"] = torch.zeros(7, dtype=torch.float32).pin_memory()
+            # per-step scalars travel through a RING of pinned staging buffers, each guarded by an event recorded behind its copies: the
+            # host may run many steps ahead of the GPU (losses stay on the device), and one shared staging pair would let step N's
+            # asynchronous copy read step N + 1's values
+            st["ring"] = [dict(seed=torch.zeros(1, dtype=torch.int64).pin_memory(), hyper=torch.zeros(7, dtype=torch.float32).pin_memory(),
+                               ev=None) for _ in range(self.SCALAR_RING)]
+            st["ring_pos"] = 0
             m = self.model
             m._seed_dev, m._static_olens = st["seed"], [int(v) for v in batch["olens"].tolist()]
             g = torch.cuda.CUDAGraph()
+            # every cached device tensor the step is handed during the capture (length uploads, ragged geometry, positional tables, the
+            # forward-sum prior, frame / token selectors) lives in bounded caches that evict: the graph reads them at their addresses on
+            # every replay, so the graph's own record pins them
+            st["keep"] = hip.keep_begin()
             try:
                 torch.cuda.synchronize()
                 with torch.cuda.graph(g):
@@ -447,7 +461,14 @@ class FastSpeech2Trainer:
                     st["out"] = {k: v.detach() for k, v in losses.items()}
                     if ss is not None:
                         st["out"]["grad_norm"] = ss.sqrt()
+            except BaseException:
+                # a failed capture must not be retried forever, nor leave the parameters without their .grad views: this signature runs eagerly
+                self._graphs[sig] = {"graph": None, "eager_only": True}
+                for p_, v_ in zip(self.params, self._grad_views):
+                    p_.grad = v_
+                raise
             finally:
+                hip.keep_end()
                 hip.zero_pool_end()
                 m._seed_dev, m._static_olens = None, None
             st["graph"] = g
@@ -461,16 +482,31 @@ class FastSpeech2Trainer:
         lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **self._sched_params())
         self.last_lr = lr
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
-        st["seed_host"][0] = ((self.steps - 1) * self.accumulate + 1) * 4099 * 1000003 + rank * 1000003   # == _Ctx's (seed * 4099 + rank) * 1000003
-        st["hyper_host"].copy_(torch.tensor(hip.adam_hyper(lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps), dtype=torch.float32))
-        st["seed"].copy_(st["seed_host"], non_blocking=True)
-        st["hyper"].copy_(st["hyper_host"], non_blocking=True)
+        slot = st["ring"][st["ring_pos"] % len(st["ring"])]
+        st["ring_pos"] += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()         # this slot's copies of SCALAR_RING steps ago have run (normally long since)
+        slot["seed"][0] = ((self.steps - 1) * self.accumulate + 1) * 4099 * 1000003 + rank * 1000003   # == _Ctx's (seed * 4099 + rank) * 1000003
+        slot["hyper"].copy_(torch.tensor(hip.adam_hyper(lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps), dtype=torch.float32))
+        st["seed"].copy_(slot["seed"], non_blocking=True)
+        st["hyper"].copy_(slot["hyper"], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
         st["graph"].replay()
         st["used"] = self.steps
         self.model._prep = None
         if self._bad_ids is None:
             self._bad_ids = hip.bad_ids_async(dev)
-        return dict(st["out"])
+        # the graph's outputs are STATIC tensors that the next replay overwrites: hand out stream-ordered copies (one concatenation per dtype),
+        # so that a caller who collects loss tensors and reads them later sees each step's own values
+        out, by_dtype = {}, {}
+        for k, v in st["out"].items():
+            by_dtype.setdefault(v.dtype, []).append(k)
+        for ks in by_dtype.values():
+            vals = torch.stack([st["out"][k].reshape(()) for k in ks])
+            for i, k in enumerate(ks):
+                out[k] = vals[i]
+        return out
 
     def train_step(self, batch):
         """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
@@ -480,7 +516,7 @@ class FastSpeech2Trainer:
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         if self.capture_graph and not multi and self.accumulate == 1:
             sig_seen = self._graphs.get(self._signature(batch))
-            if sig_seen is not None:
+            if sig_seen is not None and not sig_seen.get("eager_only"):
                 return self._graph_step(batch)          # capture / replay
             hip.zero_pool_begin(self.flat_p.device)
             try:

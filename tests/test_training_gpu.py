@@ -798,3 +798,52 @@ def test_graph_mode_replays_the_same_training(cuda, lib):
     for _ in range(2):
         out = b.train_step(batch)
     assert sum(v.get("graph") is not None for v in b._graphs.values()) == 1 and math.isfinite(float(out["loss"]))
+
+
+def test_captured_graph_pins_its_cached_inputs_and_stages_scalars_per_step(cuda, lib):
+    """(1) a captured step reads its length uploads / ragged geometry / positional tables at baked-in addresses, while the caches
+    that own those tensors are bounded and evict -- the graph's record (st["keep"]) must pin them: flood the caches until every entry of the
+    capture is gone, free the allocator's cache, allocate over the freed blocks, replay; (2) the per-step scalars (dropout seed, Adam
+    step size) go through a ring of pinned buffers guarded by events: queue several replays WITHOUT synchronising in between and still get
+    the eager trainer's training, bit for bit (every reduction of the step is fixed-order)."""
+    import gc
+    from jatts_amd import hip
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.models import fastspeech2_train as ft
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+
+    def make():
+        m = FastSpeech2(idim=20, **{**FS2_SMALL, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+        m.load_state_dict(golden_state(keys, 0))
+        return m.to(cuda)
+    a = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=10)
+    b = FastSpeech2Trainer(make(), lr=1e-3, grad_norm=1.0, warmup_steps=10, capture_graph=True)
+    for _ in range(2):                       # eager first sight, capture
+        a.train_step(batch), b.train_step(batch)
+    (st,) = b._graphs.values()
+    assert st["graph"] is not None and len(st["keep"]) > 0
+    # evict everything the capture was handed
+    for i in range(700):
+        hip.RaggedBatch([3 + i, 5], cuda)
+    hip._H2D_CACHE.clear()
+    hip._H2D_BYTES[0] = 0
+    hip._GEOM_CACHE.clear()
+    ft._POS_TABLES.clear()
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 16,), float("nan"), device=cuda) for _ in range(64)]     # lands on whatever was freed
+    # several replays queued back to back (no host synchronisation in between), then compare with the eager trainer
+    la = [a.train_step(batch) for _ in range(6)]
+    lb = [b.train_step(batch) for _ in range(6)]
+    torch.cuda.synchronize()
+    del junk
+    for s, (x, y) in enumerate(zip(la, lb)):
+        for k in ("loss", "mel_loss", "duration_loss", "pitch_loss", "energy_loss", "grad_norm"):
+            assert float(x[k]) == float(y[k]), (s, k, float(x[k]), float(y[k]))
+    assert torch.equal(a.flat_p, b.flat_p)
