@@ -29,7 +29,9 @@ int jatts_conv1d_f32_direct(const jatts_conv_desc& d, int variant, hipStream_t s
     case 3: return launch_conv_direct<2, 2, 2, 2, 2>(d, s);      // 128n x 128t, 256 threads, ring 2: three workgroups per CU
     case 4: return launch_conv_direct<2, 2, 2, 2, 4>(d, s);      // ring 4 (two workgroups per CU)
     case 5: return launch_conv_direct<2, 1, 2, 2, 2>(d, s);      // 128n x 64t (64n x 32t wave tiles): twice the workgroups for small launches
-    case 8: return launch_conv_direct<2, 2, 2, 2, 2, 1>(d, s);   // DIAGNOSIS, wrong results: nothing streamed in the main loop
+#ifdef JATTS_DIAG   // diagnosis builds only (make DIAG=1, used by tools/): never in the shipped library
+    case 8: return launch_conv_direct<2, 2, 2, 2, 2, 1>(d, s);   // WRONG RESULTS by design: nothing streamed in the main loop (profiles/r03_notes.md)
+#endif
     default: return 1;
   }
 }

@@ -14,8 +14,11 @@
 #pragma once
 #include <stdlib.h>
 
-#ifndef JATTS_ABLATE
-#define JATTS_ABLATE 0  // profiling-only ablations of the fused unit (tools/ablate_unit.sh); 0 = product
+// Profiling-only ablations of the fused unit (tools/ablate_unit.sh) exist in DIAGNOSIS builds only (-DJATTS_DIAG -DJATTS_ABLATE=n, written to
+// a separate library): in the shipped library the switch is the constant 0 whatever the command line says, so every ablated branch is dead code.
+#if !defined(JATTS_DIAG) || !defined(JATTS_ABLATE)
+#undef JATTS_ABLATE
+#define JATTS_ABLATE 0
 #endif
 
 #include "common.h"

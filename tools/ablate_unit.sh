@@ -1,12 +1,12 @@
 #!/bin/bash
-# Build profiling-only ablation variants of the fused unit kernel (JATTS_ABLATE=n) into jatts_amd/lib/ablate/.
+# DIAGNOSIS builds of libjatts_hip.so -- never the shipped library (jatts_amd/lib/libjatts_hip.so is built without JATTS_DIAG, where
+# JATTS_ABLATE is forced to 0 and conv variant 8 does not exist):
+#   tools/ablate_unit.sh           -> jatts_amd/lib/diag_ab<n>/libjatts_hip.so for n in ABLATE_SET (profiling-only ablations of the fused unit)
+#   ABLATE_SET=0 tools/ablate_unit.sh -> jatts_amd/lib/diag_ab0/ (DIAG only: jatts_conv1d variant 8, "nothing streamed", wrong results by design)
+# Point a tool at one of them with JATTS_HIP_LIB=<path> (jatts_amd/_abi.py).
 set -e
 cd "$(dirname "$0")/../jatts_amd/csrc"
-mkdir -p ../lib/ablate
 for n in ${ABLATE_SET:-1 2 3 4 5 6 7 8 9}; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-pass-failed -Wno-unused-variable -DJATTS_ABLATE=$n -c conv_mfma.hip -o ../lib/ablate/conv_$n.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ablate/libjatts_hip_ab$n.so ../lib/ablate/conv_$n.o ../lib/api.o ../lib/attention.o ../lib/rowwise.o ) &
-  if (( n % 3 == 0 )); then wait; fi
+  make -j8 OUT=../lib/diag_ab$n CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -DJATTS_DIAG -DJATTS_ABLATE=$n"
 done
-wait
-ls -la ../lib/ablate/*.so
+ls -la ../lib/diag_ab*/libjatts_hip.so
