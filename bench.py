@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--pipeline", action="store_true",
                     help="two-stream executor (jatts_amd.pipeline): text2mel of step k+1 overlaps the vocoder of step k; "
                          "per-kernel and per-stage timings then overlap too, so the default run stays sequential")
+    ap.add_argument("--profile-config", default=None, choices=["matcha", "vits"],
+                    help="run ONLY that BASELINE config's leg (configs[2] / configs[4]'s share) at --precision for --warmup + --steps steps and print "
+                         "nothing: the command tools/profile_models.sh puts under rocprofv3 (profiles/r04_infer_*_kernel_stats.csv)")
     ap.add_argument("--cpu-t-text", type=int, default=128, help="phonemes in the CPU-baseline sample utterance")
     ap.add_argument("--cpu-budget", type=float, default=45.0, help="seconds of N-thread CPU work before the sample is cut")
     return ap.parse_args()
@@ -372,6 +375,35 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     )
 
 
+def family_report(recs, prec):
+    """Per-kernel-family roofline of one recorded step of ANY config (BASELINE configs 3 / 5: VERDICT r3 item 4): algorithmic FLOPs from the
+    launch metadata the C-ABI wrappers record (fused unit 4 C^2 k rows, conv 2 c_in n_out k rows, attention 4 d_k H sum T^2) over the
+    family's HIP-event time.  -> {"dominant": {...}, "families": [...]}"""
+    unit_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
+    mm_peak = MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF
+    fam = {}
+    for tag, meta, ms in recs:
+        if tag in ("resunit", "resblock"):
+            C, k, d, rows, _ = meta
+            fl, name, peak = 4.0 * C * C * k * rows * (len(d) if tag == "resblock" else 1), "resunit (fused HiFi-GAN dilation unit)", unit_peak
+        elif tag == "conv1d":
+            fl, name, peak = 2.0 * meta[0] * meta[1] * meta[2] * meta[3], "conv1d (every jatts_conv1d launch: acoustic model + vocoder input / upsampling convs)", mm_peak
+        elif tag == "relattn":
+            fl, name, peak = 4.0 * meta[0] * meta[1] * meta[3], "relattn (fused attention)", mm_peak
+        else:
+            continue
+        f = fam.setdefault(name, dict(kernel=name, ms=0.0, flops=0.0, launches=0, peak=peak))
+        f["ms"] += ms
+        f["flops"] += fl
+        f["launches"] += 1
+    rows = []
+    for f in fam.values():
+        rows.append(dict(kernel=f["kernel"], bound="mfma", ms_per_step=f["ms"], launches_per_step=f["launches"], alg_tflop_per_step=f["flops"] / 1e12,
+                         achieved=f["flops"] / f["ms"] / 1e9, peak=f["peak"], unit="TFLOP/s", frac=f["flops"] / f["ms"] / 1e9 / f["peak"]))
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return {"dominant": rows[0] if rows else None, "families": rows}
+
+
 def train_setup(dev, kind="fs2", batch=32, t_text=128, frames=6):
     """The recipes' model (synthetic weights), one synthetic batch and the trainer class for a training leg
     -> (model, batch dict, trainer class, trainer kwargs, name, model TFLOP per utterance or None)."""
@@ -518,7 +550,11 @@ def compact_line(out, detail_path=None):
         c["configs"] = {("matcha_mas_b64" if "Matcha" in e["config"] else "vits_spk192_b32"):
                         {"f32_ms": e["ms_per_step"], "f32_value": e["value"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
                          "f16_ms": (e.get("fast_mode") or {}).get("ms_per_step"),
-                         "f16_err_wave": (e.get("fast_mode") or {}).get("max_abs_err_wave")} for e in out["configs"]}
+                         "f16_err_wave": (e.get("fast_mode") or {}).get("max_abs_err_wave"),
+                         "split_ms": (e.get("f32_split_mode") or {}).get("ms_per_step"),
+                         "split_err_wave": (e.get("f32_split_mode") or {}).get("max_abs_err_wave"),
+                         "roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac"),
+                         "roofline_kernel": (((e.get("roofline") or {}).get("dominant") or {}).get("kernel") or "")[:24]} for e in out["configs"]}
     if out.get("training"):
         c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "mean_ms": e.get("ms_per_step_mean"),
                                      "tflop": e.get("dense_tflops_per_step"), "frac": e.get("frac_of_f32_mfma_peak")}
@@ -528,7 +564,7 @@ def compact_line(out, detail_path=None):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_LIMIT:      # never let the line outgrow the driver's tail again: drop the optional blocks
-        for k in ("training", "configs", "fast_mode", "f32_mode", "f32_split_mode", "stage_ms", "roofline_conv1d", "executor"):
+        for k in ("executor", "roofline_conv1d", "training", "fast_mode", "configs", "stage_ms", "f32_mode", "f32_split_mode"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
@@ -632,6 +668,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if a.profile_config:
+        j = Job(a.profile_config, a, dev, rank, a.batch if a.profile_config == "matcha" else 32)
+        j.set_precision(a.precision)
+        run_timed(j, a, 1, None, record=False)
+        return
     job = Job("fs2", a, dev, rank, a.batch)
     if a.pmc_child:   # profiled child: one step of each arithmetic, nothing printed
         a.steps, a.warmup = 1, 1
@@ -705,7 +746,7 @@ def main():
             line = {"config": label, "workload": f"{j.name}+HiFi-GAN v1 {a.vocoder}, {nb} utts x {a.t_text} phonemes x "
                                                  f"{a.frames_per_token} frames", "steps": aa.steps, "warmup": aa.warmup}
             ref = None
-            for p in ("fp32", "fp16"):
+            for p in ("fp32", "fp32_split", "fp16"):
                 j.set_precision(p)
                 r = run_timed(j, aa, 1, None, record=False)
                 e = {"value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "rtf": r["rtf"],
@@ -713,12 +754,18 @@ def main():
                 if p == "fp32":
                     ref = (r["mel"].float().clone(), r["wave"].float().clone())
                     line.update(dtype="f32", **e)
+                    from jatts_amd import hip as _hip          # one more step with per-launch HIP events: the config's own roofline block
+                    _hip.profile_begin()
+                    rr = j.text2mel()
+                    j.voc.decode_batch(rr["feats_rb"], rr["feat_gen"])
+                    line["roofline"] = family_report(_hip.profile_end(), "fp32")
+                    del rr
                 else:
                     e["dtype"] = DTYPE_NAME[p]
                     e["max_abs_err_mel"] = float((r["mel"].float() - ref[0]).abs().max())
                     e["max_abs_err_wave"] = float((r["wave"].float() - ref[1]).abs().max())
                     e["mel_abs_max"], e["wave_abs_max"] = float(ref[0].abs().max()), float(ref[1].abs().max())
-                    line["fast_mode"] = e
+                    line[MODE_KEY[p]] = e
                 del r
             cfgs.append(line)
             del j, ref

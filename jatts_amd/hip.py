@@ -513,7 +513,7 @@ def relpos_attention(rb, q, ldq, k, ldk, vt, ldvt, g, ldg, ku, scale, n_heads, d
     d.rel_mode, d.rel_center = rel_mode, rel_center
     d.vt_col0 = _ptr(vt_col0)
     d.kv_len = _ptr(kv_len)
-    with _Timed("relattn", (n_heads, d_k, rb.total)):
+    with _Timed("relattn", (n_heads, d_k, rb.total, sum(v * v for v in rb.lens))):
         _abi.check(lib.jatts_relpos_attention(C.byref(d), _stream()), "jatts_relpos_attention")
     return out
 
