@@ -34,8 +34,9 @@ extern "C" {
 /* f32 activations in HBM, error-corrected split-precision MFMA operands (round 4): every operand value, scaled by a
  * power of two, travels as hi = f16(v), lo = f16(v - hi) and a product is hi.hi + hi.lo + lo.hi on
  * v_mfma_f32_32x32x16_f16 with f32 accumulate (3/16 of the matrix-pipe cycles of the exact-f32 chain, ~22 significand
- * bits per operand).  Accepted by jatts_hifigan_resunit only; weights packed by the host as [hi x8 | lo x8] per lane
- * (jatts_amd.hip.pack_conv_weight_split) with the inverse per-output-channel scales in ws1 / ws2. */
+ * bits per operand).  Accepted by jatts_hifigan_resunit and jatts_conv1d; weights packed by the host as [hi x8 | lo x8] per lane
+ * (jatts_amd.hip.pack_conv_weight_split) with the inverse per-output-channel scales in ws1 / ws2 (unit) or w_inv (conv).
+ * Activation scales are chosen per workgroup tile inside the kernels (powers of two: scaling and un-scaling are exact). */
 #define JATTS_F32S 2
 
 #define JATTS_ACT_NONE 0
@@ -118,6 +119,8 @@ typedef struct jatts_conv_desc {
                         * 1 = LDS-staged 128n x 64t, 2 = LDS-staged 128n x 128t, 3 = register-streamed ("direct": one zero-padded input, optionally with the
                         * LeakyReLU prologue; csrc/conv1d_direct.h) 128n x 128t with a 2-step operand ring, 4 = the same with a
                         * 4-step ring, 5 = register-streamed 128n x 64t.  Unknown / inapplicable values fall back to 0. */
+  const float* w_inv;  /* JATTS_F32S only (NULL otherwise): round_up(n_out, 32) floats, 2^-s[n] where w holds the hi / lo f16 halves of
+                        * W[n] * 2^s[n] (jatts_amd.hip.pack_conv_weight_split); x_i, resid and y are f32 */
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);

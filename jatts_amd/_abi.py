@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
         ("dil", C.c_int32), ("pad", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
         ("alpha", C.c_float), ("resid", C.c_void_p), ("ldr", C.c_int32), ("y", C.c_void_p),
         ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32), ("y_seq_col0", C.c_void_p),
-        ("pad_mode", C.c_int32), ("variant", C.c_int32),
+        ("pad_mode", C.c_int32), ("variant", C.c_int32), ("w_inv", C.c_void_p),
     ]
 
 

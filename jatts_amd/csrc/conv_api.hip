@@ -9,6 +9,7 @@ unsigned jatts_g_trace_cap = 0;
 
 int jatts_conv1d_f16(const jatts_conv_desc& d, hipStream_t s);
 int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s);
+int jatts_conv1d_split(const jatts_conv_desc& d, hipStream_t s);           // JATTS_F32S
 int jatts_resunit_f16_narrow(const jatts_resunit_desc& d, hipStream_t s);  // C = 32, 64
 int jatts_resunit_f16_wide(const jatts_resunit_desc& d, hipStream_t s);    // C = 128, 256, 512
 int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
@@ -39,6 +40,11 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return jatts_conv1d_f16(*d, s);
   if (d->dtype == JATTS_F32) return jatts_conv1d_f32(*d, s);
+  if (d->dtype == JATTS_F32S) {
+    if (!d->w_inv) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32S needs w_inv");
+    if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32S writes f32 (y_is_f32 = 1)");
+    return jatts_conv1d_split(*d, s);
+  }
   return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: unknown dtype");
 }
 

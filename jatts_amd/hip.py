@@ -377,8 +377,9 @@ def convtranspose_as_conv(w, stride, padding):
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
            in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
-           y_seq_col0=None, reflect=False, variant=0):
-    """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors."""
+           y_seq_col0=None, reflect=False, variant=0, w_inv=None):
+    """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors.  dtype F32S: f32 tensors, ``w_packed`` / ``w_inv``
+    from pack_conv_weight_split (c_mult 64)."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
         xs = [xs]
@@ -394,7 +395,10 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     if pad is None:
         pad = (k_w - 1) // 2 * dil
     n_pad = round_up(n_out, 32)
-    if w_packed.dtype != tdt or w_packed.numel() != n_pad * c_in * k_w:
+    if dtype == F32S:
+        if w_packed.dtype != torch.float16 or w_packed.numel() != 2 * n_pad * c_in * k_w or w_inv is None or w_inv.numel() != n_pad:
+            raise ValueError("conv1d: F32S takes the (packed, inverse scales) pair of pack_conv_weight_split")
+    elif w_packed.dtype != tdt or w_packed.numel() != n_pad * c_in * k_w:
         raise ValueError("conv1d: packed weight has wrong dtype/size")
     odt = torch.float32 if out_f32 else tdt
     if out is None:
@@ -428,6 +432,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     d.y, d.ldy = _ptr(out, out_col0), ldy
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
     d.y_seq_col0 = _ptr(y_seq_col0) if transposed else None
+    d.w_inv = _ptr(w_inv) if dtype == F32S else None
     _count(2.0 * c_in * n_out * k_w * rows)
     with _Timed("conv1d", (c_in, n_out, k_w, rows)):
         _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")

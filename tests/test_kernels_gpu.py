@@ -110,6 +110,62 @@ def test_conv1d(cuda, lib, prec, case):
     assert e <= TOL[prec], f"conv1d {case} {prec}: rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("xkind", ["unit", "wide"])
+@pytest.mark.parametrize("case", CONV_CASES + [
+    (384, 1536, 3, 1, [1024, 700], "relu", False, False, None, 1),      # the 128 x 128 tile (> 600 workgroups need more rows; forced below too)
+    (1536, 384, 3, 1, [640], None, True, False, None, 1),
+    (512, 512, 5, 2, [300, 41], "tanh", False, False, None, 1),
+    (256, 1024, 3, 1, [90, 200], None, False, False, 0.1, 1),           # HiFi-GAN upsampling conv shape with the LeakyReLU prologue
+    (64, 64, 4, 1, [5000], None, False, False, 0.1, 1),                  # n_out <= 64 tile
+])
+def test_conv1d_split(cuda, lib, case, xkind):
+    """jatts_conv1d with JATTS_F32S (round 4): f32 tensors, split f16 hi/lo MFMA operands, per-chunk-tile power-of-two activation scales.
+    Same tolerance as the exact-f32 kernels (relative L2 <= 2e-5 vs fp64); maximum error at most twice the exact-f32 kernel's on the same
+    inputs; `wide`: input channel blocks differing by up to 8 orders of magnitude (every 64-channel chunk gets its own scale, the
+    accumulators are rescaled in between) and rows by 6."""
+    from jatts_amd import hip
+    c_in, n_out, k, dil, lens, act, resid, transposed, pre, n_in = case
+    g = torch.Generator().manual_seed((hash(case[:4]) & 0xFFFF) + 1)
+    R = sum(lens)
+    xs = [torch.randn(R, c_in, generator=g) for _ in range(n_in)]
+    if xkind == "wide":
+        blk = torch.pow(10.0, torch.randint(-4, 5, ((c_in + 63) // 64,), generator=g).float()).repeat_interleave(64)[:c_in]
+        rowm = torch.pow(10.0, torch.rand(R, 1, generator=g) * 6 - 3)
+        xs = [x * blk * rowm for x in xs]
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k) * torch.pow(10.0, torch.rand(n_out, 1, 1, generator=g) * 2 - 1)
+    b = torch.randn(n_out, generator=g)
+    res = torch.randn(R, n_out, generator=g) if resid else None
+    pad = (k - 1) // 2 * dil
+    in_scale = 1.0 / n_in
+    ref = _ref_conv(sum(xs) * in_scale, w, b, lens, dil, pad, k, pre, act)
+    alpha = 0.5 if resid else 1.0
+    ref = ref * alpha + (res.double() if resid else 0)
+    rb = _ragged(lens, cuda)
+    c_pad = hip.round_up(c_in, 64)
+    xs = [F.pad(x, (0, c_pad - c_in)).to(cuda).contiguous() for x in xs]
+    wsp, winv = hip.pack_conv_weight_split(w.to(cuda), 64)
+    actc = {"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act]
+    kw = dict(dil=dil, bias=b.to(cuda), act=actc, alpha=alpha, out_f32=True, transposed=transposed, pre_lrelu=pre, in_scale=in_scale)
+    y = hip.conv1d(rb, xs, wsp, c_pad, n_out, k, dtype=hip.F32S, w_inv=winv, resid=None if res is None else res.to(cuda), **kw)
+    y32 = hip.conv1d(rb, xs, hip.pack_conv_weight(w.to(cuda), hip.F32), c_pad, n_out, k, dtype=hip.F32, resid=None if res is None else res.to(cuda), **kw)
+    torch.cuda.synchronize()
+    yt, y32 = (y.t(), y32.t()) if transposed else (y, y32)
+    assert torch.isfinite(yt).all()
+    e, m, m32 = relerr(yt, ref), _maxerr(yt, ref), _maxerr(y32, ref)
+    assert e <= TOL["fp32"], f"split conv1d {case} {xkind}: rel err {e:.3e} (exact f32 {relerr(y32, ref):.3e})"
+    assert m <= 2.0 * m32 + 1e-30, f"split conv1d {case} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
+    # an utterance alone == inside the batch, bit for bit (one tile geometry whatever the launch size)
+    if len(lens) > 1 and not transposed:
+        L0 = lens[0]
+        y0 = hip.conv1d(_ragged([L0], cuda), [x[:L0].contiguous() for x in xs], wsp, c_pad, n_out, k, dtype=hip.F32S, w_inv=winv,
+                        resid=None if res is None else res[:L0].to(cuda).contiguous(), **kw)
+        assert torch.equal(y0, y[:L0])
+
+
+def _maxerr(y, ref):
+    return float((y.double().cpu() - ref).abs().max())
+
+
 def _ref_unit(x, w1, b1, w2, b2, lens, k, d, slope, round16):
     outs, o = [], 0
     for L in lens:
@@ -160,10 +216,6 @@ def test_hifigan_resunit(cuda, lib, prec, C, k, d, lens):
     assert torch.isfinite(y.float()).all(), "unwritten / non-finite outputs"
     e = relerr(y.float(), ref)
     assert e <= TOL[prec], f"resunit C={C} k={k} d={d} {prec}: rel err {e:.3e}"
-
-
-def _maxerr(y, ref):
-    return float((y.double().cpu() - ref).abs().max())
 
 
 @pytest.mark.parametrize("xkind", ["unit", "tiny", "large", "wide"])
