@@ -222,7 +222,7 @@ class Job:
             self.noise = [torch.randn(frames, 384, generator=g).to(dev) for _ in self.texts]
 
     def set_precision(self, p):
-        self.m.set_precision("fp32" if p == "fp32_split" else p)      # the split mode is the vocoder's (its ResBlock units): text2mel stays exact f32
+        self.m.set_precision(p)      # fp32_split: every conv of the acoustic model but the duration predictor's, and the whole vocoder generator
         self.voc.set_precision(p)
 
     def text2mel(self):
@@ -304,7 +304,7 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     esz = 2 if prec == "fp16" else 4                      # bytes per activation element in HBM
     # matrix-pipe peak per ALGORITHMIC FLOP: the split mode spends three dense f16 MFMAs per product
     unit_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
-    conv_peak = MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF      # jatts_conv1d stays exact f32 in the split mode
+    conv_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
     fam = {}
     for tag, meta, ms in recs:
         fam.setdefault((tag, meta), []).append(ms)
@@ -380,7 +380,7 @@ def family_report(recs, prec):
     launch metadata the C-ABI wrappers record (fused unit 4 C^2 k rows, conv 2 c_in n_out k rows, attention 4 d_k H sum T^2) over the
     family's HIP-event time.  -> {"dominant": {...}, "families": [...]}"""
     unit_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
-    mm_peak = MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF
+    mm_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
     fam = {}
     for tag, meta, ms in recs:
         if tag in ("resunit", "resblock"):
@@ -389,7 +389,7 @@ def family_report(recs, prec):
         elif tag == "conv1d":
             fl, name, peak = 2.0 * meta[0] * meta[1] * meta[2] * meta[3], "conv1d (every jatts_conv1d launch: acoustic model + vocoder input / upsampling convs)", mm_peak
         elif tag == "relattn":
-            fl, name, peak = 4.0 * meta[0] * meta[1] * meta[3], "relattn (fused attention)", mm_peak
+            fl, name, peak = 4.0 * meta[0] * meta[1] * meta[3], "relattn (fused attention)", MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF
         else:
             continue
         f = fam.setdefault(name, dict(kernel=name, ms=0.0, flops=0.0, launches=0, peak=peak))
@@ -594,7 +594,8 @@ def write_detail(out):
 
 MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode"}
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate",
-              "fp32_split": "f32 activations; HiFi-GAN ResBlock units on split f16 hi/lo MFMA operands (3 MFMAs per product), f32 accumulate"}
+              "fp32_split": "f32 tensors; every conv / fused HiFi-GAN unit on split f16 hi/lo MFMA operands (3 MFMAs per product, power-of-two scales), "
+                            "f32 accumulate; attention, normalisations and the duration predictor exact f32"}
 
 
 def self_launch(n, argv):

@@ -206,7 +206,7 @@ def main(argv=None):
     model_class = getattr(jatts_amd.models, config["model_type"])          # tts_decode.py:139
     model = model_class(**config["model_params"])
     model.load_state_dict(torch.load(args.checkpoint, map_location="cpu")["model"])
-    model = model.eval().to(device).set_precision("fp32" if args.precision == "fp32_split" else args.precision)
+    model = model.eval().to(device).set_precision(args.precision)
     logging.info(f"Loaded model parameters from {args.checkpoint}.")
 
     stats = read_stats(args.stats, config["out_feat_type"])                # tts_decode.py:160-164

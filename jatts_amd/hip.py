@@ -5,6 +5,7 @@ HIP stream and dtype bookkeeping.  Every wrapper validates shapes, fills the POD
 descriptor and launches asynchronously on ``torch.cuda.current_stream()``.
 """
 import collections
+import contextlib
 import ctypes as C
 
 import torch
@@ -343,6 +344,34 @@ def pack_conv_weight_split(w, c_mult=32):
     return torch.stack([ph, pl], dim=1).reshape(-1).contiguous(), inv.contiguous()
 
 
+class SplitWeight:
+    """A conv weight prepared for JATTS_F32S (the pair of pack_conv_weight_split).  hip.conv1d recognises it in place of a packed f32
+    weight -- call sites stay `dtype=hip.F32` -- and takes the split kernel; shapes the split kernel does not cover (a halo beyond 32
+    rows) fall back, loudly never silently wrong, to the exact-f32 kernel on a lazily packed f32 copy of the same weight."""
+
+    def __init__(self, w, c_mult=64):
+        self.packed, self.inv = pack_conv_weight_split(w, c_mult)
+        self._src, self._c_mult, self._f32 = w.detach(), c_mult, None
+
+    def f32(self):
+        if self._f32 is None:
+            self._f32 = pack_conv_weight(self._src, F32, self._c_mult)
+        return self._f32
+
+
+_SPLIT_WEIGHTS = [False]
+
+
+@contextlib.contextmanager
+def split_weights(on=True):
+    """Inside: PackedConv(..., dtype=F32) packs SplitWeight operands (the models' set_precision("fp32_split")).  Nests; off by default."""
+    prev, _SPLIT_WEIGHTS[0] = _SPLIT_WEIGHTS[0], bool(on)
+    try:
+        yield
+    finally:
+        _SPLIT_WEIGHTS[0] = prev
+
+
 def pack_conv_weight_dev(w, dtype_code, c_mult=64, dgrad=False):
     """pack_conv_weight as ONE HIP launch on a device f32 weight (n_out, c_in, k); dgrad=True packs the data-gradient operand
     W'[c][n][k-1-tap] directly (no permute / flip copies).  -> (packed, padded c_in of the packed conv)."""
@@ -383,6 +412,13 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
         xs = [xs]
+    if isinstance(w_packed, SplitWeight):
+        if dtype != F32:
+            raise ValueError("conv1d: a SplitWeight goes with dtype F32 tensors")
+        if (k_w - 1) * dil <= 32:
+            dtype, w_inv, w_packed, out_f32 = F32S, w_packed.inv, w_packed.packed, True
+        else:                                  # outside the split kernel's tiles: the exact-f32 kernel on the same weight
+            w_packed = w_packed.f32()
     x0 = _dev(xs[0])
     rows = rb.total * len_mul
     tdt = torch_dtype(dtype)

@@ -55,7 +55,8 @@ class PackedConv:
             b = (b * scale if b is not None else torch.zeros_like(scale)) + shift
         self.n_out, c, self.k = w.shape
         self.c_in = hip.round_up(c, c_mult)
-        self.w = hip.pack_conv_weight(w.to(device), dtype, c_mult)
+        # set_precision("fp32_split"): f32 tensors, split f16 hi/lo MFMA operands (hip.split_weights is on while the model prepares)
+        self.w = hip.SplitWeight(w.to(device), c_mult) if (dtype == hip.F32 and hip._SPLIT_WEIGHTS[0]) else hip.pack_conv_weight(w.to(device), dtype, c_mult)
         self.b = None if b is None else b.to(device).contiguous()
 
 

@@ -146,8 +146,8 @@ class FastSpeech2(torch.nn.Module):
     # ------------------------------------------------------------------ weight preparation
     def set_precision(self, precision: str):
         """'fp16' (f16 MFMA operands, f32 accumulate — fast mode) or 'fp32' (exact-f32 MFMA, parity mode)."""
-        if precision not in ("fp16", "fp32"):
-            raise ValueError(precision)
+        if precision not in ("fp16", "fp32", "fp32_split"):     # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on
+            raise ValueError(precision)                          # split f16 hi/lo MFMA operands (hip.SplitWeight; csrc/conv1d_split.h)
         if precision != self.precision:
             self.precision, self._prep = precision, None
         return self
@@ -176,13 +176,18 @@ class FastSpeech2(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
+        with hip.split_weights(self.precision == "fp32_split"):
+            return self._prepare_packed(dev, key, dt)
+
+    def _prepare_packed(self, dev, key, dt):
         sd = self.state_dict()
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
         P = {"key": key, "dtype": dt, "dev": dev}
         P["emb"] = f32(sd["encoder.embed.0.weight"])
         P["enc"] = ConformerRunner(sd, "encoder.", self.aheads, dt, dev)
         P["dec"] = ConformerRunner(sd, "decoder.", self.aheads, dt, dev)
-        P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32: durations are integers, a
+        with hip.split_weights(False):     # exact f32 always: durations are integers
+            P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32: durations are integers, a
         # rounding-boundary flip under f16 would change the utterance length (the trunk is 0.3 % of the FLOPs)
         P["pitch"] = _Predictor(sd, "pitch_predictor.", dt, dev)
         P["energy"] = _Predictor(sd, "energy_predictor.", dt, dev)

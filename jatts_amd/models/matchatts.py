@@ -248,8 +248,8 @@ class _MatchaBase(torch.nn.Module):
         return self
 
     def set_precision(self, precision):
-        if precision not in ("fp16", "fp32"):
-            raise ValueError(precision)
+        if precision not in ("fp16", "fp32", "fp32_split"):     # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on
+            raise ValueError(precision)                          # split f16 hi/lo MFMA operands (hip.SplitWeight; csrc/conv1d_split.h)
         if precision != self.precision:
             self.precision, self._prep = precision, None
         return self
@@ -271,12 +271,17 @@ class _MatchaBase(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
+        with hip.split_weights(self.precision == "fp32_split"):
+            return self._prepare_packed(dev, key, dt)
+
+    def _prepare_packed(self, dev, key, dt):
         sd = self.state_dict()
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
         P = {"key": key, "dtype": dt, "dev": dev}
         P["emb"] = f32(sd["encoder.embed.0.weight"])
         P["enc"] = ConformerRunner(sd, "encoder.", self.aheads, dt, dev)  # legacy rel-pos (matchatts_mas.py:196-218)
-        P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
+        with hip.split_weights(False):     # exact f32 always: durations are integers
+            P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
         P["eproj"] = PackedConv(sd["encoder_proj.weight"], sd["encoder_proj.bias"], dt, dev)
         if self.spk_embed_dim is not None:
             P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)

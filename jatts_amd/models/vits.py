@@ -147,8 +147,8 @@ class VITS(torch.nn.Module):
         return self
 
     def set_precision(self, precision):
-        if precision not in ("fp16", "fp32"):
-            raise ValueError(precision)
+        if precision not in ("fp16", "fp32", "fp32_split"):     # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on
+            raise ValueError(precision)                          # split f16 hi/lo MFMA operands (hip.SplitWeight; csrc/conv1d_split.h)
         if precision != self.precision:
             self.precision, self._prep = precision, None
         return self
@@ -170,6 +170,10 @@ class VITS(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
+        with hip.split_weights(self.precision == "fp32_split"):
+            return self._prepare_packed(dev, key, dt)
+
+    def _prepare_packed(self, dev, key, dt):
         sd = self.state_dict()
         A = self.adim
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
@@ -180,7 +184,8 @@ class VITS(torch.nn.Module):
         P["dec"] = ConformerRunner(sd, "decoder.", self.aheads, dt, dev, rel_style="new")
         P["te_proj"] = PackedConv(sd["text_encoder.proj.weight"], sd["text_encoder.proj.bias"], dt, dev)
         P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
-        P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
+        with hip.split_weights(False):     # exact f32 always: durations are integers
+            P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
         flows = []
         for i in range(self.flow_flows):
             q = f"flow.flows.{2 * i}."

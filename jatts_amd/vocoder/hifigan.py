@@ -101,9 +101,10 @@ class HiFiGANGenerator(torch.nn.Module):
 
     def set_precision(self, precision):
         """"fp32": exact-f32 MFMA (the reference's arithmetic, the default); "fp16": f16 operands and activations (fast mode);
-        "fp32_split" (round 4): f32 activations everywhere, the ResBlock dilation units (97 % of the generator's FLOPs) on
-        error-corrected split-precision MFMA operands (JATTS_F32S: hi/lo f16 halves, f32 accumulate, power-of-two scales) -- measured
-        at or below the exact-f32 path's error against fp64 (tests/test_kernels_gpu.py::test_hifigan_resunit_split)."""
+        "fp32_split" (round 4): f32 activations everywhere, the ResBlock dilation units (97 % of the generator's FLOPs) and the input /
+        upsampling convs on error-corrected split-precision MFMA operands (JATTS_F32S: hi/lo f16 halves, f32 accumulate, power-of-two
+        scales) -- measured at or below the exact-f32 path's error against fp64 (tests/test_kernels_gpu.py::test_hifigan_resunit_split,
+        test_conv1d_split; tests/test_benchsize_gpu.py::test_hifigan_split_mode_at_bench_size)."""
         if precision not in ("fp16", "fp32", "fp32_split"):
             raise ValueError(precision)
         if precision != self.precision:
@@ -153,8 +154,9 @@ class HiFiGANGenerator(torch.nn.Module):
             return o
 
         c_prev = hip.round_up(self.channels, 64)   # input conv feeds the generic conv: 64-channel chunks
-        P["in"] = PackedConv(padw(sd["input_conv.weight"], c_prev, sd["input_conv.weight"].shape[1]),
-                             padb(sd["input_conv.bias"], c_prev), dt, dev)
+        with hip.split_weights(split):      # fp32_split: the input / upsampling convs take the split conv kernel too (csrc/conv1d_split.h)
+            P["in"] = PackedConv(padw(sd["input_conv.weight"], c_prev, sd["input_conv.weight"].shape[1]),
+                                 padb(sd["input_conv.bias"], c_prev), dt, dev)
         for i, (s, uk) in enumerate(zip(self.upsample_scales, self.upsample_kernel_sizes)):
             w = sd[f"upsamples.{i}.1.weight"].detach().float()            # ConvTranspose1d: (c_in, c_out, k)
             c_out = cp(w.shape[1])
@@ -163,7 +165,8 @@ class HiFiGANGenerator(torch.nn.Module):
             wp = torch.zeros(c_prev, c_out, w.shape[2], dtype=torch.float32)
             wp[: w.shape[0], : w.shape[1]] = w
             wc, pad = hip.convtranspose_as_conv(wp, s, s // 2 + s % 2)
-            pc = PackedConv(wc, padb(sd[f"upsamples.{i}.1.bias"], c_out).repeat(s), dt, dev)
+            with hip.split_weights(split):
+                pc = PackedConv(wc, padb(sd[f"upsamples.{i}.1.bias"], c_out).repeat(s), dt, dev)
             P["ups"].append((pc, pad, s, c_out))
             stage = []
             for j, rk in enumerate(self.resblock_kernel_sizes):

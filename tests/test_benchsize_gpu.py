@@ -58,6 +58,42 @@ def test_fs2_bench_utterances_match_the_reference(bench_stack):
         assert torch.equal(rb["duration"][128 * u:128 * (u + 1)].cpu(), torch.tensor(z[f"u{j}_duration"]))
 
 
+def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack):
+    """set_precision("fp32_split") on the acoustic model (round 4: every conv but the duration predictor's on split f16 hi/lo MFMA operands)
+    against the SAME real-reference golden and tolerance as the exact-f32 path (abs 2e-3, durations exact), alone and inside the batch of 64
+    (bit-identical to each other), with its error next to the exact-f32 path's: at most twice as far from the reference."""
+    import json
+    import os
+    z, m, voc, vsd, texts = bench_stack
+    utts = [int(u) for u in z["utts"]]
+    rec = {}
+    try:
+        m.set_precision("fp32_split")
+        rb = m.inference_batch(texts)
+        assert rb["olens"] == [768] * 64
+        for j, u in enumerate(utts):
+            ref = torch.tensor(z[f"u{j}_feat_gen"])
+            m.set_precision("fp32_split")
+            r1 = m.inference_batch([texts[u]])
+            m.set_precision("fp32")
+            rf = m.inference_batch([texts[u]])
+            assert torch.equal(r1["duration"].cpu(), torch.tensor(z[f"u{j}_duration"]))
+            assert torch.equal(r1["feat_gen"], rb["feat_gen"][768 * u:768 * (u + 1)]), "split mode: utterance alone != inside the batch"
+            es, ef = maxdiff(r1["feat_gen"], ref), maxdiff(rf["feat_gen"], ref)
+            rec[f"utt{u}"] = {"split_vs_reference_max": es, "exact_f32_vs_reference_max": ef, "split_vs_exact_f32_max": maxdiff(r1["feat_gen"], rf["feat_gen"]),
+                              "mel_abs_max": float(ref.abs().max())}
+            assert es <= 2e-3, f"bench utterance {u}: split {es:.3e}"
+            assert es <= 2.0 * ef + 1e-6, f"bench utterance {u}: split {es:.3e} vs exact f32 {ef:.3e} against the reference"
+            assert maxdiff(r1["pitch"].reshape(-1), z[f"u{j}_pitch"].reshape(-1)) <= 2e-3
+            assert maxdiff(r1["energy"].reshape(-1), z[f"u{j}_energy"].reshape(-1)) <= 2e-3
+    finally:
+        m.set_precision("fp32")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r04_split_errors_fs2.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+
+
 def test_hifigan_bench_size_matches_the_oracle(bench_stack):
     """HiFi-GAN v1 (22.05 kHz, hop 256, 512 channels) on a 768-frame mel: 196 608 samples vs oracle.hifigan_generate (f32, abs 2e-4 on a
     signal in [-1, 1]), alone and as utterances 0 / 37 inside the batch of 64 the bench times."""

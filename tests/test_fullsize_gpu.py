@@ -20,7 +20,7 @@ def _make_stack(cuda, prec):
     from jatts_amd.vocoder import Vocoder
     m = FastSpeech2(idim=45, **FS2_JSUT)
     m.load_state_dict(pin_duration_head(synth_state_dict(m.state_dict(), 0), 6))
-    m = m.to(cuda).set_precision("fp32" if prec == "fp32_split" else prec)
+    m = m.to(cuda).set_precision(prec)
     ones, zeros = [1.0] * 80, [0.0] * 80
     voc = Vocoder(synth_hifigan_state(HIFIGAN_V1_22K, 0),
                   {"sampling_rate": 22050, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_22K},
@@ -56,7 +56,7 @@ def _synth(stack, texts):
 
 @pytest.fixture(scope="module")
 def stack_split(cuda, lib):
-    """f32 text2mel + the fp32_split vocoder (round 4)."""
+    """fp32_split (round 4): f32 tensors, split f16 hi/lo MFMA operands in every conv and fused unit."""
     return _make_stack(cuda, "fp32_split")
 
 
