@@ -146,13 +146,23 @@ def test_conv1d_split(cuda, lib, case, xkind):
     wsp, winv = hip.pack_conv_weight_split(w.to(cuda), 64)
     actc = {"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act]
     kw = dict(dil=dil, bias=b.to(cuda), act=actc, alpha=alpha, out_f32=True, transposed=transposed, pre_lrelu=pre, in_scale=in_scale)
+    if (k - 1) * dil > 32:       # outside the split kernel's tiles: refused loudly through the C ABI; the product wrapper (hip.SplitWeight) takes
+        from jatts_amd._abi import JattsHipError          # the exact-f32 kernel on the same weight instead
+        with pytest.raises(JattsHipError):
+            hip.conv1d(rb, xs, wsp, c_pad, n_out, k, dtype=hip.F32S, w_inv=winv, **kw)
+        y = hip.conv1d(rb, xs, hip.SplitWeight(w.to(cuda), 64), c_pad, n_out, k, dtype=hip.F32, **kw)
+        assert relerr(y, ref) <= TOL["fp32"]
+        return
     y = hip.conv1d(rb, xs, wsp, c_pad, n_out, k, dtype=hip.F32S, w_inv=winv, resid=None if res is None else res.to(cuda), **kw)
     y32 = hip.conv1d(rb, xs, hip.pack_conv_weight(w.to(cuda), hip.F32), c_pad, n_out, k, dtype=hip.F32, resid=None if res is None else res.to(cuda), **kw)
     torch.cuda.synchronize()
     yt, y32 = (y.t(), y32.t()) if transposed else (y, y32)
     assert torch.isfinite(yt).all()
     e, m, m32 = relerr(yt, ref), _maxerr(yt, ref), _maxerr(y32, ref)
-    assert e <= TOL["fp32"], f"split conv1d {case} {xkind}: rel err {e:.3e} (exact f32 {relerr(y32, ref):.3e})"
+    e32 = relerr(y32, ref)
+    # (the adversarial `wide` inputs put the exact-f32 kernel itself past 2e-5 on some shapes -- tanh of sums spanning 14 orders of magnitude:
+    #  the claim under test is "no worse than twice the exact-f32 kernel", with the f32 tolerance as the floor)
+    assert e <= max(TOL["fp32"], 2.0 * e32), f"split conv1d {case} {xkind}: rel err {e:.3e} (exact f32 {e32:.3e})"
     assert m <= 2.0 * m32 + 1e-30, f"split conv1d {case} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
     # an utterance alone == inside the batch, bit for bit (one tile geometry whatever the launch size)
     if len(lens) > 1 and not transposed:
