@@ -47,12 +47,49 @@ __device__ __forceinline__ bool det_arrive(unsigned* ticket, unsigned n_parts, u
 }
 
 // The last arriver's sum: total[i] = sum_p slab[p * n + i] for i < n, parts in a FIXED order -- wave w of the NW waves takes the
-// contiguous part range [w P / NW, (w + 1) P / NW), the NW wave sums are added in wave order through `red` (NW x 64 floats of LDS) --
-// then add(i, total).  A function of (P, NW, n) only: bit-identical from run to run.  T = float or double.
+// contiguous part range [w P / NW, (w + 1) P / NW), the NW wave sums are added in wave order through `red` (NW x 64 x VEC elements of
+// LDS) -- then add(i, total).  A function of (P, NW, n) only: bit-identical from run to run.  T = float or double.
+// n % 4 == 0 (floats): a lane owns FOUR consecutive columns and moves them as one 16-byte load, eight loads in flight: a single
+// workgroup pulling slabs that other XCDs wrote is latency-bound, bytes in flight are its bandwidth (4-byte loads, four in flight:
+// 16 GB/s -- a 512-part LayerNorm reduction took 80 us; profiles/r04_notes.md).
+// red_cap: elements of T available at `red` (the 16-byte form needs NW x 256 floats).
 template <int NW, typename T, typename F>
-__device__ __forceinline__ void det_sum_slabs(const T* slab, int n_parts, int n, T* red, F&& add) {
+__device__ __forceinline__ void det_sum_slabs(const T* slab, int n_parts, int n, T* red, int red_cap, F&& add) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p0 = (int)((int64_t)wave * n_parts / NW), p1 = (int)((int64_t)(wave + 1) * n_parts / NW);
+  if constexpr (sizeof(T) == 4) {
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && red_cap >= NW * 256) {
+      const int nv = n >> 2;
+      for (int c0 = 0; c0 < nv; c0 += 64) {
+        const int i = c0 + lane;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < nv) {
+          const f32x4* q = reinterpret_cast<const f32x4*>(slab) + (int64_t)p0 * nv + i;
+          int p = p0;
+          for (; p + 8 <= p1; p += 8, q += 8 * (int64_t)nv) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = q[j * (int64_t)nv];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];          // part order
+          }
+          for (; p < p1; ++p, q += nv) s += q[0];
+        }
+        __syncthreads();                                     // (red is free again)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(red) + (wave * 64 + lane) * 4) = s;
+        __syncthreads();
+        if (wave == 0 && i < nv) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(red) + lane * 4);
+#pragma unroll
+          for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(reinterpret_cast<float*>(red) + (w * 64 + lane) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) add(4 * i + e, (T)t[e]);
+        }
+      }
+      __syncthreads();
+      return;
+    }
+  }
   for (int c0 = 0; c0 < n; c0 += 64) {
     const int i = c0 + lane;
     T s = 0;
@@ -75,6 +112,23 @@ __device__ __forceinline__ void det_sum_slabs(const T* slab, int n_parts, int n,
     }
     __syncthreads();
   }
+}
+
+// Two-level form for reductions over HUNDREDS of workgroups (LayerNorm / the Q|K|V split: one slab per workgroup of a row-parallel
+// launch): parts are grouped G at a time; the last arriver of a group adds its G slabs into a level-2 slab, the last of those group
+// reducers adds the level-2 slabs and accumulates into the result.  The group reductions run concurrently on different CUs while other
+// groups are still computing; only the last group's sum and the short final sum are exposed.  Order: parts within a group, then groups
+// -- fixed.  tickets: n_groups + 1 words; slabs: (n_parts + n_groups) * n floats.
+template <int NW, typename F>
+__device__ __forceinline__ void det_reduce_tree(float* slabs, unsigned* tickets, int part, int n_parts, int G, int n, float* red,
+                                                int red_cap, unsigned* flag, F&& add) {
+  const int n_groups = (n_parts + G - 1) / G, g = part / G;
+  const int in_g = min(G, n_parts - g * G);
+  float* l2 = slabs + (int64_t)n_parts * n;
+  if (!det_arrive(tickets + g, in_g, flag)) return;
+  det_sum_slabs<NW>(slabs + (int64_t)g * G * n, in_g, n, red, red_cap, [&](int i, float t) { l2[(int64_t)g * n + i] = t; });
+  if (!det_arrive(tickets + n_groups, n_groups, flag)) return;
+  det_sum_slabs<NW>(l2, n_groups, n, red, red_cap, add);
 }
 
 }  // namespace

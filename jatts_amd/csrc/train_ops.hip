@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int LN_MAXPL = 24;   // LayerNorm backward: channels per lane (C <= 1536)
+constexpr int LN_GROUP = 32;   // workgroups per first-level group of the two-level slab sums (det_reduce_tree)
 
 // ------------------------------------------------------------------ LayerNorm backward
 // y = (x - mean) * rstd * g + b over the channels of each row (biased variance, eps inside the sqrt).
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g, int64_t rows, int C, float eps,
                                                             float* __restrict__ dx, int lddx, float* __restrict__ dg, float* __restrict__ db,
                                                             float* __restrict__ slabs, unsigned* __restrict__ tickets) {
-  __shared__ float red[2][4][64];
+  __shared__ __attribute__((aligned(16))) float red[4][4][64];     // ([2][4][64] for the workgroup's own fold; all of it for the slab sums)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pg[LN_MAXPL], pb[LN_MAXPL], gv[LN_MAXPL];
 #pragma unroll
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     __syncthreads();
   }
-  if (det_arrive(tickets, gridDim.x, reinterpret_cast<unsigned*>(&red[0][0][0])))
-    det_sum_slabs<4>(slabs, (int)gridDim.x, 2 * C, &red[0][0][0], [&](int i, float t) { if (i < C) dg[i] += t; else db[i - C] += t; });
+  det_reduce_tree<4>(slabs, tickets, (int)blockIdx.x, (int)gridDim.x, LN_GROUP, 2 * C, &red[0][0][0], 1024, reinterpret_cast<unsigned*>(&red[0][0][0]),
+                     [&](int i, float t) { if (i < C) dg[i] += t; else db[i - C] += t; });
 }
 
 // ------------------------------------------------------------------ activations
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(jatts_ragged rg
                                                                  float* __restrict__ dw, int C, int pad, int tiles_per_block,
                                                                  float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float xs[DWT + K - 1][64];
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   const int s = blockIdx.y, c0 = blockIdx.z * 64;
   const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
   const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6, c = c0 + cl;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(jatts_ragged rg
     if (tq == 0) gslab[(int64_t)part * (64 * K) + k * 64 + cl] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
   }
   if (det_arrive(tickets + blockIdx.z, n_parts, reinterpret_cast<unsigned*>(&red[0][0])))
-    det_sum_slabs<4>(gslab, n_parts, 64 * K, &red[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, n_parts, 64 * K, &red[0][0], 1024, [&](int i, float t) {
       const int k = i >> 6, cc = c0 + (i & 63);
       if (cc < C) dw[cc * K + k] += t;
     });
@@ -263,7 +264,7 @@ constexpr int DW_KMAX = 32;
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dw, int C, int K, int pad,
                                                            float* __restrict__ slabs, unsigned* __restrict__ tickets) {
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   const int s = blockIdx.y;
   const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(jatts_ragged rg, cons
     __syncthreads();
   }
   if (det_arrive(tickets + blockIdx.x, n_parts, reinterpret_cast<unsigned*>(&red[0][0])))
-    det_sum_slabs<4>(gslab, n_parts, 64 * K, &red[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, n_parts, 64 * K, &red[0][0], 1024, [&](int i, float t) {
       const int k = i >> 6, cc = blockIdx.x * 64 + (i & 63);
       if (cc < C) dw[cc * K + k] += t;
     });
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
                                                         float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
-  __shared__ float red[2][4][64];
+  __shared__ __attribute__((aligned(16))) float red[4][4][64];
   float s0 = 0.f, s1 = 0.f;
   if (c < dim) {
     const float sh = shift ? shift[c] : 0.f, m = mul ? mul[c] : 1.f;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
     gslab[blockIdx.y * 128 + 64 + threadIdx.x] = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
   }
   if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0][0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.y, 128, &red[0][0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 128, &red[0][0][0], 1024, [&](int i, float t) {
       const int cc = blockIdx.x * 64 + (i & 63);
       if (cc < dim) (i < 64 ? out0 : out1)[cc] += t;
     });
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // kernel of the speaker-embedding path (one workgroup per sequence) left 7/8 of the chip idle on a 32-utterance batch.
 __global__ __launch_bounds__(256) void seq_sum_kernel(jatts_ragged rg, const float* __restrict__ x, int C, float* __restrict__ out,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets) {
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, s = blockIdx.y;
   const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
   float a = 0.f;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void seq_sum_kernel(jatts_ragged rg, const flo
   float* gslab = slabs + (int64_t)grp * gridDim.z * 64;
   if (part == 0) gslab[blockIdx.z * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   if (det_arrive(tickets + grp, gridDim.z, reinterpret_cast<unsigned*>(&red[0][0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.z, 64, &red[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.z, 64, &red[0][0], 1024, [&](int i, float t) {
       const int cc = blockIdx.x * 64 + i;
       if (cc < C) out[(int64_t)s * C + cc] += t;
     });
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void col_wsum_kernel(const float* __restrict__
                                                        float* __restrict__ out, float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   float s = 0.f;
   if (c < dim)
     for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += v[r] * x[r * ld + c];
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256) void col_wsum_kernel(const float* __restrict__
   float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 64;
   if (part == 0) gslab[blockIdx.y * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], 1024, [&](int i, float t) {
       const int cc = blockIdx.x * 64 + i;
       if (cc < dim) out[cc] += t;
     });
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dvv, int B, int T, int H, int dk, float* __restrict__ dqkv,
                                                             float* __restrict__ du, float* __restrict__ dv, int rows_per_block,
                                                             float* __restrict__ slabs, unsigned* __restrict__ tickets) {
-  __shared__ float red[4 * 64];
+  __shared__ __attribute__((aligned(16))) float red[1024];
   const int A = H * dk;
   const int64_t rows = (int64_t)B * T, r0 = (int64_t)blockIdx.x * rows_per_block;
   float* slab = slabs + (int64_t)blockIdx.x * 2 * A;        // this workgroup's partial [du | dv]
@@ -735,11 +736,10 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const float* __restr
     }
   }
   if (!du && !dv) return;
-  if (det_arrive(tickets, gridDim.x, reinterpret_cast<unsigned*>(red)))
-    det_sum_slabs<4>(slabs, (int)gridDim.x, 2 * A, red, [&](int i, float t) {
-      if (i < A) { if (du) du[i] += t; }
-      else if (dv) dv[i - A] += t;
-    });
+  det_reduce_tree<4>(slabs, tickets, (int)blockIdx.x, (int)gridDim.x, LN_GROUP, 2 * A, red, 1024, reinterpret_cast<unsigned*>(red), [&](int i, float t) {
+    if (i < A) { if (du) du[i] += t; }
+    else if (dv) dv[i - A] += t;
+  });
 }
 
 // y = resid + alpha * dropout(x): the residual connections of the conformer layers (encoder_layer.py:100-170: x + ff_scale * dropout(ffn),
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   }
   if (threadIdx.x == 0) slabs[blockIdx.x] = red[0];
   if (det_arrive(tickets, gridDim.x, reinterpret_cast<unsigned*>(&red[1])))
-    det_sum_slabs<4>(slabs, (int)gridDim.x, 1, red, [&](int, double t) { *out += t; });
+    det_sum_slabs<4>(slabs, (int)gridDim.x, 1, red, 256, [&](int, double t) { *out += t; });
 }
 // torch.optim.Adam (no amsgrad): g' = g * gscale (+ wd * p); m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
 // p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps); the scalars (bias corrections, step size, 1 - beta) are computed in double on the
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(jatts_ragged rg, con
                                                             const float* __restrict__ rstd_in, float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float red[4];
-  __shared__ float cred[2][256];
+  __shared__ __attribute__((aligned(16))) float cred[4][256];
   const int s = blockIdx.y, g = blockIdx.x, cg = C / G;
   const int row0 = rg.cu_rows[s], L = rg.cu_rows[s + 1] - row0;
   const int c = g * cg + threadIdx.x % cg, r0 = threadIdx.x / cg, rs = 256 / cg;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(jatts_ragged rg, con
     gslab[(int64_t)s * 2 * cg + cg + threadIdx.x] = b;
   }
   if (det_arrive(tickets + g, gridDim.y, reinterpret_cast<unsigned*>(&red[0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.y, 2 * cg, &cred[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 2 * cg, &cred[0][0], 1024, [&](int i, float t) {
       if (i < cg) dgamma[g * cg + i] += t; else dbeta[g * cg + i - cg] += t;
     });
 }
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void snakebeta_bwd_kernel(const float* __restr
                                                             float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
-  __shared__ float red[2][4][64];
+  __shared__ __attribute__((aligned(16))) float red[4][4][64];
   float sa = 0.f, sb = 0.f;
   if (c < C) {
     const float a = expf(alpha[c]), b = expf(beta[c]), ib = 1.f / (b + 1e-9f);
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void snakebeta_bwd_kernel(const float* __restr
     gslab[blockIdx.y * 128 + 64 + threadIdx.x] = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
   }
   if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0][0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.y, 128, &red[0][0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 128, &red[0][0][0], 1024, [&](int i, float t) {
       const int cc = blockIdx.x * 64 + (i & 63);
       if (cc < C) (i < 64 ? dalpha : dbeta)[cc] += t;
     });
@@ -1040,7 +1040,7 @@ extern "C" int jatts_layernorm_bwd(const float* x, int32_t ldx, const float* dy,
   if (rows <= 0) return JATTS_OK;
   // <= 512 workgroups (8 waves per CU over the chip): the last arriver adds up one [dgamma | dbeta] slab per workgroup
   const unsigned nb = blocks_for(rows, 16, 512);
-  if (dgamma) WS_NEED(1, (int64_t)nb * 2 * dim);
+  if (dgamma) WS_NEED((nb + LN_GROUP - 1) / LN_GROUP + 1, (int64_t)(nb + (nb + LN_GROUP - 1) / LN_GROUP) * 2 * dim);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, S_, x, ldx, dy, lddy, gamma, rows, dim, eps, dx, lddx, dgamma, dbeta, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
@@ -1282,7 +1282,7 @@ extern "C" int jatts_qkv_split_bwd(const float* dqu, const float* dqv, const flo
   int rpb = 32;
   while ((rows + rpb - 1) / rpb > 512) rpb += 32;
   const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
-  if (du || dv) WS_NEED(1, (int64_t)nb * 2 * n_heads * d_k);
+  if (du || dv) WS_NEED((nb + LN_GROUP - 1) / LN_GROUP + 1, (int64_t)(nb + (nb + LN_GROUP - 1) / LN_GROUP) * 2 * n_heads * d_k);
   hipLaunchKernelGGL(qkv_split_bwd_kernel, dim3(nb), dim3(256), 0, S_, dqu, dqv, dk, dvv, n_batch, t_len, n_heads, d_k, dqkv, du, dv, rpb, WS_);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;

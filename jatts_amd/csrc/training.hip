@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
                                                          int n_out, int k_w, int dil, int pad, int seq_groups, float* dw, int overwrite,
                                                          float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   __shared__ float dys[WG_TT][64 + 4];
-  __shared__ float xs[WG_TT][64 + 4];
+  __shared__ __attribute__((aligned(16))) float xs[WG_TT][64 + 4];
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tap = blockIdx.z % k_w, grp = blockIdx.z / k_w;
   const int tn = threadIdx.x >> 4, tc = threadIdx.x & 15;   // 16 x 16 threads, 4 x 4 outputs each
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
   for (int i = 0; i < 4; ++i)
     *reinterpret_cast<f32x4*>(gslab + (int64_t)grp * 4096 + (4 * tn + i) * 64 + 4 * tc) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
   if (det_arrive(tickets + tile, seq_groups, reinterpret_cast<unsigned*>(&dys[0][0])))
-    det_sum_slabs<4>(gslab, seq_groups, 4096, &xs[0][0], [&](int e, float t) {
+    det_sum_slabs<4>(gslab, seq_groups, 4096, &xs[0][0], WG_TT * 68, [&](int e, float t) {
       const int n = n0 + (e >> 6), c = c0 + (e & 63);
       if (n < n_out && c < c_in) {
         float* o = &dw[((int64_t)n * c_in + c) * k_w + tap];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, in
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   float s = 0.f;
   if (c < dim)
     for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, in
   float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 64;      // group = channel tile, parts = the row splits
   if (part == 0) gslab[blockIdx.y * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], 1024, [&](int i, float t) {
       const int cc = blockIdx.x * 64 + i;
       if (cc < dim) out[cc] = overwrite ? t : out[cc] + t;
     });
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void col_sum_ragged_kernel(jatts_ragged rg, co
   const int64_t rows = (int64_t)rg.cu_rows[rg.n_seq] * rg.len_mul;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   float s = 0.f;
   if (c < dim)
     for (int64_t r = (int64_t)blockIdx.y * 4 + part; r < rows; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void col_sum_ragged_kernel(jatts_ragged rg, co
   float* gslab = slabs + (int64_t)blockIdx.x * gridDim.y * 64;      // group = channel tile, parts = the row splits
   if (part == 0) gslab[blockIdx.y * 64 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   if (det_arrive(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(&red[0][0])))
-    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], [&](int i, float t) {
+    det_sum_slabs<4>(gslab, (int)gridDim.y, 64, &red[0][0], 1024, [&](int i, float t) {
       const int cc = blockIdx.x * 64 + i;
       if (cc < dim) out[cc] = overwrite ? t : out[cc] + t;
     });
