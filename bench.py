@@ -538,7 +538,7 @@ def compact_line(out, detail_path=None):
         c["cpu_baseline"] = None
         if out.get("cpu_baseline_note"):
             c["cpu_baseline_note"] = out["cpu_baseline_note"]
-    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 io, split f16 hi/lo MFMA in the ResBlock units")):
+    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 tensors, split f16 hi/lo MFMA operands in every conv and fused unit")):
         fm = out.get(key)
         if fm:
             c[key] = {"dtype": short, "value": fm["value"], "ms_per_step": fm["ms_per_step"],

@@ -66,6 +66,7 @@ class ConformerRunner:
         (FastSpeech2 / Matcha, fastspeech2.py fallback), "new" = RelPositionalEncoding +
         RelPositionMultiHeadedAttention (VITS text encoder and decoder)."""
         self.dtype, self.device, self.H = dtype, device, n_heads
+        self.split = dtype == hip.F32 and hip._SPLIT_WEIGHTS[0]     # set_precision("fp32_split"): the run-time packed position operands follow
         self.rel_style = rel_style
         g = lambda k: sd[prefix + k]  # noqa: E731
         self.n_layers = 0
@@ -141,8 +142,8 @@ class ConformerRunner:
             P = hip.conv1d(rb, pe_t, L["pos"].w, L["pos"].c_in, self.A, 1, dtype=self.dtype)  # (cap, A)
             cv = hip.rowdot(P, self.A, n_pos, self.H, self.dk, L["vb"]).t().contiguous()      # (H, n_pos)
             # per-head weight operand of the BD GEMM (n = position m, contraction d_k): pure re-layout
-            heads = [hip.pack_conv_weight(P[:, h * self.dk:(h + 1) * self.dk].float().unsqueeze(-1), self.dtype)
-                     for h in range(self.H)]
+            pk = (lambda w: hip.SplitWeight(w, 64)) if self.split else (lambda w: hip.pack_conv_weight(w, self.dtype))
+            heads = [pk(P[:, h * self.dk:(h + 1) * self.dk].float().unsqueeze(-1)) for h in range(self.H)]
             per_layer.append((heads, cv))
         if len(self._pos_cache) >= 8:
             self._pos_cache.pop(next(iter(self._pos_cache)))
