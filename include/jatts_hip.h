@@ -177,7 +177,7 @@ int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);
  * ------------------------------------------------------------------------------- */
 typedef struct jatts_resblock_desc {
   jatts_ragged rg;
-  int32_t dtype;     /* JATTS_F16 (channels 32 / 64 / 128), or JATTS_F32 for channels 32 / 64 with a chain halo of <= 16 rows a side (k = 3) */
+  int32_t dtype;     /* JATTS_F16 (channels 32 / 64 / 128), JATTS_F32 for channels 32 / 64 with a chain halo of <= 16 rows a side (k = 3), or JATTS_F32S */
   int32_t channels;
   int32_t k_w;
   int32_t n_units;
@@ -192,6 +192,10 @@ typedef struct jatts_resblock_desc {
   const void* add0;
   const void* add1;
   float out_scale;
+  /* JATTS_F32S (round 4: channels 32 with k_w 3 / 7, channels 64 with k_w 3; x / y f32, weights as for jatts_hifigan_resunit): channels
+   * floats each, the inverse per-output-channel weight scales of w1[u] / w2[u] (NULL otherwise) */
+  const float* ws1[3];
+  const float* ws2[3];
 } jatts_resblock_desc;
 
 int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream);
@@ -354,6 +358,17 @@ int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, dou
  * at start, x staged, conv1 done, h written, conv2 done, y assembled, y stored, then s_memrealtime (100 MHz) at start
  * and end, 6 unused}.  buf: device memory of n_workgroups*128 bytes.  Pass NULL to switch tracing off (the default). */
 int jatts_debug_trace(void* buf, int64_t n_workgroups);
+
+/* Batched f32 GEMM on the exact-f32 matrix pipe, for the attention products of the TRAINING step and their gradients (round 4; reference:
+ * torch.matmul inside LegacyRelPositionMultiHeadedAttention.forward / forward_attention, modules/transformer/attention.py:63-93,164-206,
+ * under autograd):  C[o][i] (m x n) = alpha * op(A[o][i]) (m x k) * op(B[o][i]) (k x n)  [+ C[o][i] if accumulate]
+ * for o < n_outer, i < n_inner; matrix (o, i) of an operand starts at base + o * s?_outer + i * s?_inner elements (a stride may be 0: an
+ * operand shared over that index, e.g. the position projection over the batch).  trans_a = 0: A is stored (m x k) with leading dimension
+ * lda, 1: stored (k x m); trans_b = 0: B stored (k x n), 1: stored (n x k).  Rows are contiguous (unit inner stride); a matrix whose start and
+ * leading dimension are 16-byte multiples is read with 16-byte loads.  Deterministic (no split-K, no atomics). */
+int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, int32_t lda, int32_t trans_a, const float* b, int64_t sb_outer,
+                int64_t sb_inner, int32_t ldb, int32_t trans_b, float* c, int64_t sc_outer, int64_t sc_inner, int32_t ldc, int32_t n_outer,
+                int32_t n_inner, int32_t m, int32_t n, int32_t k, float alpha, int32_t accumulate, void* stream);
 
 /* Scratch of the DETERMINISTIC reductions of the training kernels (round 4): jatts_layernorm_bwd, jatts_groupnorm_bwd,
  * jatts_snakebeta_bwd, jatts_dwconv_wgrad, jatts_col_stats, jatts_col_sum, jatts_col_wsum, jatts_seq_sum, jatts_qkv_split_bwd,

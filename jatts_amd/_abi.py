@@ -49,6 +49,7 @@ class ResBlockDesc(C.Structure):
         ("dil", C.c_int32 * 3), ("slope", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
         ("w1", C.c_void_p * 3), ("b1", C.c_void_p * 3), ("w2", C.c_void_p * 3), ("b2", C.c_void_p * 3),
         ("add0", C.c_void_p), ("add1", C.c_void_p), ("out_scale", C.c_float),
+        ("ws1", C.c_void_p * 3), ("ws2", C.c_void_p * 3),
     ]
 
 
@@ -73,6 +74,9 @@ PROTOTYPES = {
     "jatts_hifigan_resblock": (C.c_int, [C.POINTER(ResBlockDesc), C.c_void_p]),
     "jatts_debug_trace": (C.c_int, [C.c_void_p, C.c_int64]),
     "jatts_set_workspace": (C.c_int, [C.c_void_p, C.c_int64]),
+    "jatts_bgemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                              C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                              C.c_int32, C.c_void_p]),
     "jatts_pcm16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "jatts_alignment_logp": (C.c_int, [C.POINTER(Ragged), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_int32, C.c_void_p]),

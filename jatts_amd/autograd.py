@@ -2,7 +2,8 @@
 
 torch.autograd is the tape (it orders the backward calls and sums fan-out gradients); every layer's arithmetic, forward and
 backward, is a HIP kernel from csrc/train_ops.hip / training.hip / the MFMA conv -- except the dense [T x T] products of the
-attention, which are plain batched GEMMs and go to rocBLAS through torch.matmul.  All tensors are f32 and packed
+attention, which are plain batched GEMMs: jatts_bgemm (csrc/bgemm.hip, exact-f32 MFMA; round 4 -- they went to rocBLAS before; what still does
+is the FLOAT64 backward of the alignment module's distance matrix, AlignLogProb.backward, in the MAS-phase trainers).  All tensors are f32 and packed
 (rows, channels) row-major with a RaggedBatch describing the sequences; a padded batch is a RaggedBatch of equal lengths.
 Each Function names the reference module whose autograd it stands for.  No CPU fallback.
 """
@@ -263,6 +264,31 @@ class QKVSplit(torch.autograd.Function):
         dqu, dqv, dk_, dvv = grads
         dqkv, du, dv = hip.qkv_split_bwd(dqu.contiguous(), dqv.contiguous(), dk_.contiguous(), dvv.contiguous())
         return dqkv, du.view(ctx.shapes[0]), dv.view(ctx.shapes[1]), None, None, None
+
+
+class BMM(torch.autograd.Function):
+    """Batched matmul of the attention products on the exact-f32 matrix pipe (jatts_bgemm; round 4: these were torch.matmul -> rocBLAS):
+    c = a @ b (trans_b False: b (..., k, n)) or a @ b^T (trans_b True: b (..., n, k)); a is (O, I, m, k), b is (O, I, ., .) or (I, ., .) --
+    shared over O, as the position projection p_h is over the batch; its gradient is then summed over O."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_b):
+        ctx.trans_b = bool(trans_b)
+        ctx.save_for_backward(a, b)
+        return hip.bgemm(a, b, trans_b=ctx.trans_b)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dc.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = hip.bgemm(dc, b, trans_b=not ctx.trans_b)                       # dc @ b^T   |   dc @ b
+        if ctx.needs_input_grad[1]:
+            db = hip.bgemm(dc, a, trans_a=True) if ctx.trans_b else hip.bgemm(a, dc, trans_a=True)   # dc^T @ a (n x k)  |  a^T @ dc (k x n)
+            if b.dim() == 3:
+                db = db.sum(0)
+        return da, db, None
 
 
 class SumAll(torch.autograd.Function):

@@ -16,6 +16,7 @@ int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
 int jatts_resunit_split(const jatts_resunit_desc& d, hipStream_t s);       // JATTS_F32S
 int jatts_resblock_f16(const jatts_resblock_desc& d, hipStream_t s);
 int jatts_resblock_f32(const jatts_resblock_desc& d, hipStream_t s);
+int jatts_resblock_split(const jatts_resblock_desc& d, hipStream_t s);     // JATTS_F32S
 
 extern "C" int jatts_debug_trace(void* buf, int64_t n_workgroups) {
   jatts_g_trace = (unsigned long long*)buf;
@@ -75,6 +76,12 @@ extern "C" int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream
   if (d->x == d->y) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: y must not alias x");
   if (d->k_w < 1 || !(d->k_w & 1)) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: odd k_w required");
   if (!(d->slope >= 0.f && d->slope <= 1.f)) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: LeakyReLU slope must be in [0, 1]");
+  if (d->dtype == JATTS_F32S) {
+    for (int u = 0; u < d->n_units; ++u)
+      if (!d->ws1[u] || !d->ws2[u]) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: JATTS_F32S needs ws1 / ws2");
+    if (d->rg.max_len <= 0) return JATTS_OK;
+    return jatts_resblock_split(*d, (hipStream_t)stream);
+  }
   if (d->dtype != JATTS_F16 && d->dtype != JATTS_F32) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: unknown dtype");
   if (d->rg.max_len <= 0) return JATTS_OK;
   return d->dtype == JATTS_F16 ? jatts_resblock_f16(*d, (hipStream_t)stream) : jatts_resblock_f32(*d, (hipStream_t)stream);

@@ -501,8 +501,9 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
     return y
 
 
-def hifigan_resblock(rb, len_mul, x, y, units, channels, k_w, slope, dtype, add=None, out_scale=1.0):
-    """jatts_hifigan_resblock: ``units`` = [(w1, b1, w2, b2, dil), ...] (<= 3), all dilation units of one ResBlock in one launch."""
+def hifigan_resblock(rb, len_mul, x, y, units, channels, k_w, slope, dtype, add=None, out_scale=1.0, ws=None):
+    """jatts_hifigan_resblock: ``units`` = [(w1, b1, w2, b2, dil), ...] (<= 3), all dilation units of one ResBlock in one launch.
+    dtype F32S: ``ws`` = [(inverse scales of w1, of w2), ...] per unit (pack_conv_weight_split)."""
     lib = _abi.load()
     d = _abi.ResBlockDesc()
     d.rg = rb.struct(len_mul)
@@ -513,6 +514,11 @@ def hifigan_resblock(rb, len_mul, x, y, units, channels, k_w, slope, dtype, add=
     d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
     for i, (w1, b1, w2, b2, dil) in enumerate(units):
         d.w1[i], d.b1[i], d.w2[i], d.b2[i], d.dil[i] = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), dil
+    if dtype == F32S:
+        if ws is None or len(ws) != len(units):
+            raise ValueError("hifigan_resblock: F32S needs the inverse weight scales of every unit")
+        for i, (a, b) in enumerate(ws):
+            d.ws1[i], d.ws2[i] = a.data_ptr(), b.data_ptr()
     if add:
         for a in add:
             if a.numel() != rows * channels or a.dtype != x.dtype:
@@ -1390,4 +1396,37 @@ def seq_sum(rb, x):
     rg = rb.struct()
     _ws(x.device)
     _abi.check(lib.jatts_seq_sum(C.byref(rg), x.data_ptr(), x.shape[1], out.data_ptr(), _stream()), "jatts_seq_sum")
+    return out
+
+
+def bgemm(a, b, trans_a=False, trans_b=False, alpha=1.0, out=None):
+    """jatts_bgemm: C[o][i] = alpha * op(a[o][i]) @ op(b[o][i]) on the exact-f32 matrix pipe (the training step's attention products).
+    a, b: f32 device tensors of 4 dims (O, I, rows, cols) -- any strides on the two batch dims, rows contiguous -- or 3 dims (I, rows, cols)
+    = shared over O.  trans_a: a holds (k x m); trans_b: b holds (n x k).  -> (O, I, m, n) contiguous."""
+    lib = _abi.load()
+    a, b = _dev(a), _dev(b)
+
+    def geom(t):
+        if t.dtype != torch.float32 or t.dim() not in (3, 4) or t.stride(-1) != 1:
+            raise ValueError("bgemm: f32 tensors of 3 / 4 dims with contiguous rows")
+        if t.dim() == 3:
+            return None, t.shape[0], 0, t.stride(0), t.stride(1)
+        return t.shape[0], t.shape[1], t.stride(0), t.stride(1), t.stride(2)
+    ao, ai, sao, sai, lda = geom(a)
+    bo, bi, sbo, sbi, ldb = geom(b)
+    O = ao if ao is not None else bo
+    if O is None:
+        O = 1
+    if ai != bi or (ao is not None and ao != O) or (bo is not None and bo != O):
+        raise ValueError("bgemm: batch dims differ")
+    m, k = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    n, kb = (b.shape[-2], b.shape[-1]) if trans_b else (b.shape[-1], b.shape[-2])
+    if k != kb:
+        raise ValueError("bgemm: contraction sizes differ")
+    if out is None:
+        out = torch.empty(O, ai, m, n, dtype=torch.float32, device=a.device)
+    _count(2.0 * O * ai * m * n * k)
+    with _Timed("bgemm", (O * ai, m, n, k)):
+        _abi.check(lib.jatts_bgemm(a.data_ptr(), sao, sai, lda, int(trans_a), b.data_ptr(), sbo, sbi, ldb, int(trans_b), out.data_ptr(), out.stride(0),
+                                   out.stride(1), out.stride(2), O, ai, m, n, k, float(alpha), 0, _stream()), "jatts_bgemm")
     return out

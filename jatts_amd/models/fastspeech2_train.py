@@ -124,11 +124,12 @@ def _conformer(c, prefix, x, rb, kv, H, rates, rel_style="legacy"):
         qkv2 = A.Conv1dFunction.apply(h, wqkv, bqkv, rb, 1, 0)                               # (rows, 3 A)
         qu, qv, kh, vh = A.QKVSplit.apply(qkv2, c.p[a + "pos_bias_u"], c.p[a + "pos_bias_v"], B, T, H)      # each (B, H, T, dk), one launch
         ph = A.Conv1dFunction.apply(pos, c.p[a + "linear_pos.weight"].unsqueeze(-1), None, rbp, 1, 0).view(n_pos, H, dk).permute(1, 0, 2)
-        ac = torch.matmul(qu, kh.transpose(-2, -1))                                         # rocBLAS batched GEMMs
-        bd = torch.matmul(qv, ph.transpose(-2, -1)[None])
+        ph = ph.contiguous()
+        ac = A.BMM.apply(qu, kh, True)                                                      # q k^T, q p^T, P v: jatts_bgemm (exact-f32 MFMA), forward
+        bd = A.BMM.apply(qv, ph, True)                                                      # and backward; p_h is shared over the batch
         p_attn = A.ShiftSoftmax.apply(ac, bd, kv, 1.0 / math.sqrt(dk), 2 if rel_style == "new" else 1)
         p_attn = c.drop(p_attn, rates["attn"])
-        ctxv = torch.matmul(p_attn, vh).permute(0, 2, 1, 3).reshape(B * T, Ad)
+        ctxv = A.BMM.apply(p_attn, vh, False).permute(0, 2, 1, 3).reshape(B * T, Ad)
         x = c.resid_drop(x, c.conv(ctxv, a + "linear_out", rb), rates["layer"])
         # convolution module (convolution.py:56-79)
         if (q + "conv_module.pointwise_conv1.weight") in c.p:

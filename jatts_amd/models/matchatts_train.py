@@ -47,9 +47,9 @@ def _tblock(c, p, x, rb, heads, key_bias, rate):
     dh = inner // heads
     qh, kh, vh = A.QKVSplit.apply(A.Conv1dFunction.apply(n, wqkv, None, rb, 1, 0), None, None, B, T, heads)       # each (B, heads, T, dh)
     scale = dh ** -0.5
-    sc = torch.matmul(qh, kh.transpose(-2, -1)) + (key_bias / scale)[:, None, None, :]                 # rocBLAS batched GEMM
+    sc = A.BMM.apply(qh, kh, True) + (key_bias / scale)[:, None, None, :]                              # jatts_bgemm (exact-f32 MFMA)
     pa = A.ShiftSoftmax.apply(sc, None, None, scale)
-    a = torch.matmul(pa, vh).permute(0, 2, 1, 3).reshape(B * T, inner)
+    a = A.BMM.apply(pa, vh, False).permute(0, 2, 1, 3).reshape(B * T, inner)
     x = x + c.drop(c.conv(a, p + "attn1.to_out.0", rb), rate)
     n = A.LayerNorm.apply(x, c.p[p + "norm3.weight"], c.p[p + "norm3.bias"], GN_EPS)
     u = A.SnakeBeta.apply(c.conv(n, p + "ff.net.0.proj", rb), c.p[p + "ff.net.0.alpha"], c.p[p + "ff.net.0.beta"])
@@ -174,7 +174,7 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
         cen = ds.cumsum(-1) - ds / 2
         energy = -0.1 * (tpos.unsqueeze(-1) - cen.unsqueeze(1)) ** 2
         p_up = torch.softmax(energy.masked_fill(~tm_.unsqueeze(1), float("-inf")), dim=2)
-        up = torch.matmul(p_up, hs.view(B, Tm, Ad))[:, :Te].reshape(B * Te, Ad)             # rocBLAS batched GEMM
+        up = A.BMM.apply(p_up.unsqueeze(1), hs.view(B, 1, Tm, Ad), False).squeeze(1)[:, :Te].reshape(B * Te, Ad)   # jatts_bgemm
         extra.update(bin_loss=bin_loss, log_p_attn=log_p_attn, ds=ds)
     else:
         d_flat = durations[:, : int(durations_lengths.max())].to(dev).reshape(-1).to(torch.int64).contiguous()

@@ -111,7 +111,7 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, spembs, post_
     tpos = torch.arange(To, device=dev).float().unsqueeze(0) * fm
     cen = ds.cumsum(-1) - ds / 2
     p_up = torch.softmax((-0.1 * (tpos.unsqueeze(-1) - cen.unsqueeze(1)) ** 2).masked_fill(~tmk.unsqueeze(1), float("-inf")), dim=2)
-    up = torch.matmul(p_up, stats_p.view(B, Tm, 2 * Ad))                                       # (B, To, 2A), rocBLAS
+    up = A.BMM.apply(p_up.unsqueeze(1), stats_p.view(B, 1, Tm, 2 * Ad), False).squeeze(1)   # (B, To, 2A): jatts_bgemm
 
     def pad_frames(v):     # ragged (valid frames, C) -> padded (B, To, C) with zeros (differentiable row scatter)
         out = torch.zeros(B * To, v.shape[1], dtype=v.dtype, device=dev)

@@ -194,6 +194,9 @@ class HiFiGANGenerator(torch.nn.Module):
     # (7.78 vs 7.48 ms: the 24-row chain halo of a 256-column window) and stays on the per-unit path (tools/bench_unit.py --resblock
     # --dtype f32); JATTS_HIFIGAN_FUSE_F32=0 switches the fused launch off (A/B runs)
     fused_blocks_f32 = frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE_F32", "1") == "0" else frozenset({(32, 3)})
+    # fp32_split (round 4): the HBM-bound blocks -- x in + y out once per ResBlock (csrc/resblock_split_impl.h); JATTS_HIFIGAN_FUSE_SPLIT=0: per-unit launches
+    fused_blocks_split = (frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE_SPLIT", "1") == "0"
+                          else frozenset(tuple(int(v) for v in t.split("x")) for t in os.environ.get("JATTS_HIFIGAN_FUSE_SPLIT_SET", "32x3,32x7,64x3").split(",")))
 
     # tuning knob (profiles/r01_notes.md): run the independent ResBlock chains of a stage on separate HIP streams
     concurrent = os.environ.get("JATTS_HIFIGAN_STREAMS", "0") == "1"
@@ -243,12 +246,14 @@ class HiFiGANGenerator(torch.nn.Module):
                 cur = up
                 st = side[j] if j < len(side) else None
                 # HBM-bound shapes: the whole ResBlock in one launch (x read once, y written once; residual in registers)
-                if udt != hip.F32S and (c_out, units[0][2]) in (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32) and len(units) <= 3 and st is None \
-                        and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if dt == hip.F16 else 16):
+                fset = self.fused_blocks_split if udt == hip.F32S else (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32)
+                if (c_out, units[0][2]) in fset and len(units) <= 3 and st is None \
+                        and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if (dt == hip.F16 or udt == hip.F32S) else 16):
                     lastb = fuse_mean and j == len(blocks) - 1
                     hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(c1.w, c1.b, c2.w, c2.b, d) for c1, c2, _, d in units],
-                                         c_out, units[0][2], self.slope, dt, add=outs if lastb else None,
-                                         out_scale=1.0 / len(blocks) if lastb else 1.0)
+                                         c_out, units[0][2], self.slope, udt, add=outs if lastb else None,
+                                         out_scale=1.0 / len(blocks) if lastb else 1.0,
+                                         ws=[(c1.inv, c2.inv) for c1, c2, _, _ in units] if udt == hip.F32S else None)
                     outs.append(bufs[j][0])
                     continue
                 if st is not None:

@@ -119,3 +119,33 @@ def test_shard_utterances_is_a_balanced_partition():
     assert sorted(i for p in parts for i in p) == list(range(len(lens)))
     assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert parts == shard_utterances(lens, 4)
+
+
+def test_split_weight_packing_is_an_exact_scaled_hi_lo_pair():
+    """hip.pack_conv_weight_split (the JATTS_F32S operand, CPU-checkable: pure torch): per output channel a power-of-two scale puts max |w| in
+    [2^14, 2^15); hi + lo reconstructs w * 2^s to 2^-22 of the channel maximum or better; the inverse scales are exact powers of two; an all-zero
+    channel takes scale 1; elements sit where jatts_conv_weight_index says, hi and lo halves of a lane side by side."""
+    import math
+
+    import torch
+
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(3)
+    n, c, k = 40, 64, 3
+    w = torch.randn(n, c, k, generator=g) * torch.pow(10.0, torch.rand(n, 1, 1, generator=g) * 6 - 4)
+    w[7] = 0.0
+    packed, inv = hip.pack_conv_weight_split(w, 64)
+    n_pad = 64
+    assert packed.dtype == torch.float16 and packed.numel() == 2 * n_pad * c * k and inv.shape == (n_pad,)
+    m, e = torch.frexp(inv)
+    assert torch.all(m == 0.5) and float(inv[7]) == 1.0 and torch.all(inv[n:] == 1.0)        # exact powers of two
+    pk = packed.view(-1, 2, 8).float()              # [fragment lane slot][hi | lo][8]
+    for (nn, tap, cc) in [(0, 0, 0), (5, 2, 17), (39, 1, 63), (7, 0, 3), (33, 2, 40)]:
+        idx = ((tap * (c // 16) + cc // 16) * (n_pad // 32) + nn // 32) * 64 + 32 * ((cc % 16) // 8) + nn % 32
+        hi, lo = float(pk[idx, 0, cc % 8]), float(pk[idx, 1, cc % 8])
+        ws = float(w[nn, cc, tap]) / float(inv[nn])
+        amax = float(w[nn].abs().max()) / float(inv[nn])
+        assert amax == 0.0 or 2.0 ** 14 <= amax < 2.0 ** 15
+        assert abs(hi + lo - ws) <= max(amax, 1.0) * 2.0 ** -22, (nn, tap, cc, hi, lo, ws)
+        assert hi == float(torch.tensor(ws).half())                                            # hi = f16(ws), round to nearest
+    assert math.isfinite(float(packed.float().abs().max())) and float(packed.float().abs().max()) < 65504.0

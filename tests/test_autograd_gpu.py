@@ -501,3 +501,35 @@ def test_qkv_split_backward(cuda, lib):
         sum((o * g_.to(cuda)).sum() for o, g_ in zip(outs, gs)).backward()
         assert len(outs) == 3
         _check([(f"p{i}", o, r) for i, (o, r) in enumerate(zip(outs, ref))] + [("dqkv", qd.grad, qr.grad)])
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 70, 50, 33), (2, 2, 257, 192, 300), (1, 1, 128, 128, 16), (4, 1, 5, 81, 7)])
+def test_bgemm_and_bmm_function(cuda, lib, shape):
+    """jatts_bgemm (exact-f32 MFMA batched GEMM: the training step's attention products, rocBLAS before round 4) in all four transpose forms
+    against fp64 matmul, with strided batch dims and an operand shared over the outer batch index; autograd.BMM forward and gradients
+    against torch autograd of the same expression in fp64."""
+    from jatts_amd import autograd as A
+    from jatts_amd import hip
+    O, I, M, N, K = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    a = torch.randn(O, I, M, K, generator=g).to(cuda)
+    b = torch.randn(O, I, K, N, generator=g).to(cuda)
+    ref = a.double() @ b.double()
+    assert relerr(hip.bgemm(a, b), ref) <= 2e-6
+    assert relerr(hip.bgemm(a, b.transpose(-1, -2).contiguous(), trans_b=True), ref) <= 2e-6
+    assert relerr(hip.bgemm(a.transpose(-1, -2).contiguous(), b, trans_a=True), ref) <= 2e-6
+    assert relerr(hip.bgemm(a.transpose(-1, -2).contiguous(), b.transpose(-1, -2).contiguous(), trans_a=True, trans_b=True), ref) <= 2e-6
+    # batch dims with foreign strides (a (O, I, ..) view of an (I, O, ..) tensor), and b shared over O
+    a2 = torch.randn(I, O, M, K, generator=g).to(cuda).permute(1, 0, 2, 3)
+    bs = torch.randn(I, N, K, generator=g).to(cuda)
+    assert relerr(hip.bgemm(a2, bs, trans_b=True), a2.double() @ bs.double().transpose(-1, -2)[None]) <= 2e-6
+    # the autograd Function
+    for trans_b, bb in ((True, bs), (False, b), (True, b.transpose(-1, -2).contiguous())):
+        x1, y1 = a.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+        x2, y2 = a.double().clone().requires_grad_(True), bb.double().clone().requires_grad_(True)
+        c1 = A.BMM.apply(x1, y1, trans_b)
+        c2 = x2 @ ((y2.transpose(-1, -2) if trans_b else y2) if y2.dim() == 4 else y2.transpose(-1, -2)[None])
+        w = torch.randn(c2.shape, generator=g).to(cuda)
+        (c1 * w).sum().backward()
+        (c2 * w.double()).sum().backward()
+        assert relerr(c1, c2) <= 2e-6 and relerr(x1.grad, x2.grad) <= 2e-6 and relerr(y1.grad, y2.grad) <= 3e-6

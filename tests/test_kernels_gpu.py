@@ -276,6 +276,66 @@ def test_hifigan_resunit_split(cuda, lib, C, k, d, lens, xkind):
         assert torch.equal(y0, y[:L0])
 
 
+@pytest.mark.parametrize("xkind", ["unit", "wide"])
+@pytest.mark.parametrize("C,k,dils,lens,mrf", [
+    (32, 3, (1, 3, 5), [1300, 3, 250, 40], False), (32, 7, (1, 3, 5), [900, 31], False), (64, 3, (1, 3, 5), [513, 700], False),
+    (32, 3, (1, 3, 5), [700, 90], True), (64, 3, (1, 3), [260, 31], True), (32, 7, (2,), [500], False), (32, 3, (1, 3, 5), [2000], False),
+])
+def test_hifigan_resblock_split(cuda, lib, C, k, dils, lens, mrf, xkind):
+    """jatts_hifigan_resblock with JATTS_F32S (round 4): the whole ResBlock in one launch, residual stream in f32 registers, every conv on split
+    operands with per-tile scales -- against the fp64 chain of units (the exact-f32 tolerance), against the chain of per-unit split launches
+    (same arithmetic up to the scale blocks: the fused window is wider than a unit's tile), and an utterance alone == inside the batch."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + len(dils))
+    R = sum(lens)
+    x = torch.randn(R, C, generator=g)
+    if xkind == "wide":
+        x = x * torch.pow(10.0, torch.rand(R, 1, generator=g) * 6 - 4)
+    ws = [(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), torch.randn(C, generator=g) * 0.1,
+           torch.randn(C, C, k, generator=g) * 0.5 / math.sqrt(C * k), torch.randn(C, generator=g) * 0.1) for _ in dils]
+    adds = [torch.randn(R, C, generator=g) for _ in range(2)] if mrf else None
+    ref = x.double()
+    for (w1, b1, w2, b2), d in zip(ws, dils):
+        ref = _ref_unit(ref, w1, b1, w2, b2, lens, k, d, 0.1, False)
+    if mrf:
+        ref = (ref + adds[0].double() + adds[1].double()) / 3.0
+    rb = _ragged(lens, cuda)
+    xd = x.to(cuda)
+    packed, invs = [], []
+    for (w1, b1, w2, b2), d in zip(ws, dils):
+        (p1, i1), (p2, i2) = hip.pack_conv_weight_split(w1.to(cuda), 32), hip.pack_conv_weight_split(w2.to(cuda), 32)
+        packed.append((p1, b1.to(cuda), p2, b2.to(cuda), d))
+        invs.append((i1, i2))
+    y = torch.full_like(xd, float("nan"))
+    addd = [a.to(cuda) for a in adds] if mrf else None
+    hip.hifigan_resblock(rb, 1, xd, y, packed, C, k, 0.1, hip.F32S, add=addd, out_scale=1.0 / 3.0 if mrf else 1.0, ws=invs)
+    cur, bufs = xd, [torch.empty_like(xd), torch.empty_like(xd)]
+    for i, ((w1, b1, w2, b2, d), iv) in enumerate(zip(packed, invs)):
+        lastu = i == len(packed) - 1
+        hip.hifigan_resunit(rb, 1, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, hip.F32S, add=addd if (mrf and lastu) else None,
+                            out_scale=1.0 / 3.0 if (mrf and lastu) else 1.0, ws=iv)
+        cur = bufs[i & 1]
+    # exact f32 per-unit chain: the error yardstick
+    c32, b32 = xd, [torch.empty_like(xd), torch.empty_like(xd)]
+    for i, ((w1, b1, w2, b2), d) in enumerate(zip(ws, dils)):
+        lastu = i == len(ws) - 1
+        hip.hifigan_resunit(rb, 1, c32, b32[i & 1], hip.pack_conv_weight(w1.to(cuda), hip.F32, 32), b1.to(cuda), hip.pack_conv_weight(w2.to(cuda), hip.F32, 32),
+                            b2.to(cuda), C, k, d, 0.1, hip.F32, add=addd if (mrf and lastu) else None, out_scale=1.0 / 3.0 if (mrf and lastu) else 1.0)
+        c32 = b32[i & 1]
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all(), "unwritten / non-finite outputs"
+    e, e32 = relerr(y, ref), relerr(c32, ref)
+    assert e <= max(TOL["fp32"], 2.0 * e32), f"split resblock C={C} k={k} dils={dils} {xkind}: rel err {e:.3e} (exact f32 units {e32:.3e})"
+    assert _maxerr(y, ref) <= 2.0 * _maxerr(c32, ref) + 1e-30
+    assert relerr(y, cur.double()) <= 1e-5
+    if len(lens) > 1:
+        L0 = lens[0]
+        y0 = torch.empty(L0, C, device=cuda)
+        hip.hifigan_resblock(_ragged([L0], cuda), 1, xd[:L0].contiguous(), y0, packed, C, k, 0.1, hip.F32S,
+                             add=[a[:L0].contiguous() for a in addd] if mrf else None, out_scale=1.0 / 3.0 if mrf else 1.0, ws=invs)
+        assert torch.equal(y0, y[:L0])
+
+
 def test_hifigan_resunit_split_mrf_and_errors(cuda, lib):
     """The fused MRF mean of the split unit's output pass; zero input (tile maximum 0) stays exact; missing scales are refused."""
     from jatts_amd import hip

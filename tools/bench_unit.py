@@ -54,18 +54,23 @@ def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5), dt=hip.F16):
     x = (torch.randn(rows, C, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     units = []
+    invs = []
     for d in dils:
-        w1 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), dt, 32)
-        w2 = hip.pack_conv_weight((torch.randn(C, C, k, generator=g) * 0.3 / (C * k) ** 0.5).to(dev), dt, 32)
+        wa, wb = (torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(dev), (torch.randn(C, C, k, generator=g) * 0.3 / (C * k) ** 0.5).to(dev)
+        if dt == hip.F32S:
+            (w1, i1), (w2, i2) = hip.pack_conv_weight_split(wa, 32), hip.pack_conv_weight_split(wb, 32)
+            invs.append((i1, i2))
+        else:
+            w1, w2 = hip.pack_conv_weight(wa, dt, 32), hip.pack_conv_weight(wb, dt, 32)
         units.append((w1, torch.zeros(C, device=dev), w2, torch.zeros(C, device=dev), d))
 
     def fused():
-        hip.hifigan_resblock(rb, rate, x, bufs[0], units, C, k, 0.1, dt)
+        hip.hifigan_resblock(rb, rate, x, bufs[0], units, C, k, 0.1, dt, ws=invs or None)
 
     def unfused():
         cur = x
         for i, (w1, b1, w2, b2, d) in enumerate(units):
-            hip.hifigan_resunit(rb, rate, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, dt)
+            hip.hifigan_resunit(rb, rate, cur, bufs[i & 1], w1, b1, w2, b2, C, k, d, 0.1, dt, ws=invs[i] if invs else None)
             cur = bufs[i & 1]
 
     res = []
@@ -81,7 +86,7 @@ def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5), dt=hip.F16):
         torch.cuda.synchronize()
         res.append(a.elapsed_time(b) / iters)
     flops = 4.0 * C * C * k * rows * len(dils)
-    byts = 2.0 * rows * C * (2 if dt == hip.F16 else 4)
+    byts = 2.0 * rows * C * (2 if dt == hip.F16 else 4)      # (F32S: f32 tensors)
     print(f"ResBlock C={C:4d} k={k:2d} rows={rows:9d}: fused {res[0]:7.3f} ms ({flops / res[0] / 1e9:7.1f} TFLOP/s, {byts / res[0] / 1e6:7.1f} GB/s "
           f"of x-in + y-out)   3 unit launches {res[1]:7.3f} ms   speed-up {res[1] / res[0]:.2f}x")
     return res
@@ -102,7 +107,9 @@ def main():
     dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S}[a.dtype]
     if a.resblock:
         for C in ((32, 64, 128) if dt == hip.F16 else (32, 64)):
-            for k in ((3, 7) if dt == hip.F16 else (3,)):
+            for k in ((3, 7) if dt != hip.F32 else (3,)):
+                if dt == hip.F32S and (C, k) == (64, 7):
+                    continue
                 run_block(C, k, rates[C], a.iters, dt=dt)
         return
     if a.all:
