@@ -12,11 +12,16 @@ namespace {
 
 template <typename T> struct V8 { typedef typename Elem<T>::vec8 type; };
 
+// G<T>: what an operand of arithmetic T looks like in HBM and in the registers between a global load and the LDS store.
+// f16s (JATTS_F32S, round 4): f32 in memory, split into hi / lo f16 planes on the way into LDS / into the MFMA operand registers.
+template <typename T> struct G { typedef T type; typedef typename Elem<T>::vec8 vec8; static constexpr bool split = false; };
+template <> struct G<f16s> { typedef float type; typedef f32x8 vec8; static constexpr bool split = true; };
+
 template <typename T>
-__device__ __forceinline__ typename Elem<T>::vec8 load8(const T* p) {
-  typename Elem<T>::vec8 v;
-  if (sizeof(T) == 2) {
-    v = *reinterpret_cast<const typename Elem<T>::vec8*>(p);
+__device__ __forceinline__ typename G<T>::vec8 load8(const typename G<T>::type* p) {
+  typename G<T>::vec8 v;
+  if (sizeof(typename G<T>::type) == 2) {
+    v = *reinterpret_cast<const typename G<T>::vec8*>(p);
   } else {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -24,13 +29,46 @@ __device__ __forceinline__ typename Elem<T>::vec8 load8(const T* p) {
   }
   return v;
 }
+// LDS fragment read: 8 contraction elements of arithmetic T at `p` (f16s: one planar unit, 16 B of hi then 16 B of lo)
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::vec8 lds8(const char* p) {
+  if constexpr (G<T>::split) return f16sx8{*reinterpret_cast<const f16x8*>(p), *reinterpret_cast<const f16x8*>(p + 16)};
+  else return load8<T>(reinterpret_cast<const T*>(p));
+}
+// 8 f32 values, scaled by the power of two `sc`, as a split operand
+__device__ __forceinline__ f16sx8 split8(const f32x8& v, float sc) {
+  f16sx8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float sv = v[e] * sc;
+    o.hi[e] = (f16)sv;
+    o.lo[e] = (f16)(sv - (float)o.hi[e]);
+  }
+  return o;
+}
+__device__ __forceinline__ float amax8(const f32x8& v, float m) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  return m;
+}
+// exponent of the power-of-two scale that puts amax in [2^14, 2^15) (resunit_split_impl.h: split_exp), and 2^s
+__device__ __forceinline__ int attn_split_exp(float amax) {
+  const int bexp = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  const int s = 15 - (bexp - 126);
+  return amax > 0.f ? (s > 60 ? 60 : (s < -60 ? -60 : s)) : 0;
+}
+__device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }
 
 constexpr int QB = 64;  // queries per workgroup
 constexpr int KB = 64;  // keys per tile
 
 template <typename T>
-__device__ __forceinline__ void store8(char* p, const typename Elem<T>::vec8& v) {
-  if (sizeof(T) == 2) {
+__device__ __forceinline__ void store8(char* p, const typename G<T>::vec8& v, float sc = 1.f) {
+  if constexpr (G<T>::split) {
+    const f16sx8 o = split8(v, sc);
+    *reinterpret_cast<f16x8*>(p) = o.hi;
+    *reinterpret_cast<f16x8*>(p + 16) = o.lo;
+  } else if (sizeof(T) == 2) {
     *reinterpret_cast<typename Elem<T>::vec8*>(p) = v;
   } else {
     *reinterpret_cast<f32x4*>(p) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
@@ -41,7 +79,7 @@ __device__ __forceinline__ void store8(char* p, const typename Elem<T>::vec8& v)
 // 4 consecutive elements from an address that is only element-aligned (the rel-pos diagonal starts anywhere):
 // gfx950 under the amdhsa ABI runs in unaligned-access mode, so this is one 8/16-byte load.
 template <typename T>
-__device__ __forceinline__ void load4u(const T* p, float (&o)[4]) {
+__device__ __forceinline__ void load4u(const T* p, float (&o)[4]) {     // (T = the type in memory)
   T v[4];
   __builtin_memcpy(v, p, 4 * sizeof(T));
 #pragma unroll
@@ -54,14 +92,15 @@ __device__ __forceinline__ void load4u(const T* p, float (&o)[4]) {
 template <typename T, int DK, int KBT>
 struct TileRegs {
   static constexpr int N = KBT * DK / 2048;  // 8-element chunks per thread for K and for V^T (KBT x DK elements over 256 threads)
-  typename Elem<T>::vec8 k[N], v[N];
+  typename G<T>::vec8 k[N], v[N];
   float ku;
 };
 
 template <typename T, int DK, int KBT>
-__device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_relattn_desc& d, const T* kg, const T* vtg,
-                                          int row0, int h, int j0, int Tn, bool vt_vec) {
-  typedef typename Elem<T>::vec8 Vec;
+__device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
+                                          const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec) {
+  typedef typename G<T>::vec8 Vec;
+  typedef typename G<T>::type TG;
   constexpr int UPR = DK / 8;
 #pragma unroll
   for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
@@ -70,20 +109,20 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_
       const int r = u / UPR, cu = u - r * UPR, j = j0 + r;
       Vec z;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
+      for (int e = 0; e < 8; ++e) z[e] = from_f32<TG>(0.f);
       tr.k[i] = (j >= 0 && j < Tn) ? load8<T>(kg + (int64_t)j * d.ldk + cu * 8) : z;
     }
     {  // V^T rows: channels, 8 keys per chunk
       const int r = u / (KBT / 8), jc = j0 + 8 * (u % (KBT / 8));
       Vec z;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = from_f32<T>(0.f);
-      const T* src = vtg + (int64_t)r * d.ldvt + jc;
+      for (int e = 0; e < 8; ++e) z[e] = from_f32<TG>(0.f);
+      const TG* src = vtg + (int64_t)r * d.ldvt + jc;
       if (vt_vec) {
         if (jc + 7 >= 0 && jc < Tn) z = load8<T>(src);   // aligned: (row0 + j0) % 8 == 0, ldvt % 8 == 0
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (jc + e < 0 || jc + e >= Tn) z[e] = from_f32<T>(0.f);   // never multiply P = 0 by stray bits
+          if (jc + e < 0 || jc + e >= Tn) z[e] = from_f32<TG>(0.f);   // never multiply P = 0 by stray bits
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -100,14 +139,15 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_
 }
 
 template <typename T, int DK, int KBT>
-__device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char* ks, char* vs, float* kus, int KP, int VP) {
+__device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char* ks, char* vs, float* kus, int KP, int VP, float sk = 1.f,
+                                           float sv = 1.f) {
   constexpr int UPR = DK / 8;
 #pragma unroll
   for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
     const int u = threadIdx.x + 256 * i;
     const int r = u / UPR, cu = u - r * UPR;
-    store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i]);
-    store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i]);
+    store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i], sk);
+    store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i], sv);
   }
   if (threadIdx.x < KBT) kus[threadIdx.x] = tr.ku;
 }
@@ -118,6 +158,8 @@ template <typename T, int DK, int KBT>
 __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<T>::vec8 Vec;
+  typedef typename G<T>::type TG;          // element type in HBM (f32 for the split arithmetic)
+  constexpr bool SPLIT = G<T>::split;
   // K tile pitch: the score MFMAs read 16 key rows x 4 channel groups per ds_read_b128; with the pitch = 2 (mod 4)
   // 16-byte units the hardware's 16-lane groups hit 16 distinct slots (+16 left 41 % of the LDS cycles in conflict)
   constexpr int KP = DK * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
@@ -128,6 +170,7 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   char* ks = smem;
   char* vs = smem + KBT * KP;
   float* kus = reinterpret_cast<float*>(smem + KBT * KP + DK * VP);
+  float* slots = kus + KBT;                // split arithmetic: per-wave block maxima [4 waves][K | V] (+ Q at start)
 
   const int b = blockIdx.y, h = blockIdx.z;
   const int row0 = d.rg.cu_rows[b];
@@ -141,11 +184,11 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   const int qc = lane & 15, g = lane >> 4;
   const int qi = i0 + wave * 16 + qc;          // this lane's query (may be >= Tn: never stored)
   const int qi_c = qi < Tn ? qi : Tn - 1;      // clamped for loads
-  const T* qg = (const T*)d.q + (int64_t)(row0 + qi_c) * d.ldq + h * DK;
-  const T* kg = (const T*)d.k + (int64_t)row0 * d.ldk + h * DK;
+  const TG* qg = (const TG*)d.q + (int64_t)(row0 + qi_c) * d.ldq + h * DK;
+  const TG* kg = (const TG*)d.k + (int64_t)row0 * d.ldk + h * DK;
   const int vcol0 = d.vt_col0 ? d.vt_col0[b] : row0;
-  const T* vtg = (const T*)d.vt + (int64_t)(h * DK) * d.ldvt + vcol0;
-  const T* gg = d.g ? (const T*)d.g : nullptr;
+  const TG* vtg = (const TG*)d.vt + (int64_t)(h * DK) * d.ldvt + vcol0;
+  const TG* gg = d.g ? (const TG*)d.g : nullptr;
   const int H = d.n_heads;
   // Key tiles always start at the sequence's first key (results do not depend on the position in the packed batch).
   // V^T is staged with aligned 16-byte loads when the sequence's first column is (vt_col0, RaggedBatch.vt_layout).
@@ -153,8 +196,28 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   constexpr int j_start = 0;
 
   Vec qf[NKS];
+  int eq = 0;                               // split arithmetic: Q lives at scale 2^eq (one scale per workgroup = 64 queries of one head)
+  if constexpr (SPLIT) {
+    typename G<T>::vec8 qr[NKS];
+    float m = 0.f;
 #pragma unroll
-  for (int s = 0; s < NKS; ++s) qf[s] = load8<T>(qg + 32 * s + 8 * g);
+    for (int s = 0; s < NKS; ++s) {
+      qr[s] = load8<T>(qg + 32 * s + 8 * g);
+      m = amax8(qr[s], m);
+    }
+    if (qi >= Tn) m = 0.f;                  // (clamped duplicate rows of the last tile: same values, but keep the maximum a function of real queries)
+    m = wave_max(m);
+    if (lane == 0) slots[wave] = m;
+    __syncthreads();
+    eq = attn_split_exp(fmaxf(fmaxf(slots[0], slots[1]), fmaxf(slots[2], slots[3])));
+    __syncthreads();
+    const float sq = attn_exp2i(eq);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) qf[s] = split8(qr[s], sq);
+  } else {
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) qf[s] = load8<T>(qg + 32 * s + 8 * g);
+  }
 
   f32x4 ot[NDF];
 #pragma unroll
@@ -162,8 +225,8 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   float m_run = -INFINITY, l_run = 0.f;
 
   // rel-pos bias rows of this lane's query (legacy rel_shift reads row qi for j <= qi, row qi + 1 beyond)
-  const T* g_q = gg ? gg + ((int64_t)(row0 + qi_c) * H + h) * d.ldg : nullptr;
-  const T* g_q1 = gg ? gg + ((int64_t)(row0 + (qi_c + 1 < Tn ? qi_c + 1 : qi_c)) * H + h) * d.ldg : nullptr;
+  const TG* g_q = gg ? gg + ((int64_t)(row0 + qi_c) * H + h) * d.ldg : nullptr;
+  const TG* g_q1 = gg ? gg + ((int64_t)(row0 + (qi_c + 1 < Tn ? qi_c + 1 : qi_c)) * H + h) * d.ldg : nullptr;
 
   // d_k <= 192: the next tile is prefetched into registers during the current tile's MFMAs.  d_k = 256 does not
   // have the registers for that at 2 waves/SIMD: it loads and stores the tile back to back (still 16-byte batched)
@@ -171,9 +234,27 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   constexpr bool PREFETCH = (DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192);   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
   TileRegs<T, DK, KBT> tr;
   if (PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
+  int ev_prev = 0;
   for (int j0 = j_start; j0 < Tk; j0 += KBT) {
     if (!PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec);
-    tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP);
+    int ek = 0, ev = 0;
+    if constexpr (SPLIT) {    // block maxima of the K and V^T tiles that sit in registers -> their power-of-two scales
+      float mk = 0.f, mv = 0.f;
+#pragma unroll
+      for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
+        mk = amax8(tr.k[i], mk);
+        mv = amax8(tr.v[i], mv);
+      }
+      mk = wave_max(mk);
+      mv = wave_max(mv);
+      if (lane == 0) { slots[2 * wave] = mk; slots[2 * wave + 1] = mv; }
+      __syncthreads();
+      ek = attn_split_exp(fmaxf(fmaxf(slots[0], slots[2]), fmaxf(slots[4], slots[6])));
+      ev = attn_split_exp(fmaxf(fmaxf(slots[1], slots[3]), fmaxf(slots[5], slots[7])));
+      tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev));
+    } else {
+      tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP);
+    }
     __syncthreads();
     if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec);
 
@@ -187,16 +268,16 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
       if (gg && qi < Tn) {
         const bool inside = jq >= 0 && jq + 3 < Tn;
         if (d.rel_mode == 2) {  // new rel_shift: plain diagonal map, no wrap
-          const T* p = g_q + (d.rel_center - qi + jq);
-          if (inside) load4u<T>(p, bd[f]);
+          const TG* p = g_q + (d.rel_center - qi + jq);
+          if (inside) load4u<TG>(p, bd[f]);
           else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (jq + r >= 0 && jq + r < Tn) bd[f][r] = to_f32(p[r]);
           }
         } else {                // legacy rel_shift (view-reinterpretation wrap)
-          if (inside && jq + 3 <= qi) load4u<T>(g_q + (Tn - 1 - qi + jq), bd[f]);
-          else if (inside && jq > qi + 1) load4u<T>(g_q1 + (jq - qi - 2), bd[f]);
+          if (inside && jq + 3 <= qi) load4u<TG>(g_q + (Tn - 1 - qi + jq), bd[f]);
+          else if (inside && jq > qi + 1) load4u<TG>(g_q1 + (jq - qi - 2), bd[f]);
           else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -218,20 +299,20 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
     for (int s = 0; s < NKS; ++s) {   // NF independent accumulator chains per contraction step
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        const T* ap = reinterpret_cast<const T*>(ks + (size_t)(16 * f + qc) * KP) + 32 * s + 8 * g;
-        Vec a = load8<T>(ap);
+        const Vec a = lds8<T>(ks + (size_t)(16 * f + qc) * KP + (size_t)(32 * s + 8 * g) * sizeof(T));
         mma16(a, qf[s], st[f]);
       }
     }
     // ---- bias terms, scale, mask, online softmax ----
     float mx = -INFINITY;
+    const float inv_qk = SPLIT ? attn_exp2i(-(eq + ek)) : 1.f;     // exact un-scale of q . k
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const f32x4 kq = *reinterpret_cast<const f32x4*>(kus + 16 * f + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * f + 4 * g + r;
-        float s = (j >= 0 && j < Tk) ? (st[f][r] + kq[r] + bd[f][r]) * d.scale : -INFINITY;
+        float s = (j >= 0 && j < Tk) ? ((SPLIT ? st[f][r] * inv_qk : st[f][r]) + kq[r] + bd[f][r]) * d.scale : -INFINITY;
         st[f][r] = s;
         mx = fmaxf(mx, s);
       }
@@ -251,27 +332,49 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
         psum += p;
       }
     l_run = l_run * alpha + psum;
+    // split arithmetic: the O accumulators live at 2^(15 + ev) (P at the fixed scale 2^15, V^T at this tile's 2^ev): moving from the previous
+    // tile's scale to this one's is an exact power of two folded into the online-softmax rescale
+    const float oscale = SPLIT ? alpha * attn_exp2i(ev - ev_prev) : alpha;
+    ev_prev = ev;
 #pragma unroll
     for (int f = 0; f < NDF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ot[f][r] *= alpha;
+      for (int r = 0; r < 4; ++r) ot[f][r] *= oscale;
 
     // ---- O^T += V^T P^T over two 32-key blocks.  Contraction slots of k-group g in block kb:
     //      keys {32kb + 4g + r} (from st[2kb]) then {32kb + 16 + 4g + r} (from st[2kb+1]) ----
 #pragma unroll
     for (int kb = 0; kb < KBT / 32; ++kb) {
       Vec pb;
+      if constexpr (SPLIT) {          // P in [0, 1] at the fixed scale 2^15
+        f32x8 pv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pb[r] = from_f32<T>(st[2 * kb][r]);
-        pb[4 + r] = from_f32<T>(st[2 * kb + 1][r]);
+        for (int r = 0; r < 4; ++r) { pv[r] = st[2 * kb][r]; pv[4 + r] = st[2 * kb + 1][r]; }
+        pb = split8(pv, 32768.f);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pb[r] = from_f32<T>(st[2 * kb][r]);
+          pb[4 + r] = from_f32<T>(st[2 * kb + 1][r]);
+        }
       }
 #pragma unroll
       for (int f = 0; f < NDF; ++f) {
-        const T* vr = reinterpret_cast<const T*>(vs + (size_t)(16 * f + qc) * VP) + 32 * kb + 4 * g;
         Vec a;
+        if constexpr (SPLIT) {        // keys 32 kb + 4 g + {0..3} and + 16: two half-units of the planar layout (8 keys = 16 B hi | 16 B lo)
+          const char* vrow = vs + (size_t)(16 * f + qc) * VP;
+          const int c0 = 32 * kb + 4 * g, c1 = c0 + 16;
+          const char* p0 = vrow + (size_t)(c0 >> 3) * 32 + (size_t)(c0 & 7) * 2;
+          const char* p1 = vrow + (size_t)(c1 >> 3) * 32 + (size_t)(c1 & 7) * 2;
+          const f16x4 h0 = *reinterpret_cast<const f16x4*>(p0), l0 = *reinterpret_cast<const f16x4*>(p0 + 16);
+          const f16x4 h1 = *reinterpret_cast<const f16x4*>(p1), l1 = *reinterpret_cast<const f16x4*>(p1 + 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = vr[r]; a[4 + r] = vr[16 + r]; }
+          for (int r = 0; r < 4; ++r) { a.hi[r] = h0[r]; a.hi[4 + r] = h1[r]; a.lo[r] = l0[r]; a.lo[4 + r] = l1[r]; }
+        } else {
+          const T* vr = reinterpret_cast<const T*>(vs + (size_t)(16 * f + qc) * VP) + 32 * kb + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] = vr[r]; a[4 + r] = vr[16 + r]; }
+        }
         mma16(a, pb, ot[f]);
       }
     }
@@ -281,18 +384,18 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
   if (qi < Tn) {
-    const float inv = 1.f / l_run;
-    T* og = (T*)d.out + (int64_t)(row0 + qi) * d.ldo + h * DK;
+    const float inv = (SPLIT ? attn_exp2i(-(15 + ev_prev)) : 1.f) / l_run;
+    TG* og = (TG*)d.out + (int64_t)(row0 + qi) * d.ldo + h * DK;
 #pragma unroll
     for (int f = 0; f < NDF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) og[16 * f + 4 * g + r] = from_f32<T>(ot[f][r] * inv);
+      for (int r = 0; r < 4; ++r) og[16 * f + 4 * g + r] = from_f32<TG>(ot[f][r] * inv);
   }
 }
 
 template <typename T, int DK, int KBT = KB>
 int launch_attn_kb(const jatts_relattn_desc& d, hipStream_t s) {
-  const size_t lds = (size_t)KBT * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KBT * sizeof(T) + 16) + KBT * sizeof(float);
+  const size_t lds = (size_t)KBT * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KBT * sizeof(T) + 16) + KBT * sizeof(float) + 64;
   dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
   auto kern = relattn_kernel<T, DK, KBT>;
   if (lds > 64 * 1024) {
@@ -349,6 +452,7 @@ extern "C" int jatts_relpos_attention(const jatts_relattn_desc* d, void* stream)
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return dispatch_dk<f16>(*d, s);
   if (d->dtype == JATTS_F32) return dispatch_dk<float>(*d, s);
+  if (d->dtype == JATTS_F32S) return dispatch_dk<f16s>(*d, s);     // f32 tensors, split f16 hi / lo MFMA operands (round 4)
   return jatts_set_error_msg(JATTS_ERR_ARG, "relpos_attention: unknown dtype");
 }
 

@@ -4,14 +4,14 @@
 // inside a SURVEY row counted as implemented (missing #5).  A two-level batch index (outer, inner) with independent strides per
 // operand covers (B, H, ...) tensors with an operand shared over B (the position projection p_h: outer stride 0).
 //
-// One workgroup = 4 waves = a 128 x 128 tile of C (each wave 64 x 64 = 2 x 2 fragments, 64 accumulator registers); K runs in chunks of 16
+// One workgroup = 4 waves = a 128 x 128 (or 128 x 64) tile of C (each wave 64 x 64 = 2 x 2 fragments, or 64 x 32); K runs in chunks of 32
 // through a double-buffered LDS pair As[k][m], Bs[k][n] (pitch 132: the transposing store of a K-contiguous operand hits 64 distinct
 // banks); the loads of chunk i + 1 are issued before the MFMAs of chunk i.  A fragment operand is one ds_read_b32 per lane and K-pair.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, BP = BM + 4;   // LDS pitch in floats
+constexpr int BM = 128, BK = 32, BP = BM + 4;   // LDS pitch in floats.  BN = 128 or 64 (template): n = d_k = 192 wastes a third of a 128-wide tile
 
 struct BgemmArgs {
   const float* a;
@@ -24,102 +24,114 @@ struct BgemmArgs {
   int accumulate;
 };
 
-// One operand chunk (rows r0 .. r0 + 127 of the "long" dimension, k0 .. k0 + 15) -> registers.  trans_k = the operand is stored with K
-// contiguous (A untransposed / B transposed): a thread takes 2 x 4 consecutive k of one row; otherwise the long dimension is contiguous:
-// 2 x 4 consecutive rows of one k.
-__device__ __forceinline__ void chunk_load(f32x4 (&v)[2], const float* base, int ld, bool k_contig, int r0, int R, int k0, int K, bool vec) {
+// One operand chunk (RW rows of the "long" dimension from r0, BK contraction steps from k0) -> registers, 16 bytes per load.  k_contig = the
+// operand is stored with K contiguous (A untransposed / B transposed): a thread takes 4 consecutive k of one row per load; otherwise the
+// long dimension is contiguous: 4 consecutive rows of one k.
+template <int RW>
+struct Chunk {
+  static constexpr int NL = RW * BK / 4 / 256;      // 16-byte loads per thread
+  f32x4 v[NL];
+  __device__ __forceinline__ void load(const float* base, int ld, bool k_contig, int r0, int R, int k0, int K, bool vec) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (k_contig) {
-      const int r = r0 + (int)(threadIdx.x >> 2) + 64 * j, k = k0 + 4 * (int)(threadIdx.x & 3);
-      if (r < R) {
-        const float* p = base + (int64_t)r * ld + k;
-        if (k + 3 < K && vec) o = *reinterpret_cast<const f32x4*>(p);
-        else {
+    for (int j = 0; j < NL; ++j) {
+      const int u = (int)threadIdx.x + 256 * j;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (k_contig) {
+        const int r = r0 + u / (BK / 4), k = k0 + 4 * (u % (BK / 4));
+        if (r < R) {
+          const float* p = base + (int64_t)r * ld + k;
+          if (k + 3 < K && vec) o = *reinterpret_cast<const f32x4*>(p);
+          else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < K) o[e] = p[e];
+            for (int e = 0; e < 4; ++e)
+              if (k + e < K) o[e] = p[e];
+          }
+        }
+      } else {
+        const int k = k0 + u / (RW / 4), r = r0 + 4 * (u % (RW / 4));
+        if (k < K) {
+          const float* p = base + (int64_t)k * ld + r;
+          if (r + 3 < R && vec) o = *reinterpret_cast<const f32x4*>(p);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r + e < R) o[e] = p[e];
+          }
         }
       }
-    } else {
-      const int k = k0 + (int)(threadIdx.x >> 5) + 8 * j, r = r0 + 4 * (int)(threadIdx.x & 31);
-      if (k < K) {
-        const float* p = base + (int64_t)k * ld + r;
-        if (r + 3 < R && vec) o = *reinterpret_cast<const f32x4*>(p);
-        else {
+      v[j] = o;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, bool k_contig) const {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (r + e < R) o[e] = p[e];
-        }
+    for (int j = 0; j < NL; ++j) {
+      const int u = (int)threadIdx.x + 256 * j;
+      if (k_contig) {      // transpose on the way in: s[k][r]
+        const int r = u / (BK / 4), k = 4 * (u % (BK / 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[(k + e) * BP + r] = v[j][e];
+      } else {
+        const int k = u / (RW / 4), r = 4 * (u % (RW / 4));
+        *reinterpret_cast<f32x4*>(s + k * BP + r) = v[j];
       }
     }
-    v[j] = o;
   }
-}
-__device__ __forceinline__ void chunk_store(const f32x4 (&v)[2], float* s, bool k_contig) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (k_contig) {      // transpose on the way in: s[k][r]
-      const int r = (int)(threadIdx.x >> 2) + 64 * j, k = 4 * (int)(threadIdx.x & 3);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s[(k + e) * BP + r] = v[j][e];
-    } else {
-      const int k = (int)(threadIdx.x >> 5) + 8 * j, r = 4 * (int)(threadIdx.x & 31);
-      *reinterpret_cast<f32x4*>(s + k * BP + r) = v[j];
-    }
-  }
-}
+};
 
+template <int WNF>      // 32-column fragments per wave along n: 2 -> 128 x 128 tile, 1 -> 128 x 64
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float sm[2][2][BK * BP];   // [buffer][A | B][k][m or n]
+  constexpr int BN = 64 * WNF;
+  extern __shared__ __attribute__((aligned(16))) float sm_raw[];      // [buffer][A | B][k][m or n]: 2 x 2 x BK x BP floats (67.6 KB)
+  float (*sm)[2][BK * BP] = reinterpret_cast<float (*)[2][BK * BP]>(sm_raw);
   const int bo = blockIdx.z / g.n_inner, bi = blockIdx.z - bo * g.n_inner;
   const float* A = g.a + bo * g.sa_o + bi * g.sa_i;
   const float* B = g.b + bo * g.sb_o + bi * g.sb_i;
   float* C = g.c + bo * g.sc_o + bi * g.sc_i;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32 * WNF;
   const int lo = lane & 31, hi = lane >> 5;
   const bool ak = g.ta == 0, bk = g.tb != 0;      // K contiguous in memory?
   // 16-byte loads where this matrix allows them (leading dimension and start aligned); element loads otherwise
   const bool va = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0, vb = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][WNF];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WNF; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[2], rb[2];
-  chunk_load(ra, A, g.lda, ak, m0, g.M, 0, g.K, va);
-  chunk_load(rb, B, g.ldb, bk, n0, g.N, 0, g.K, vb);
-  chunk_store(ra, sm[0][0], ak);
-  chunk_store(rb, sm[0][1], bk);
+  Chunk<BM> ra;
+  Chunk<BN> rb;
+  ra.load(A, g.lda, ak, m0, g.M, 0, g.K, va);
+  rb.load(B, g.ldb, bk, n0, g.N, 0, g.K, vb);
+  ra.store(sm[0][0], ak);
+  rb.store(sm[0][1], bk);
   __syncthreads();
   const int n_chunks = (g.K + BK - 1) / BK;
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
     if (more) {
-      chunk_load(ra, A, g.lda, ak, m0, g.M, (ci + 1) * BK, g.K, va);
-      chunk_load(rb, B, g.ldb, bk, n0, g.N, (ci + 1) * BK, g.K, vb);
+      ra.load(A, g.lda, ak, m0, g.M, (ci + 1) * BK, g.K, va);
+      rb.load(B, g.ldb, bk, n0, g.N, (ci + 1) * BK, g.K, vb);
     }
     const float* as = sm[ci & 1][0] + hi * BP + wm + lo;
     const float* bs = sm[ci & 1][1] + hi * BP + wn + lo;
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
       const float a0 = as[2 * kp * BP], a1 = as[2 * kp * BP + 32];
-      const float b0 = bs[2 * kp * BP], b1 = bs[2 * kp * BP + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < WNF; ++j) {
+        const float bj = bs[2 * kp * BP + 32 * j];
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bj, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bj, acc[1][j], 0, 0, 0);
+      }
     }
     if (more) {
-      chunk_store(ra, sm[(ci + 1) & 1][0], ak);
-      chunk_store(rb, sm[(ci + 1) & 1][1], bk);
+      ra.store(sm[(ci + 1) & 1][0], ak);
+      rb.store(sm[(ci + 1) & 1][1], bk);
     }
     __syncthreads();
   }
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WNF; ++j) {
       const int n = n0 + wn + 32 * j + lo;
       if (n >= g.N) continue;
 #pragma unroll
@@ -151,8 +163,21 @@ extern "C" int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, i
     return jatts_set_error_msg(JATTS_ERR_ARG, "bgemm: bad geometry");
   if ((int64_t)n_outer * n_inner > 65535) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "bgemm: at most 65 535 matrices per launch");
   BgemmArgs g{a, b, c, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner, lda, ldb, ldc, trans_a, trans_b, n_inner, m, n, k, alpha, accumulate};
-  dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((m + BM - 1) / BM), (unsigned)(n_outer * n_inner));
-  hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+  // 64-wide n tiles where a 128-wide one would be more than a quarter empty (n = d_k = 192: 3 x 64 instead of 2 x 128 with 64 idle columns)
+  const int n128 = (n + 127) / 128 * 128, n64 = (n + 63) / 64 * 64;
+  constexpr int lds = 2 * 2 * BK * BP * (int)sizeof(float);
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute((const void*)bgemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+           hipFuncSetAttribute((const void*)bgemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+  }();
+  if (!attr_ok) return jatts_set_error_msg(JATTS_ERR_HIP, "bgemm: could not raise the dynamic LDS limit");
+  if (n64 * 4 <= n128 * 3) {
+    dim3 grid((unsigned)(n64 / 64), (unsigned)((m + BM - 1) / BM), (unsigned)(n_outer * n_inner));
+    hipLaunchKernelGGL(bgemm_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, g);
+  } else {
+    dim3 grid((unsigned)(n128 / 128), (unsigned)((m + BM - 1) / BM), (unsigned)(n_outer * n_inner));
+    hipLaunchKernelGGL(bgemm_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, g);
+  }
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

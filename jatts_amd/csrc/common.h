@@ -77,6 +77,12 @@ __device__ __forceinline__ void mma16(const f32x8& a, const f32x8& b, f32x4& c) 
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
 }
 
+__device__ __forceinline__ void mma16(const f16sx8& a, const f16sx8& b, f32x4& c) {   // split operands: lo.hi + hi.lo + hi.hi, one accumulator
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+}
+
 // C/D fragment maps (dtype independent on gfx950):
 //  32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), reg in [0,16)
 //  16x16: col = lane&15, row = 4*(lane>>4) + reg,                  reg in [0,4)

@@ -179,7 +179,7 @@ class ConformerRunner:
                 hip.conv1d(rb, qk, heads[h], hip.round_up(dk, 64), n_pos, 1, dtype=self.dtype, bias=cv[h], ldx=2 * A,
                            x_col0=h * dk, out=g, out_ld=H * ldg, out_col0=h * ldg)
         ctx = hip.relpos_attention(rb, qk, 2 * A, qk, 2 * A, vt, ldvt, g, ldg, ku, 1.0 / math.sqrt(dk),
-                                   H, dk, self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center, vt_col0=vcol,
+                                   H, dk, hip.F32S if self.split else self.dtype, q_col0=0, k_col0=A, rel_mode=rel_mode, rel_center=rel_center, vt_col0=vcol,
                                    kv_len=kv_len)
         hip.conv1d(rb, ctx, L["o"].w, A, A, 1, dtype=self.dtype, bias=L["o"].b, resid=x, out=x, out_f32=True)
 

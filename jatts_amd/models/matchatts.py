@@ -88,6 +88,7 @@ class _TBlock:
     def __init__(self, sd, p, heads, dt, dev):
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
         self.heads = heads
+        self.split = dt == hip.F32 and hip._SPLIT_WEIGHTS[0]      # set_precision("fp32_split"): the attention takes the split arithmetic too
         self.n1 = (f32(sd[p + "norm1.weight"]), f32(sd[p + "norm1.bias"]))
         self.n3 = (f32(sd[p + "norm3.weight"]), f32(sd[p + "norm3.bias"]))
         wq, wk = sd[p + "attn1.to_q.weight"], sd[p + "attn1.to_k.weight"]
@@ -112,7 +113,7 @@ class _TBlock:
         vcol, ldvt = rb.vt_layout()
         vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt, y_seq_col0=vcol)
         a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, ldvt, None, 0, key_bias, self.dh ** -0.5, self.heads,
-                                 self.dh, dt, q_col0=0, k_col0=I, rel_mode=0, vt_col0=vcol)
+                                 self.dh, hip.F32S if self.split else dt, q_col0=0, k_col0=I, rel_mode=0, vt_col0=vcol)
         hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)
         n = hip.layernorm(x, self.n3[0], self.n3[1], dt, GN_EPS)
         u = hip.conv1d(rb, n, self.ff1.w, self.ff1.c_in, self.ff1.n_out, 1, dtype=dt, bias=self.ff1.b)

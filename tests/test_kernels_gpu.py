@@ -492,7 +492,7 @@ def test_hifigan_resunit_len_mul(cuda, lib):
     assert relerr(y, ref) <= TOL["fp32"]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32_split", "fp16"])     # fp32_split (round 4): f32 tensors, split hi / lo MFMA operands, the f32 tolerance
 @pytest.mark.parametrize("pad_vt", [False, True])   # True: RaggedBatch.vt_layout -> aligned 16-byte V^T staging
 @pytest.mark.parametrize("H,dk,lens,rel", [(2, 32, [24, 9, 33], True), (2, 192, [130, 64], True),
                                           (2, 96, [65], True), (4, 64, [100, 1, 17], False),
@@ -521,7 +521,7 @@ def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
         outs.append((p @ vs).transpose(0, 1).reshape(T, A))
         o += T
     ref = torch.cat(outs)
-    dt = _dt(prec)
+    dt = hip.F32S if prec == "fp32_split" else _dt(prec)
     tdt = hip.torch_dtype(dt)
     rb = _ragged(lens, cuda)
     vcol, ldvt = rb.vt_layout() if pad_vt else (None, R)
@@ -535,7 +535,21 @@ def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
                                gm.reshape(R, H * ldg).to(cuda).to(tdt) if rel else None, ldg,
                                ku.to(cuda), scale, H, dk, dt, vt_col0=vcol)
     e = relerr(out.float(), ref)
-    assert e <= (5e-5 if prec == "fp32" else 3e-3), f"attention {H}x{dk} {prec}: rel err {e:.3e}"
+    assert e <= (3e-3 if prec == "fp16" else 5e-5), f"attention {H}x{dk} {prec}: rel err {e:.3e}"
+    if prec == "fp32_split":      # next to the exact-f32 kernel on the same inputs (not narrower: at most twice its error), and batch independence
+        o32 = hip.relpos_attention(rb, q.to(cuda), A, k.to(cuda), A, vt, ldvt, gm.reshape(R, H * ldg).to(cuda) if rel else None, ldg,
+                                   ku.to(cuda), scale, H, dk, hip.F32, vt_col0=vcol)
+        assert e <= max(2.0 * relerr(o32, ref), 2e-6), (e, relerr(o32, ref))
+        if len(lens) > 1 and pad_vt:
+            T0 = lens[0]
+            rb0 = _ragged([T0], cuda)
+            vc0, ld0 = rb0.vt_layout()
+            vt0 = torch.zeros(A, ld0, device=cuda)
+            vt0[:, :T0] = v[:T0].t().to(cuda)
+            o0 = hip.relpos_attention(rb0, q[:T0].contiguous().to(cuda), A, k[:T0].contiguous().to(cuda), A, vt0, ld0,
+                                      gm[:T0].reshape(T0, H * ldg).contiguous().to(cuda) if rel else None, ldg, ku[:T0].contiguous().to(cuda), scale, H, dk,
+                                      hip.F32S, vt_col0=vc0)
+            assert torch.equal(o0, out[:T0])
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
