@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 32, BP = BM + 4;   // LDS pitch in floats.  BN = 128 or 64 (template): n = d_k = 192 wastes a third of a 128-wide tile
+constexpr int BM = 128, BP = BM + 4;   // LDS pitch of the A tile in floats.  BN = 64 / 128 / 192 and the chunk depth BK are template parameters
 
 struct BgemmArgs {
   const float* a;
@@ -22,20 +22,23 @@ struct BgemmArgs {
   int n_inner, M, N, K;
   float alpha;
   int accumulate;
+  int n_batch, gx, gy;      // XCD-aware 1-D grid: workgroup id -> (matrix, tile), see bgemm_kernel
 };
 
 // One operand chunk (RW rows of the "long" dimension from r0, BK contraction steps from k0) -> registers, 16 bytes per load.  k_contig = the
 // operand is stored with K contiguous (A untransposed / B transposed): a thread takes 4 consecutive k of one row per load; otherwise the
 // long dimension is contiguous: 4 consecutive rows of one k.
-template <int RW>
+template <int RW, int BK, int PITCH>
 struct Chunk {
-  static constexpr int NL = RW * BK / 4 / 256;      // 16-byte loads per thread
+  static constexpr int NL = (RW * BK / 4 + 255) / 256;      // 16-byte loads per thread
+  static constexpr int TOTAL = RW * BK / 4;
   f32x4 v[NL];
   __device__ __forceinline__ void load(const float* base, int ld, bool k_contig, int r0, int R, int k0, int K, bool vec) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int u = (int)threadIdx.x + 256 * j;
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (TOTAL % 256 != 0 && u >= TOTAL) { v[j] = o; continue; }
       if (k_contig) {
         const int r = r0 + u / (BK / 4), k = k0 + 4 * (u % (BK / 4));
         if (r < R) {
@@ -66,28 +69,38 @@ struct Chunk {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int u = (int)threadIdx.x + 256 * j;
+      if (TOTAL % 256 != 0 && u >= TOTAL) continue;
       if (k_contig) {      // transpose on the way in: s[k][r]
         const int r = u / (BK / 4), k = 4 * (u % (BK / 4));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[(k + e) * BP + r] = v[j][e];
+        for (int e = 0; e < 4; ++e) s[(k + e) * PITCH + r] = v[j][e];
       } else {
         const int k = u / (RW / 4), r = 4 * (u % (RW / 4));
-        *reinterpret_cast<f32x4*>(s + k * BP + r) = v[j];
+        *reinterpret_cast<f32x4*>(s + k * PITCH + r) = v[j];
       }
     }
   }
 };
 
-template <int WNF>      // 32-column fragments per wave along n: 2 -> 128 x 128 tile, 1 -> 128 x 64
+// WNF = 32-column fragments per wave along n: 1 -> 128 x 64 tile, 2 -> 128 x 128, 3 -> 128 x 192 (n = d_k = 192 in ONE tile: the T x T operand of
+// P v and of the key / value gradients is then read once instead of once per n tile).
+// 1-D grid in XCD-aware order: workgroup id lands on XCD id % 8 (each with its own L2), so matrix b = 8 (m / tiles) + id % 8 with m = id / 8 --
+// all tiles of a matrix run on ONE XCD, back to back, and its operands are fetched from HBM once instead of once per XCD that happens to
+// hold one of its tiles (the first version, a 3-D grid, ran at 45-65 TFLOP/s against rocBLAS' 100-110).
+template <int WNF, int BK>
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
-  constexpr int BN = 64 * WNF;
-  extern __shared__ __attribute__((aligned(16))) float sm_raw[];      // [buffer][A | B][k][m or n]: 2 x 2 x BK x BP floats (67.6 KB)
-  float (*sm)[2][BK * BP] = reinterpret_cast<float (*)[2][BK * BP]>(sm_raw);
-  const int bo = blockIdx.z / g.n_inner, bi = blockIdx.z - bo * g.n_inner;
+  constexpr int BN = 64 * WNF, BPN = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm_raw[];      // [buffer][A: BK x BP | B: BK x BPN]
+  constexpr int BUF = BK * (BP + BPN);
+  const int xcd = (int)(blockIdx.x & 7u), mloc = (int)(blockIdx.x >> 3);
+  const int tiles = g.gx * g.gy;
+  const int bz = 8 * (mloc / tiles) + xcd, tile = mloc % tiles;
+  if (bz >= g.n_batch) return;
+  const int bo = bz / g.n_inner, bi = bz - bo * g.n_inner;
   const float* A = g.a + bo * g.sa_o + bi * g.sa_i;
   const float* B = g.b + bo * g.sb_o + bi * g.sb_i;
   float* C = g.c + bo * g.sc_o + bi * g.sc_i;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = (tile / g.gx) * BM, n0 = (tile % g.gx) * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32 * WNF;
   const int lo = lane & 31, hi = lane >> 5;
@@ -103,12 +116,12 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Chunk<BM> ra;
-  Chunk<BN> rb;
+  Chunk<BM, BK, BP> ra;
+  Chunk<BN, BK, BPN> rb;
   ra.load(A, g.lda, ak, m0, g.M, 0, g.K, va);
   rb.load(B, g.ldb, bk, n0, g.N, 0, g.K, vb);
-  ra.store(sm[0][0], ak);
-  rb.store(sm[0][1], bk);
+  ra.store(sm_raw, ak);
+  rb.store(sm_raw + BK * BP, bk);
   __syncthreads();
   const int n_chunks = (g.K + BK - 1) / BK;
   for (int ci = 0; ci < n_chunks; ++ci) {
@@ -117,21 +130,33 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
       ra.load(A, g.lda, ak, m0, g.M, (ci + 1) * BK, g.K, va);
       rb.load(B, g.ldb, bk, n0, g.N, (ci + 1) * BK, g.K, vb);
     }
-    const float* as = sm[ci & 1][0] + hi * BP + wm + lo;
-    const float* bs = sm[ci & 1][1] + hi * BP + wn + lo;
+    const float* as = sm_raw + (ci & 1) * BUF + hi * BP + wm + lo;
+    const float* bs = sm_raw + (ci & 1) * BUF + BK * BP + hi * BPN + wn + lo;
+    // fragments of 8 K-pairs at a time into registers, THEN their MFMAs: a ds_read right in front of its MFMA exposes the LDS latency 16 times
+    // per chunk (the first version ran at 55-63 TFLOP/s)
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      const float a0 = as[2 * kp * BP], a1 = as[2 * kp * BP + 32];
+    for (int k8 = 0; k8 < BK / 2; k8 += 8) {
+      float av[8][2], bv[8][WNF];
 #pragma unroll
-      for (int j = 0; j < WNF; ++j) {
-        const float bj = bs[2 * kp * BP + 32 * j];
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bj, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bj, acc[1][j], 0, 0, 0);
+      for (int q = 0; q < 8; ++q) {
+        av[q][0] = as[2 * (k8 + q) * BP];
+        av[q][1] = as[2 * (k8 + q) * BP + 32];
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) bv[q][j] = bs[2 * (k8 + q) * BPN + 32 * j];
       }
+      __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks every read next to its MFMA behind an lgkmcnt(0))
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], bv[q][j], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], bv[q][j], acc[1][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
-      ra.store(sm[(ci + 1) & 1][0], ak);
-      rb.store(sm[(ci + 1) & 1][1], bk);
+      ra.store(sm_raw + ((ci + 1) & 1) * BUF, ak);
+      rb.store(sm_raw + ((ci + 1) & 1) * BUF + BK * BP, bk);
     }
     __syncthreads();
   }
@@ -161,23 +186,27 @@ extern "C" int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, i
   if (!a || !b || !c) return jatts_set_error_msg(JATTS_ERR_ARG, "bgemm: null pointer");
   if (n_outer < 1 || n_inner < 1 || m < 1 || n < 1 || k < 1 || lda < 1 || ldb < 1 || ldc < 1)
     return jatts_set_error_msg(JATTS_ERR_ARG, "bgemm: bad geometry");
-  if ((int64_t)n_outer * n_inner > 65535) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "bgemm: at most 65 535 matrices per launch");
-  BgemmArgs g{a, b, c, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner, lda, ldb, ldc, trans_a, trans_b, n_inner, m, n, k, alpha, accumulate};
-  // 64-wide n tiles where a 128-wide one would be more than a quarter empty (n = d_k = 192: 3 x 64 instead of 2 x 128 with 64 idle columns)
+  BgemmArgs g{a, b, c, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner, lda, ldb, ldc, trans_a, trans_b, n_inner, m, n, k, alpha, accumulate, 0, 0, 0};
+  // n tile: 192 in one piece (n = d_k = 192), else 64-wide where a 128-wide tile would be more than a quarter empty
+  const int n_batch = n_outer * n_inner;
+  auto launch = [&](auto kern, int bn, int bk) -> int {
+    const int lds = 2 * bk * (BP + bn + 4) * (int)sizeof(float);
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return jatts_set_error_msg(JATTS_ERR_HIP, "bgemm: could not raise the dynamic LDS limit");
+    g.n_batch = n_batch;
+    g.gx = (n + bn - 1) / bn;
+    g.gy = (m + BM - 1) / BM;
+    const int64_t total = (int64_t)8 * ((n_batch + 7) / 8) * g.gx * g.gy;
+    if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "bgemm: launch too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, (hipStream_t)stream, g);
+    return JATTS_OK;
+  };
   const int n128 = (n + 127) / 128 * 128, n64 = (n + 63) / 64 * 64;
-  constexpr int lds = 2 * 2 * BK * BP * (int)sizeof(float);
-  static const bool attr_ok = [] {
-    return hipFuncSetAttribute((const void*)bgemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-           hipFuncSetAttribute((const void*)bgemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-  }();
-  if (!attr_ok) return jatts_set_error_msg(JATTS_ERR_HIP, "bgemm: could not raise the dynamic LDS limit");
-  if (n64 * 4 <= n128 * 3) {
-    dim3 grid((unsigned)(n64 / 64), (unsigned)((m + BM - 1) / BM), (unsigned)(n_outer * n_inner));
-    hipLaunchKernelGGL(bgemm_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, g);
-  } else {
-    dim3 grid((unsigned)(n128 / 128), (unsigned)((m + BM - 1) / BM), (unsigned)(n_outer * n_inner));
-    hipLaunchKernelGGL(bgemm_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, g);
-  }
+  int rc;
+  if (n > 128 && n <= 192) rc = launch(bgemm_kernel<3, 16>, 192, 16);
+  else if (n64 * 4 <= n128 * 3) rc = launch(bgemm_kernel<1, 32>, 64, 32);
+  else rc = launch(bgemm_kernel<2, 32>, 128, 32);
+  if (rc != JATTS_OK) return rc;
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
