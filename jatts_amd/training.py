@@ -387,6 +387,7 @@ class FastSpeech2Trainer:
 
     _graph_capable = True      # a subclass whose step synchronises with the host switches it off
     SCALAR_RING = 8            # pinned staging slots for the per-step scalars of a replayed graph
+    GRAD_NORM_SANITY = 1e12    # a replayed step whose (pre-clip) gradient norm is not finite or beyond this is treated as a broken capture
 
     def _signature(self, batch):
         sig = []
@@ -434,7 +435,7 @@ class FastSpeech2Trainer:
             # host may run many steps ahead of the GPU (losses stay on the device), and one shared staging pair would let step N's
             # asynchronous copy read step N + 1's values
             st["ring"] = [dict(seed=torch.zeros(1, dtype=torch.int64).pin_memory(), hyper=torch.zeros(7, dtype=torch.float32).pin_memory(),
-                               ev=None) for _ in range(self.SCALAR_RING)]
+                               gn=torch.zeros(1, dtype=torch.float64).pin_memory(), step=0, ev=None) for _ in range(self.SCALAR_RING)]
             st["ring_pos"] = 0
             m = self.model
             m._seed_dev, m._static_olens = st["seed"], [int(v) for v in batch["olens"].tolist()]
@@ -482,6 +483,17 @@ class FastSpeech2Trainer:
         lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **self._sched_params())
         self.last_lr = lr
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        # guard: the gradient norm of every replayed step comes back through the ring; a finished slot that holds a non-finite or
+        # absurd norm means the replay produced garbage (a reduction that does not survive capture on this stack, see _graph_step's notes):
+        # refuse to go on silently -- the signature is marked eager-only and the step raises, a few steps late, without a host sync per step
+        for sl in st["ring"]:
+            if sl["ev"] is not None and sl["step"] and sl["ev"].query():
+                v = float(sl["gn"][0])
+                sl["step"] = 0
+                if not (v == v and abs(v) < self.GRAD_NORM_SANITY):
+                    self._graphs[sig] = {"graph": None, "eager_only": True}
+                    raise FloatingPointError(f"graph replay produced a gradient norm of {v} (trainer step {sl['at']}): replay of this batch signature is "
+                                             "disabled, later steps of it run eagerly; the parameters are suspect -- resume from the last checkpoint")
         slot = st["ring"][st["ring_pos"] % len(st["ring"])]
         st["ring_pos"] += 1
         if slot["ev"] is not None:
@@ -490,9 +502,12 @@ class FastSpeech2Trainer:
         slot["hyper"].copy_(torch.tensor(hip.adam_hyper(lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps), dtype=torch.float32))
         st["seed"].copy_(slot["seed"], non_blocking=True)
         st["hyper"].copy_(slot["hyper"], non_blocking=True)
+        st["graph"].replay()
+        if "grad_norm" in st["out"]:
+            slot["gn"].copy_(st["out"]["grad_norm"].reshape(1), non_blocking=True)
+            slot["step"], slot["at"] = 1, self.steps
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
-        st["graph"].replay()
         st["used"] = self.steps
         self.model._prep = None
         if self._bad_ids is None:

@@ -847,3 +847,32 @@ def test_captured_graph_pins_its_cached_inputs_and_stages_scalars_per_step(cuda,
         for k in ("loss", "mel_loss", "duration_loss", "pitch_loss", "energy_loss", "grad_norm"):
             assert float(x[k]) == float(y[k]), (s, k, float(x[k]), float(y[k]))
     assert torch.equal(a.flat_p, b.flat_p)
+
+
+def test_graph_replay_guard_trips_on_an_absurd_gradient_norm(cuda, lib):
+    """a capture that replays garbage must not train on silently.  Every replayed step's gradient norm travels back through
+    the pinned ring (no host synchronisation per step); a finished slot beyond GRAD_NORM_SANITY raises, the signature falls back to eager.
+    Provoked here by lowering the threshold below any real norm."""
+    from jatts_amd.models import FastSpeech2
+    from jatts_amd.training import FastSpeech2Trainer
+    z, zi, keys, cfg = _train_golden()
+    t = lambda k: torch.tensor(zi[k])  # noqa: E731
+    il, ol = t("text_lengths"), t("feats_lengths")
+    batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
+                 pitch_lens=il, energys=t("energy"), energy_lens=il)
+    m = FastSpeech2(idim=20, **{**FS2_SMALL, "stop_gradient_from_pitch_predictor": True, "use_masking": True})
+    m.load_state_dict(golden_state(keys, 0))
+    tr = FastSpeech2Trainer(m.to(cuda), lr=1e-3, grad_norm=1.0, warmup_steps=10, capture_graph=True)
+    for _ in range(3):                      # eager, capture, one replay: fine at the real threshold
+        out = tr.train_step(batch)
+    torch.cuda.synchronize()
+    assert math.isfinite(float(out["loss"]))
+    tr.GRAD_NORM_SANITY = 1e-30
+    with pytest.raises(FloatingPointError):
+        for _ in range(4):
+            tr.train_step(batch)
+            torch.cuda.synchronize()
+    (st,) = tr._graphs.values()
+    assert st.get("eager_only")
+    tr.GRAD_NORM_SANITY = 1e12
+    assert math.isfinite(float(tr.train_step(batch)["loss"]))      # the signature keeps training, eagerly
