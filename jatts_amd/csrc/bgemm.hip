@@ -28,12 +28,39 @@ struct BgemmArgs {
 // One operand chunk (RW rows of the "long" dimension from r0, BK contraction steps from k0) -> registers, 16 bytes per load.  k_contig = the
 // operand is stored with K contiguous (A untransposed / B transposed): a thread takes 4 consecutive k of one row per load; otherwise the
 // long dimension is contiguous: 4 consecutive rows of one k.
-template <int RW, int BK, int PITCH>
-struct Chunk {
+template <int RW, int BK, int PITCH, bool KC, bool VEC>      // KC: K contiguous in memory; VEC: 16-byte loads allowed (compile time: a
+struct Chunk {                                               // run-time flag made hipcc emit every combination inside one kernel, waits and all)
   static constexpr int NL = (RW * BK / 4 + 255) / 256;      // 16-byte loads per thread
   static constexpr int TOTAL = RW * BK / 4;
   f32x4 v[NL];
-  __device__ __forceinline__ void load(const float* base, int ld, bool k_contig, int r0, int R, int k0, int K, bool vec) {
+  // vec (the matrix starts on a 16-byte boundary and ld % 4 == 0: every attention operand): ALL loads are issued unconditionally from clamped
+  // addresses and masked afterwards -- a load inside a per-element branch makes hipcc wait vmcnt(0) right behind it, i.e. one L2 round trip
+  // per 16 bytes, eight times per chunk (the first version of this kernel spent 4/5 of its time there).  A 16-byte piece that straddles the
+  // edge (k + 3 >= K or r + 3 >= R) stays inside its row because ld % 4 == 0.
+  __device__ __forceinline__ void load(const float* base, int ld, int r0, int R, int k0, int K) {
+    constexpr bool k_contig = KC;
+    if constexpr (VEC) {
+      int lim[NL], at[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int u = (int)threadIdx.x + 256 * j;
+        int r, k;
+        if (k_contig) { r = r0 + u / (BK / 4); k = k0 + 4 * (u % (BK / 4)); }
+        else { k = k0 + u / (RW / 4); r = r0 + 4 * (u % (RW / 4)); }
+        const bool in = (TOTAL % 256 == 0 || u < TOTAL) && r < R && k < K;
+        const int rc = r < R ? r : R - 1, kc = k < K ? k : K - 1;
+        // vector index along the contiguous dimension: clamp to the last full-or-partial piece of the row
+        const int64_t off = k_contig ? (int64_t)rc * ld + (kc & ~3) : (int64_t)kc * ld + (rc & ~3);
+        v[j] = *reinterpret_cast<const f32x4*>(base + off);
+        at[j] = k_contig ? k : r;
+        lim[j] = in ? (k_contig ? K : R) : -1;      // component e is valid iff at + e < lim
+      }
+#pragma unroll
+      for (int j = 0; j < NL; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = at[j] + e < lim[j] ? v[j][e] : 0.f;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int u = (int)threadIdx.x + 256 * j;
@@ -43,29 +70,24 @@ struct Chunk {
         const int r = r0 + u / (BK / 4), k = k0 + 4 * (u % (BK / 4));
         if (r < R) {
           const float* p = base + (int64_t)r * ld + k;
-          if (k + 3 < K && vec) o = *reinterpret_cast<const f32x4*>(p);
-          else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (k + e < K) o[e] = p[e];
-          }
+          for (int e = 0; e < 4; ++e)
+            if (k + e < K) o[e] = p[e];
         }
       } else {
         const int k = k0 + u / (RW / 4), r = r0 + 4 * (u % (RW / 4));
         if (k < K) {
           const float* p = base + (int64_t)k * ld + r;
-          if (r + 3 < R && vec) o = *reinterpret_cast<const f32x4*>(p);
-          else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (r + e < R) o[e] = p[e];
-          }
+          for (int e = 0; e < 4; ++e)
+            if (r + e < R) o[e] = p[e];
         }
       }
       v[j] = o;
     }
   }
-  __device__ __forceinline__ void store(float* s, bool k_contig) const {
+  __device__ __forceinline__ void store(float* s) const {
+    constexpr bool k_contig = KC;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int u = (int)threadIdx.x + 256 * j;
@@ -87,7 +109,7 @@ struct Chunk {
 // 1-D grid in XCD-aware order: workgroup id lands on XCD id % 8 (each with its own L2), so matrix b = 8 (m / tiles) + id % 8 with m = id / 8 --
 // all tiles of a matrix run on ONE XCD, back to back, and its operands are fetched from HBM once instead of once per XCD that happens to
 // hold one of its tiles (the first version, a 3-D grid, ran at 45-65 TFLOP/s against rocBLAS' 100-110).
-template <int WNF, int BK>
+template <int WNF, int BK, bool AK, bool BKC, bool VEC>      // AK / BKC: K contiguous in A (trans_a == 0) / in B (trans_b != 0)
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
   constexpr int BN = 64 * WNF, BPN = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float sm_raw[];      // [buffer][A: BK x BP | B: BK x BPN]
@@ -104,9 +126,6 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32 * WNF;
   const int lo = lane & 31, hi = lane >> 5;
-  const bool ak = g.ta == 0, bk = g.tb != 0;      // K contiguous in memory?
-  // 16-byte loads where this matrix allows them (leading dimension and start aligned); element loads otherwise
-  const bool va = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0, vb = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
 
   f32x16 acc[2][WNF];
 #pragma unroll
@@ -116,19 +135,19 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Chunk<BM, BK, BP> ra;
-  Chunk<BN, BK, BPN> rb;
-  ra.load(A, g.lda, ak, m0, g.M, 0, g.K, va);
-  rb.load(B, g.ldb, bk, n0, g.N, 0, g.K, vb);
-  ra.store(sm_raw, ak);
-  rb.store(sm_raw + BK * BP, bk);
+  Chunk<BM, BK, BP, AK, VEC> ra;
+  Chunk<BN, BK, BPN, BKC, VEC> rb;
+  ra.load(A, g.lda, m0, g.M, 0, g.K);
+  rb.load(B, g.ldb, n0, g.N, 0, g.K);
+  ra.store(sm_raw);
+  rb.store(sm_raw + BK * BP);
   __syncthreads();
   const int n_chunks = (g.K + BK - 1) / BK;
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
     if (more) {
-      ra.load(A, g.lda, ak, m0, g.M, (ci + 1) * BK, g.K, va);
-      rb.load(B, g.ldb, bk, n0, g.N, (ci + 1) * BK, g.K, vb);
+      ra.load(A, g.lda, m0, g.M, (ci + 1) * BK, g.K);
+      rb.load(B, g.ldb, n0, g.N, (ci + 1) * BK, g.K);
     }
     const float* as = sm_raw + (ci & 1) * BUF + hi * BP + wm + lo;
     const float* bs = sm_raw + (ci & 1) * BUF + BK * BP + hi * BPN + wn + lo;
@@ -155,8 +174,8 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
-      ra.store(sm_raw + ((ci + 1) & 1) * BUF, ak);
-      rb.store(sm_raw + ((ci + 1) & 1) * BUF + BK * BP, bk);
+      ra.store(sm_raw + ((ci + 1) & 1) * BUF);
+      rb.store(sm_raw + ((ci + 1) & 1) * BUF + BK * BPN * 0 + BK * BP);
     }
     __syncthreads();
   }
@@ -202,10 +221,25 @@ extern "C" int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, i
     return JATTS_OK;
   };
   const int n128 = (n + 127) / 128 * 128, n64 = (n + 63) / 64 * 64;
-  int rc;
-  if (n > 128 && n <= 192) rc = launch(bgemm_kernel<3, 16>, 192, 16);
-  else if (n64 * 4 <= n128 * 3) rc = launch(bgemm_kernel<1, 32>, 64, 32);
-  else rc = launch(bgemm_kernel<2, 32>, 128, 32);
+  // 16-byte loads when EVERY matrix of both operands starts on a 16-byte boundary with a leading dimension of 4 k elements
+  const bool vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 &&
+                   ((sa_outer | sa_inner | sb_outer | sb_inner | (int64_t)lda | (int64_t)ldb) & 3) == 0;
+  const int tile = (n > 128 && n <= 192) ? 3 : (n64 * 4 <= n128 * 3 ? 1 : 2);
+  int rc = JATTS_ERR_UNSUPPORTED;
+#define JATTS_BGEMM_CASE(WNF, BKC_, AKv, BKv, VECv) rc = launch(bgemm_kernel<WNF, BKC_, AKv, BKv, VECv>, 64 * WNF, BKC_)
+#define JATTS_BGEMM_ORIENT(WNF, BKC_, VECv)                                         \
+  do {                                                                              \
+    if (!trans_a && trans_b) JATTS_BGEMM_CASE(WNF, BKC_, true, true, VECv);         \
+    else if (!trans_a && !trans_b) JATTS_BGEMM_CASE(WNF, BKC_, true, false, VECv);  \
+    else if (trans_a && !trans_b) JATTS_BGEMM_CASE(WNF, BKC_, false, false, VECv);  \
+    else JATTS_BGEMM_CASE(WNF, BKC_, false, true, VECv);                            \
+  } while (0)
+  if (!vec) JATTS_BGEMM_ORIENT(2, 16, false);            // element loads: any alignment (nothing on the training path takes it)
+  else if (tile == 3) JATTS_BGEMM_ORIENT(3, 16, true);
+  else if (tile == 1) JATTS_BGEMM_ORIENT(1, 32, true);
+  else JATTS_BGEMM_ORIENT(2, 32, true);
+#undef JATTS_BGEMM_ORIENT
+#undef JATTS_BGEMM_CASE
   if (rc != JATTS_OK) return rc;
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
