@@ -59,7 +59,9 @@ __device__ __forceinline__ int split_commit(StageRegs<float, MAXU, NIN>& sr, cha
   return ex;
 }
 
-template <int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC>
+// HALO: rows beyond the time tile the staging registers must cover (32, or 0 for the k = 1 instantiation: 128-channel chunks then fit the
+// register file); RD: weight ring depth in K-steps.
+template <int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 4>
 __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_split_kernel(jatts_conv_desc d, int f32_tile, XcdOrder xo, unsigned slot_off) {
   typedef f16s T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_split_kernel(jatts_co
   zero_acc<NF, NT>(acc);
 
   constexpr int UPRC = KCHT / 8;
-  constexpr int MAXU = ((BT + 32) * UPRC + NTHR - 1) / NTHR;     // halo <= 32 rows (the launcher refuses more)
-  constexpr int RD = 4;                                          // a step is 3 NF NT 32-cycle MFMAs: four steps of look-ahead cover an L2 round trip
+  constexpr int MAXU = ((BT + HALO) * UPRC + NTHR - 1) / NTHR;   // halo <= HALO rows (the launcher refuses more)
+  // (RD: a step is 3 NF NT 32-cycle MFMAs; four steps of look-ahead cover an L2 round trip, two do when two workgroups share the CU)
   static_assert((KCHT / 16) % RD == 0, "ring depth must divide the steps per chunk and tap");
   WRing<T, NF, RD> ring;
   const int n_chunks = d.c_in / KCHT;
@@ -169,10 +171,10 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_split_kernel(jatts_co
   }
 }
 
-template <int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC>
+template <int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 4>
 int launch_conv_split(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
-  if ((d.k_w - 1) * d.dil > 32) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (split): halo beyond 32 rows");
+  if ((d.k_w - 1) * d.dil > HALO) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (split): halo beyond 32 rows");
   if (d.c_in % KCHT) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (split): c_in must be a multiple of the chunk width");
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + BT - 1) / BT), (unsigned)d.rg.n_seq, (unsigned)((d.n_out + BN - 1) / BN));
@@ -186,7 +188,7 @@ int launch_conv_split(const jatts_conv_desc& d, hipStream_t s) {
   const unsigned slot_off = (unsigned)lds;
   lds += 64;                                                              // one amax slot per wave
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (split): tile exceeds 160 KiB LDS");
-  auto kern = conv1d_split_kernel<NF, NT, WN, WT, NIN, KCHT, OCC>;
+  auto kern = conv1d_split_kernel<NF, NT, WN, WT, NIN, KCHT, OCC, HALO, RD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);

@@ -10,5 +10,7 @@ int jatts_conv1d_split(const jatts_conv_desc& d, hipStream_t s) {
   if (d.n_in > 1)     // summed inputs (an unfused MRF mean in front of a HiFi-GAN upsampling conv; rare): 3x the staging registers, one workgroup per CU
     return launch_conv_split<2, 2, 2, 2, 3, 64, 1>(d, s);
   if (d.n_out <= 64) return launch_conv_split<2, 1, 1, 4, 1, 64, 2>(d, s);          // 64 n x 128 t, light on registers: the HBM-bound last upsampling conv
+  // (measured and dropped: 128-channel chunks for k = 1 -- half the block-maximum exchanges and barriers per K, but the double-buffered tile is then
+  //  135 KB of LDS = ONE workgroup per CU: 128-170 TFLOP/s against 165-213 with 64-channel chunks and two workgroups; profiles/r04_notes.md)
   return launch_conv_split<2, 2, 2, 2, 1, 64, 2>(d, s);                             // 128 n x 128 t
 }
