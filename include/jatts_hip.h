@@ -213,11 +213,10 @@ int jatts_masked_loss(const jatts_ragged* rg, const float* a, int32_t lda, const
                       void* stream);
 /* dw[n][c][tap] = sum_t dy[t][n] * x[t + tap*dil - pad][c] over all sequences (torch weight layout (n_out, c_in, k_w), f32).
  * workspace != NULL (n_seq * (k_w * pad64(n_out) * pad64(c_in) + pad64(n_out)) floats): split-K partials are written there and summed
- * by a second launch, dw is OVERWRITTEN (deterministic, no atomics).  workspace == NULL: dw += with f32 atomics (caller zeroes dw; order
- * not fixed).
+ * by a second launch, dw is OVERWRITTEN (deterministic, no atomics).  workspace == NULL: refused on the MFMA path (k_w 1 / 3 / 5); the VALU
+ * path (other widths) then ACCUMULATES into dw, through the fixed-order slabs of jatts_set_workspace (round 4: no f32 atomics anywhere).
  * db (nullable, n_out floats, OVERWRITTEN): the bias gradient sum_t dy[t][n] of the same convolution (torch.nn.Conv1d's bias.grad).  On
- * the MFMA path with a workspace it falls out of the dy tiles the kernel stages anyway (no second pass over dy); otherwise a column-sum
- * launch (f32 atomics). */
+ * the MFMA path it falls out of the dy tiles the kernel stages anyway (no second pass over dy); otherwise a fixed-order column-sum launch. */
 int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, const float* dy, int32_t ldy, int32_t c_in,
                        int32_t n_out, int32_t k_w, int32_t dil, int32_t pad, float* dw, float* db, float* workspace, void* stream);
 /* Pack a torch-layout f32 weight (n_out, c_in, k_w) into jatts_conv1d's fragment order (zero padded: n to 32, c to c_mult) as
@@ -225,6 +224,11 @@ int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_t ldx, cons
  * n_out to c_in channels; padded sizes follow the swapped roles).  out: k_w * pad32(n) * pad(c, c_mult) elements. */
 int jatts_pack_conv_weight(const float* w, int32_t n_out, int32_t c_in, int32_t k_w, int32_t c_mult, int32_t mode, int32_t dtype,
                            void* out, void* stream);
+/* The same for the JATTS_F32S operand (round 4): per packed row n (mode 0: output channel; mode 1: input channel of W) the power-of-two scale
+ * that puts max |w| of the row in [2^14, 2^15); out: 2 * k_w * pad32(n) * pad(c, c_mult) f16 = [tap][c/16][n/32][lane][hi x8 | lo x8] of
+ * w * 2^s[n]; inv: pad32(n) floats, 2^-s[n] (1 for all-zero and padding rows).  Two launches (row maxima, pack); deterministic. */
+int jatts_pack_conv_weight_split(const float* w, int32_t n_out, int32_t c_in, int32_t k_w, int32_t c_mult, int32_t mode, void* out, float* inv,
+                                 void* stream);
 /* out[c] += sum over rows of x[row][c] (bias gradient; caller zeroes out). */
 int jatts_col_sum(const float* x, int32_t ld, int64_t rows, int32_t dim, float* out, void* stream);
 

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "jatts_hifigan_resblock": (C.c_int, [C.POINTER(ResBlockDesc), C.c_void_p]),
     "jatts_debug_trace": (C.c_int, [C.c_void_p, C.c_int64]),
     "jatts_set_workspace": (C.c_int, [C.c_void_p, C.c_int64]),
+    "jatts_pack_conv_weight_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_bgemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                               C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                               C.c_int32, C.c_void_p]),

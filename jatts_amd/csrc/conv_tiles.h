@@ -23,6 +23,17 @@
 
 #include "common.h"
 
+// s_setprio around the MFMA clusters (MI355X guide T5: the scheduler then prefers the wave that is feeding the matrix pipe over a co-resident
+// wave in its staging / epilogue phase).  -DJATTS_SETPRIO=1 switches it on (A/B builds: make OUT=../lib/prio CXXFLAGS+=-DJATTS_SETPRIO=1).
+#ifndef JATTS_SETPRIO
+#define JATTS_SETPRIO 0
+#endif
+#if JATTS_SETPRIO
+#define JATTS_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define JATTS_PRIO(p) ((void)0)
+#endif
+
 namespace {
 
 template <typename T> struct Vec8IO;
@@ -246,10 +257,12 @@ __device__ __forceinline__ void conv_group(f32x16 (&acc)[NF][NT], typename Elem<
     if (kk + 1 < KCG) fetch_b<T, NT>(bb[(kk + 1) & 1], bcur + (size_t)(kk + 1) * 16 * sizeof(T), pitch);
     else fetch_b<T, NT>(bb[0], bnext, pitch);
     __builtin_amdgcn_sched_barrier(0);
+    JATTS_PRIO(1);
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int t = 0; t < NT; ++t) mma32(ring[kk][f], bb[kk & 1][t], acc[f][t]);
+    JATTS_PRIO(0);
 #pragma unroll
     for (int f = 0; f < NF; ++f) ring[kk][f] = Vec8IO<T>::ldg(next_base + (size_t)kk * wf.stride + wf.nfo[f]);
     __builtin_amdgcn_sched_barrier(0);
@@ -408,10 +421,12 @@ __device__ __forceinline__ void conv_stage(f32x16 (&acc)[NF][NT], WRing<T, NF, D
     for (int j = 0; j < D; ++j) {
       fetch_bb(bb[(j + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+      JATTS_PRIO(1);
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int t = 0; t < NT; ++t) mma32(ring.r[j][f], bb[j & 1][t], acc[f][t]);
+      JATTS_PRIO(0);
       ring.fetch(ring.r[j]);
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -284,6 +284,57 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
   }
 }
 
+// The JATTS_F32S operand of a weight, on the device (round 4: the training step re-packs every weight twice per step): packed row n of the
+// operand (mode 0: output channel n of W; mode 1, the data-gradient operand: INPUT channel n of W) gets the power-of-two scale that puts its
+// largest magnitude in [2^14, 2^15) -- exactly hip.pack_conv_weight_split's rule -- and inv[n] = 2^-s[n]; rows of zero padding take 1.
+__global__ __launch_bounds__(256) void wscale_kernel(const float* __restrict__ w, int n_out, int c_in, int K, int mode, int n_rows, float* __restrict__ inv) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  float m = 0.f;
+  if (n < n_rows) {
+    if (mode == 0) {
+      const float* p = w + (int64_t)n * c_in * K;
+      for (int i = threadIdx.x; i < c_in * K; i += 256) m = fmaxf(m, fabsf(p[i]));
+    } else {
+      for (int i = threadIdx.x; i < n_out * K; i += 256) m = fmaxf(m, fabsf(w[((int64_t)(i / K) * c_in + n) * K + i % K]));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int bexp = (int)((__float_as_uint(m) >> 23) & 0xff);
+    int s = 15 - (bexp - 126);
+    s = m > 0.f ? (s > 60 ? 60 : (s < -60 ? -60 : s)) : 0;
+    inv[n] = __uint_as_float((unsigned)(127 - s) << 23);
+  }
+}
+// out: [tap][c/16][n/32][lane][hi x8 | lo x8] f16 (pack_conv_weight_split's layout)
+__global__ __launch_bounds__(256) void pack_conv_weight_split_kernel(const float* __restrict__ w, int n_out, int c_in, int K, int n_pad, int c_pad,
+                                                                     int mode, const float* __restrict__ inv, f16* __restrict__ out) {
+  const int64_t total = (int64_t)K * n_pad * c_pad;
+  const int KC16 = c_pad / 16, NFR = n_pad / 32;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int e = (int)(i & 7), nl = (int)((i >> 3) & 31), g = (int)((i >> 8) & 1);
+    int64_t r = i >> 9;
+    const int nf = (int)(r % NFR);
+    r /= NFR;
+    const int c16 = (int)(r % KC16), tap = (int)(r / KC16);
+    const int n = nf * 32 + nl, c = c16 * 16 + g * 8 + e;
+    float v = 0.f;
+    if (mode == 0) {
+      if (n < n_out && c < c_in) v = w[((int64_t)n * c_in + c) * K + tap];
+    } else {
+      if (n < c_in && c < n_out) v = w[((int64_t)c * c_in + n) * K + (K - 1 - tap)];
+    }
+    const float sv = v / inv[n];                 // exact: inv is a power of two
+    const f16 hi = (f16)sv;
+    out[(i >> 3) * 16 + e] = hi;
+    out[(i >> 3) * 16 + 8 + e] = (f16)(sv - (float)hi);
+  }
+}
+
 // out[c] += sum over rows of x[row][c]
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* x, int ld, int64_t rows, int dim, float* out, int overwrite,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets) {
@@ -428,6 +479,21 @@ extern "C" int jatts_pack_conv_weight(const float* w, int32_t n_out, int32_t c_i
     hipLaunchKernelGGL(pack_conv_weight_kernel<f16>, dim3(blocks), dim3(256), 0, S_, w, n_out, c_in, k_w, n_pad, c_pad, mode, (f16*)out);
   else
     return jatts_set_error_msg(JATTS_ERR_ARG, "pack_conv_weight: dtype");
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+extern "C" int jatts_pack_conv_weight_split(const float* w, int32_t n_out, int32_t c_in, int32_t k_w, int32_t c_mult, int32_t mode, void* out,
+                                            float* inv, void* stream) {
+  if (!w || !out || !inv) return jatts_set_error_msg(JATTS_ERR_ARG, "pack_conv_weight_split: null pointer");
+  if (n_out < 1 || c_in < 1 || k_w < 1 || c_mult < 16 || c_mult % 16 != 0 || (mode != 0 && mode != 1))
+    return jatts_set_error_msg(JATTS_ERR_ARG, "pack_conv_weight_split: bad geometry");
+  const int pn = mode == 0 ? n_out : c_in, pc = mode == 0 ? c_in : n_out;
+  const int n_pad = (pn + 31) / 32 * 32, c_pad = (pc + c_mult - 1) / c_mult * c_mult;
+  const int64_t total = (int64_t)k_w * n_pad * c_pad;
+  hipLaunchKernelGGL(wscale_kernel, dim3((unsigned)n_pad), dim3(256), 0, S_, w, n_out, c_in, k_w, mode, pn, inv);
+  hipLaunchKernelGGL(pack_conv_weight_split_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, S_, w, n_out,
+                     c_in, k_w, n_pad, c_pad, mode, inv, (f16*)out);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

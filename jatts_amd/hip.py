@@ -333,14 +333,17 @@ def pack_conv_weight_split(w, c_mult=32):
     n_pad = round_up(n, 32)
     amax = w.abs().reshape(n, -1).amax(dim=1)
     e = torch.frexp(amax)[1]                               # amax = m 2^e, m in [0.5, 1)
-    s = torch.where(amax > 0, 15 - e, torch.zeros_like(e)).clamp(-60, 60)
-    ws = torch.ldexp(w, s.view(-1, 1, 1).expand_as(w).to(torch.int32))
+    s = torch.where(amax > 0, 15 - e, torch.zeros_like(e)).clamp(-60, 60).to(torch.int32)
+    # 2^s and 2^-s assembled from their bit patterns: torch.ldexp goes through pow() on the GPU and is an ulp off for some exponents -- the
+    # scales must be EXACT powers of two (tests/test_training_gpu.py::test_split_weight_packer_on_the_device_equals_the_host_packing)
+    scale = ((127 + s) << 23).view(torch.float32)
+    ws = w * scale.view(-1, 1, 1)
     hi = ws.half()
     lo = (ws - hi.float()).half()
     ph = pack_conv_weight(hi.float(), F16, c_mult).view(-1, 8)
     pl = pack_conv_weight(lo.float(), F16, c_mult).view(-1, 8)
     inv = torch.ones(n_pad, dtype=torch.float32, device=w.device)
-    inv[:n] = torch.ldexp(torch.ones_like(amax), (-s).to(torch.int32))
+    inv[:n] = ((127 - s) << 23).view(torch.float32)
     return torch.stack([ph, pl], dim=1).reshape(-1).contiguous(), inv.contiguous()
 
 
@@ -386,6 +389,23 @@ def pack_conv_weight_dev(w, dtype_code, c_mult=64, dgrad=False):
     _abi.check(lib.jatts_pack_conv_weight(w.data_ptr(), n, c, k, c_mult, int(dgrad), dtype_code, out.data_ptr(), _stream()),
                "jatts_pack_conv_weight")
     return out, c_pad
+
+
+def pack_conv_weight_split_dev(w, c_mult=64, dgrad=False):
+    """pack_conv_weight_split on the device (two launches: per-row maxima, pack), for weights that change every step (training).
+    -> (packed f16, inverse scales f32 (n_pad,), padded c_in of the packed conv)."""
+    lib = _abi.load()
+    w = _dev(w)
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    n, c, k = w.shape
+    pn, pc = (c, n) if dgrad else (n, c)
+    n_pad, c_pad = round_up(pn, 32), round_up(pc, c_mult)
+    out = torch.empty(2 * k * n_pad * c_pad, dtype=torch.float16, device=w.device)
+    inv = torch.empty(n_pad, dtype=torch.float32, device=w.device)
+    _abi.check(lib.jatts_pack_conv_weight_split(w.data_ptr(), n, c, k, c_mult, int(dgrad), out.data_ptr(), inv.data_ptr(), _stream()),
+               "jatts_pack_conv_weight_split")
+    return out, inv, c_pad
 
 
 def convtranspose_as_conv(w, stride, padding):

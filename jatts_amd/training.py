@@ -11,6 +11,8 @@ mode (models/fastspeech2_train.py on the HIP forward / backward pairs of jatts_a
 gradient all-reduce, clip_grad_norm_ + Adam as HIP kernels, the reference's WarmupLR schedule.  What is NOT here yet: the
 training paths of Matcha-TTS / VITS, f16 training.  No CPU fallback: CPU tensors raise.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -52,6 +54,21 @@ def fastspeech2_losses(ret, durations, pitch, energy, ilens, use_masking=True):
 
 
 # ------------------------------------------------------------------------------------------ conv1d with a backward
+# precision="fp32_split" of the trainers (round 4): the forward and data-gradient convs of every Conv1dFunction on split-precision MFMA operands
+# (JATTS_F32S, csrc/conv1d_split.h); weight gradients, normalisations, attention products and the optimiser stay exact f32.  Module-level
+# switch set around a step by the trainer (split_convs()); a captured graph bakes in whatever was on during its capture.
+SPLIT_CONVS = [False]
+
+
+@contextlib.contextmanager
+def split_convs(on=True):
+    prev, SPLIT_CONVS[0] = SPLIT_CONVS[0], bool(on)
+    try:
+        yield
+    finally:
+        SPLIT_CONVS[0] = prev
+
+
 class Conv1dFunction(torch.autograd.Function):
     """y = conv1d(x) on a packed ragged batch (rows, c_in) -> (rows, n_out), f32; "same"-style geometry via (dil, pad).
     forward: jatts_conv1d.  backward: dx = jatts_conv1d(dy, W'[c][n][k-1-tap], pad' = (k-1) dil - pad),
@@ -60,24 +77,32 @@ class Conv1dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rb, dil, pad):
         n_out, c_in, k = weight.shape
-        wp, c_pad = hip.pack_conv_weight_dev(weight.detach(), hip.F32)
+        split = SPLIT_CONVS[0] and (k - 1) * dil <= 32        # (beyond the split kernel's tiles: the exact-f32 kernel)
+        if split:
+            wp, winv, c_pad = hip.pack_conv_weight_split_dev(weight.detach())
+        else:
+            (wp, c_pad), winv = hip.pack_conv_weight_dev(weight.detach(), hip.F32), None
         xin = x.contiguous() if c_in == c_pad else hip.affine_cast(x.contiguous(), hip.F32, ldy=c_pad)
-        y = hip.conv1d(rb, xin, wp, c_pad, n_out, k, dtype=hip.F32, dil=dil, pad=pad, bias=None if bias is None else bias.detach().contiguous())
+        y = hip.conv1d(rb, xin, wp, c_pad, n_out, k, dtype=hip.F32S if split else hip.F32, dil=dil, pad=pad,
+                       bias=None if bias is None else bias.detach().contiguous(), w_inv=winv, out_f32=True)
         ctx.save_for_backward(x, weight)
-        ctx.geom = (rb, dil, pad, bias is not None)
+        ctx.geom = (rb, dil, pad, bias is not None, split)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        rb, dil, pad, has_bias = ctx.geom
+        rb, dil, pad, has_bias, split = ctx.geom
         n_out, c_in, k = weight.shape
         dy = dy.contiguous().float()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wp, c_pad = hip.pack_conv_weight_dev(weight.detach(), hip.F32, dgrad=True)       # W'[c][n][k-1-tap], packed in one launch
+            if split:      # the data gradient is a conv like the forward: same split arithmetic (the WEIGHT gradient below stays exact f32)
+                wp, winv, c_pad = hip.pack_conv_weight_split_dev(weight.detach(), dgrad=True)
+            else:
+                (wp, c_pad), winv = hip.pack_conv_weight_dev(weight.detach(), hip.F32, dgrad=True), None       # W'[c][n][k-1-tap], packed in one launch
             dyp = dy if n_out == c_pad else hip.affine_cast(dy, hip.F32, ldy=c_pad)
-            dx = hip.conv1d(rb, dyp, wp, c_pad, c_in, k, dtype=hip.F32, dil=dil, pad=(k - 1) * dil - pad)
+            dx = hip.conv1d(rb, dyp, wp, c_pad, c_in, k, dtype=hip.F32S if split else hip.F32, dil=dil, pad=(k - 1) * dil - pad, w_inv=winv, out_f32=True)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = hip.conv1d_wgrad(rb, x.detach().contiguous().float(), dy, c_in, n_out, k, dil, pad, want_db=want_db)
@@ -179,7 +204,11 @@ class FastSpeech2Trainer:
 
     def __init__(self, model, lr=0.0008, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_norm=1.0, warmup_steps=4000, group=None,
                  bucket_bytes=64 << 20, overlap=True, gradient_accumulate_steps=1, scheduler="warmuplr", scheduler_params=None, capture_graph=False,
-                 max_graphs=8):
+                 max_graphs=8, precision="fp32"):
+        if precision not in ("fp32", "fp32_split"):
+            raise ValueError("trainer precision: 'fp32' (exact-f32 MFMA, the reference's arithmetic) or 'fp32_split' (f32 tensors; the forward and "
+                             "data-gradient convs on split f16 hi / lo MFMA operands, everything else exact f32)")
+        self.precision = precision
         self.model, self.base_lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
         self.grad_norm, self.warmup_steps, self.group, self.bucket_bytes = grad_norm, warmup_steps, group, bucket_bytes
         self.overlap = overlap
@@ -376,6 +405,10 @@ class FastSpeech2Trainer:
 
     @torch.no_grad()
     def eval_step(self, batch):
+        with split_convs(self.precision == "fp32_split"):
+            return self._eval_step(batch)
+
+    def _eval_step(self, batch):
         """`_eval_step` of the reference trainers (e.g. trainers/fastspeech2.py:150-215): the same forward + criterion in eval() mode
         (running-statistics BatchNorm, no dropout), no gradients, no update.  -> dict of loss tensors."""
         was = self.model.training
@@ -524,6 +557,10 @@ class FastSpeech2Trainer:
         return out
 
     def train_step(self, batch):
+        with split_convs(self.precision == "fp32_split"):
+            return self._train_step_any(batch)
+
+    def _train_step_any(self, batch):
         """batch: dict with the collater's keys (xs, ilens, ys, olens, durations, duration_lens, pitch, pitch_lens, energys,
         energy_lens).  -> dict of the loss tensors (on the GPU; .item() them only when logging)."""
         m = self.model

@@ -416,7 +416,7 @@ def test_graph_mode_matches_eager_at_the_recipe_batch(cuda, lib, kind):
     assert any(st["graph"] is not None for st in c._graphs.values())
 
 
-@pytest.mark.parametrize("kind", ["fs2", "matcha", "matcha_mas", "vits"])
+@pytest.mark.parametrize("kind", ["fs2", "matcha", "matcha_mas", "vits", "fs2:fp32_split", "vits:fp32_split"])
 def test_two_eager_trainers_are_bit_identical_at_the_recipe_batch(cuda, lib, kind):
     """Run-to-run reproducibility (the reference is bit-identical run to run): two trainers built from the same seed and fed the
     same batch and the same draws produce bit-identical losses, gradients and parameters step by step AT THE RECIPE BATCH, where every
@@ -427,10 +427,11 @@ def test_two_eager_trainers_are_bit_identical_at_the_recipe_batch(cuda, lib, kin
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     g = torch.Generator().manual_seed(9)
+    kind, _, precision = kind.partition(":")
     trainers = []
     for _ in range(2):
         m, b, cls, extra, _, _ = bench.train_setup(cuda, kind)
-        trainers.append(cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=False, **extra))
+        trainers.append(cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=False, precision=precision or "fp32", **extra))
     B, To = b["ys"].shape[0], b["ys"].shape[1]
     if kind in ("matcha", "matcha_mas"):
         b["cfm_t"], b["cfm_noise"] = torch.rand(B, generator=g), torch.randn(B, To, 80, generator=g)

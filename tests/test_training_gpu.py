@@ -112,8 +112,10 @@ def _train_golden():
     return z, zi, keys, cfg
 
 
-def test_fastspeech2_train_step_matches_reference(cuda, lib):
-    """One whole `_train_step` (trainers/fastspeech2.py:24-100) against the REAL reference run on the CPU
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
+def test_fastspeech2_train_step_matches_reference(cuda, lib, precision):
+    """(precision fp32_split, round 4: the forward / data-gradient convs on split f16 hi / lo MFMA operands -- held to the SAME tolerances.)
+    One whole `_train_step` (trainers/fastspeech2.py:24-100) against the REAL reference run on the CPU
     (tests/golden/make_golden_train.py): train()-mode forward on the padded batch (batch-statistics BatchNorm, dropout 0),
     the four losses, EVERY parameter's gradient norm, full gradients of 22 parameters spread over all layer types, the total
     norm, the BatchNorm running statistics, and the parameters after clip_grad_norm_(1.0) + Adam under WarmupLR."""
@@ -129,10 +131,12 @@ def test_fastspeech2_train_step_matches_reference(cuda, lib):
     il, ol = t("text_lengths"), t("feats_lengths")
     batch = dict(xs=t("text"), ilens=il, ys=t("feats"), olens=ol, durations=t("durations"), duration_lens=il, pitch=t("pitch"),
                  pitch_lens=il, energys=t("energy"), energy_lens=il)
-    tr = FastSpeech2Trainer(m, lr=0.0008, grad_norm=1.0, warmup_steps=4000)
+    tr = FastSpeech2Trainer(m, lr=0.0008, grad_norm=1.0, warmup_steps=4000, precision=precision)
     # forward + backward only first (gradients are consumed by the step)
     m.train()
+    from jatts_amd import training as _tr
     from jatts_amd.models.fastspeech2_train import criterion
+    _tr.SPLIT_CONVS[0] = precision == "fp32_split"          # (what the trainer sets around its own steps; reset at the end of the manual part)
     ret = m(batch["xs"], il, batch["ys"], ol, batch["durations"], il, batch["pitch"], il, batch["energys"], il)
     for k in ("before_outs", "after_outs", "d_outs", "p_outs", "e_outs"):
         assert relerr(ret[k].detach(), z["ref_" + k]) <= 2e-5, (k, relerr(ret[k].detach(), z["ref_" + k]))
@@ -140,6 +144,7 @@ def test_fastspeech2_train_step_matches_reference(cuda, lib):
     for k in ("mel_loss", "duration_loss", "pitch_loss", "energy_loss"):
         assert abs(float(losses[k]) - float(z[k])) <= 2e-5 * max(1.0, abs(float(z[k]))), (k, float(losses[k]), float(z[k]))
     losses["loss"].backward()
+    _tr.SPLIT_CONVS[0] = False
     names = json.loads(str(z["grad_names"]))
     P = dict(m.named_parameters())
     worst = ("", 0.0)
@@ -163,7 +168,7 @@ def test_fastspeech2_train_step_matches_reference(cuda, lib):
     m2 = FastSpeech2(idim=20, **{**FS2_SMALL, **cfg})
     m2.load_state_dict(sd0)
     m2 = m2.to(cuda)
-    tr = FastSpeech2Trainer(m2, lr=0.0008, grad_norm=1.0, warmup_steps=4000)
+    tr = FastSpeech2Trainer(m2, lr=0.0008, grad_norm=1.0, warmup_steps=4000, precision=precision)
     out = tr.train_step(batch)
     assert abs(tr.last_lr - float(z["lr_step1"])) <= 1e-12
     assert abs(float(out["grad_norm"]) - float(z["total_grad_norm"])) <= 1e-3 * float(z["total_grad_norm"])
@@ -531,6 +536,24 @@ def test_pack_conv_weight_kernel_matches_the_host_packing(cuda, lib, n, c, k):
         assert c_pad == hip.round_up(c, 64) and torch.equal(got, hip.pack_conv_weight(w, dt))
         got, c_pad = hip.pack_conv_weight_dev(w, dt, dgrad=True)
         assert c_pad == hip.round_up(n, 64) and torch.equal(got, hip.pack_conv_weight(w.permute(1, 0, 2).flip(2).contiguous(), dt))
+
+
+@pytest.mark.parametrize("n,c,k", [(96, 80, 3), (1, 256, 1), (384, 1, 1), (64, 64, 5), (33, 17, 4)])
+def test_split_weight_packer_on_the_device_equals_the_host_packing(cuda, lib, n, c, k):
+    """jatts_pack_conv_weight_split (per-row maxima + pack, two launches: the training step re-packs every weight twice per step) is bit-identical
+    to hip.pack_conv_weight_split -- packed halves and inverse scales -- for the weight itself and for the data-gradient operand; rows of
+    zeros and padding rows take scale 1."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(n + c + k)
+    w = (torch.randn(n, c, k, generator=g) * torch.pow(10.0, torch.rand(n, 1, 1, generator=g) * 6 - 4)).to(cuda)
+    if n > 2:
+        w[1] = 0.0
+    got, inv, c_pad = hip.pack_conv_weight_split_dev(w)
+    ref, rinv = hip.pack_conv_weight_split(w, 64)
+    assert c_pad == hip.round_up(c, 64) and torch.equal(inv, rinv) and torch.equal(got, ref)
+    got, inv, c_pad = hip.pack_conv_weight_split_dev(w, dgrad=True)
+    ref, rinv = hip.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous(), 64)
+    assert c_pad == hip.round_up(n, 64) and torch.equal(inv, rinv) and torch.equal(got, ref)
 
 
 def test_fastspeech2_train_step_nine_tap_embeddings(cuda, lib):
