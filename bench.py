@@ -443,7 +443,7 @@ def train_setup(dev, kind="fs2", batch=32, t_text=128, frames=6):
     return m, b, cls, extra, name, flop_per_utt
 
 
-def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
+def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6, precision="fp32"):
     """One `_train_step` of the reference trainers on the recipes' models (jatts/trainers/fastspeech2.py:24-100 on
     conf/fastspeech2.v1.yaml; jatts/trainers/matchatts.py:23-120 on the tts1 conf/matcha_tts.v1.prior.steplr.large.yaml): forward in
     train mode, the losses, backward, clip + Adam -- f32, synthetic weights / targets, batch 32."""
@@ -453,7 +453,7 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     # the whole step replayed as ONE captured hipGraph per batch signature (lengths + loss-schedule phase); a signature's first call runs
     # eagerly, its second captures, the timed ones replay (tts1 Matcha's signature changes once after step 1, when the duration loss joins)
     graph = True
-    tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=graph, **extra)
+    tr = cls(m, lr=1e-4, grad_norm=1.0, warmup_steps=0, capture_graph=graph, precision=precision, **extra)
     from jatts_amd import hip
     hip.flops_begin()            # dense work of ONE step as launched: 2 c_in n_out k rows per conv forward / dgrad / wgrad launch
     first = float(tr.train_step(b)["loss"])
@@ -473,7 +473,8 @@ def train_step_line(dev, steps, kind="fs2", batch=32, t_text=128, frames=6):
     dt = sorted(per)[len(per) // 2]
     n_frames = int(ol.sum())
     mean = sum(per) / len(per)
-    line = {"kind": kind, "workload": f"{name} _train_step, batch {batch} x {t_text} phonemes x {frames} frames", "dtype": "f32",
+    line = {"kind": kind, "workload": f"{name} _train_step, batch {batch} x {t_text} phonemes x {frames} frames",
+            "dtype": "f32" if precision == "fp32" else "f32 tensors; forward / data-gradient convs on split f16 hi/lo MFMA operands",
             "executor": "hipGraph replay (one graph per batch signature)" if graph and tr.capture_graph else "eager (one Python launch per kernel)",
             "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_mean": mean * 1e3, "ms_per_step_all": [round(v * 1e3, 2) for v in per],
             "frames_per_s": n_frames / dt, "loss_first": first, "loss_last": float(o["loss"]),
@@ -557,7 +558,8 @@ def compact_line(out, detail_path=None):
                          "roofline_kernel": (((e.get("roofline") or {}).get("dominant") or {}).get("kernel") or "")[:24]} for e in out["configs"]}
     if out.get("training"):
         c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "mean_ms": e.get("ms_per_step_mean"),
-                                     "tflop": e.get("dense_tflops_per_step"), "frac": e.get("frac_of_f32_mfma_peak")}
+                                     "tflop": e.get("dense_tflops_per_step"), "frac": e.get("frac_of_f32_mfma_peak"),
+                                     "split_ms": (e.get("fp32_split") or {}).get("ms_per_step")}
                          for e in out["training"]}
     if detail_path:
         c["detail"] = detail_path
@@ -784,7 +786,12 @@ def main():
         for kind in ("fs2", "matcha", "matcha_mas", "vits"):
             gc.collect()               # (the inference jobs above hold reference cycles; a live 10+ GB job slows the step by 20 %)
             torch.cuda.empty_cache()
-            out["training"].append(train_step_line(dev, 5, kind))
+            ln = train_step_line(dev, 5, kind)
+            gc.collect()
+            torch.cuda.empty_cache()
+            sp = train_step_line(dev, 5, kind, precision="fp32_split")      # the same step with precision="fp32_split" (weight gradients stay exact f32)
+            ln["fp32_split"] = {k: sp[k] for k in ("ms_per_step", "ms_per_step_mean", "loss_first", "loss_last", "dtype")}
+            out["training"].append(ln)
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from jatts_amd.synthetic import synth_texts
