@@ -38,7 +38,7 @@ expdir=""      # exp/<expname>; derived from conf / tag like the reference when 
 # decoding related setting
 outdir=
 checkpoint=""  # checkpoint path to be used for decoding; if not provided, the latest one will be used
-precision=fp32        # fp32 = the reference's arithmetic; fp16 = fast mode (f16 MFMA operands, f32 accumulate)
+precision=fp32        # fp32 = the reference's arithmetic; fp32_split = f32 tensors + split-precision MFMA operands (2.5x, same error); fp16 = fast mode
 decode_batch_size=64  # utterances per ragged batch
 master_port=29517
 

@@ -85,6 +85,25 @@ def test_stage4_cli_end_to_end(cuda, lib, tmp_path):
             assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
 
 
+@pytest.mark.gpu
+def test_stage4_cli_split_precision_matches_fp32(cuda, lib, tmp_path):
+    """`--precision fp32_split` (round 4: f32 tensors, split-precision MFMA operands) through the whole CLI: the same utterance lengths and wav
+    files as the exact-f32 run, PCM samples at most one 16-bit step apart (the two arithmetics differ by ~1e-6 on a [-1, 1] signal)."""
+    from jatts_amd.bin import tts_decode
+    d = tmp_path
+    _make_expdir(d)
+    base = ["--csv", str(d / "dev.csv"), "--stats", str(d / "stats.npz"), "--token-list", str(d / "tokens.txt"), "--token-column", "phonemes",
+            "--checkpoint", str(d / "checkpoint-1steps.pkl"), "--verbose", "0", "--batch-size", "2"]
+    tts_decode.main(base + ["--outdir", str(d / "out32")])
+    tts_decode.main(base + ["--outdir", str(d / "outs"), "--precision", "fp32_split"])
+    for i in range(3):
+        with wave.open(str(d / "out32" / "wav" / f"utt{i}.wav")) as a, wave.open(str(d / "outs" / "wav" / f"utt{i}.wav")) as b:
+            assert a.getnframes() == b.getnframes() > 0
+            x = np.frombuffer(a.readframes(a.getnframes()), dtype="<i2").astype(np.int32)
+            y = np.frombuffer(b.readframes(b.getnframes()), dtype="<i2").astype(np.int32)
+            assert np.abs(x - y).max() <= 1
+
+
 def test_recipe_option_parser(tmp_path):
     """egs/common/parse_options.sh: `--name value` / `--name=value` set declared variables (dashes or underscores), unknown
     options are refused -- the interface the reference recipes get from their utils/parse_options.sh."""
