@@ -44,6 +44,7 @@ extern "C" {
 #define JATTS_ACT_TANH 2
 #define JATTS_ACT_SWISH 3
 #define JATTS_ACT_MISH 4
+#define JATTS_ACT_SNAKEBETA 5 /* v + act_b[n] * sin^2(act_a[n] * v): Matcha's feed-forward activation (jatts_snakebeta) in the conv's epilogue */
 
 #define JATTS_PAD_ZERO 0
 #define JATTS_PAD_REFLECT 1
@@ -121,6 +122,8 @@ typedef struct jatts_conv_desc {
                         * 4-step ring, 5 = register-streamed 128n x 64t.  Unknown / inapplicable values fall back to 0. */
   const float* w_inv;  /* JATTS_F32S only (NULL otherwise): round_up(n_out, 32) floats, 2^-s[n] where w holds the hi / lo f16 halves of
                         * W[n] * 2^s[n] (jatts_amd.hip.pack_conv_weight_split); x_i, resid and y are f32 */
+  const float* act_a;  /* JATTS_ACT_SNAKEBETA only (NULL otherwise): [n_out] exp(alpha) and ... */
+  const float* act_b;  /* ... [n_out] 1 / (exp(beta) + 1e-9), the two per-channel vectors jatts_snakebeta takes */
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
 F32, F16, F32S = 0, 1, 2      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH, ACT_SNAKEBETA = 0, 1, 2, 3, 4, 5
 PRE_NONE, PRE_LRELU = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 
@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
         ("dil", C.c_int32), ("pad", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
         ("alpha", C.c_float), ("resid", C.c_void_p), ("ldr", C.c_int32), ("y", C.c_void_p),
         ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32), ("y_seq_col0", C.c_void_p),
-        ("pad_mode", C.c_int32), ("variant", C.c_int32), ("w_inv", C.c_void_p),
+        ("pad_mode", C.c_int32), ("variant", C.c_int32), ("w_inv", C.c_void_p), ("act_a", C.c_void_p), ("act_b", C.c_void_p),
     ]
 
 

@@ -51,7 +51,9 @@ __device__ __forceinline__ void apply_act_alpha(f32x16 (&acc)[NF][NT], int act, 
 
 // DIAG (tools/bench_conv.py --variant 8, wrong results, kept for the record of profiles/r03_notes.md): 1 = nothing is streamed in the
 // main loop (the operands of the first D steps are reused) -- the pure-MFMA ceiling of this launch geometry.
-template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false>
+// SNAKE: the SnakeBeta epilogue (JATTS_ACT_SNAKEBETA) as its own instantiation -- behind a runtime branch its 64 inlined sin^2 bodies
+// made the register allocator spill an accumulator fragment inside the main loop of EVERY launch.
+template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false, bool SNAKE = false>
 __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap, XcdOrder xo) {
   const unsigned wg_lin = blockIdx.x;     // 1-D grid in XCD-aware order (conv1d_impl.h: XcdOrder)
   int bx, by, bz;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_k
   // check.  A quarter of the instructions of an LDS-coalesced pass (no LDS round trip, no barrier, no per-unit index math).
   const bool rowmajor = !d.y_transposed && (d.n_out & 7) == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 && (d.ldy & 3) == 0 &&
                         (!d.resid || ((d.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(d.resid) & 15) == 0));
+  if constexpr (SNAKE) snake_acc<NF, NT>(acc, d.act_a, d.act_b, nf0, d.n_out, lane);
   if (rowmajor) {
     apply_act_alpha<NF, NT>(acc, d.act, d.alpha);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)d.y + seq_row0 * (int64_t)d.ldy), 0,
@@ -211,14 +214,14 @@ inline bool conv_direct_ok(const jatts_conv_desc& d) {
          (maxL + 256 + (int64_t)d.k_w * d.dil) * ld * 4 < (int64_t)1 << 31 && (int64_t)d.k_w * d.c_in * n_pad * 4 < (int64_t)1 << 31;
 }
 
-template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false>
+template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false, bool SNAKE = false>
 int launch_conv_direct(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   XcdOrder xo;
   const int64_t total = xo.plan((int)((maxL + BT - 1) / BT), d.rg.n_seq, (d.n_out + BN - 1) / BN, (int64_t)BN * d.c_in * d.k_w * 4);
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
-  hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG, PRE>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
+  hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG, PRE, SNAKE>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
                      jatts_g_trace_cap, xo);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;

@@ -4,6 +4,8 @@
 // -> JATTS_OK / error, or 1 when the variant does not apply (the caller falls back to the LDS-staged kernel)
 int jatts_conv1d_f32_direct(const jatts_conv_desc& d, int variant, hipStream_t s) {
   if (!conv_direct_ok(d)) return 1;
+  const bool snake = d.act == JATTS_ACT_SNAKEBETA;   // Matcha's feed-forward convs (256 -> 1024 ... k1): the two wide tiles carry the epilogue
+  if (snake && (d.n_out <= 64 || d.pre_act != JATTS_PRE_NONE || (variant != 0 && variant != 3 && variant != 5))) return 1;
   if (d.n_out <= 64) {   // narrow outputs (HiFi-GAN's last upsampling conv: 64 -> 2 x 32 channels at 6.3 M rows): 64n x 256t, four waves along time
     if (variant != 0 && variant != 3) return 1;
     return d.pre_act != JATTS_PRE_NONE ? launch_conv_direct<2, 2, 1, 4, 2, 0, true>(d, s) : launch_conv_direct<2, 2, 1, 4, 2>(d, s);
@@ -25,6 +27,7 @@ int jatts_conv1d_f32_direct(const jatts_conv_desc& d, int variant, hipStream_t s
     if (variant == 5) return launch_conv_direct<2, 1, 2, 2, 2, 0, true>(d, s);
     return launch_conv_direct<2, 2, 2, 2, 2, 0, true>(d, s);
   }
+  if (snake) return variant == 5 ? launch_conv_direct<2, 1, 2, 2, 2, 0, false, true>(d, s) : launch_conv_direct<2, 2, 2, 2, 2, 0, false, true>(d, s);
   switch (variant) {
     case 3: return launch_conv_direct<2, 2, 2, 2, 2>(d, s);      // 128n x 128t, 256 threads, ring 2: three workgroups per CU
     case 4: return launch_conv_direct<2, 2, 2, 2, 4>(d, s);      // ring 4 (two workgroups per CU)

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   // epilogue, specialised per activation by ONE uniform branch: a runtime switch inside the 64-element
   // unrolled body inlined tanh/mish 128 times, the unroller gave up and the accumulators went to scratch
   // (1.8x slower conv, profiles/r01_notes.md).
+  if (d.act == JATTS_ACT_SNAKEBETA) snake_acc<NF, NT>(acc, d.act_a, d.act_b, nf0, d.n_out, lane);
   {
     // the loop's last barrier has retired every read of the activation buffers: reuse them as the output tile
     constexpr int BN = WN * NF * 32;

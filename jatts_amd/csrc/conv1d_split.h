@@ -147,6 +147,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_split_kernel(jatts_co
           for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = fmaf(acc[f][t][4 * q + e], is[e] * inv_sx, bq[e]);
       }
   }
+  if (d.act == JATTS_ACT_SNAKEBETA) snake_acc<NF, NT>(acc, d.act_a, d.act_b, nf0, d.n_out, lane);
   {
     constexpr int BN = WN * NF * 32;
     const int n_base = bz * BN;

@@ -37,6 +37,8 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   if (d->ldx % 8) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: ldx must be a multiple of 8");
   if (d->n_in < 1 || d->n_in > 3 || d->k_w < 1 || d->dil < 1 || d->n_out < 1 || d->rg.n_seq < 1 || d->rg.len_mul < 1)
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: bad geometry");
+  if (d->act == JATTS_ACT_SNAKEBETA && (!d->act_a || !d->act_b || (d->n_out & 3) || ((uintptr_t)d->act_a & 15) || ((uintptr_t)d->act_b & 15)))
+    return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_ACT_SNAKEBETA needs 16-byte aligned act_a / act_b and n_out % 4 == 0");
   if (d->rg.max_len <= 0) return JATTS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return jatts_conv1d_f16(*d, s);

@@ -443,4 +443,29 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NF][NT]) {
       for (int r = 0; r < 16; ++r) acc[f][t][r] = 0.f;
 }
 
+// SnakeBeta on the accumulators (bias already in): acc <- acc + b[n] sin^2(a[n] acc), channel n of register 4q + e being
+// (nf0 + f) 32 + 8q + 4 (lane >> 5) + e.  The same expression as rowwise.hip's snakebeta_kernel, so fusing Matcha's feed-forward
+// activation into the conv that produces its input changes no value; the caller then runs the JATTS_ACT_NONE epilogue.
+template <int NF, int NT>
+__device__ __forceinline__ void snake_acc(f32x16 (&acc)[NF][NT], const float* a, const float* b, int nf0, int n_out, int lane) {
+  const int gq = lane >> 5;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // n_out is a multiple of 4 (jatts_conv1d checks): a quad is inside or outside as a whole, and an outside one (never stored) reads
+      // the last quad instead of branching
+      const int n0 = min((nf0 + f) * 32 + 8 * q + 4 * gq, n_out - 4);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(a + n0), b4 = *reinterpret_cast<const f32x4*>(b + n0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[f][t][4 * q + e];
+          acc[f][t][4 * q + e] = fmaf(b4[e], sin2_f(v * a4[e]), v);
+        }
+      __builtin_amdgcn_sched_barrier(0);   // one channel quad at a time (all 4 NF quads in flight spill registers)
+    }
+}
+
 }  // namespace

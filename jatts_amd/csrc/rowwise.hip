@@ -482,8 +482,7 @@ __global__ void snakebeta_kernel(const T* x, T* y, int64_t rows, int C, const fl
       T o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float sn = sinf(v[e] * (e < 4 ? a0[e & 3] : a1[e & 3]));
-        o[e] = from_f32<T>(v[e] + (e < 4 ? b0[e & 3] : b1[e & 3]) * sn * sn);
+        o[e] = from_f32<T>(fmaf(e < 4 ? b0[e & 3] : b1[e & 3], sin2_f(v[e] * (e < 4 ? a0[e & 3] : a1[e & 3])), v[e]));   // == conv_tiles.h snake_acc
       }
       if (sizeof(T) == 2) *reinterpret_cast<f16x8*>(y + i) = f16x8{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
       else {
@@ -496,8 +495,7 @@ __global__ void snakebeta_kernel(const T* x, T* y, int64_t rows, int C, const fl
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const float v = to_f32(x[i]);
-    const float sn = sinf(v * alpha[c]);
-    y[i] = from_f32<T>(v + inv_beta[c] * sn * sn);
+    y[i] = from_f32<T>(fmaf(inv_beta[c], sin2_f(v * alpha[c]), v));
   }
 }
 

@@ -426,9 +426,10 @@ def convtranspose_as_conv(w, stride, padding):
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
            in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
-           y_seq_col0=None, reflect=False, variant=0, w_inv=None):
+           y_seq_col0=None, reflect=False, variant=0, w_inv=None, snake=None):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors.  dtype F32S: f32 tensors, ``w_packed`` / ``w_inv``
-    from pack_conv_weight_split (c_mult 64)."""
+    from pack_conv_weight_split (c_mult 64).  ``snake`` = (exp(alpha), 1 / (exp(beta) + 1e-9)) f32 vectors of n_out: the SnakeBeta
+    activation (the ``snakebeta`` op) applied in the epilogue instead of ``act``."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
         xs = [xs]
@@ -481,6 +482,10 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     d.w, d.c_in, d.n_out, d.k_w, d.dil, d.pad = w_packed.data_ptr(), c_in, n_out, k_w, dil, pad
     d.bias = _ptr(bias)
     d.act, d.alpha = act, alpha
+    if snake is not None:
+        if act != ACT_NONE or any(v.dtype != torch.float32 or v.numel() != n_out or not v.is_contiguous() for v in snake):
+            raise ValueError("conv1d: snake takes two contiguous f32 vectors of n_out and replaces act")
+        d.act, d.act_a, d.act_b = _abi.ACT_SNAKEBETA, snake[0].data_ptr(), snake[1].data_ptr()
     if resid is not None:
         if resid.dtype != torch.float32:
             raise ValueError("conv1d: residual must be f32")

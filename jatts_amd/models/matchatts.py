@@ -116,8 +116,8 @@ class _TBlock:
                                  self.dh, hip.F32S if self.split else dt, q_col0=0, k_col0=I, rel_mode=0, vt_col0=vcol)
         hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)
         n = hip.layernorm(x, self.n3[0], self.n3[1], dt, GN_EPS)
-        u = hip.conv1d(rb, n, self.ff1.w, self.ff1.c_in, self.ff1.n_out, 1, dtype=dt, bias=self.ff1.b)
-        u = hip.snakebeta(u, self.alpha, self.inv_beta)
+        # SnakeBeta rides in the epilogue of the conv that feeds it (one launch and one round trip of the widest tensor less)
+        u = hip.conv1d(rb, n, self.ff1.w, self.ff1.c_in, self.ff1.n_out, 1, dtype=dt, bias=self.ff1.b, snake=(self.alpha, self.inv_beta))
         hip.conv1d(rb, u, self.ff2.w, self.ff2.c_in, C, 1, dtype=dt, bias=self.ff2.b, resid=x, out=x, out_f32=True)
 
 

@@ -836,3 +836,57 @@ def test_snakebeta(cuda, lib, prec):
     ref = x.double() + inv_beta.double() * torch.sin(x.double() * alpha.double()) ** 2
     y = hip.snakebeta(x.to(cuda).to(hip.torch_dtype(_dt(prec))), alpha.to(cuda), inv_beta.to(cuda))
     assert relerr(y.float(), ref) <= (2e-6 if prec == "fp32" else 1e-3)
+
+
+def test_snakebeta_argument_range(cuda, lib):
+    """The activation's own sin^2 (csrc/common.h sin2_f: Cody-Waite reduction by pi/2 + the Cephes kernels, no libm slow path):
+    absolute error <= 3e-7 for arguments up to 1e5 in magnitude, exact zeros / NaN propagation at the edges."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(33)
+    mags = torch.tensor([1e-3, 1.0, 10.0, 1e2, 1e3, 1e4, 1e5])
+    x = (torch.randn(4096, 8, generator=g) * mags[torch.randint(0, 7, (4096, 1), generator=g)]).contiguous()
+    x[0] = torch.tensor([0.0, -0.0, math.pi / 2, -math.pi / 2, math.pi, 1e5, -1e5, float("nan")])
+    one = torch.ones(8)
+    y = hip.snakebeta(x.to(cuda), one.to(cuda), one.to(cuda)).cpu()
+    ref = x.double() + torch.sin(x.float().double()) ** 2
+    ok = torch.isfinite(x)
+    assert float((y.double() - ref)[ok].abs().max() - 0) <= 3e-7 + float((ref[ok].abs() * 6e-8).max())
+    assert torch.isnan(y[0, 7]) and y[0, 0] == 0 and y[0, 1] == 0
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp32_v3", "fp32_v5", "fp32_lds", "fp32_split", "fp16"])
+def test_conv1d_snakebeta_epilogue(cuda, lib, mode):
+    """JATTS_ACT_SNAKEBETA (round 4): Matcha's feed-forward activation in the epilogue of the conv that feeds it
+    (modules/matchatts/transformer.py:84-102 after ff.net.0.proj).  Same arithmetic as conv1d followed by the snakebeta op: bit-identical
+    in the f32 / split modes (every kernel family that can carry it), and closer to fp64 than the two-launch f16 path (no f16 rounding in
+    between)."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(34)
+    c_in, n_out, lens = 256, 1024, [70, 300, 129]
+    R = sum(lens)
+    x = torch.randn(R, c_in, generator=g)
+    w = torch.randn(n_out, c_in, 1, generator=g) / math.sqrt(c_in)
+    b = torch.randn(n_out, generator=g)
+    la, lb = torch.randn(n_out, generator=g) * 0.5, torch.randn(n_out, generator=g) * 0.5
+    a, ib = torch.exp(la), 1.0 / (torch.exp(lb) + 1e-9)
+    u = _ref_conv(_round(x, "fp16" if mode == "fp16" else "fp32"), _round(w, "fp16" if mode == "fp16" else "fp32"), b, lens, 1, 0, 1, None, None)
+    ref = u + ib.double() * torch.sin(u * a.double()) ** 2
+    rb = _ragged(lens, cuda)
+    dt = hip.F16 if mode == "fp16" else hip.F32
+    xd = x.to(cuda).to(hip.torch_dtype(dt))
+    wp = hip.SplitWeight(w.to(cuda), 64) if mode == "fp32_split" else hip.pack_conv_weight(w.to(cuda), dt)
+    kw = dict(dtype=dt, bias=b.to(cuda), variant={"fp32_lds": 1, "fp32_v3": 3, "fp32_v5": 5}.get(mode, 0))   # both register-streamed tiles + the LDS-staged kernel
+    ad, ibd = a.to(cuda), ib.to(cuda)
+    y = hip.conv1d(rb, xd, wp, c_in, n_out, 1, snake=(ad, ibd), **kw)
+    two = hip.snakebeta(hip.conv1d(rb, xd, wp, c_in, n_out, 1, **kw), ad, ibd)
+    torch.cuda.synchronize()
+    if mode == "fp16":
+        assert relerr(y.float(), ref) <= relerr(two.float(), ref) * 1.05 <= TOL["fp16"]
+    else:
+        assert torch.equal(y, two)
+        assert relerr(y, ref) <= TOL["fp32"]
+    from jatts_amd._abi import JattsHipError
+    with pytest.raises(JattsHipError):       # n_out % 4: refused loudly
+        hip.conv1d(rb, xd, wp, c_in, n_out - 2, 1, snake=(ad[:-2].contiguous(), ibd[:-2].contiguous()), dtype=dt, bias=b.to(cuda))
+    with pytest.raises(ValueError):
+        hip.conv1d(rb, xd, wp, c_in, n_out, 1, snake=(ad, ibd), act=hip.ACT_RELU, **kw)
