@@ -2,14 +2,23 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-PARITY UNPINNED for the generator: the reference calls
+PARITY for the generator: the reference calls
 ``parallel_wavegan.utils.load_model(...)``, ``.remove_weight_norm()`` and
 ``.inference(c, normalize_before=False)`` (/root/reference/jatts/vocoder/vocoder.py:
 13,41,43,64); `parallel-wavegan` is an un-vendored, unpinned pip dependency
 (setup.cfg:17) that is not installed here, and the reference holds no test or
-golden vector for it.  This file restates the published architecture (HiFi-GAN,
-arXiv 2010.05646 §2 / App. A, generator V1) with the state_dict key schema of
-parallel_wavegan.models.HiFiGANGenerator [recalled]:
+golden vector for it -- against parallel_wavegan ITSELF this file stays unpinned.
+It IS pinned on an independent public implementation of the same published network
+(HiFi-GAN, arXiv 2010.05646 section 2 / App. A, generator V1): Hugging Face transformers
+5.15.0 `FastSpeech2ConformerHifiGan`, run in this container on the same weights and mels
+(tests/golden/make_golden_hifigan_xcheck.py -> hifigan_xcheck.npz: the 22.05 kHz V1
+config at full width, two narrower / differently blocked ones, and weight-norm (g, v)
+loading).  In fp64 the two agree to rounding (<= 1e-15); tests/test_oracle_golden.py
+checks the fixture and a live run, tests/test_hifigan_gpu.py holds the HIP path to the
+same waveforms.  What that cannot pin: the odd-stride padding convention of the
+transposed convs (`s // 2 + s % 2`, output_padding `s % 2`: the 24 kHz config 5, 5, 4, 3),
+where transformers' `(k - s) // 2` differs and parallel_wavegan's is [recalled]; and the
+state_dict key schema of parallel_wavegan.models.HiFiGANGenerator [recalled]:
 
   input_conv.{weight,bias}                      Conv1d(in, C, k7, pad 3)
   upsamples.<i>.1.{weight,bias}                 LeakyReLU(0.1) -> ConvTranspose1d(C_i, C_i/2, k_i, s_i,

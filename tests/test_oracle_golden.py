@@ -155,6 +155,39 @@ def test_hifigan_oracle_structure():
     assert maxdiff(y, y2) <= 1e-5
 
 
+@pytest.mark.parametrize("case", ["v1", "w128", "two_blocks", "wn"])
+def test_hifigan_oracle_matches_an_independent_implementation(case):
+    """The generator restatement against waveforms produced by Hugging Face transformers' FastSpeech2ConformerHifiGan -- an independent
+    public implementation of the same published network (tests/golden/make_golden_hifigan_xcheck.py explains why the two agree for the
+    22.05 kHz V1 strides, and that parallel_wavegan itself is absent).  fp64 oracle == fp64 fixture to rounding; the f32 oracle within the
+    f32 run's own distance; activations after conv_pre / the first transposed conv as well; `wn` goes through fold_weight_norm."""
+    from helpers import hifigan_xcheck_case
+    params, sd, mel, z = hifigan_xcheck_case(case)
+    taps = {}
+    y64 = HO.hifigan_generate({k: v.double() for k, v in sd.items()}, mel.double(), params["upsample_scales"], params["resblock_dilations"], taps=taps)
+    ref = z[f"{case}_wave_f64"]
+    assert y64.shape == ref.shape and maxdiff(y64, ref) <= 1e-12
+    assert maxdiff(taps["input_conv"], z[f"{case}_input_conv"]) <= 1e-5 and maxdiff(taps["up0"], z[f"{case}_up0"]) <= 1e-5
+    y32 = HO.hifigan_generate(sd, mel, params["upsample_scales"], params["resblock_dilations"])
+    assert maxdiff(y32, ref) <= 2e-6 and maxdiff(z[f"{case}_wave_f32"], ref) <= 2e-6
+
+
+def test_hifigan_oracle_matches_transformers_live():
+    """The same cross-check run live where `transformers` is importable (this image): another seed / length than the fixture's."""
+    pytest.importorskip("transformers")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_hifigan_xcheck import hf_generator, run
+    from jatts_amd.synthetic import HIFIGAN_V1_22K, synth_hifigan_state
+    params = dict(HIFIGAN_V1_22K, channels=256)
+    sd = synth_hifigan_state(params, seed=21)
+    mel = torch.randn(11, 80, generator=torch.Generator().manual_seed(22))
+    y, _ = run(hf_generator(params, sd), mel, torch.float64)
+    yo = HO.hifigan_generate({k: v.double() for k, v in sd.items()}, mel.double(), params["upsample_scales"], params["resblock_dilations"])
+    assert maxdiff(yo, y) <= 1e-12
+
+
 def test_masks_golden():
     from jatts_amd.hostlogic import make_non_pad_mask, make_pad_mask
 
