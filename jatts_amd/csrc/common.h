@@ -147,8 +147,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Maximum over the wave, in every lane.  DPP inside the rows of 16 (quad swaps, then row rotations) and four v_readlane across them: ~10
+// dependent VALU issues instead of six ds_bpermute round trips (each a full LDS latency with a wait) -- the block maxima of the split
+// arithmetic sit on the critical path of every operand tile.
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+#define JATTS_DPP_MAX(ctrl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+  JATTS_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
+  JATTS_DPP_MAX(0x4E);    // quad_perm [2, 3, 0, 1]
+  JATTS_DPP_MAX(0x124);   // row_ror 4
+  JATTS_DPP_MAX(0x128);   // row_ror 8
+#undef JATTS_DPP_MAX
+  const int i = __builtin_bit_cast(int, v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, e));
 }
