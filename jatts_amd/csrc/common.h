@@ -96,10 +96,12 @@ template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 // Mish = v tanh(softplus v).  tanh(log(1 + w)) = (w^2 + 2w) / (w^2 + 2w + 2) with w = e^v: one exp and one divide instead of
 // exp + log1p + tanh (the activation was VALU-bound in the GroupNorm apply kernel).  v > 20: torch's softplus threshold (= v).
+// Branch-free: at the threshold w^2 + 2w = 2.4e17 and the ratio rounds to exactly 1, so clamping the exponent's argument IS the
+// threshold rule.  v_exp_f32 / v_rcp_f32 (1 ulp each) instead of libm's expf and an IEEE divide: 54 -> 20 VALU per element in the
+// GroupNorm apply pass, relative error <= 3e-7.
 __device__ __forceinline__ float mish_f(float v) {
-  if (v > 20.f) return v;
-  const float w = expf(v), n = w * (w + 2.f);
-  return v * n / (n + 2.f);
+  const float w = __expf(fminf(v, 20.f)), n = w * (w + 2.f);
+  return v * (n * __builtin_amdgcn_rcpf(n + 2.f));
 }
 
 // sin^2(x) for SnakeBeta: three-constant Cody-Waite reduction by pi/2 (exact products under FMA) and the Cephes single-precision

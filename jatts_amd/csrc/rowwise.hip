@@ -411,9 +411,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(jatts_ragged rg, const T*
   }
 }
 
-// Row-streaming form of the apply pass: a workgroup takes GN_TCH full rows (ALL groups: contiguous C-element rows instead of one
+// Row-streaming form of the apply pass: a workgroup takes GN_AROWS full rows (ALL groups: contiguous C-element rows instead of one
 // group's 256-byte pieces 2 KB apart), merges the chunk statistics of every group of its utterance once into LDS, then streams.
+// GN_AROWS is independent of the statistics chunking: at 64 rows the bench shapes gave 768 workgroups of 8 dependent load -> Mish ->
+// store rounds each, 24 KB in flight per CU and 2.4 TB/s; 16 rows quadruple the workgroups (12 per CU) with two rounds each.
 constexpr int GN_MAXG = 32;
+constexpr int GN_AROWS = 16;
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(jatts_ragged rg, const T* __restrict__ x, TO* __restrict__ y, int C, int groups,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(jatts_ragged rg, con
   const int b = blockIdx.y, ch = blockIdx.x;
   const int row0 = rg.cu_rows[b];
   const int L = rg.cu_rows[b + 1] - row0;
-  const int r0 = ch * GN_TCH;
+  const int r0 = ch * GN_AROWS;
   if (r0 >= L) return;
   if (threadIdx.x < groups) {
     const float* st = ws + ((int64_t)b * groups + threadIdx.x) * n_chunks * 3;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(jatts_ragged rg, con
     s_rstd[threadIdx.x] = rsqrtf(m2a / na + eps);
   }
   __syncthreads();
-  const int rows = min(GN_TCH, L - r0);
+  const int rows = min(GN_AROWS, L - r0);
   const int gc = C / groups, upr = C >> 3, total = rows * upr;
   const T* xb = x + (int64_t)(row0 + r0) * C;
   TO* yb = y + (int64_t)(row0 + r0) * C;
@@ -453,12 +456,12 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(jatts_ragged rg, con
     load8f<T>(xb + (int64_t)r * C + c, v);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (av) { a0 = *reinterpret_cast<const f32x4*>(av + c); a1 = *reinterpret_cast<const f32x4*>(av + c + 4); }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = (v[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
-      t = mish_f(t);
-      if (av) t += av[c + e];
-      o[e] = t;
+      const float t = (v[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+      o[e] = mish_f(t) + (e < 4 ? a0[e] : a1[e - 4]);
     }
     TO* dst = yb + (int64_t)r * C + c;
     if (sizeof(TO) == 2) *reinterpret_cast<f16x8*>(dst) = f16x8{(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
@@ -970,7 +973,7 @@ extern "C" int jatts_groupnorm_mish(const jatts_ragged* rg, const void* x, int32
   do {                                                                                                                   \
     hipLaunchKernelGGL((gn_partial_kernel<TI>), grid3, blk3, 0, S_, *rg, (const TI*)x, channels, groups, workspace, n_chunks); \
     if (rows_form)                                                                                                          \
-      hipLaunchKernelGGL((gn_apply_rows_kernel<TI, TO>), dim3((unsigned)n_chunks, (unsigned)rg->n_seq), blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
+      hipLaunchKernelGGL((gn_apply_rows_kernel<TI, TO>), dim3((unsigned)((rg->max_len + GN_AROWS - 1) / GN_AROWS), (unsigned)rg->n_seq), blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
     else                                                                                                                    \
       hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), grid3, blk3, 0, S_, *rg, (const TI*)x, (TO*)y, channels, groups, gamma, beta, eps, addvec, workspace, n_chunks); \
   } while (0)

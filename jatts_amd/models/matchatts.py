@@ -349,25 +349,30 @@ class _MatchaBase(torch.nn.Module):
         def masked(rbx, t, vl, len_mul=1):     # `x * mask` in front of a conv / a skip connection (no-op on ragged batches)
             return t if vl is None else hip.zero_pad_rows(rbx, t, vl, len_mul)
 
+        tdt = hip.torch_dtype(dt)
+
+        def operand(t):     # conv operand dtype.  f32 / split modes on a ragged batch: the f32 stream itself (no copy); the padded training-
+            return t if (valid is None and t.dtype == tdt) else hip.affine_cast(t, dt)   # time forward masks its operands in place -> own buffer
+
         h0 = stage(P["d0"], rb, [x_t, mu_t], v1, kb1)            # (R, C0) f32; skip connection 0
-        h0_t = masked(rb, hip.affine_cast(h0, dt), v1)
+        h0_t = masked(rb, operand(h0), v1)
         C0 = h0.shape[1]
         dn = P["down"]
         h = hip.conv1d(rb2, h0_t.view(-1, 2 * C0), dn.w, dn.c_in, C0, 2, dtype=dt, bias=dn.b, pad=1)   # (R/2, C0)
         h1 = stage(P["d1"], rb2, [masked(rb2, h, v2)], v2, kb2)  # skip connection 1
-        h1_t = masked(rb2, hip.affine_cast(h1, dt), v2)
+        h1_t = masked(rb2, operand(h1), v2)
         c = P["d1c"]
         h = hip.conv1d(rb2, h1_t, c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
         for blk in P["mid"]:
-            h = hip.affine_cast(stage(blk, rb2, [masked(rb2, h, v2)], v2, kb2), dt)
+            h = operand(stage(blk, rb2, [masked(rb2, h, v2)], v2, kb2))
         h = stage(P["u0"], rb2, [masked(rb2, h, v2), h1_t], v2, kb2)
         up, pad = P["up"]
         C1 = h.shape[1]
-        h = hip.conv1d(rb2, masked(rb2, hip.affine_cast(h, dt), v2), up.w, up.c_in, 2 * C1, up.k, dtype=dt, bias=up.b, pad=pad)
+        h = hip.conv1d(rb2, masked(rb2, operand(h), v2), up.w, up.c_in, 2 * C1, up.k, dtype=dt, bias=up.b, pad=pad)
         h = h.view(-1, C1)                                        # (R, C1): polyphase rows are already interleaved
         h = stage(P["u1"], rb, [masked(rb, h, v1), h0_t], v1, kb1)
         c = P["u1c"]
-        h = hip.conv1d(rb, masked(rb, hip.affine_cast(h, dt), v1), c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
+        h = hip.conv1d(rb, masked(rb, operand(h), v1), c.w, c.c_in, c.n_out, 3, dtype=dt, bias=c.b)
         fbc, g, b = P["fb"]
         h = hip.conv1d(rb, masked(rb, h, v1), fbc.w, fbc.c_in, fbc.n_out, 3, dtype=dt, bias=fbc.b)
         h = masked(rb, hip.groupnorm_mish(rb, h, fbc.n_out, 8, g, b, dt, GN_EPS), v1)
