@@ -29,6 +29,22 @@ __device__ __forceinline__ typename G<T>::vec8 load8(const typename G<T>::type* 
   }
   return v;
 }
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// The same 8 elements through a buffer descriptor: wave-uniform base + 32-bit per-lane byte offset + scalar byte offset, zeros past the
+// descriptor's range (no 64-bit address registers, no bounds compare / select per chunk in the tile loads).
+template <typename T>
+__device__ __forceinline__ typename G<T>::vec8 load8_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  typename G<T>::vec8 v;
+  if constexpr (sizeof(typename G<T>::type) == 2) {
+    v = __builtin_bit_cast(typename G<T>::vec8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  } else {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[e + 4] = b[e]; }
+  }
+  return v;
+}
 // LDS fragment read: 8 contraction elements of arithmetic T at `p` (f16s: one planar unit, 16 B of hi then 16 B of lo)
 template <typename T>
 __device__ __forceinline__ typename Elem<T>::vec8 lds8(const char* p) {
@@ -59,6 +75,9 @@ __device__ __forceinline__ int attn_split_exp(float amax) {
 }
 __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }
 
+#ifndef JATTS_ATTN_HALFPF
+#define JATTS_ATTN_HALFPF 1
+#endif
 constexpr int QB = 64;  // queries per workgroup
 constexpr int KB = 64;  // keys per tile
 
@@ -96,30 +115,36 @@ struct TileRegs {
   float ku;
 };
 
-template <typename T, int DK, int KBT>
+// WHICH: 1 = the K tile (+ the u . k bias of its keys), 2 = the V^T tile, 3 = both
+template <typename T, int DK, int KBT, int WHICH = 3>
 __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
-                                          const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec) {
+                                          const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec,
+                                          __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv) {
   typedef typename G<T>::vec8 Vec;
   typedef typename G<T>::type TG;
   constexpr int UPR = DK / 8;
+  if constexpr (WHICH & 1) {   // (first: anything the compiler reloads from scratch for this address must not sit behind the tile's loads --
+    tr.ku = 0.f;               //  a scratch reload waits on vmcnt(0), i.e. on every global load issued before it)
+    if (d.ku && threadIdx.x < KBT) {
+      const int j = j0 + (int)threadIdx.x;
+      if (j >= 0 && j < Tn) tr.ku = d.ku[(int64_t)(row0 + j) * d.n_heads + h];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
     const int u = threadIdx.x + 256 * i;
-    {  // K rows: keys, 8 channels per chunk
-      const int r = u / UPR, cu = u - r * UPR, j = j0 + r;
-      Vec z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = from_f32<TG>(0.f);
-      tr.k[i] = (j >= 0 && j < Tn) ? load8<T>(kg + (int64_t)j * d.ldk + cu * 8) : z;
+    if constexpr (WHICH & 1) {  // K rows: keys, 8 channels per chunk
+      const int r = u / UPR, cu = u - r * UPR;        // rows >= Tn lie past the descriptor: zeros (key tiles start at key 0)
+      tr.k[i] = load8_buf<T>(rk, (unsigned)(r * d.ldk + cu * 8) * (unsigned)sizeof(TG), (unsigned)(j0 * d.ldk) * (unsigned)sizeof(TG));
     }
-    {  // V^T rows: channels, 8 keys per chunk
+    if constexpr (WHICH & 2) {  // V^T rows: channels, 8 keys per chunk
       const int r = u / (KBT / 8), jc = j0 + 8 * (u % (KBT / 8));
       Vec z;
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = from_f32<TG>(0.f);
       const TG* src = vtg + (int64_t)r * d.ldvt + jc;
-      if (vt_vec) {
-        if (jc + 7 >= 0 && jc < Tn) z = load8<T>(src);   // aligned: (row0 + j0) % 8 == 0, ldvt % 8 == 0
+      if (vt_vec) {   // aligned: (row0 + j0) % 8 == 0, ldvt % 8 == 0; chunks at or past round_up(Tn, 8) lie past the descriptor
+        z = load8_buf<T>(rv, (unsigned)(r * d.ldvt + 8 * (u % (KBT / 8))) * (unsigned)sizeof(TG), (unsigned)j0 * (unsigned)sizeof(TG));
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (jc + e < 0 || jc + e >= Tn) z[e] = from_f32<TG>(0.f);   // never multiply P = 0 by stray bits
@@ -131,14 +156,9 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_
       tr.v[i] = z;
     }
   }
-  tr.ku = 0.f;
-  if (d.ku && threadIdx.x < KBT) {
-    const int j = j0 + (int)threadIdx.x;
-    if (j >= 0 && j < Tn) tr.ku = d.ku[(int64_t)(row0 + j) * d.n_heads + h];
-  }
 }
 
-template <typename T, int DK, int KBT>
+template <typename T, int DK, int KBT, int WHICH = 3>
 __device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char* ks, char* vs, float* kus, int KP, int VP, float sk = 1.f,
                                            float sv = 1.f) {
   constexpr int UPR = DK / 8;
@@ -146,15 +166,19 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char*
   for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
     const int u = threadIdx.x + 256 * i;
     const int r = u / UPR, cu = u - r * UPR;
-    store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i], sk);
-    store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i], sv);
+    if constexpr (WHICH & 1) store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i], sk);
+    if constexpr (WHICH & 2) store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i], sv);
   }
-  if (threadIdx.x < KBT) kus[threadIdx.x] = tr.ku;
+  if constexpr (WHICH & 1) {
+    if (threadIdx.x < KBT) kus[threadIdx.x] = tr.ku;
+  }
 }
 
 // KBT = keys per tile: 64, or 32 for f32 at d_k >= 128 -- there a 64-key tile pair is 102-136 KB of LDS, ONE workgroup (one wave per SIMD)
 // per CU, and every softmax / rescale instruction stalls the matrix pipe (0.33 of the f32 MFMA peak); half tiles fit two workgroups.
-template <typename T, int DK, int KBT>
+// REL = false: an instantiation without the rel-pos bias machinery (d.g is NULL: Matcha's plain attention) -- its pointers and gather
+// registers are what pushed the f32 d_k 256 kernel into scratch.
+template <typename T, int DK, int KBT, bool REL = true>
 __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<T>::vec8 Vec;
@@ -188,12 +212,17 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   const TG* kg = (const TG*)d.k + (int64_t)row0 * d.ldk + h * DK;
   const int vcol0 = d.vt_col0 ? d.vt_col0[b] : row0;
   const TG* vtg = (const TG*)d.vt + (int64_t)(h * DK) * d.ldvt + vcol0;
-  const TG* gg = d.g ? (const TG*)d.g : nullptr;
+  const TG* gg = (REL && d.g) ? (const TG*)d.g : nullptr;
   const int H = d.n_heads;
   // Key tiles always start at the sequence's first key (results do not depend on the position in the packed batch).
   // V^T is staged with aligned 16-byte loads when the sequence's first column is (vt_col0, RaggedBatch.vt_layout).
   const bool vt_vec = (d.ldvt & 7) == 0 && (vcol0 & 7) == 0 && (reinterpret_cast<uintptr_t>(d.vt) & 31) == 0;
   constexpr int j_start = 0;
+  // buffer descriptors of this (utterance, head)'s K rows and V^T rows (tile_load): K = Tn rows of ldk elements from kg; V^T = d_k rows
+  // of ldvt elements from vtg, the last one cut at round_up(Tn, 8) columns
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, (unsigned)((int64_t)Tn * d.ldk * sizeof(TG)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv =
+      __builtin_amdgcn_make_buffer_rsrc((void*)vtg, 0, (unsigned)(((int64_t)(DK - 1) * d.ldvt + ((Tn + 7) & ~7)) * sizeof(TG)), 0x00020000);
 
   Vec qf[NKS];
   int eq = 0;                               // split arithmetic: Q lives at scale 2^eq (one scale per workgroup = 64 queries of one head)
@@ -232,13 +261,26 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   // have the registers for that at 2 waves/SIMD: it loads and stores the tile back to back (still 16-byte batched)
   // and relies on the second resident workgroup to cover the round trip.
   constexpr bool PREFETCH = (DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192);   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
+  // Without the registers for a whole tile pair (plain operands only): HALF a tile in flight at a time.  V^T(t) is loaded under the score
+  // MFMAs of tile t and lands in LDS before P V; K(t+1) is loaded under P V(t) and lands after it -- each global round trip behind one
+  // MFMA phase, the same two barriers per tile, 32 staging registers instead of 64 (f32 d_k 256 at two workgroups per CU waited on
+  // every tile before: matrix pipe 54 % busy).
+  constexpr bool HALFPF = JATTS_ATTN_HALFPF && !PREFETCH && !SPLIT && sizeof(T) == 4;   // (f16 d_k 256 keeps its 64-key tiles: the half pipeline spilled 80 bytes there)
   TileRegs<T, DK, KBT> tr;
-  if (PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec);
+  if (PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
+  if constexpr (HALFPF) {
+    tile_load<T, DK, KBT, 1>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
+    tile_store<T, DK, KBT, 1>(tr, ks, vs, kus, KP, VP);
+    __syncthreads();
+  }
   int ev_prev = 0;
   for (int j0 = j_start; j0 < Tk; j0 += KBT) {
-    if (!PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec);
+    if constexpr (HALFPF) tile_load<T, DK, KBT, 2>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
+    else if (!PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
     int ek = 0, ev = 0;
-    if constexpr (SPLIT) {    // block maxima of the K and V^T tiles that sit in registers -> their power-of-two scales
+    if constexpr (HALFPF) {
+      // (K(t) is in LDS since the previous iteration's last barrier)
+    } else if constexpr (SPLIT) {    // block maxima of the K and V^T tiles that sit in registers -> their power-of-two scales
       float mk = 0.f, mv = 0.f;
 #pragma unroll
       for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
@@ -255,8 +297,8 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
     } else {
       tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP);
     }
-    __syncthreads();
-    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec);
+    if constexpr (!HALFPF) __syncthreads();
+    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
 
     // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
     float bd[NF][4];
@@ -265,7 +307,7 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
       const int jq = j0 + 16 * f + 4 * g;  // this lane's 4 consecutive keys jq .. jq+3 of fragment f
 #pragma unroll
       for (int r = 0; r < 4; ++r) bd[f][r] = 0.f;
-      if (gg && qi < Tn) {
+      if (REL && gg && qi < Tn) {
         const bool inside = jq >= 0 && jq + 3 < Tn;
         if (d.rel_mode == 2) {  // new rel_shift: plain diagonal map, no wrap
           const TG* p = g_q + (d.rel_center - qi + jq);
@@ -341,6 +383,11 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
 #pragma unroll
       for (int r = 0; r < 4; ++r) ot[f][r] *= oscale;
 
+    if constexpr (HALFPF) {
+      tile_store<T, DK, KBT, 2>(tr, ks, vs, kus, KP, VP);
+      __syncthreads();            // V^T(t) visible; every wave is past its score MFMAs and its u . k reads: the K buffer is free
+      if (j0 + KBT < Tk) tile_load<T, DK, KBT, 1>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
+    }
     // ---- O^T += V^T P^T over two 32-key blocks.  Contraction slots of k-group g in block kb:
     //      keys {32kb + 4g + r} (from st[2kb]) then {32kb + 16 + 4g + r} (from st[2kb+1]) ----
 #pragma unroll
@@ -378,6 +425,9 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
         mma16(a, pb, ot[f]);
       }
     }
+    if constexpr (HALFPF) {
+      if (j0 + KBT < Tk) tile_store<T, DK, KBT, 1>(tr, ks, vs, kus, KP, VP);
+    }
     __syncthreads();
   }
 
@@ -393,11 +443,11 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   }
 }
 
-template <typename T, int DK, int KBT = KB>
+template <typename T, int DK, int KBT = KB, bool REL = true>
 int launch_attn_kb(const jatts_relattn_desc& d, hipStream_t s) {
   const size_t lds = (size_t)KBT * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KBT * sizeof(T) + 16) + KBT * sizeof(float) + 64;
   dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
-  auto kern = relattn_kernel<T, DK, KBT>;
+  auto kern = relattn_kernel<T, DK, KBT, REL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
@@ -410,6 +460,9 @@ template <typename T, int DK>
 int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
   if constexpr (sizeof(T) == 4 && DK >= 128 && DK % 64 == 0) {
     static const int half = [] { const char* e = getenv("JATTS_ATTN_KB32"); return e ? atoi(e) : 1; }();
+    if constexpr (DK == 256 && sizeof(typename G<T>::type) == 4 && !G<T>::split) {
+      if (half && !d.g) return launch_attn_kb<T, DK, 32, false>(d, s);
+    }
     if (half) return launch_attn_kb<T, DK, 32>(d, s);
   }
   return launch_attn_kb<T, DK, KB>(d, s);
