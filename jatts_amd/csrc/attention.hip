@@ -78,7 +78,6 @@ __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((uns
 #ifndef JATTS_ATTN_HALFPF
 #define JATTS_ATTN_HALFPF 1
 #endif
-constexpr int QB = 64;  // queries per workgroup
 constexpr int KB = 64;  // keys per tile
 
 template <typename T>
@@ -108,16 +107,16 @@ __device__ __forceinline__ void load4u(const T* p, float (&o)[4]) {     // (T = 
 // One K / V^T tile in flight in registers: the global loads of tile t+1 are issued before the MFMAs of tile t
 // and land in LDS after them, so no wave ever waits on a tile load (the first version staged V^T with one
 // 2-byte load per element, each a serialized round trip: 1.1 ms per decoder layer, profiles/r01_notes.md).
-template <typename T, int DK, int KBT>
+template <typename T, int DK, int KBT, int NW = 4>
 struct TileRegs {
-  static constexpr int N = KBT * DK / 2048;  // 8-element chunks per thread for K and for V^T (KBT x DK elements over 256 threads)
+  static constexpr int N = KBT * DK / (512 * NW);  // 8-element chunks per thread for K and for V^T (KBT x DK elements over 64 NW threads)
   typename G<T>::vec8 k[N], v[N];
   float ku;
 };
 
 // WHICH: 1 = the K tile (+ the u . k bias of its keys), 2 = the V^T tile, 3 = both
-template <typename T, int DK, int KBT, int WHICH = 3>
-__device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4>
+__device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
                                           const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec,
                                           __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv) {
   typedef typename G<T>::vec8 Vec;
@@ -131,8 +130,8 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_
     }
   }
 #pragma unroll
-  for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
-    const int u = threadIdx.x + 256 * i;
+  for (int i = 0; i < TileRegs<T, DK, KBT, NW>::N; ++i) {
+    const int u = threadIdx.x + 64 * NW * i;
     if constexpr (WHICH & 1) {  // K rows: keys, 8 channels per chunk
       const int r = u / UPR, cu = u - r * UPR;        // rows >= Tn lie past the descriptor: zeros (key tiles start at key 0)
       tr.k[i] = load8_buf<T>(rk, (unsigned)(r * d.ldk + cu * 8) * (unsigned)sizeof(TG), (unsigned)(j0 * d.ldk) * (unsigned)sizeof(TG));
@@ -158,13 +157,13 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT>& tr, const jatts_
   }
 }
 
-template <typename T, int DK, int KBT, int WHICH = 3>
-__device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char* ks, char* vs, float* kus, int KP, int VP, float sk = 1.f,
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4>
+__device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT, NW>& tr, char* ks, char* vs, float* kus, int KP, int VP, float sk = 1.f,
                                            float sv = 1.f) {
   constexpr int UPR = DK / 8;
 #pragma unroll
-  for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
-    const int u = threadIdx.x + 256 * i;
+  for (int i = 0; i < TileRegs<T, DK, KBT, NW>::N; ++i) {
+    const int u = threadIdx.x + 64 * NW * i;
     const int r = u / UPR, cu = u - r * UPR;
     if constexpr (WHICH & 1) store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i], sk);
     if constexpr (WHICH & 2) store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i], sv);
@@ -178,8 +177,10 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT>& tr, char*
 // per CU, and every softmax / rescale instruction stalls the matrix pipe (0.33 of the f32 MFMA peak); half tiles fit two workgroups.
 // REL = false: an instantiation without the rel-pos bias machinery (d.g is NULL: Matcha's plain attention) -- its pointers and gather
 // registers are what pushed the f32 d_k 256 kernel into scratch.
-template <typename T, int DK, int KBT, bool REL = true>
-__global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ? 2 : 1) void relattn_kernel(jatts_relattn_desc d) {
+// NW = 8: 512-thread workgroups of 128 queries, one per CU (the same two waves per SIMD): a K / V^T tile is staged once for twice the
+// MFMA work and each thread holds half as much of it, so the whole next tile pair fits in registers again (full prefetch at d_k 256).
+template <typename T, int DK, int KBT, bool REL = true, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) == 2) || KBT == 32) ? 2 : 1)) void relattn_kernel(jatts_relattn_desc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Elem<T>::vec8 Vec;
   typedef typename G<T>::type TG;          // element type in HBM (f32 for the split arithmetic)
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   const int b = blockIdx.y, h = blockIdx.z;
   const int row0 = d.rg.cu_rows[b];
   const int Tn = d.rg.cu_rows[b + 1] - row0;
-  const int i0 = blockIdx.x * QB;
+  const int i0 = blockIdx.x * (16 * NW);
   if (i0 >= Tn) return;
   // keys >= Tk are masked out of the softmax (a PADDED batch, the reference's training-time forward(): Tn is then the padded
   // length, which the rel-shift geometry keeps using, and Tk the utterance's own length; attention.py:80-88)
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
     m = wave_max(m);
     if (lane == 0) slots[wave] = m;
     __syncthreads();
-    eq = attn_split_exp(fmaxf(fmaxf(slots[0], slots[1]), fmaxf(slots[2], slots[3])));
+    float mq = slots[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mq = fmaxf(mq, slots[w]);
+    eq = attn_split_exp(mq);
     __syncthreads();
     const float sq = attn_exp2i(eq);
 #pragma unroll
@@ -260,30 +264,30 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   // d_k <= 192: the next tile is prefetched into registers during the current tile's MFMAs.  d_k = 256 does not
   // have the registers for that at 2 waves/SIMD: it loads and stores the tile back to back (still 16-byte batched)
   // and relies on the second resident workgroup to cover the round trip.
-  constexpr bool PREFETCH = (DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192);   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
+  constexpr bool PREFETCH = NW == 8 || ((DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192));   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
   // Without the registers for a whole tile pair (plain operands only): HALF a tile in flight at a time.  V^T(t) is loaded under the score
   // MFMAs of tile t and lands in LDS before P V; K(t+1) is loaded under P V(t) and lands after it -- each global round trip behind one
   // MFMA phase, the same two barriers per tile, 32 staging registers instead of 64 (f32 d_k 256 at two workgroups per CU waited on
   // every tile before: matrix pipe 54 % busy).
   constexpr bool HALFPF = JATTS_ATTN_HALFPF && !PREFETCH && !SPLIT && sizeof(T) == 4;   // (f16 d_k 256 keeps its 64-key tiles: the half pipeline spilled 80 bytes there)
-  TileRegs<T, DK, KBT> tr;
-  if (PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
+  TileRegs<T, DK, KBT, NW> tr;
+  if (PREFETCH) tile_load<T, DK, KBT, 3, NW>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
   if constexpr (HALFPF) {
-    tile_load<T, DK, KBT, 1>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
-    tile_store<T, DK, KBT, 1>(tr, ks, vs, kus, KP, VP);
+    tile_load<T, DK, KBT, 1, NW>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
+    tile_store<T, DK, KBT, 1, NW>(tr, ks, vs, kus, KP, VP);
     __syncthreads();
   }
   int ev_prev = 0;
   for (int j0 = j_start; j0 < Tk; j0 += KBT) {
-    if constexpr (HALFPF) tile_load<T, DK, KBT, 2>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
-    else if (!PREFETCH) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
+    if constexpr (HALFPF) tile_load<T, DK, KBT, 2, NW>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
+    else if (!PREFETCH) tile_load<T, DK, KBT, 3, NW>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
     int ek = 0, ev = 0;
     if constexpr (HALFPF) {
       // (K(t) is in LDS since the previous iteration's last barrier)
     } else if constexpr (SPLIT) {    // block maxima of the K and V^T tiles that sit in registers -> their power-of-two scales
       float mk = 0.f, mv = 0.f;
 #pragma unroll
-      for (int i = 0; i < TileRegs<T, DK, KBT>::N; ++i) {
+      for (int i = 0; i < TileRegs<T, DK, KBT, NW>::N; ++i) {
         mk = amax8(tr.k[i], mk);
         mv = amax8(tr.v[i], mv);
       }
@@ -291,14 +295,17 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
       mv = wave_max(mv);
       if (lane == 0) { slots[2 * wave] = mk; slots[2 * wave + 1] = mv; }
       __syncthreads();
-      ek = attn_split_exp(fmaxf(fmaxf(slots[0], slots[2]), fmaxf(slots[4], slots[6])));
-      ev = attn_split_exp(fmaxf(fmaxf(slots[1], slots[3]), fmaxf(slots[5], slots[7])));
-      tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev));
+      float sk = slots[0], sv = slots[1];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) { sk = fmaxf(sk, slots[2 * w]); sv = fmaxf(sv, slots[2 * w + 1]); }
+      ek = attn_split_exp(sk);
+      ev = attn_split_exp(sv);
+      tile_store<T, DK, KBT, 3, NW>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev));
     } else {
-      tile_store<T, DK, KBT>(tr, ks, vs, kus, KP, VP);
+      tile_store<T, DK, KBT, 3, NW>(tr, ks, vs, kus, KP, VP);
     }
     if constexpr (!HALFPF) __syncthreads();
-    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
+    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT, 3, NW>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
 
     // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
     float bd[NF][4];
@@ -384,9 +391,9 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
       for (int r = 0; r < 4; ++r) ot[f][r] *= oscale;
 
     if constexpr (HALFPF) {
-      tile_store<T, DK, KBT, 2>(tr, ks, vs, kus, KP, VP);
+      tile_store<T, DK, KBT, 2, NW>(tr, ks, vs, kus, KP, VP);
       __syncthreads();            // V^T(t) visible; every wave is past its score MFMAs and its u . k reads: the K buffer is free
-      if (j0 + KBT < Tk) tile_load<T, DK, KBT, 1>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
+      if (j0 + KBT < Tk) tile_load<T, DK, KBT, 1, NW>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
     }
     // ---- O^T += V^T P^T over two 32-key blocks.  Contraction slots of k-group g in block kb:
     //      keys {32kb + 4g + r} (from st[2kb]) then {32kb + 16 + 4g + r} (from st[2kb+1]) ----
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
       }
     }
     if constexpr (HALFPF) {
-      if (j0 + KBT < Tk) tile_store<T, DK, KBT, 1>(tr, ks, vs, kus, KP, VP);
+      if (j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW>(tr, ks, vs, kus, KP, VP);
     }
     __syncthreads();
   }
@@ -443,16 +450,16 @@ __global__ __launch_bounds__(256, ((DK <= 256 && sizeof(T) == 2) || KBT == 32) ?
   }
 }
 
-template <typename T, int DK, int KBT = KB, bool REL = true>
+template <typename T, int DK, int KBT = KB, bool REL = true, int NW = 4>
 int launch_attn_kb(const jatts_relattn_desc& d, hipStream_t s) {
   const size_t lds = (size_t)KBT * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KBT * sizeof(T) + 16) + KBT * sizeof(float) + 64;
-  dim3 grid((unsigned)((d.rg.max_len + QB - 1) / QB), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
-  auto kern = relattn_kernel<T, DK, KBT, REL>;
+  dim3 grid((unsigned)((d.rg.max_len + 16 * NW - 1) / (16 * NW)), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
+  auto kern = relattn_kernel<T, DK, KBT, REL, NW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, d);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }
@@ -460,6 +467,13 @@ template <typename T, int DK>
 int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
   if constexpr (sizeof(T) == 4 && DK >= 128 && DK % 64 == 0) {
     static const int half = [] { const char* e = getenv("JATTS_ATTN_KB32"); return e ? atoi(e) : 1; }();
+    // d_k 256: the split arithmetic takes 512-thread workgroups (half the hi / lo conversion work per wave, the whole next tile pair
+    // prefetched: T = 768 511 -> 466 us); exact f32 is slower that way (738 -> 771 us: eight waves in lockstep on the barriers) and
+    // keeps four waves with half a tile in flight.  JATTS_ATTN_NW8 = 0 / 1 forces either (tools/ A/B only).
+    static const int wide = [] { const char* e = getenv("JATTS_ATTN_NW8"); return e ? atoi(e) : -1; }();
+    if constexpr (DK == 256 && sizeof(typename G<T>::type) == 4) {
+      if (half && (wide >= 0 ? wide != 0 : G<T>::split)) return launch_attn_kb<T, DK, 32, true, 8>(d, s);
+    }
     if constexpr (DK == 256 && sizeof(typename G<T>::type) == 4 && !G<T>::split) {
       if (half && !d.g) return launch_attn_kb<T, DK, 32, false>(d, s);
     }
