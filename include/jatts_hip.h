@@ -404,7 +404,8 @@ int jatts_hifigan_output(const jatts_ragged* rg, int32_t dtype, const void* cons
  *             = g[i+1][j-i-2]    (j >  i+1)      (the view-reinterpretation wrap)
  * where g[row][h][m] = (q_row,h + pos_bias_v_h) . p_h[m] is produced by jatts_conv1d and
  * ku[row][h] = pos_bias_u_h . k_row,h by jatts_rowdot.  out = softmax(score) V.
- * d_k must be a multiple of 32.
+ * d_k must be a multiple of 32.  One sequence's K rows (max_len * ldk * 4 bytes) and one head's V^T rows (d_k * ldvt * 4 bytes) are
+ * addressed through 32-bit buffer offsets: launches beyond 4 GiB of either are refused with JATTS_ERR_UNSUPPORTED (split the batch).
  * ------------------------------------------------------------------------------- */
 typedef struct jatts_relattn_desc {
   jatts_ragged rg;

@@ -516,6 +516,9 @@ extern "C" int jatts_relpos_attention(const jatts_relattn_desc* d, void* stream)
     return jatts_set_error_msg(JATTS_ERR_ARG, "relpos_attention: null pointer");
   if (d->n_heads < 1 || d->ldq % 8 || d->ldk % 8) return jatts_set_error_msg(JATTS_ERR_ARG, "relpos_attention: bad strides");
   if (d->rg.max_len <= 0) return JATTS_OK;
+  // the tile loads address one (utterance, head)'s K rows and V^T rows through 32-bit buffer offsets
+  if ((int64_t)d->rg.max_len * d->ldk * 4 >= ((int64_t)1 << 32) || (int64_t)d->d_k * d->ldvt * 4 >= ((int64_t)1 << 32))
+    return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "relpos_attention: a sequence's K rows / a head's V^T rows exceed 4 GiB (split the batch)");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return dispatch_dk<f16>(*d, s);
   if (d->dtype == JATTS_F32) return dispatch_dk<float>(*d, s);

@@ -552,6 +552,18 @@ def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
             assert torch.equal(o0, out[:T0])
 
 
+def test_relpos_attention_refuses_offsets_beyond_32_bits(cuda, lib):
+    """The tile loads use 32-bit buffer offsets per (utterance, head): a V^T row stride that would overflow them is refused loudly
+    (JATTS_ERR_UNSUPPORTED) before any memory is touched."""
+    from jatts_amd import hip
+    from jatts_amd._abi import JattsHipError
+    rb = _ragged([8], cuda)
+    q = torch.zeros(8, 512, device=cuda)
+    vt = torch.zeros(256, 8, device=cuda)
+    with pytest.raises(JattsHipError, match="4 GiB"):
+        hip.relpos_attention(rb, q, 512, q, 512, vt, 1 << 23, None, 0, None, 1.0, 1, 256, hip.F32, q_col0=0, k_col0=256)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_relpos_attention_new_style(cuda, lib, prec):
     """rel_mode 2 (RelPositionMultiHeadedAttention, attention.py:237-261): BD'[i,j] = g[i][center - i + j]."""
