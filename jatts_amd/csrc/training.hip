@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
 // fragments come straight out of row-major LDS tiles with one ds_read_b32 each.  A workgroup (4 waves, one 32 x 32 fragment each)
 // owns a 64(n) x 64(c) tile for ALL taps (accumulators [KW] x 16 registers): dy and x are staged once per 32-step chunk instead of
 // once per tap.  Split over the sequences like the VALU kernel; partial tiles are added with f32 atomics.
+#ifndef JATTS_WGRAD_UNROLL
+#define JATTS_WGRAD_UNROLL 8   // (4 / 8 / 16 measured: 848 / 833 / 814 us at 1536 x 384 k3, 360 / 350 / 376 us at 512 x 512 k3)
+#endif
 template <int KW>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, const float* __restrict__ x, int ldx, const float* __restrict__ dy,
                                                               int ldy, int c_in, int n_out, int dil, int pad, int seq_groups,
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(jatts_ragged rg, c
     const float* cur = sm + (it & 1) * buf_floats;
     const float* ap = cur + hi * P + wn * 32 + lo;
     const float* bp = cur + TT * P + hi * P + wc * 32 + lo;
-#pragma unroll 4
+#pragma unroll JATTS_WGRAD_UNROLL
     for (int tp = 0; tp < TT / 2; ++tp) {
       const float a = ap[2 * tp * P];
 #pragma unroll
@@ -415,7 +418,25 @@ extern "C" int jatts_conv1d_wgrad(const jatts_ragged* rg, const float* x, int32_
   static const int use_mfma = [] { const char* e = getenv("JATTS_WGRAD_MFMA"); return e ? atoi(e) : 1; }();
   if (use_mfma && (k_w == 1 || k_w == 3 || k_w == 5) && (k_w - 1) * dil <= 32) {
     const int tiles_m = ((n_out + 63) / 64) * ((c_in + 63) / 64);
-    int g = (1536 + tiles_m - 1) / tiles_m;
+    // Sequence groups (split-K factor): the launch ends when the fullest CU has walked its workgroups, each over ceil(n_seq / g) sequences
+    // -- minimise ceil(tiles g / 256) ceil(n_seq / g) (the old "at least 1 536 workgroups" rule gave 1 584 for 1536 x 384: 7 on some CUs, 6
+    // on others, each 3 sequences long = 21 units against 18 for g = 16: 840 -> 782 us; tools/sweep_wgrad_groups.sh), preferring four resident
+    // workgroups per CU, with a small tax per group for the reduction pass.  Deterministic: a function of the shapes only.
+    static const int g_env = [] { const char* e = getenv("JATTS_WGRAD_GROUPS"); return e ? atoi(e) : 0; }();   // (tools/ A/B only)
+    int g = 1;
+    {
+      double best = 1e300;
+      for (int c = 1; c <= rg->n_seq; ++c) {
+        const int64_t wgs = (int64_t)tiles_m * c;
+        double cost = (double)((wgs + 255) / 256) * (double)((rg->n_seq + c - 1) / c);
+        const int64_t per_cu = (wgs + 255) / 256;
+        if (wgs < 512) cost *= 512.0 / (double)wgs;
+        if (per_cu < 4) cost *= 1.0 + 0.06 * (double)(4 - per_cu);   // four resident workgroups per CU hide the staging (2048 x 512 k1: g = 2 638 us, g = 4 544 us)
+        cost *= 1.0 + 0.002 * c;
+        if (cost < best) { best = cost; g = c; }
+      }
+    }
+    if (g_env > 0) g = g_env;
     if (g > rg->n_seq) g = rg->n_seq;
     if (g < 1) g = 1;
     const dim3 grid((unsigned)((n_out + 63) / 64), (unsigned)((c_in + 63) / 64), (unsigned)g);
