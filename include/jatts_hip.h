@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define JATTS_ABI_VERSION 1
+#define JATTS_ABI_VERSION 2   /* 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
+                                * bumped whenever a descriptor's layout or an entry point's signature changes: a stale library is refused at load */
 
 #define JATTS_F32 0
 #define JATTS_F16 1

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
 F32, F16, F32S = 0, 1, 2      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
+ABI_VERSION = 2      # JATTS_ABI_VERSION of include/jatts_hip.h (tests/test_abi_cpu.py compares the two)
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH, ACT_SNAKEBETA = 0, 1, 2, 3, 4, 5
 PRE_NONE, PRE_LRELU = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -202,8 +203,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so misses a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.jatts_abi_version() != 1:
-        raise JattsHipError("libjatts_hip.so ABI version mismatch")
+    if lib.jatts_abi_version() != ABI_VERSION:
+        raise JattsHipError(f"libjatts_hip.so ABI version {lib.jatts_abi_version()} != {ABI_VERSION} (include/jatts_hip.h): rebuild with __graft_entry__.build()")
     _lib = lib
     return lib
 

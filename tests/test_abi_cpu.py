@@ -19,7 +19,8 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_abi.PROTOTYPES), declared ^ set(_abi.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.jatts_abi_version() == 1
+    ver = int(re.search(r"#define JATTS_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.jatts_abi_version() == ver == _abi.ABI_VERSION
 
 
 def test_ctypes_structs_match_header_field_order():
