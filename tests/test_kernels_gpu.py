@@ -496,7 +496,9 @@ def test_hifigan_resunit_len_mul(cuda, lib):
 @pytest.mark.parametrize("pad_vt", [False, True])   # True: RaggedBatch.vt_layout -> aligned 16-byte V^T staging
 @pytest.mark.parametrize("H,dk,lens,rel", [(2, 32, [24, 9, 33], True), (2, 192, [130, 64], True),
                                           (2, 96, [65], True), (4, 64, [100, 1, 17], False),
-                                          (2, 64, [3, 70, 5, 129], True), (1, 256, [200, 33], True), (2, 128, [70, 31], False)])
+                                          (2, 64, [3, 70, 5, 129], True), (1, 256, [200, 33], True), (2, 128, [70, 31], False),
+                                          # d_k 256 without a bias (Matcha's blocks): the half-tile pipeline at f32, 512-thread workgroups in the split mode
+                                          (2, 256, [300, 77, 130], False)])
 def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
     from jatts_amd import hip
     from oracle.fs2_oracle import rel_shift_legacy
