@@ -151,7 +151,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 // Maximum over the wave, in every lane.  DPP inside the rows of 16 (quad swaps, then row rotations) and four v_readlane across them: ~10
 // dependent VALU issues instead of six ds_bpermute round trips (each a full LDS latency with a wait) -- the block maxima of the split
-// arithmetic sit on the critical path of every operand tile.
+// arithmetic sit on the critical path of every operand tile.  All 64 lanes must be active (every caller is a block-level reduction in
+// converged code): v_readlane of an inactive lane returns stale data.
 __device__ __forceinline__ float wave_max(float v) {
 #define JATTS_DPP_MAX(ctrl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
   JATTS_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
