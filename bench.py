@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the Matcha-TTS / VITS config lines")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child: one step, no JSON
+    ap.add_argument("--no-detail", action="store_true", help="do not (over)write bench_detail.json -- partial runs under a profiler (tools/profile_*.sh)")
     ap.add_argument("--pipeline", action="store_true",
                     help="two-stream executor (jatts_amd.pipeline): text2mel of step k+1 overlaps the vocoder of step k; "
                          "per-kernel and per-stage timings then overlap too, so the default run stays sequential")
@@ -823,7 +824,7 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         sys.stderr.flush()
-        print(compact_line(out, write_detail(out)), flush=True)
+        print(compact_line(out, None if a.no_detail else write_detail(out)), flush=True)
     if dist:
         dist.destroy_process_group()
 
