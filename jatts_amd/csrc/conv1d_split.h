@@ -40,7 +40,12 @@ __device__ __forceinline__ int split_commit(StageRegs<float, MAXU, NIN>& sr, cha
 #pragma unroll
     for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(sr.v[0][j][e]));     // (units past the tile hold zeros)
   }
+#if defined(JATTS_DIAG) && defined(JATTS_DIAG_NOSPLIT)      // WRONG RESULTS: ceiling probes for tools/ only (no block maximum / no barrier; level 2: no lo half either)
+  const int ex = 0;
+  (void)amax;
+#else
   const int ex = split_exp(block_amax(amax, slots, wave, lane, NTHR / 64));
+#endif
   const float sx = exp2i(ex);
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
@@ -52,7 +57,11 @@ __device__ __forceinline__ int split_commit(StageRegs<float, MAXU, NIN>& sr, cha
     for (int e = 0; e < 8; ++e) {
       const float sv = sr.v[0][j][e] * sx;
       o.hi[e] = (f16)sv;
+#if defined(JATTS_DIAG) && JATTS_DIAG_NOSPLIT == 2
+      o.lo[e] = (f16)0.f;
+#else
       o.lo[e] = (f16)(sv - (float)o.hi[e]);
+#endif
     }
     Vec8IO<f16s>::sts(lds + (size_t)r * pitch + (size_t)cu * 32, o);
   }
