@@ -37,7 +37,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TF = 2500.0   # dense f16/bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 (= the f32 vector rate)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
+# matrix-pipe peak per ALGORITHMIC FLOP of each arithmetic: split = 3 dense f16 MFMAs per product, bf16x3 emulation = 6 dense bf16 MFMAs
+ALG_PEAK_TF = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0, "fp32_bf16x3": MFMA_F16_PEAK_TF / 6.0}
+PRECISIONS = ("fp32", "fp32_bf16x3", "fp32_split", "fp16")
 
 
 def parse():
@@ -48,10 +51,15 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--t-text", type=int, default=128)
     ap.add_argument("--frames-per-token", type=int, default=6)
-    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split"],
+    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3"],
                     help="arithmetic of the headline numbers (the reference computes in f32)")
     ap.add_argument("--vocoder", default="22k", choices=["22k", "24k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length leg (T_text ~ U{64..t_text}, SURVEY 8d's optional variant)")
+    ap.add_argument("--ragged-min", type=int, default=64, help="shortest utterance of the ragged leg, phonemes")
+    ap.add_argument("--ragged-seed", type=int, default=7)
+    ap.add_argument("--only-ragged", action="store_true", help="run ONLY the ragged leg at --precision and print nothing (the command under rocprofv3 for "
+                                                              "profiles/rNN_bench_ragged_kernel_stats.csv)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the f16 fast-mode leg")
     ap.add_argument("--no-train", action="store_true", help="skip the FastSpeech2 train-step line")
     ap.add_argument("--no-configs", action="store_true", help="skip the Matcha-TTS / VITS config lines")
@@ -154,26 +162,32 @@ def pmc_passes(argv_tail, timeout_s=240):
 
 
 def committed_traffic():
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
-        if os.path.exists(path):
-            return json.load(open(path))["kernels"], f"profiles/{rnd}_traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run)"
-    return None, None
+    """The committed PMC table of THIS round's code (profiles/<round>_traffic.json, tools/pmc_bench.sh + tools/pmc_traffic.py) or
+    (None, reason).  Never an older round's table: its kernels are not this code's (VERDICT r4 weak #9)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_traffic.json")
+    if os.path.exists(path):
+        return json.load(open(path))["kernels"], f"profiles/{PROFILE_ROUND}_traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run)"
+    return None, f"profiles/{PROFILE_ROUND}_traffic.json not found"
+
+
+UNIT_KERNEL = {"fp32_split": "resunit_split_kernel", "fp32_bf16x3": "resunit_emul_kernel"}
 
 
 def lookup_traffic(table, prec, c):
+    """-> (HBM bytes per launch of the fused-unit family at `c` channels, None) or (None, why not): a table that lacks the kernel it is
+    asked about answers null with the reason, never another kernel's number."""
     if not table:
-        return None
-    if prec == "fp32_split":
-        key, alt = f"resunit_split_kernelILi{c}E", f"resunit_split_kernel<{c},"
+        return None, "no traffic table"
+    if prec in UNIT_KERNEL:
+        key, alt = f"{UNIT_KERNEL[prec]}ILi{c}E", f"{UNIT_KERNEL[prec]}<{c},"
     else:
         key = f"resunit_kernelI{'DF16_' if prec == 'fp16' else 'f'}Li{c}E"
         alt = f"resunit_kernel<{'_Float16' if prec == 'fp16' else 'float'}, {c},"
     hits = [v for k, v in table.items() if key in k or alt in k]
     if not hits:
-        return None
+        return None, f"the traffic table holds no '{alt}...' kernel"
     n = sum(h.get("launches", 1) for h in hits)             # tile variants of one family: launch-weighted mean
-    return sum(h["hbm_bytes"] * h.get("launches", 1) for h in hits) / n
+    return sum(h["hbm_bytes"] * h.get("launches", 1) for h in hits) / n, None
 
 
 # ------------------------------------------------------------------------------------------- workloads
@@ -297,6 +311,30 @@ def run_timed(job, a, world, dist, pipeline=False, record=True):
                 stages=stages, recs=recs, rank_ms=rank_ms, mel=r["feat_gen"], wave=y, frames=sum(r["olens"]), samples_per_step=sum(lens) * world)
 
 
+def ragged_leg(job, a, world, dist, rank, uniform_value, record=True):
+    """SURVEY 8d's optional ragged variant (the reference's stage-4 loop is ragged by nature, tts_decode.py:203-255): the same number of
+    utterances with T_text ~ U{ragged_min..t_text}, same frames per phoneme, in the job's current arithmetic.  per_sample_efficiency =
+    ragged samples/s / uniform samples/s: 1.0 when a sample costs the same in a ragged batch (tile tails, early-exit workgroups of a grid
+    sized for the longest utterance and, at N > 1, the ranks' unequal shares all push it below 1)."""
+    from jatts_amd.synthetic import synth_texts
+    uniform = job.texts
+    job.texts = [t.to(job.dev) for t in synth_texts(job.batch, a.t_text, job.vocab, seed=a.ragged_seed + rank, ragged_min=a.ragged_min)]
+    lens = [int(t.numel()) for t in job.texts]
+    try:
+        r = run_timed(job, a, world, dist, record=record)
+    finally:
+        job.texts = uniform
+    blk = {"t_text": f"U{{{a.ragged_min}..{a.t_text}}}", "seed": a.ragged_seed, "utterances_per_gpu": job.batch,
+           "phonemes_rank0": sum(lens), "min_max_phonemes_rank0": [min(lens), max(lens)],
+           "value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "samples_per_step": r["samples_per_step"],
+           "stage_ms_per_step": r["stages"], "rank_ms_per_step": r["rank_ms"],
+           "per_sample_efficiency": r["value"] / uniform_value}
+    if r["recs"]:
+        units = [ms for tag, _, ms in r["recs"] if tag in ("resunit", "resblock")]
+        blk["resunit_ms_per_step"] = sum(units) / a.steps
+    return blk
+
+
 def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     """Per-kernel live timings (HIP events on the launch stream inside the timed region) -> roofline of the dominant
     fused-unit family + per-shape tables.  Algorithmic work per dilation unit: 4 C^2 k FLOP and
@@ -304,8 +342,8 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     MRF mean its epilogue carries (n_add more reads of C sizeof bytes per row)."""
     esz = 2 if prec == "fp16" else 4                      # bytes per activation element in HBM
     # matrix-pipe peak per ALGORITHMIC FLOP: the split mode spends three dense f16 MFMAs per product
-    unit_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
-    conv_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
+    # ... the emulated mode six dense bf16 MFMAs
+    unit_peak = conv_peak = ALG_PEAK_TF[prec]
     fam = {}
     for tag, meta, ms in recs:
         fam.setdefault((tag, meta), []).append(ms)
@@ -342,12 +380,16 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     else:
         roof = dict(bound="hbm", achieved=dom_bytes / dom_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s")
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = lookup_traffic(traffic_table, prec, dom_c)
+    roof["traffic"], why = lookup_traffic(traffic_table, prec, dom_c)
     roof["traffic_source"] = traffic_source if roof["traffic"] is not None else None
+    if why:
+        roof["traffic_note"] = why if traffic_table else (traffic_source or why)
     roof["algorithmic_bytes_per_launch"] = dom_bytes / n_launch
     roof["algorithmic_flops_per_launch"] = dom_flops / n_launch
     roof["kernel"] = (f"resunit_split_kernel<C={dom_c}> (fused HiFi-GAN dilation unit, f32 I/O, split f16 hi/lo MFMA operands: 3 MFMAs per product, "
                       f"peak = dense f16 / 3; 9 launches per step)" if prec == "fp32_split" else
+                      f"resunit_emul_kernel<C={dom_c}> (fused HiFi-GAN dilation unit, f32 I/O, three exact bf16 terms per operand: 6 MFMAs per product, "
+                      f"peak = dense bf16 / 6; 9 launches per step)" if prec == "fp32_bf16x3" else
                       f"resunit_kernel<{'f16' if esz == 2 else 'float'}, C={dom_c}> (fused HiFi-GAN dilation unit, 9 launches per step)")
     roof["avg_launch_ms"] = dom_ms / n_launch
     roof["arith_intensity_flop_per_byte"] = ai
@@ -380,8 +422,7 @@ def family_report(recs, prec):
     """Per-kernel-family roofline of one recorded step of ANY config (BASELINE configs 3 / 5: VERDICT r3 item 4): algorithmic FLOPs from the
     launch metadata the C-ABI wrappers record (fused unit 4 C^2 k rows, conv 2 c_in n_out k rows, attention 4 d_k H sum T^2) over the
     family's HIP-event time.  -> {"dominant": {...}, "families": [...]}"""
-    unit_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
-    mm_peak = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0}[prec]
+    unit_peak = mm_peak = ALG_PEAK_TF[prec]
     fam = {}
     for tag, meta, ms in recs:
         if tag in ("resunit", "resblock"):
@@ -389,7 +430,7 @@ def family_report(recs, prec):
             fl, name, peak = 4.0 * C * C * k * rows * (len(d) if tag == "resblock" else 1), "resunit (fused HiFi-GAN dilation unit)", unit_peak
         elif tag == "conv1d":
             fl, name, peak = 2.0 * meta[0] * meta[1] * meta[2] * meta[3], "conv1d (every jatts_conv1d launch: acoustic model + vocoder input / upsampling convs)", mm_peak
-        elif tag == "relattn":
+        elif tag == "relattn":     # (exact f32 in the emulated mode too)
             fl, name, peak = 4.0 * meta[0] * meta[1] * meta[3], "relattn (fused attention)", MFMA_F16_PEAK_TF if prec == "fp16" else MFMA_F32_PEAK_TF
         else:
             continue
@@ -527,6 +568,11 @@ def compact_line(out, detail_path=None):
     if out.get("rank_ms_per_step"):
         c["rank_ms"] = out["rank_ms_per_step"]
     c["roofline"] = _roof(out.get("roofline"))
+    if out.get("ragged"):
+        rg = out["ragged"]
+        c["ragged"] = {k: rg.get(k) for k in ("t_text", "seed", "value", "ms_per_step", "per_sample_efficiency")}
+        if rg.get("rank_ms_per_step"):
+            c["ragged"]["rank_ms"] = rg["rank_ms_per_step"]
     if out.get("roofline_conv1d"):
         c["roofline_conv1d"] = out["roofline_conv1d"]
     cb = out.get("cpu_baseline")
@@ -540,7 +586,8 @@ def compact_line(out, detail_path=None):
         c["cpu_baseline"] = None
         if out.get("cpu_baseline_note"):
             c["cpu_baseline_note"] = out["cpu_baseline_note"]
-    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 tensors, split f16 hi/lo MFMA operands in every conv and fused unit")):
+    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 tensors, split f16 hi/lo MFMA operands in every conv and fused unit"),
+                       ("f32_emul_mode", "f32 tensors; 3 exact bf16 terms per operand, 6 MFMA products (bound 2^-23), f32 accumulate")):
         fm = out.get(key)
         if fm:
             c[key] = {"dtype": short, "value": fm["value"], "ms_per_step": fm["ms_per_step"],
@@ -555,6 +602,8 @@ def compact_line(out, detail_path=None):
                          "f16_err_wave": (e.get("fast_mode") or {}).get("max_abs_err_wave"),
                          "split_ms": (e.get("f32_split_mode") or {}).get("ms_per_step"),
                          "split_err_wave": (e.get("f32_split_mode") or {}).get("max_abs_err_wave"),
+                         "emul_ms": (e.get("f32_emul_mode") or {}).get("ms_per_step"),
+                         "emul_err_wave": (e.get("f32_emul_mode") or {}).get("max_abs_err_wave"),
                          "roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac"),
                          "roofline_kernel": (((e.get("roofline") or {}).get("dominant") or {}).get("kernel") or "")[:24]} for e in out["configs"]}
     if out.get("training"):
@@ -567,7 +616,7 @@ def compact_line(out, detail_path=None):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_LIMIT:      # never let the line outgrow the driver's tail again: drop the optional blocks
-        for k in ("executor", "roofline_conv1d", "training", "fast_mode", "configs", "stage_ms", "f32_mode", "f32_split_mode"):
+        for k in ("executor", "roofline_conv1d", "training", "fast_mode", "configs", "stage_ms", "f32_mode", "f32_split_mode", "ragged", "f32_emul_mode"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
@@ -595,8 +644,10 @@ def write_detail(out):
     return rel
 
 
-MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode"}
+MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode", "fp32_bf16x3": "f32_emul_mode"}
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate",
+              "fp32_bf16x3": "f32 tensors; every conv / fused HiFi-GAN unit on f32-equivalent emulated MFMA operands (each value exactly as three bf16 terms, six "
+                             "products per product: per-product error bound 2^-23, no scales), f32 accumulate; attention, normalisations and the duration predictor exact f32",
               "fp32_split": "f32 tensors; every conv / fused HiFi-GAN unit on split f16 hi/lo MFMA operands (3 MFMAs per product, power-of-two scales), "
                             "f32 accumulate; attention, normalisations and the duration predictor exact f32"}
 
@@ -648,8 +699,7 @@ def main():
         if traffic_table is None:
             note = traffic_source
             traffic_table, traffic_source = committed_traffic()
-            if traffic_source:
-                traffic_source += f" [live passes unavailable: {note}]"
+            traffic_source = f"{traffic_source} [live passes unavailable: {note}]"
     elif rank == 0 and not a.pmc_child:
         traffic_table, traffic_source = committed_traffic()
 
@@ -680,12 +730,15 @@ def main():
     job = Job("fs2", a, dev, rank, a.batch)
     if a.pmc_child:   # profiled child: one step of each arithmetic, nothing printed
         a.steps, a.warmup = 1, 1
-        for p in ("fp32", "fp32_split", "fp16"):
+        for p in PRECISIONS:
             job.set_precision(p)
             run_timed(job, a, 1, None)
         return
 
     job.set_precision(a.precision)
+    if a.only_ragged:
+        ragged_leg(job, a, world, dist, rank, 1.0, record=False)
+        return
     head = run_timed(job, a, world, dist, a.pipeline)
     rep = kernel_report(head["recs"], a.steps, a.precision, head["dt"], traffic_table, traffic_source)
 
@@ -708,10 +761,15 @@ def main():
     }
     out.update(rep)
 
+    # ---- the ragged-length leg, same arithmetic as the headline
+    if not a.no_ragged:
+        out["ragged"] = ragged_leg(job, a, world, dist, rank, out["value"])
+        out["ragged"]["resunit_ms_per_step_uniform"] = rep["resunit_ms_per_step"]
+
     # ---- the other arithmetics on the same batch, and how far apart their outputs are from the headline's
     if not a.no_fast_mode:
         mel0, wav0 = head["mel"].float().clone(), head["wave"].float().clone()
-        others = [p for p in ("fp32", "fp32_split", "fp16") if p != a.precision]
+        others = [p for p in PRECISIONS if p != a.precision]
         for other in others:
             job.set_precision(other)
             alt = run_timed(job, a, world, dist, a.pipeline)
@@ -750,7 +808,7 @@ def main():
             line = {"config": label, "workload": f"{j.name}+HiFi-GAN v1 {a.vocoder}, {nb} utts x {a.t_text} phonemes x "
                                                  f"{a.frames_per_token} frames", "steps": aa.steps, "warmup": aa.warmup}
             ref = None
-            for p in ("fp32", "fp32_split", "fp16"):
+            for p in PRECISIONS:
                 j.set_precision(p)
                 r = run_timed(j, aa, 1, None, record=False)
                 e = {"value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "rtf": r["rtf"],
@@ -814,7 +872,7 @@ def main():
         cb["single_thread"]["rtf"] = c1["seconds"] / (c1["samples"] / job_sr)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_rtf"] = cb["rtf"] / out["rtf"]
-        for k in ("fast_mode", "f32_split_mode", "f32_mode"):
+        for k in ("fast_mode", "f32_split_mode", "f32_emul_mode", "f32_mode"):
             if k in out:
                 out[k]["speedup_vs_cpu_rtf"] = cb["rtf"] / out[k]["rtf"]
     else:

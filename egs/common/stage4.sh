@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # Stage 4 (network decoding) of the jatts recipes on the MI355X path.  Sourced by egs/*/tts*/run.sh with the
 # reference's variables set: expdir, checkpoint, test_set, token_column, verbose, n_gpus
-# (reference egs/jsut/tts1/run.sh:237-260).  One difference, additive: n_gpus > 1 is honoured (the reference
+# (reference egs/jsut/tts1/run.sh:237-260) and, optionally, decode_sets: the csv names under data/ to decode (default: the test set;
+# the hificaptain recipes also decode dev_raw_feat, reference egs/hificaptain_jp_female/tts1/run.sh:228).  One difference, additive: n_gpus > 1 is honoured (the reference
 # forces 1) -- every rank decodes its own shard of the csv, one process per GPU.
 # shellcheck disable=SC2154
 stage4_decode() {
@@ -16,7 +17,8 @@ stage4_decode() {
         if [ -e "${expdir}/stats.npz" ]; then stats="${expdir}/stats.npz"
         else log "h5py is not installed and ${expdir}/stats.npz does not exist: run tools/h5stats_to_npz.py ${expdir}/stats.h5 where h5py is available"; exit 1; fi
     fi
-    for name in "${test_set}"; do
+    # shellcheck disable=SC2086
+    for name in ${decode_sets:-${test_set}}; do
         [ ! -e "${outdir}/${name}" ] && mkdir -p "${outdir}/${name}"
         log "Decoding start. See the progress via ${outdir}/${name}/decode.log."
         local launcher=("${python}" -m jatts_amd.bin.tts_decode)

@@ -39,6 +39,13 @@ extern "C" {
  * (jatts_amd.hip.pack_conv_weight_split) with the inverse per-output-channel scales in ws1 / ws2 (unit) or w_inv (conv).
  * Activation scales are chosen per workgroup tile inside the kernels (powers of two: scaling and un-scaling are exact). */
 #define JATTS_F32S 2
+/* f32 activations in HBM, f32-EQUIVALENT emulated MFMA operands (round 5): every operand value v travels EXACTLY as three
+ * bfloat16 terms b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1) (3 x 8 significand bits, f32's exponent range: no
+ * scales, no block maxima) and a product keeps the six terms of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 with f32
+ * accumulate (6/16 of the matrix-pipe cycles of the exact-f32 chain).  Per-product error bound 2^-23 = 2 x an f32 FMA's for
+ * every finite input with |v| >= 2^-110.  Accepted by jatts_hifigan_resunit; weights packed by the host as [b0 x8 | b1 x8 | b2 x8]
+ * per lane (jatts_amd.hip.pack_conv_weight_bf16x3), ws1 / ws2 unused. */
+#define JATTS_F32E 3
 
 #define JATTS_ACT_NONE 0
 #define JATTS_ACT_RELU 1

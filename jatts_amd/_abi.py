@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
-F32, F16, F32S = 0, 1, 2      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
+F32, F16, F32S, F32E = 0, 1, 2, 3      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
 ABI_VERSION = 2      # JATTS_ABI_VERSION of include/jatts_hip.h (tests/test_abi_cpu.py compares the two)
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH, ACT_SNAKEBETA = 0, 1, 2, 3, 4, 5
 PRE_NONE, PRE_LRELU = 0, 1

@@ -158,9 +158,10 @@ def get_parser():
     p.add_argument("--config", default=None, type=str)
     p.add_argument("--verbose", type=int, default=1)
     p.add_argument("--batch-size", type=int, default=64, help="utterances per ragged batch (extension)")
-    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split"],
+    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3"],
                    help="fp32 = the reference's arithmetic (default); fp16 = fast mode: f16 MFMA operands, f32 accumulate; fp32_split = f32 "
-                        "everywhere except the vocoder's ResBlock units, which run on error-corrected split f16 hi/lo MFMA operands (extensions)")
+                        "tensors, convs and fused vocoder units on error-corrected split f16 hi/lo MFMA operands; fp32_bf16x3 = f32 tensors, the "
+                        "same kernels on three exact bf16 terms per operand and six MFMA products (per-product error bound 2^-23) (extensions)")
     p.add_argument("--plot", action="store_true", help="also write <outdir>/outs/<id>.png like the reference")
     p.add_argument("--n_gpus", "--n-gpus", dest="n_gpus", type=int, default=1,
                    help="one process per GPU, every rank decodes its own shard of the csv (extension; the recipes' n_gpus). "

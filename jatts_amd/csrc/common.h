@@ -47,6 +47,31 @@ template <> struct Elem<f16s> {
   static constexpr int kBytes = 4;
 };
 
+// f32-EQUIVALENT emulated operand (round 5, JATTS_F32E): every f32 value v is carried EXACTLY as three bfloat16 terms
+//   b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1)      (round-to-nearest-even; both differences are exact in f32)
+// 3 x 8 significand bits = f32's 24 and bf16 has f32's exponent field: v == b0 + b1 + b2 for every finite f32 whose last bit lies at or
+// above bf16's smallest subnormal 2^-133 (|v| >= 2^-110): NO scales, no block maxima, no element-dependent loss of relative precision.
+// A product w v keeps the six terms of weight >= 2^-16: w0 v0 | w0 v1, w1 v0 | w1 v1, w0 v2, w2 v0; dropped: w1 v2 + w2 v1 + w2 v2
+// <= (2^-24 + 2^-24 + 2^-32) |w v| (|b1| <= 2^-8 |v|, |b2| <= 2^-16 |v| under round-to-nearest), i.e. a per-product error bound of
+// 2^-23 = 2 x an f32 FMA's, every bf16 x bf16 product exact in the f32 accumulate.  Six v_mfma_f32_32x32x16_bf16 = 6/16 of the pipe
+// cycles of the exact-f32 chain.  The element TAG is 6 bytes wide; 8 consecutive elements are stored PLANAR (16 B of b0 | b1 | b2).
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct bf3 { bf16 b0, b1, b2; };
+struct bf3x8 { bf16x8 b0, b1, b2; };
+template <> struct Elem<bf3> {
+  typedef bf3x8 vec8;
+  static constexpr int kBytes = 6;
+};
+// v -> (b0, b1, b2), exact (see above).  v_cvt_pk_bf16_f32 rounds to nearest even; bf16 -> f32 is a shift.
+__device__ __forceinline__ void bf3_split(float v, bf16& b0, bf16& b1, bf16& b2) {
+  b0 = (bf16)v;
+  const float r1 = v - (float)b0;
+  b1 = (bf16)r1;
+  b2 = (bf16)(r1 - (float)b1);
+}
+
 // One "K=16" step of a 32x32 output fragment.  Lane l supplies row/col (l&31) and
 // contraction elements 8*(l>>5) .. 8*(l>>5)+7 of both operands.
 //  f16 : v_mfma_f32_32x32x16_f16 (dense f16 MFMA rate, f32 accumulate)
@@ -66,6 +91,15 @@ __device__ __forceinline__ void mma32(const f16sx8& a, const f16sx8& b, f32x16& 
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+}
+//  bf3 : the six products of weight >= 2^-16, smallest first, into ONE f32 accumulator
+__device__ __forceinline__ void mma32(const bf3x8& a, const bf3x8& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b2, b.b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b2, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b0, c, 0, 0, 0);
 }
 // 16x16 output fragment, "K=32" step: lane supplies row/col (l&15) and contraction
 // elements 8*(l>>4) .. +7.

@@ -10,10 +10,12 @@ unsigned jatts_g_trace_cap = 0;
 int jatts_conv1d_f16(const jatts_conv_desc& d, hipStream_t s);
 int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s);
 int jatts_conv1d_split(const jatts_conv_desc& d, hipStream_t s);           // JATTS_F32S
+int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s);            // JATTS_F32E
 int jatts_resunit_f16_narrow(const jatts_resunit_desc& d, hipStream_t s);  // C = 32, 64
 int jatts_resunit_f16_wide(const jatts_resunit_desc& d, hipStream_t s);    // C = 128, 256, 512
 int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
 int jatts_resunit_split(const jatts_resunit_desc& d, hipStream_t s);       // JATTS_F32S
+int jatts_resunit_emul(const jatts_resunit_desc& d, hipStream_t s);        // JATTS_F32E
 int jatts_resblock_f16(const jatts_resblock_desc& d, hipStream_t s);
 int jatts_resblock_f32(const jatts_resblock_desc& d, hipStream_t s);
 int jatts_resblock_split(const jatts_resblock_desc& d, hipStream_t s);     // JATTS_F32S
@@ -48,6 +50,10 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
     if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32S writes f32 (y_is_f32 = 1)");
     return jatts_conv1d_split(*d, s);
   }
+  if (d->dtype == JATTS_F32E) {
+    if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32E writes f32 (y_is_f32 = 1)");
+    return jatts_conv1d_emul(*d, s);
+  }
   return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: unknown dtype");
 }
 
@@ -65,6 +71,7 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
     if (!d->ws1 || !d->ws2) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: JATTS_F32S needs ws1 / ws2");
     return jatts_resunit_split(*d, s);
   }
+  if (d->dtype == JATTS_F32E) return jatts_resunit_emul(*d, s);
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels/dtype (use jatts_conv1d)");
 }
 

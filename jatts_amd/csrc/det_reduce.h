@@ -90,6 +90,9 @@ __device__ __forceinline__ void det_sum_slabs(const T* slab, int n_parts, int n,
       return;
     }
   }
+  // callers alias det_arrive's flag word into `red`: every wave must have read it before the first store below (a wave without slab
+  // loads of its own gets here early; each pass of the loop ends on a barrier, so one barrier in front covers them all)
+  __syncthreads();
   for (int c0 = 0; c0 < n; c0 += 64) {
     const int i = c0 + lane;
     T s = 0;

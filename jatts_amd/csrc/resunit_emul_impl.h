@@ -1,0 +1,228 @@
+// Fused HiFi-GAN dilation unit  y = x + conv_1(lrelu(conv_d(lrelu(x))))  with f32 activations in HBM and
+// f32-EQUIVALENT EMULATED MFMA operands (JATTS_F32E, round 5): every operand value is carried exactly as three bfloat16
+// terms and a product keeps the six partial products of weight >= 2^-16 (common.h: bf3, bf3_split, mma32) --
+// six v_mfma_f32_32x32x16_bf16 with f32 accumulate = 6/16 of the pipe cycles of the exact-f32 chain.
+//
+// Unlike the split-f16 path (resunit_split_impl.h) there is nothing to scale: bf16 has f32's exponent range, so there are no
+// block maxima, no scale barriers and no element whose relative precision depends on its neighbours.  The per-product error
+// bound is 2^-23 (the dropped terms w1 v2 + w2 v1 + w2 v2) for EVERY finite input with |v| >= 2^-110, accumulation is f32.
+// The LDS tile holds 6 bytes per element (three planes of 16 B per 8 channels), the result tile and the residual / MRF store
+// pass are the f32 kernel's.
+#pragma once
+#include "resunit_impl.h"
+
+namespace {
+
+// 4 values -> the three bf16 planes of a channel quad
+__device__ __forceinline__ void bf3_split4(const float (&v)[4], bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bf16 a, b, c;
+    bf3_split(v[e], a, b, c);
+    p0[e] = a; p1[e] = b; p2[e] = c;
+  }
+}
+
+template <int C, int WGCOLS, int WN, int NT, int KCG, int OCC>
+__global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emul_kernel(jatts_resunit_desc d, unsigned long long* trace,
+                                                                                         unsigned trace_cap, unsigned bias_off) {
+  typedef bf3 T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WT = WGCOLS / (NT * 32);
+  constexpr int NF = C / (WN * 32);
+  constexpr int KC16 = C / 16, NFR = C / 32;
+  constexpr int pitch = C * 6 + 16;
+  constexpr int NTHR = WN * WT * 64;
+  static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
+  static_assert(sizeof(T) == 6, "bf3 is three packed bf16");
+  const unsigned wg_lin = blockIdx.x + blockIdx.y * gridDim.x;
+  const bool tracing = trace != nullptr && wg_lin < trace_cap && threadIdx.x == 0;
+#define JATTS_STAMP(i) do { if (tracing) trace[(size_t)wg_lin * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (tracing) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    trace[(size_t)wg_lin * 16] = ((unsigned long long)xcc << 32) | hwid;
+    trace[(size_t)wg_lin * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+  }
+  JATTS_STAMP(1);
+  const int K = d.k_w, dil = d.dil;
+  const int p2 = (K - 1) / 2, p1 = p2 * dil;
+  const int tt_out = WGCOLS - 2 * p2;
+
+  const int b = blockIdx.y;
+  const int row_b = d.rg.cu_rows[b];
+  const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
+  const int t0 = blockIdx.x * tt_out;
+  if (t0 >= L) return;
+  const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wn = wave / WT, wt = wave % WT;
+  const int g = lane >> 5;
+  const int col0 = wt * NT * 32;
+  const int nf0 = wn * NF;
+
+  const int rx = WGCOLS + 2 * p1;   // x tile rows: row r <-> position t0 - p2 - p1 + r
+  char* xs = smem;                  // bf3 lrelu(x) tile; h overlays it; finally the f32 y tile
+  char* hs = smem;
+  float* bs = reinterpret_cast<float*>(smem + bias_off);   // b1 | b2
+  for (int u = threadIdx.x; u < 2 * C; u += NTHR) bs[u] = u < C ? d.b1[u] : d.b2[u - C];
+
+  WStream<T, NF, KCG> ws;
+  ws.prefetch((const T*)d.w1, NFR, nf0, lane);
+
+  // ---- stage: lrelu(x) tile -> registers -> three bf16 planes in LDS (all loads of a batch in flight before the first is used)
+  {
+    constexpr int UPR = C / 8;
+    constexpr int UB = 8;
+    const float* x = (const float*)d.x;
+    const int total = rx * UPR, pos0 = t0 - p2 - p1;
+    for (int base = threadIdx.x; base < total; base += NTHR * UB) {
+      f32x8 v[UB];
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int u = base + j * NTHR;
+        const int r = u / UPR, cu = u - r * UPR;
+        const int pos = pos0 + r;
+        if (u < total && pos >= 0 && pos < L) v[j] = Vec8IO<float>::ldg(x + (seq_row0 + pos) * (int64_t)C + cu * 8);
+        else v[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int u = base + j * NTHR;
+        if (u >= total) continue;
+        const int r = u / UPR, cu = u - r * UPR;
+        lrelu8(v[j], d.slope);
+        bf3x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bf16 a, bq, c;
+          bf3_split(v[j][e], a, bq, c);
+          o.b0[e] = a; o.b1[e] = bq; o.b2[e] = c;
+        }
+        Vec8IO<T>::sts(xs + (size_t)r * pitch + (size_t)cu * 48, o);
+      }
+    }
+  }
+  __syncthreads();
+  JATTS_STAMP(2);
+
+  f32x16 acc[NF][NT];
+  auto bias_acc = [&](const float* bv) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bv + (nf0 + f) * 32 + 8 * q + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = bb[e];
+      }
+  };
+  bias_acc(bs);
+  conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w1, (const T*)d.w2, K, dil, xs, pitch, col0, lane);
+  JATTS_STAMP(3);
+
+  // ---- epilogue 1: h = lrelu(acc), 0 outside the sequence (conv2's zero padding) -> three planes over the dead x tile
+  lds_barrier();     // every wave is done reading x (conv2's first weights stay in flight)
+  JATTS_STAMP(10);
+  for (int u = threadIdx.x; u < (K - 1) * (C / 8); u += NTHR) {   // rows past the computed columns: read by discarded columns only
+    const int r = WGCOLS + u / (C / 8), cu = u % (C / 8);
+    bf3x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z.b0[e] = z.b1[e] = z.b2[e] = (bf16)0.f;
+    Vec8IO<T>::sts(hs + (size_t)r * pitch + (size_t)cu * 48, z);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + (lane & 31);
+    const int pos = t0 - p2 + col;
+    const float keep = (pos >= 0 && pos < L) ? 1.f : 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cu = (nf0 + f) * 4 + q;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = acc[f][t][4 * q + e] * keep;
+          v[e] = fmaxf(a, a * d.slope);
+        }
+        bf16x4 q0, q1, q2;
+        bf3_split4(v, q0, q1, q2);
+        char* p = hs + (size_t)col * pitch + (size_t)cu * 48 + 8 * g;
+        *reinterpret_cast<bf16x4*>(p) = q0;
+        *reinterpret_cast<bf16x4*>(p + 16) = q1;
+        *reinterpret_cast<bf16x4*>(p + 32) = q2;
+      }
+  }
+  JATTS_STAMP(12);
+  lds_barrier();
+  JATTS_STAMP(4);
+
+  bias_acc(bs + C);
+  conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w2, nullptr, K, 1, hs, pitch, col0, lane);
+  JATTS_STAMP(5);
+
+  // ---- epilogue 2: acc (+ b2, already in) assembled as an f32 tile in LDS; the residual (and the MRF mean) are added in the
+  // row-contiguous 16-byte store pass shared with the f32 kernel
+  __syncthreads();
+  char* ys = smem;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + (lane & 31);
+    if (col >= tt_out || t0 + col >= L) continue;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e];
+        *reinterpret_cast<f32x4*>(ys + (size_t)col * pitch + (size_t)n0 * 4) = o;
+      }
+  }
+  __syncthreads();
+  JATTS_STAMP(6);
+  {
+    const int vrows = min(tt_out, L - t0);
+    const int64_t g0 = (seq_row0 + t0) * (int64_t)C;
+    constexpr bool keep_small = C <= 64;
+    const float* xg = (const float*)d.x;
+    float* yg = (float*)d.y;
+    if (d.add0) unit_store_pass<float, C, keep_small ? 2 : 4, true, NTHR>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
+    else unit_store_pass<float, C, keep_small ? 4 : 8, false, NTHR>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
+  }
+  JATTS_STAMP(7);
+  if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+#undef JATTS_STAMP
+}
+
+template <int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2>
+int launch_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
+  constexpr int WT = WGCOLS / (NT * 32);
+  const int K = d.k_w, p2 = (K - 1) / 2, p1 = p2 * d.dil;
+  const int tt_out = WGCOLS - 2 * p2;
+  if (tt_out < 8) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: kernel too wide for tile");
+  const size_t pitch = C * 6 + 16;
+  const size_t rows_x = WGCOLS + 2 * p1, rows_h = WGCOLS + K - 1;
+  size_t lds = (rows_x > rows_h ? rows_x : rows_h) * pitch;
+  const unsigned bias_off = (unsigned)lds;
+  lds += 2 * C * sizeof(float);                                // b1 | b2
+  if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: tile exceeds 160 KiB LDS");
+  const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
+  dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
+  auto kern = resunit_emul_kernel<C, WGCOLS, WN, NT, KCG, OCC>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, jatts_g_trace, jatts_g_trace_cap, bias_off);
+  JATTS_CHECK_LAUNCH();
+  return JATTS_OK;
+}
+
+}  // namespace

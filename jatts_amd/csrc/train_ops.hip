@@ -2,7 +2,7 @@
 // FastSpeech2 layers around the conv op -- LayerNorm, ReLU / tanh / Swish / GLU, depthwise conv, batch-statistics BatchNorm,
 // embedding, the legacy rel_shift + masked softmax of the attention, the length regulator, the masked losses, dropout, Adam.
 // All f32, rows x channels row-major like the inference kernels.  HBM-bound element / row / column reductions: one coalesced
-// read of each operand, f32 atomics only for the [C]-sized parameter gradients.
+// read of each operand; the [C]-sized parameter gradients are summed deterministically (det_reduce.h: slabs + last-arriver sum, no atomics on data).
 // Reference: torch autograd of jatts/modules/conformer/{encoder_layer,convolution}.py, modules/transformer/{attention,layer_norm}.py,
 // modules/{duration_predictor,variance_predictor,length_regulator,pre_postnets}.py, jatts/losses/*.py, jatts/trainers/fastspeech2.py:24-100.
 #include "common.h"
@@ -17,7 +17,7 @@ constexpr int LN_GROUP = 32;   // workgroups per first-level group of the two-le
 // y = (x - mean) * rstd * g + b over the channels of each row (biased variance, eps inside the sqrt).
 // dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * g;  dg += sum_rows dy * xhat;  db += sum_rows dy.
 // One wave per row (lanes stride the channels); per-lane partial dg / db live in registers over the wave's rows and are
-// folded through LDS into one atomicAdd per channel per workgroup.
+// folded through LDS into one slab per workgroup; the last-arriving workgroup adds the slabs in a fixed order (det_reduce_tree).
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                             const float* __restrict__ g, int64_t rows, int C, float eps,
                                                             float* __restrict__ dx, int lddx, float* __restrict__ dg, float* __restrict__ db,
@@ -688,8 +688,8 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(const float* __restric
 
 // Head split of the fused Q|K|V projection (attention.py:81-88,190-195): qkv [rows = B T][3 A] -> q + pos_bias_u, q + pos_bias_v, k, v,
 // each [B][H][T][d_k] contiguous (what the batched GEMMs want), one pass.  The backward gathers the four gradients back into d qkv
-// [rows][3 A] and adds the column sums of d(q + u), d(q + v) -- the bias gradients -- to du / dv (zero-initialised, f32 atomics: one per
-// thread and 32 rows).  As torch ops this was 2 broadcast adds + 3 permute copies forward and 4 zero-filled slice gradients + 3 adds back.
+// [rows][3 A] and adds the column sums of d(q + u), d(q + v) -- the bias gradients -- to du / dv (per-workgroup slabs summed in a fixed
+// order by the last arriver, det_reduce.h).  As torch ops this was 2 broadcast adds + 3 permute copies forward and 4 zero-filled slice gradients + 3 adds back.
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, const float* __restrict__ u, const float* __restrict__ v,
                                                         int B, int T, int H, int dk, float* __restrict__ qu, float* __restrict__ qv,
                                                         float* __restrict__ k, float* __restrict__ vv) {
@@ -1098,7 +1098,7 @@ extern "C" int jatts_dwconv_wgrad(const jatts_ragged* rg, const float* x, const 
   if (rg->n_seq <= 0 || rg->max_len <= 0) return JATTS_OK;
   if (k_w == 7 || k_w == 31) {
     const int tiles = (rg->max_len + DWT - 1) / DWT;
-    const int tpb = tiles > 8 ? 4 : 1;     // a few tiles per workgroup: 4x fewer atomics on long sequences
+    const int tpb = tiles > 8 ? 4 : 1;     // a few tiles per workgroup: 4x fewer slabs to sum on long sequences
     const dim3 tgrid((unsigned)((tiles + tpb - 1) / tpb), (unsigned)rg->n_seq, (unsigned)((dim + 63) / 64));
     WS_NEED(tgrid.z, (int64_t)tgrid.x * tgrid.y * tgrid.z * 64 * k_w);
     if (k_w == 7) hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel<7>, tgrid, dim3(256), 0, S_, *rg, x, dy, dw, dim, pad, tpb, WS_);

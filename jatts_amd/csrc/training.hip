@@ -44,7 +44,8 @@ __global__ void fold_loss_kernel(const double* part, int n, double scale, float*
 
 // dW[n][c][tap] += sum over sequences, t of dy[t][n] * x[t + tap*dil - pad][c] (x outside its sequence = 0).
 // One workgroup = a 64(n) x 64(c) tile of one tap over a slice of the sequences; a thread owns 4 x 4 outputs; dy / x tiles of
-// 32 time steps go through LDS; partial sums are added with f32 atomics (f32 FMA at the f32-MFMA rate on gfx950).
+// 32 time steps go through LDS; per-group partial tiles go to the workspace and are summed in a fixed order by wgrad_reduce_kernel
+// (f32 FMA at the f32-MFMA rate on gfx950).
 constexpr int WG_TT = 32;
 __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(jatts_ragged rg, const 
 // contraction runs over TIME).  In the time-major layout both operands of a 2-step MFMA are two coalesced 128-byte row pieces, so the
 // fragments come straight out of row-major LDS tiles with one ds_read_b32 each.  A workgroup (4 waves, one 32 x 32 fragment each)
 // owns a 64(n) x 64(c) tile for ALL taps (accumulators [KW] x 16 registers): dy and x are staged once per 32-step chunk instead of
-// once per tap.  Split over the sequences like the VALU kernel; partial tiles are added with f32 atomics.
+// once per tap.  Split over the sequences like the VALU kernel; partial tiles go to the workspace (wgrad_reduce_kernel sums them, no atomics).
 #ifndef JATTS_WGRAD_UNROLL
 #define JATTS_WGRAD_UNROLL 8   // (4 / 8 / 16 measured: 848 / 833 / 814 us at 1536 x 384 k3, 360 / 350 / 376 us at 512 x 512 k3)
 #endif

@@ -11,9 +11,9 @@ import ctypes as C
 import torch
 
 from . import _abi
-from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32, F32S  # noqa: F401
+from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32, F32E, F32S  # noqa: F401
 
-_TORCH = {F32: torch.float32, F16: torch.float16, F32S: torch.float32}
+_TORCH = {F32: torch.float32, F16: torch.float16, F32S: torch.float32, F32E: torch.float32}
 
 
 def torch_dtype(code):
@@ -347,6 +347,25 @@ def pack_conv_weight_split(w, c_mult=32):
     return torch.stack([ph, pl], dim=1).reshape(-1).contiguous(), inv.contiguous()
 
 
+def bf16x3_terms(w):
+    """f32 tensor -> (b0, b1, b2) bfloat16 tensors with b0 + b1 + b2 == w exactly (round-to-nearest-even at every step; both
+    differences are exact in f32): 3 x 8 significand bits = f32's 24, f32's exponent range.  Holds for every finite value whose last
+    bit lies at or above bf16's smallest subnormal (|w| >= 2^-110)."""
+    w = w.detach().float()
+    b0 = w.bfloat16()
+    r1 = w - b0.float()
+    b1 = r1.bfloat16()
+    b2 = (r1 - b1.float()).bfloat16()
+    return b0, b1, b2
+
+
+def pack_conv_weight_bf16x3(w, c_mult=32):
+    """(n_out, c_in, k) f32 -> the JATTS_F32E operand: the three bf16 terms of every weight (bf16x3_terms: exact, no scales) in the
+    fragment order of pack_conv_weight with a lane's 8 elements of each term side by side: [tap][c/16][n/32][lane][b0 x8 | b1 x8 | b2 x8]."""
+    planes = [pack_conv_weight(t.float(), F32, c_mult).view(-1, 8).bfloat16() for t in bf16x3_terms(w)]   # bf16 -> f32 -> bf16 is exact
+    return torch.stack(planes, dim=1).reshape(-1).contiguous()
+
+
 class SplitWeight:
     """A conv weight prepared for JATTS_F32S (the pair of pack_conv_weight_split).  hip.conv1d recognises it in place of a packed f32
     weight -- call sites stay `dtype=hip.F32` -- and takes the split kernel; shapes the split kernel does not cover (a halo beyond 32
@@ -362,17 +381,41 @@ class SplitWeight:
         return self._f32
 
 
-_SPLIT_WEIGHTS = [False]
+class EmulWeight:
+    """A conv weight prepared for JATTS_F32E (pack_conv_weight_bf16x3: the three bf16 terms of every weight, exact).  hip.conv1d recognises
+    it in place of a packed f32 weight -- call sites stay `dtype=hip.F32` -- and takes the emulated kernel; a halo beyond its staging
+    registers (32 rows) takes the exact-f32 kernel on a lazily packed f32 copy of the same weight."""
+
+    def __init__(self, w, c_mult=64):
+        self.packed = pack_conv_weight_bf16x3(w, c_mult)
+        self._src, self._c_mult, self._f32 = w.detach(), c_mult, None
+
+    def f32(self):
+        if self._f32 is None:
+            self._f32 = pack_conv_weight(self._src, F32, self._c_mult)
+        return self._f32
+
+
+_SPLIT_WEIGHTS = [0]     # 0: packed f32 weights; 1: SplitWeight (fp32_split); 2: EmulWeight (fp32_bf16x3)
+WEIGHT_MODE = {"fp16": 0, "fp32": 0, "fp32_split": 1, "fp32_bf16x3": 2}
 
 
 @contextlib.contextmanager
 def split_weights(on=True):
-    """Inside: PackedConv(..., dtype=F32) packs SplitWeight operands (the models' set_precision("fp32_split")).  Nests; off by default."""
-    prev, _SPLIT_WEIGHTS[0] = _SPLIT_WEIGHTS[0], bool(on)
+    """Inside: PackedConv(..., dtype=F32) packs SplitWeight operands (the models' set_precision("fp32_split")) or, with on == 2 /
+    "fp32_bf16x3", EmulWeight operands (set_precision("fp32_bf16x3")).  Accepts a bool, a mode number or a precision name.  Nests."""
+    mode = WEIGHT_MODE[on] if isinstance(on, str) else int(on)
+    prev, _SPLIT_WEIGHTS[0] = _SPLIT_WEIGHTS[0], mode
     try:
         yield
     finally:
         _SPLIT_WEIGHTS[0] = prev
+
+
+def f32_operand(w, c_mult=64):
+    """A conv weight for `dtype=F32` call sites in the current weight mode: packed exact f32, SplitWeight or EmulWeight."""
+    m = _SPLIT_WEIGHTS[0]
+    return SplitWeight(w, c_mult) if m == 1 else EmulWeight(w, c_mult) if m == 2 else pack_conv_weight(w, F32, c_mult)
 
 
 def pack_conv_weight_dev(w, dtype_code, c_mult=64, dgrad=False):
@@ -440,6 +483,13 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
             dtype, w_inv, w_packed, out_f32 = F32S, w_packed.inv, w_packed.packed, True
         else:                                  # outside the split kernel's tiles: the exact-f32 kernel on the same weight
             w_packed = w_packed.f32()
+    elif isinstance(w_packed, EmulWeight):
+        if dtype != F32:
+            raise ValueError("conv1d: an EmulWeight goes with dtype F32 tensors")
+        if (k_w - 1) * dil <= 32:
+            dtype, w_packed, out_f32 = F32E, w_packed.packed, True
+        else:
+            w_packed = w_packed.f32()
     x0 = _dev(xs[0])
     rows = rb.total * len_mul
     tdt = torch_dtype(dtype)
@@ -455,6 +505,10 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     if dtype == F32S:
         if w_packed.dtype != torch.float16 or w_packed.numel() != 2 * n_pad * c_in * k_w or w_inv is None or w_inv.numel() != n_pad:
             raise ValueError("conv1d: F32S takes the (packed, inverse scales) pair of pack_conv_weight_split")
+    elif dtype == F32E:
+        if w_packed.dtype != torch.bfloat16 or w_packed.numel() != 3 * n_pad * c_in * k_w:
+            raise ValueError("conv1d: F32E takes the packed bf16 terms of pack_conv_weight_bf16x3")
+        out_f32 = True
     elif w_packed.dtype != tdt or w_packed.numel() != n_pad * c_in * k_w:
         raise ValueError("conv1d: packed weight has wrong dtype/size")
     odt = torch.float32 if out_f32 else tdt

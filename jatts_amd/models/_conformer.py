@@ -56,8 +56,39 @@ class PackedConv:
         self.n_out, c, self.k = w.shape
         self.c_in = hip.round_up(c, c_mult)
         # set_precision("fp32_split"): f32 tensors, split f16 hi/lo MFMA operands (hip.split_weights is on while the model prepares)
-        self.w = hip.SplitWeight(w.to(device), c_mult) if (dtype == hip.F32 and hip._SPLIT_WEIGHTS[0]) else hip.pack_conv_weight(w.to(device), dtype, c_mult)
+        # set_precision("fp32_bf16x3"): f32 tensors, three exact bf16 terms per operand, six MFMA products (hip.EmulWeight)
+        self.w = hip.f32_operand(w.to(device), c_mult) if dtype == hip.F32 else hip.pack_conv_weight(w.to(device), dtype, c_mult)
         self.b = None if b is None else b.to(device).contiguous()
+
+
+class SpkProjection:
+    """_integrate_with_spk_embed (models/fastspeech2.py:737-761; the same method in matchatts.py:560-584, matchatts_mas.py:644-668,
+    vits.py:681-705).  "add": hs += projection(normalize(spembs)).  "concat": projection(cat[hs, normalize(spembs) broadcast over time])
+    -- the Linear over the concatenation is split by columns, W [hs; s] = W_h hs + (W_s s + b): one k = 1 conv over the frames plus a
+    per-utterance vector, so the (B, T, adim + D) concatenation never exists."""
+
+    def __init__(self, sd, adim, kind, dtype, device):
+        if kind not in ("add", "concat"):
+            raise NotImplementedError("support only add or concat.")       # the reference's own message (:759)
+        w, b = sd["projection.weight"], sd["projection.bias"]
+        self.kind, self.A, self.dtype = kind, adim, dtype
+        if kind == "add":
+            self.h, self.s = None, PackedConv(w, b, dtype, device)
+        else:
+            if w.shape[1] <= adim:
+                raise ValueError("projection.weight: 'concat' expects (adim, adim + spk_embed_dim)")
+            self.h, self.s = PackedConv(w[:, :adim], None, dtype, device), PackedConv(w[:, adim:], b, dtype, device)
+
+    def __call__(self, rb, hs, spembs):
+        """hs: f32 (rows, adim) of the ragged batch rb; spembs: (n_seq, D).  -> hs with the speaker integrated (in place for "add")."""
+        dev, B = hs.device, rb.n_seq
+        rbs = hip.RaggedBatch([1] * B, dev)
+        sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), self.dtype, ldy=self.s.c_in)
+        vec = hip.conv1d(rbs, sp, self.s.w, self.s.c_in, self.A, 1, dtype=self.dtype, bias=self.s.b, out_f32=True)
+        if self.h is not None:
+            hs = hip.conv1d(rb, hip.affine_cast(hs, self.dtype), self.h.w, self.h.c_in, self.A, 1, dtype=self.dtype, out_f32=True)
+        hip.add_seq_vector(rb, hs, vec)
+        return hs
 
 
 class ConformerRunner:
@@ -66,7 +97,8 @@ class ConformerRunner:
         (FastSpeech2 / Matcha, fastspeech2.py fallback), "new" = RelPositionalEncoding +
         RelPositionMultiHeadedAttention (VITS text encoder and decoder)."""
         self.dtype, self.device, self.H = dtype, device, n_heads
-        self.split = dtype == hip.F32 and hip._SPLIT_WEIGHTS[0]     # set_precision("fp32_split"): the run-time packed position operands follow
+        self.split = dtype == hip.F32 and hip._SPLIT_WEIGHTS[0] == 1     # set_precision("fp32_split"): the attention takes the split arithmetic
+        self.wmode = hip._SPLIT_WEIGHTS[0] if dtype == hip.F32 else 0    # the run-time packed position operands follow the weight mode
         self.rel_style = rel_style
         g = lambda k: sd[prefix + k]  # noqa: E731
         self.n_layers = 0
@@ -142,7 +174,8 @@ class ConformerRunner:
             P = hip.conv1d(rb, pe_t, L["pos"].w, L["pos"].c_in, self.A, 1, dtype=self.dtype)  # (cap, A)
             cv = hip.rowdot(P, self.A, n_pos, self.H, self.dk, L["vb"]).t().contiguous()      # (H, n_pos)
             # per-head weight operand of the BD GEMM (n = position m, contraction d_k): pure re-layout
-            pk = (lambda w: hip.SplitWeight(w, 64)) if self.split else (lambda w: hip.pack_conv_weight(w, self.dtype))
+            pk = ((lambda w: hip.SplitWeight(w, 64)) if self.wmode == 1 else (lambda w: hip.EmulWeight(w, 64)) if self.wmode == 2
+                  else (lambda w: hip.pack_conv_weight(w, self.dtype)))
             heads = [pk(P[:, h * self.dk:(h + 1) * self.dk].float().unsqueeze(-1)) for h in range(self.H)]
             per_layer.append((heads, cv))
         if len(self._pos_cache) >= 8:

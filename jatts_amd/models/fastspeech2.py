@@ -18,7 +18,7 @@ import torch
 from .. import hip
 from ..hip import ACT_NONE, ACT_RELU, ACT_TANH
 from . import _schema as S
-from ._conformer import BN_EPS, LN_EPS, ConformerRunner, PackedConv
+from ._conformer import BN_EPS, LN_EPS, ConformerRunner, PackedConv, SpkProjection
 
 
 class _Predictor:
@@ -103,8 +103,8 @@ class FastSpeech2(torch.nn.Module):
         self.spks = spks if (spks is not None and spks > 1) else None
         self.spk_embed_dim = spk_embed_dim if (spk_embed_dim is not None and spk_embed_dim > 0) else None
         self.spk_embed_integration_type = spk_embed_integration_type
-        if self.spk_embed_dim is not None and spk_embed_integration_type != "add":
-            raise NotImplementedError("spk_embed_integration_type='concat' is not supported")
+        if self.spk_embed_dim is not None and spk_embed_integration_type not in ("add", "concat"):
+            raise NotImplementedError("support only add or concat.")
 
         spec = S.new_spec()
         spec["encoder.embed.0.weight"] = ((idim, adim), "param")
@@ -114,7 +114,7 @@ class FastSpeech2(torch.nn.Module):
         if self.spks is not None:
             spec["sid_emb.weight"] = ((spks, adim), "param")
         if self.spk_embed_dim is not None:
-            S._lin(spec, "projection", adim, self.spk_embed_dim)
+            S._lin(spec, "projection", adim, self.spk_embed_dim + (adim if spk_embed_integration_type == "concat" else 0))
         S.predictor_spec(spec, "duration_predictor.", adim, duration_predictor_layers, duration_predictor_chans,
                          duration_predictor_kernel_size)
         S.predictor_spec(spec, "pitch_predictor.", adim, pitch_predictor_layers, pitch_predictor_chans,
@@ -146,8 +146,10 @@ class FastSpeech2(torch.nn.Module):
     # ------------------------------------------------------------------ weight preparation
     def set_precision(self, precision: str):
         """'fp16' (f16 MFMA operands, f32 accumulate — fast mode) or 'fp32' (exact-f32 MFMA, parity mode)."""
-        if precision not in ("fp16", "fp32", "fp32_split"):     # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on
-            raise ValueError(precision)                          # split f16 hi/lo MFMA operands (hip.SplitWeight; csrc/conv1d_split.h)
+        # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on split f16 hi/lo MFMA operands (hip.SplitWeight;
+        # csrc/conv1d_split.h); fp32_bf16x3: the same convs on three exact bf16 terms per operand, six products (hip.EmulWeight; csrc/conv1d_emul.h)
+        if precision not in ("fp16", "fp32", "fp32_split", "fp32_bf16x3"):
+            raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None
         return self
@@ -176,7 +178,7 @@ class FastSpeech2(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
-        with hip.split_weights(self.precision == "fp32_split"):
+        with hip.split_weights(self.precision):
             return self._prepare_packed(dev, key, dt)
 
     def _prepare_packed(self, dev, key, dt):
@@ -210,7 +212,7 @@ class FastSpeech2(torch.nn.Module):
         if self.spks is not None:
             P["sid_emb"] = f32(sd["sid_emb.weight"])
         if self.spk_embed_dim is not None:
-            P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
+            P["proj"] = SpkProjection(sd, self.adim, self.spk_embed_integration_type, dt, dev)
         self._prep = P
         return P
 
@@ -248,11 +250,7 @@ class FastSpeech2(torch.nn.Module):
         if self.spk_embed_dim is not None:
             if spembs is None:
                 raise ValueError("spembs required (spk_embed_dim is set)")
-            rbs = hip.RaggedBatch([1] * len(lens), dev)
-            c_in = P["proj"].c_in
-            sp_t = hip.l2_normalize(spembs.to(dev).float().reshape(len(lens), -1).contiguous(), dt, ldy=c_in)
-            vec = hip.conv1d(rbs, sp_t, P["proj"].w, c_in, A, 1, dtype=dt, bias=P["proj"].b, out_f32=True)
-            hip.add_seq_vector(rb, hs, vec)
+            hs = P["proj"](rb, hs, spembs)
         hs_t = hip.affine_cast(hs, dt)
         p_outs = hip.predictor_head(P["pitch"].trunk(rb, hs_t), P["pitch"].w, P["pitch"].b)
         e_outs = hip.predictor_head(P["energy"].trunk(rb, hs_t), P["energy"].w, P["energy"].b)
@@ -377,10 +375,7 @@ class FastSpeech2(torch.nn.Module):
         if self.spks is not None:
             hip.add_seq_vector(rb, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
         if self.spk_embed_dim is not None:
-            rbs = hip.RaggedBatch([1] * B, dev)
-            c_in = P["proj"].c_in
-            sp_t = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=c_in)
-            hip.add_seq_vector(rb, hs, hip.conv1d(rbs, sp_t, P["proj"].w, c_in, A, 1, dtype=dt, bias=P["proj"].b, out_f32=True))
+            hs = P["proj"](rb, hs, spembs)
         hs_t = hip.affine_cast(hs, dt)
         p_outs = hip.zero_pad_rows(rb, hip.predictor_head(P["pitch"].trunk(rb, hs_t), P["pitch"].w, P["pitch"].b), kv)
         e_outs = hip.zero_pad_rows(rb, hip.predictor_head(P["energy"].trunk(rb, hs_t), P["energy"].w, P["energy"].b), kv)

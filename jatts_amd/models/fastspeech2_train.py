@@ -76,6 +76,17 @@ class _Ctx:
         return x * s + (self.p[name + ".bias"] - self.b[name + ".running_mean"] * s)
 
 
+def spk_integrate(c, model, hs, spembs, rb, rbs):
+    """_integrate_with_spk_embed with gradients (fastspeech2.py:737-761): "add" = hs + projection(normalize(s)); "concat" = the Linear over
+    cat[hs, normalize(s)] split by columns, W_h hs + (W_s s + b) (jatts_amd.models._conformer.SpkProjection is the inference form)."""
+    sp = hip.l2_normalize(spembs.to(hs.device).float().reshape(rb.n_seq, -1).contiguous(), hip.F32)
+    if getattr(model, "spk_embed_integration_type", "add") == "add":
+        return A.AddSeqVector.apply(hs, c.conv(sp, "projection", rbs), rb)
+    w, Ad = c.p["projection.weight"], hs.shape[-1]
+    vec = A.Conv1dFunction.apply(sp, w[:, Ad:].unsqueeze(-1).contiguous(), c.p["projection.bias"], rbs, 1, 0)
+    return A.AddSeqVector.apply(A.Conv1dFunction.apply(hs, w[:, :Ad].unsqueeze(-1).contiguous(), None, rb, 1, 0), vec, rb)
+
+
 _POS_TABLES = {}
 
 
@@ -205,8 +216,7 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
         hs = A.AddSeqVector.apply(hs, sid, rb)
     if model.spk_embed_dim is not None:                              # :594-597, _integrate_with_spk_embed "add" (:750-753)
         rbs = hip.RaggedBatch([1] * B, dev)
-        sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), hip.F32)
-        hs = A.AddSeqVector.apply(hs, c.conv(sp, "projection", rbs), rb)
+        hs = spk_integrate(c, model, hs, spembs, rb, rbs)
     p_outs = A.MaskRows.apply(_predictor(c, "pitch_predictor.", hs.detach() if model.stop_gradient_from_pitch_predictor else hs, rb,
                                          R["pitch"]), rb, kv)
     e_outs = A.MaskRows.apply(_predictor(c, "energy_predictor.", hs.detach() if model.stop_gradient_from_energy_predictor else hs, rb,

@@ -22,7 +22,7 @@ import torch
 from .. import hip
 from ..hip import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH
 from . import _schema as S
-from ._conformer import ConformerRunner, PackedConv
+from ._conformer import ConformerRunner, PackedConv, SpkProjection
 from .fastspeech2 import _Predictor
 
 GN_EPS = 1e-5  # torch.nn.GroupNorm / LayerNorm defaults (decoder.py:71, transformer.py:213)
@@ -88,7 +88,7 @@ class _TBlock:
     def __init__(self, sd, p, heads, dt, dev):
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
         self.heads = heads
-        self.split = dt == hip.F32 and hip._SPLIT_WEIGHTS[0]      # set_precision("fp32_split"): the attention takes the split arithmetic too
+        self.split = dt == hip.F32 and hip._SPLIT_WEIGHTS[0] == 1      # set_precision("fp32_split"): the attention takes the split arithmetic too
         self.n1 = (f32(sd[p + "norm1.weight"]), f32(sd[p + "norm1.bias"]))
         self.n3 = (f32(sd[p + "norm3.weight"]), f32(sd[p + "norm3.bias"]))
         wq, wk = sd[p + "attn1.to_q.weight"], sd[p + "attn1.to_k.weight"]
@@ -161,8 +161,9 @@ class _MatchaBase(torch.nn.Module):
         self.n_blocks, self.n_mid = decoder_n_blocks, decoder_num_mid_blocks
         self.sigma_min = 1e-4   # CFM default (flow_matching.py:31); the reference never overrides it
         self.spk_embed_dim = spk_embed_dim if (spk_embed_dim is not None and spk_embed_dim > 0) else None
-        if self.spk_embed_dim is not None and spk_embed_integration_type != "add":
-            raise NotImplementedError("spk_embed_integration_type='concat' is not supported")
+        self.spk_embed_integration_type = spk_embed_integration_type
+        if self.spk_embed_dim is not None and spk_embed_integration_type not in ("add", "concat"):
+            raise NotImplementedError("support only add or concat.")
         spec = S.new_spec()
         spec["encoder.embed.0.weight"] = ((idim, adim), "param")
         S.conformer_spec(spec, "encoder.", adim, aheads, eunits, elayers, positionwise_layer_type,
@@ -172,7 +173,7 @@ class _MatchaBase(torch.nn.Module):
             spec["sid_emb.weight"] = ((spks, adim), "param")
         self.spks = spks if (spks is not None and spks > 1) else None
         if self.spk_embed_dim is not None:
-            S._lin(spec, "projection", adim, self.spk_embed_dim)
+            S._lin(spec, "projection", adim, self.spk_embed_dim + (adim if spk_embed_integration_type == "concat" else 0))
         S._lin(spec, "encoder_proj", odim, adim)
         S.predictor_spec(spec, "duration_predictor.", adim, duration_predictor_layers, duration_predictor_chans,
                          duration_predictor_kernel_size)
@@ -249,8 +250,10 @@ class _MatchaBase(torch.nn.Module):
         return self
 
     def set_precision(self, precision):
-        if precision not in ("fp16", "fp32", "fp32_split"):     # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on
-            raise ValueError(precision)                          # split f16 hi/lo MFMA operands (hip.SplitWeight; csrc/conv1d_split.h)
+        # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on split f16 hi/lo MFMA operands (hip.SplitWeight;
+        # csrc/conv1d_split.h); fp32_bf16x3: the same convs on three exact bf16 terms per operand, six products (hip.EmulWeight; csrc/conv1d_emul.h)
+        if precision not in ("fp16", "fp32", "fp32_split", "fp32_bf16x3"):
+            raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None
         return self
@@ -272,7 +275,7 @@ class _MatchaBase(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
-        with hip.split_weights(self.precision == "fp32_split"):
+        with hip.split_weights(self.precision):
             return self._prepare_packed(dev, key, dt)
 
     def _prepare_packed(self, dev, key, dt):
@@ -285,7 +288,7 @@ class _MatchaBase(torch.nn.Module):
             P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
         P["eproj"] = PackedConv(sd["encoder_proj.weight"], sd["encoder_proj.bias"], dt, dev)
         if self.spk_embed_dim is not None:
-            P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
+            P["proj"] = SpkProjection(sd, self.adim, self.spk_embed_integration_type, dt, dev)
         if self.spks is not None:
             P["sid_emb"] = f32(sd["sid_emb.weight"])
         e = "decoder.estimator."
@@ -397,9 +400,7 @@ class _MatchaBase(torch.nn.Module):
         if self.spks is not None:
             hip.add_seq_vector(rb, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
         if self.spk_embed_dim is not None:
-            pj = P["proj"]
-            sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
-            hip.add_seq_vector(rb, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
+            hs = P["proj"](rb, hs, spembs)
         if taps is not None:
             taps["hs"] = hs.clone()                                 # text encoding (+ speaker): what the alignment module scores
         logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
@@ -507,9 +508,7 @@ class _MatchaBase(torch.nn.Module):
         if self.spks is not None:
             hip.add_seq_vector(rbt, hs, P["sid_emb"][sids.to(dev).view(-1).long()].contiguous())
         if self.spk_embed_dim is not None:
-            pj = P["proj"]
-            sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), dt, ldy=pj.c_in)
-            hip.add_seq_vector(rbt, hs, hip.conv1d(rbs, sp, pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b, out_f32=True))
+            hs = P["proj"](rbt, hs, spembs)
         olens_in = [n - n % 2 for n in olens]
         Te = max(olens_in)
         if self._MAS:

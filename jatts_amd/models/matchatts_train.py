@@ -15,7 +15,7 @@ import torch
 
 from .. import autograd as A
 from .. import hip
-from .fastspeech2_train import _conformer, _Ctx, _predictor
+from .fastspeech2_train import _conformer, _Ctx, _predictor, spk_integrate
 
 GN_EPS = 1e-5
 LOG_2PI = math.log(2.0 * math.pi)
@@ -152,8 +152,7 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, durations, du
         sid = A.Embedding.apply(sids.to(dev).view(-1).to(torch.int64).contiguous(), c.p["sid_emb.weight"], 1.0, -1)
         hs = A.AddSeqVector.apply(hs, sid, rbt)
     if model.spk_embed_dim is not None:
-        sp = hip.l2_normalize(spembs.to(dev).float().reshape(B, -1).contiguous(), hip.F32)
-        hs = A.AddSeqVector.apply(hs, c.conv(sp, "projection", rbs), rbt)
+        hs = spk_integrate(c, model, hs, spembs, rbt, rbs)
     d_outs = A.MaskRows.apply(_predictor(c, "duration_predictor.", hs, rbt, R["dur"]), rbt, kv)
     rbe = hip.RaggedBatch([Te] * B, dev)
     rb2 = hip.RaggedBatch([Te // 2] * B, dev)

@@ -17,7 +17,7 @@ import torch
 
 from .. import hip
 from . import _schema as S
-from ._conformer import LN_EPS, ConformerRunner, PackedConv
+from ._conformer import LN_EPS, ConformerRunner, PackedConv, SpkProjection
 from .fastspeech2 import _Predictor
 
 
@@ -92,8 +92,9 @@ class VITS(torch.nn.Module):
             raise NotImplementedError("only use_only_mean_in_flow=True, flow_base_dilation=1 (reference defaults)")
         if not spk_embed_dim or spk_embed_dim <= 0:
             raise NotImplementedError("the reference's VITS stage 4 needs speaker embeddings (vits.py:485)")
-        if spk_embed_integration_type != "add":
-            raise NotImplementedError("spk_embed_integration_type='concat' is not supported")
+        if spk_embed_integration_type not in ("add", "concat"):
+            raise NotImplementedError("support only add or concat.")
+        self.spk_embed_integration_type = spk_embed_integration_type
         if text_encoder_positional_encoding_layer_type != "rel_pos" or conformer_pos_enc_layer_type != "rel_pos":
             raise NotImplementedError("only rel_pos / rel_selfattn conformers")
         self.spk_embed_dim = spk_embed_dim
@@ -108,7 +109,7 @@ class VITS(torch.nn.Module):
         S._conv(spec, "text_encoder.proj", 2 * adim, adim, 1)
         if spks is not None and spks > 1:
             raise NotImplementedError("sid embeddings are not used by the reference VITS forward")
-        S._lin(spec, "projection", adim, spk_embed_dim)
+        S._lin(spec, "projection", adim, spk_embed_dim + (adim if spk_embed_integration_type == "concat" else 0))
         # posterior encoder (training / reconstruction only; kept for strict checkpoint loading)
         S._conv(spec, "posterior_encoder.input_conv", adim, odim, 1)
         _wavenet_spec(spec, "posterior_encoder.encoder.", posterior_encoder_layers, adim, posterior_encoder_kernel_size,
@@ -147,8 +148,10 @@ class VITS(torch.nn.Module):
         return self
 
     def set_precision(self, precision):
-        if precision not in ("fp16", "fp32", "fp32_split"):     # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on
-            raise ValueError(precision)                          # split f16 hi/lo MFMA operands (hip.SplitWeight; csrc/conv1d_split.h)
+        # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on split f16 hi/lo MFMA operands (hip.SplitWeight;
+        # csrc/conv1d_split.h); fp32_bf16x3: the same convs on three exact bf16 terms per operand, six products (hip.EmulWeight; csrc/conv1d_emul.h)
+        if precision not in ("fp16", "fp32", "fp32_split", "fp32_bf16x3"):
+            raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None
         return self
@@ -170,7 +173,7 @@ class VITS(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
-        with hip.split_weights(self.precision == "fp32_split"):
+        with hip.split_weights(self.precision):
             return self._prepare_packed(dev, key, dt)
 
     def _prepare_packed(self, dev, key, dt):
@@ -183,7 +186,7 @@ class VITS(torch.nn.Module):
         P["tenc"] = ConformerRunner(sd, "text_encoder.encoder.", self.te_heads, dt, dev, rel_style="new")
         P["dec"] = ConformerRunner(sd, "decoder.", self.aheads, dt, dev, rel_style="new")
         P["te_proj"] = PackedConv(sd["text_encoder.proj.weight"], sd["text_encoder.proj.bias"], dt, dev)
-        P["proj"] = PackedConv(sd["projection.weight"], sd["projection.bias"], dt, dev)
+        P["proj"] = SpkProjection(sd, self.adim, self.spk_embed_integration_type, dt, dev)
         with hip.split_weights(False):     # exact f32 always: durations are integers
             P["dur"] = _Predictor(sd, "duration_predictor.", hip.F32, dev)   # always f32 (integer durations)
         flows = []
@@ -273,10 +276,7 @@ class VITS(torch.nn.Module):
         # speaker embedding: hs += projection(normalize(spembs))  (vits.py:441-443, :706-712)
         spembs = spembs.to(dev).float().reshape(B, -1).contiguous()
         rbs = hip.RaggedBatch([1] * B, dev)
-        pj = P["proj"]
-        vec = hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt, bias=pj.b,
-                         out_f32=True)
-        hip.add_seq_vector(rb, hs, vec)
+        hs = P["proj"](rb, hs, spembs)
         if taps is not None:
             taps["hs"] = hs.clone()                                        # text encoding + speaker: what the alignment module scores
         logd, d_pred = hip.predictor_head(P["dur"].trunk(rb, hs), P["dur"].w, P["dur"].b,
@@ -386,9 +386,7 @@ class VITS(torch.nn.Module):
         stats_p = hip.zero_pad_rows(rbt, hip.conv1d(rbt, hip.affine_cast(hs, dt), tp.w, tp.c_in, 2 * A, 1, dtype=dt, bias=tp.b,
                                                     out_f32=True), kv)                 # proj(x) * x_mask: m_p | logs_p
         spembs = spembs.to(dev).float().reshape(B, -1).contiguous()
-        pj = P["proj"]
-        hip.add_seq_vector(rbt, hs, hip.conv1d(rbs, hip.l2_normalize(spembs, dt, ldy=pj.c_in), pj.w, pj.c_in, A, 1, dtype=dt,
-                                               bias=pj.b, out_f32=True))
+        hs = P["proj"](rbt, hs, spembs)
         # ---- posterior encoder + forward flow on the valid frames (ragged)
         self._post(P)
         rbo = hip.RaggedBatch(olens, dev)

@@ -13,7 +13,7 @@ import torch
 
 from .. import autograd as A
 from .. import hip
-from .fastspeech2_train import _conformer, _Ctx, _predictor
+from .fastspeech2_train import _conformer, _Ctx, _predictor, spk_integrate
 
 
 def _wn_weight(c, stem):
@@ -76,7 +76,7 @@ def train_forward(model, text, text_lengths, feats, feats_lengths, spembs, post_
     hs = _conformer(c, "text_encoder.encoder.", x, rbt, kv, model.te_heads, dict(pos=R["te_pos"], layer=R["te"], ffn=R["te"], attn=R["te_attn"]),
                     rel_style="new")
     stats_p = A.MaskRows.apply(c.conv(hs, "text_encoder.proj", rbt), rbt, kv)                  # proj(x) * x_mask: m_p | logs_p
-    hs = A.AddSeqVector.apply(hs, c.conv(hip.l2_normalize(spk, hip.F32), "projection", rbs), rbt)
+    hs = spk_integrate(c, model, hs, spk, rbt, rbs)
     # ---- posterior encoder + forward flow on the valid frames (posterior_encoder.py:96-130, residual_coupling.py:189-227)
     rbo = hip.RaggedBatch(olens, dev)
     yv = ys.reshape(B * To, od).index_select(0, fsel).contiguous()

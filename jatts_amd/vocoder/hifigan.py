@@ -30,6 +30,15 @@ class PackedSplitConv:
         self.b = b.detach().float().contiguous()
 
 
+class PackedEmulConv:
+    """A ResBlock conv packed for the JATTS_F32E unit: the three exact bf16 terms of every weight (hip.pack_conv_weight_bf16x3), no scales."""
+
+    def __init__(self, w, b):
+        self.n_out, self.c_in, self.k = w.shape
+        self.w, self.inv = hip.pack_conv_weight_bf16x3(w, 32), None
+        self.b = b.detach().float().contiguous()
+
+
 class HiFiGANGenerator(torch.nn.Module):
     def __init__(self, in_channels=80, out_channels=1, channels=512, kernel_size=7,
                  upsample_scales=(8, 8, 2, 2), upsample_kernel_sizes=(16, 16, 4, 4),
@@ -104,8 +113,10 @@ class HiFiGANGenerator(torch.nn.Module):
         "fp32_split" (round 4): f32 activations everywhere, the ResBlock dilation units (97 % of the generator's FLOPs) and the input /
         upsampling convs on error-corrected split-precision MFMA operands (JATTS_F32S: hi/lo f16 halves, f32 accumulate, power-of-two
         scales) -- measured at or below the exact-f32 path's error against fp64 (tests/test_kernels_gpu.py::test_hifigan_resunit_split,
-        test_conv1d_split; tests/test_benchsize_gpu.py::test_hifigan_split_mode_at_bench_size)."""
-        if precision not in ("fp16", "fp32", "fp32_split"):
+        test_conv1d_split; tests/test_benchsize_gpu.py::test_hifigan_split_mode_at_bench_size);
+        "fp32_bf16x3" (round 5): f32 activations everywhere, the same kernels' operands carried EXACTLY as three bf16 terms with six MFMA
+        products per product (JATTS_F32E: no scales, per-product error bound 2^-23; csrc/resunit_emul_impl.h, conv1d_emul.h)."""
+        if precision not in ("fp16", "fp32", "fp32_split", "fp32_bf16x3"):
             raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None
@@ -124,10 +135,11 @@ class HiFiGANGenerator(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
-        split = self.precision == "fp32_split"
+        split, emul = self.precision == "fp32_split", self.precision == "fp32_bf16x3"
+        wmode = hip.WEIGHT_MODE[self.precision]
         sd = self.state_dict()
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
-        P = {"key": key, "dtype": dt, "dev": dev, "unit_dtype": hip.F32S if split else dt}
+        P = {"key": key, "dtype": dt, "dev": dev, "unit_dtype": hip.F32S if split else hip.F32E if emul else dt}
         nb = len(self.resblock_kernel_sizes)
         P["ups"], P["blocks"] = [], []
         supported = {hip.F16: (32, 64, 128, 256, 512), hip.F32: (32, 64, 128, 256)}[dt]
@@ -154,7 +166,7 @@ class HiFiGANGenerator(torch.nn.Module):
             return o
 
         c_prev = hip.round_up(self.channels, 64)   # input conv feeds the generic conv: 64-channel chunks
-        with hip.split_weights(split):      # fp32_split: the input / upsampling convs take the split conv kernel too (csrc/conv1d_split.h)
+        with hip.split_weights(wmode):      # fp32_split / fp32_bf16x3: the input / upsampling convs take the split / emulated conv kernel too
             P["in"] = PackedConv(padw(sd["input_conv.weight"], c_prev, sd["input_conv.weight"].shape[1]),
                                  padb(sd["input_conv.bias"], c_prev), dt, dev)
         for i, (s, uk) in enumerate(zip(self.upsample_scales, self.upsample_kernel_sizes)):
@@ -165,7 +177,7 @@ class HiFiGANGenerator(torch.nn.Module):
             wp = torch.zeros(c_prev, c_out, w.shape[2], dtype=torch.float32)
             wp[: w.shape[0], : w.shape[1]] = w
             wc, pad = hip.convtranspose_as_conv(wp, s, s // 2 + s % 2)
-            with hip.split_weights(split):
+            with hip.split_weights(wmode):
                 pc = PackedConv(wc, padb(sd[f"upsamples.{i}.1.bias"], c_out).repeat(s), dt, dev)
             P["ups"].append((pc, pad, s, c_out))
             stage = []
@@ -173,7 +185,7 @@ class HiFiGANGenerator(torch.nn.Module):
                 units = []
                 for di, d in enumerate(self.resblock_dilations[j]):
                     q = f"blocks.{i * nb + j}."
-                    mk = PackedSplitConv if split else (lambda w, b: PackedConv(w, b, dt, dev, c_mult=32))   # fused unit takes c_in == channels
+                    mk = PackedSplitConv if split else PackedEmulConv if emul else (lambda w, b: PackedConv(w, b, dt, dev, c_mult=32))   # fused unit takes c_in == channels
                     c1 = mk(padw(sd[q + f"convs1.{di}.1.weight"], c_out, c_out).to(dev), padb(sd[q + f"convs1.{di}.1.bias"], c_out).to(dev))
                     c2 = mk(padw(sd[q + f"convs2.{di}.1.weight"], c_out, c_out).to(dev), padb(sd[q + f"convs2.{di}.1.bias"], c_out).to(dev))
                     units.append((c1, c2, rk, d))
@@ -246,7 +258,8 @@ class HiFiGANGenerator(torch.nn.Module):
                 cur = up
                 st = side[j] if j < len(side) else None
                 # HBM-bound shapes: the whole ResBlock in one launch (x read once, y written once; residual in registers)
-                fset = self.fused_blocks_split if udt == hip.F32S else (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32)
+                fset = (self.fused_blocks_split if udt == hip.F32S else frozenset() if udt == hip.F32E      # (F32E: per-unit launches only)
+                        else (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32))
                 if (c_out, units[0][2]) in fset and len(units) <= 3 and st is None \
                         and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if (dt == hip.F16 or udt == hip.F32S) else 16):
                     lastb = fuse_mean and j == len(blocks) - 1

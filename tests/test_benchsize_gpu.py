@@ -58,8 +58,10 @@ def test_fs2_bench_utterances_match_the_reference(bench_stack):
         assert torch.equal(rb["duration"][128 * u:128 * (u + 1)].cpu(), torch.tensor(z[f"u{j}_duration"]))
 
 
-def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack):
-    """set_precision("fp32_split") on the acoustic model (round 4: every conv but the duration predictor's on split f16 hi/lo MFMA operands)
+@pytest.mark.parametrize("mode", ["fp32_split", "fp32_bf16x3"])
+def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack, mode):
+    """set_precision("fp32_split") on the acoustic model (round 4: every conv but the duration predictor's on split f16 hi/lo MFMA operands;
+    round 5, "fp32_bf16x3": the same convs on three exact bf16 terms per operand, six MFMA products)
     against the SAME real-reference golden and tolerance as the exact-f32 path (abs 2e-3, durations exact), alone and inside the batch of 64
     (bit-identical to each other), with its error next to the exact-f32 path's: at most twice as far from the reference."""
     import json
@@ -68,12 +70,12 @@ def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack):
     utts = [int(u) for u in z["utts"]]
     rec = {}
     try:
-        m.set_precision("fp32_split")
+        m.set_precision(mode)
         rb = m.inference_batch(texts)
         assert rb["olens"] == [768] * 64
         for j, u in enumerate(utts):
             ref = torch.tensor(z[f"u{j}_feat_gen"])
-            m.set_precision("fp32_split")
+            m.set_precision(mode)
             r1 = m.inference_batch([texts[u]])
             m.set_precision("fp32")
             rf = m.inference_batch([texts[u]])
@@ -90,7 +92,7 @@ def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack):
         m.set_precision("fp32")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_split_errors_fs2.json"), "w") as f:
+    with open(os.path.join(out, f"r05_{mode}_errors_fs2.json"), "w") as f:
         json.dump(rec, f, indent=1)
 
 
@@ -122,8 +124,10 @@ def test_hifigan_bench_size_matches_the_oracle(bench_stack):
         assert e1 <= 2e-4 and eb <= 2e-4, f"utterance {u}: alone {e1:.3e}, in the batch {eb:.3e}"
 
 
-def test_hifigan_split_mode_at_bench_size(bench_stack):
-    """The fp32_split vocoder (round 4: ResBlock units on split f16 hi/lo MFMA operands) on the same 768-frame mels: the SAME tolerance as
+@pytest.mark.parametrize("mode", ["fp32_split", "fp32_bf16x3"])
+def test_hifigan_split_mode_at_bench_size(bench_stack, mode):
+    """The fp32_split vocoder (round 4: ResBlock units on split f16 hi/lo MFMA operands; round 5, "fp32_bf16x3": on three exact bf16 terms per
+    operand, six MFMA products) on the same 768-frame mels: the SAME tolerance as
     the exact-f32 path against the f32 oracle (abs 2e-4), and against the oracle run in FP64 its maximum error must not exceed twice the
     exact-f32 path's -- the condition under which it is not a narrower arithmetic than the reference's.  Alone and inside the batch of 64,
     bit-identical to each other.  The measured errors go to gpurun_out/r04_split_errors.json (profiles/r04_notes.md quotes them)."""
@@ -142,7 +146,7 @@ def test_hifigan_split_mode_at_bench_size(bench_stack):
     vsd64 = {k: v.double() for k, v in vsd.items()}
     rec = {}
     try:
-        voc.set_precision("fp32_split")
+        voc.set_precision(mode)
         yb = voc.decode_batch(rbatch["feats_rb"], mel_b)
         for j, u in enumerate(utts):
             mel = torch.tensor(z[f"u{j}_feat_gen"])
@@ -150,7 +154,7 @@ def test_hifigan_split_mode_at_bench_size(bench_stack):
             with torch.no_grad():
                 ref32 = hifigan_generate(vsd, mel, HIFIGAN_V1_22K["upsample_scales"], HIFIGAN_V1_22K["resblock_dilations"]).reshape(-1)
                 ref64 = hifigan_generate(vsd64, mel.double(), HIFIGAN_V1_22K["upsample_scales"], HIFIGAN_V1_22K["resblock_dilations"]).reshape(-1)
-            voc.set_precision("fp32_split")
+            voc.set_precision(mode)
             ys = voc.decode_batch(hip.RaggedBatch([768], dev), mel.to(dev)).reshape(-1)
             voc.set_precision("fp32")
             yf = voc.decode_batch(hip.RaggedBatch([768], dev), mel.to(dev)).reshape(-1)
@@ -168,7 +172,7 @@ def test_hifigan_split_mode_at_bench_size(bench_stack):
         voc.set_precision("fp32")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_split_errors.json"), "w") as f:
+    with open(os.path.join(out, f"r05_{mode}_errors.json"), "w") as f:
         json.dump(rec, f, indent=1)
 
 
@@ -308,10 +312,10 @@ def test_conv1d_direct_edge_geometry(cuda, lib, case, variant):
 
 # ------------------------------------------------------------------------------------------------ configs 3 and 5 at the bench's length
 def _record_error(name, prec, e_alone, e_batch):
-    """max |mel - reference| per arithmetic -> gpurun_out/r04_model_errors.json (profiles/r04_notes.md quotes the table)."""
+    """max |mel - reference| per arithmetic -> gpurun_out/r05_model_errors.json (profiles/r05_notes.md quotes the table)."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04_model_errors.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_model_errors.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     rec = json.load(open(path)) if os.path.exists(path) else {}
     rec.setdefault(name, {})[prec] = {"alone": e_alone, "in_batch_of_8": e_batch}
@@ -325,7 +329,7 @@ def _seeded_noise(z):
     return torch.randn(1, shape[1], shape[0], generator=torch.Generator().manual_seed(int(z["noise_seed"])))[0].t().contiguous()
 
 
-@pytest.mark.parametrize("prec,atol", [("fp32", 5e-3), ("fp32_split", 5e-3), ("fp16", 0.15)])     # split mode: the exact-f32 tolerance
+@pytest.mark.parametrize("prec,atol", [("fp32", 5e-3), ("fp32_split", 5e-3), ("fp32_bf16x3", 5e-3), ("fp16", 0.15)])     # split / emulated modes: the exact-f32 tolerance
 def test_matcha_bench_utterance_matches_the_reference(cuda, lib, prec, atol):
     """BASELINE configs[2] at the bench's utterance length: the config-3 model (U-Net 512/512, head dim 256, 10 Euler steps) on a
     128-phoneme bench utterance -> 768 frames, against the REAL reference (matcha_bench128.npz; diffusers attention = SDPA stand-in),
@@ -352,7 +356,7 @@ def test_matcha_bench_utterance_matches_the_reference(cuda, lib, prec, atol):
     assert e1 <= atol and eb <= atol, f"{prec}: alone {e1:.3e}, in a batch {eb:.3e}"
 
 
-@pytest.mark.parametrize("prec,atol", [("fp32", 3e-3), ("fp32_split", 3e-3), ("fp16", 8e-2)])     # split mode: the exact-f32 tolerance
+@pytest.mark.parametrize("prec,atol", [("fp32", 3e-3), ("fp32_split", 3e-3), ("fp32_bf16x3", 3e-3), ("fp16", 8e-2)])     # split / emulated modes: the exact-f32 tolerance
 def test_vits_bench_utterance_matches_the_reference(cuda, lib, prec, atol):
     """BASELINE configs[4] at the bench's utterance length: mel-VITS with a 192-d speaker embedding on a 128-phoneme bench utterance ->
     768 frames, against the REAL reference (vits_bench128.npz), alone and inside a batch of 8."""

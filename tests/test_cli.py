@@ -1,6 +1,7 @@
 """Stage-4 CLI (jatts_amd.bin.tts_decode): host-side pieces on CPU, the whole recipe step on the GPU."""
 import csv
 import os
+import shutil
 import wave
 
 import numpy as np
@@ -163,8 +164,12 @@ def test_h5stats_converter_with_stub_h5py(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_recipe_run_sh_stage4(cuda, lib, tmp_path):
-    """egs/jsut/tts1/run.sh --stage 4: the reference recipe's variables and directory layout, decoding on the HIP path."""
+@pytest.mark.parametrize("recipe,sets,prec", [("jsut/tts1", ("test",), "fp32"), ("hificaptain_jp_female/tts1", ("dev_raw_feat", "test"), "fp32"),
+                                              ("hificaptain_jp_female/tts2", ("dev_raw_feat", "test"), "fp32_bf16x3")])
+def test_recipe_run_sh_stage4(cuda, lib, tmp_path, recipe, sets, prec):
+    """egs/<corpus>/ttsN/run.sh --stage 4: the reference recipe's variables and directory layout, decoding on the HIP path.  The hificaptain
+    recipes decode dev_raw_feat and the test set (reference egs/hificaptain_jp_female/tts1/run.sh:221-245); the checkpoint's config.yml names the
+    model, so every recipe directory serves any of the model families (here the small FastSpeech2)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     work = tmp_path / "recipe"
@@ -172,15 +177,18 @@ def test_recipe_run_sh_stage4(cuda, lib, tmp_path):
     os.makedirs(exp)
     os.makedirs(work / "data")
     _make_expdir(exp, "test.csv")
-    os.replace(exp / "test.csv", work / "data" / "test.csv")
-    r = subprocess.run(["bash", os.path.join(root, "egs", "jsut", "tts1", "run.sh"), "--stage", "4", "--stop_stage", "4", "--tag", "unit",
-                        "--verbose", "0", "--decode_batch_size", "2"], cwd=work, capture_output=True, text=True, timeout=600)
+    for name in sets:
+        shutil.copy(exp / "test.csv", work / "data" / f"{name}.csv")
+    os.remove(exp / "test.csv")
+    r = subprocess.run(["bash", os.path.join(root, "egs", *recipe.split("/"), "run.sh"), "--stage", "4", "--stop_stage", "4", "--tag", "unit",
+                        "--verbose", "0", "--decode_batch_size", "2", "--precision", prec], cwd=work, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    out = exp / "results" / "checkpoint-1steps" / "test"
-    assert (out / "decode.log").exists()
-    for i in range(3):
-        with wave.open(str(out / "wav" / f"utt{i}.wav")) as w:
-            assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
+    for name in sets:
+        out = exp / "results" / "checkpoint-1steps" / name
+        assert (out / "decode.log").exists()
+        for i in range(3):
+            with wave.open(str(out / "wav" / f"utt{i}.wav")) as w:
+                assert w.getframerate() == 24000 and w.getnframes() % 300 == 0 and w.getnframes() > 0
 
 
 @pytest.mark.gpu

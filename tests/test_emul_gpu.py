@@ -1,0 +1,209 @@
+"""GPU parity of the f32-EQUIVALENT emulated arithmetic (JATTS_F32E, round 5).
+
+Every operand value travels exactly as three bf16 terms (b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1): 3 x 8 significand
+bits, f32's exponent range, no scales) and a product keeps the six partial products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16
+with f32 accumulate.  The bound argument (include/jatts_hip.h, csrc/common.h): dropped terms <= 2^-23 |w v| for EVERY input, i.e.
+<= 2 x an f32 FMA's rounding; accumulation in f32.  What is asserted here:
+  * the operands round-trip exactly through the device split (identity contraction returns the input bit for bit);
+  * relative L2 <= 2e-5 against fp64 (the exact-f32 kernels' tolerance) and max error <= 2 x the exact-f32 kernel's on the same
+    inputs, INCLUDING single-non-zero contractions (K_eff = 1), over fixed shapes and a randomised draw (tools/emul_sweep.py);
+  * a row's result does not depend on its batch (bit-identical alone / inside a batch) -- there is no tile-dependent scale at all.
+"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from helpers import relerr
+from test_kernels_gpu import TOL, _ragged, _ref_conv, _ref_unit
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _maxerr(y, ref):
+    return float((y.double().cpu() - ref).abs().max())
+
+
+def test_emulated_operands_round_trip_exactly(cuda, lib):
+    """x -> (b0, b1, b2) on the device, contracted with an identity weight (whose terms are (1, 0, 0)): the six products reduce to
+    b2 + b1 + b0 accumulated in that order in f32, which is x again -- bit for bit, for every mantissa pattern and across the
+    exponent range (|x| >= 2^-110: below, b2 falls under bf16's smallest subnormal)."""
+    from jatts_amd import hip
+    C = 64
+    eye = torch.eye(C).unsqueeze(-1)
+    wp = hip.pack_conv_weight_bf16x3(eye.to(cuda), 64)
+    # the host packer's terms are exact too
+    b0, b1, b2 = hip.bf16x3_terms(eye)
+    assert torch.equal(b0.float(), eye) and not b1.float().any() and not b2.float().any()
+    g = torch.Generator().manual_seed(0)
+    m = torch.randint(0, 1 << 23, (4096, C), generator=g, dtype=torch.int32)           # random mantissas ...
+    e = torch.randint(127 - 100, 127 + 100, (4096, C), generator=g, dtype=torch.int32)    # ... exponents 2^-100 .. 2^99 ...
+    sgn = torch.randint(0, 2, (4096, C), generator=g, dtype=torch.int32)
+    x = ((sgn << 31) | (e << 23) | m).view(torch.float32)
+    allm = (torch.arange(1 << 16, dtype=torch.int32).view(-1, C) << 7 | 0x3F800055).view(torch.float32)   # ... and 2^16 consecutive upper mantissas
+    x = torch.cat([x, allm, -allm, torch.zeros(8, C)]).contiguous()
+    rb = _ragged([x.shape[0]], cuda)
+    y = hip.conv1d(rb, x.to(cuda), wp, C, C, 1, dtype=hip.F32E)
+    assert torch.equal(y.cpu(), x), f"{int((y.cpu() != x).sum())} of {x.numel()} values changed"
+    # host terms: b0 + b1 + b2 == x exactly, |b1| <= 2^-8 |x|, |b2| <= 2^-16 |x|
+    b0, b1, b2 = hip.bf16x3_terms(x)
+    assert torch.equal((b0.double() + b1.double() + b2.double()).float(), x)
+    nz = x != 0
+    assert float((b1.float().abs()[nz] / x.abs()[nz]).max()) <= 2.0 ** -8 and float((b2.float().abs()[nz] / x.abs()[nz]).max()) <= 2.0 ** -16
+
+
+EMUL_CONV_CASES = [
+    # c_in, n_out, k, dil, lens, act, resid, transposed, pre, n_in
+    (64, 128, 3, 1, [37, 256, 5], "relu", False, False, None, 1),
+    (384, 1536, 3, 1, [128, 77], "relu", False, False, None, 1),
+    (1536, 384, 3, 1, [128, 300], None, True, False, None, 1),
+    (80, 256, 5, 1, [90, 41], "tanh", False, False, None, 1),
+    (384, 80, 1, 1, [100], None, False, False, None, 1),
+    (384, 384, 1, 1, [33, 65], None, False, True, None, 1),
+    (80, 512, 7, 1, [50, 20], None, False, False, None, 1),
+    (64, 48, 3, 3, [70], None, False, False, 0.1, 3),
+    (192, 700, 1, 1, [64, 130], None, False, False, None, 1),
+    (32, 1, 3, 1, [19], None, False, False, None, 1),
+    (512, 512, 5, 2, [300, 41], "tanh", False, False, None, 1),
+    (256, 1024, 3, 1, [90, 200], None, False, False, 0.1, 1),           # HiFi-GAN upsampling conv shape with the LeakyReLU prologue
+    (64, 64, 4, 1, [3000], None, False, False, 0.1, 1),                  # n_out <= 64 tile
+    (512, 2048, 1, 1, [700], None, False, False, None, 1),
+]
+
+
+@pytest.mark.parametrize("xkind", ["unit", "wide", "single"])
+@pytest.mark.parametrize("case", EMUL_CONV_CASES)
+def test_conv1d_emul(cuda, lib, case, xkind):
+    import torch.nn.functional as F
+    from jatts_amd import hip
+    c_in, n_out, k, dil, lens, act, resid, transposed, pre, n_in = case
+    g = torch.Generator().manual_seed((hash(case[:4]) & 0xFFFF) + 7)
+    R = sum(lens)
+    xs = [torch.randn(R, c_in, generator=g) for _ in range(n_in)]
+    if xkind == "wide":
+        xs = [x * torch.pow(10.0, torch.rand(R, 1, generator=g) * 8 - 6) for x in xs]
+    w = torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k) * torch.pow(10.0, torch.rand(n_out, 1, 1, generator=g) * 2 - 1)
+    b = torch.randn(n_out, generator=g) * 0.1
+    if xkind == "single":          # one non-zero weight per output channel, no bias: every dot product is ONE product
+        from tools.emul_sweep import single_nonzero_
+        single_nonzero_(w, g)
+        b.zero_()
+    res = torch.randn(R, n_out, generator=g) if (resid and xkind != "single") else None
+    pad = (k - 1) // 2 * dil
+    in_scale = 1.0 / n_in
+    ref = _ref_conv(sum(xs) * in_scale, w, b, lens, dil, pad, k, pre, act)      # (the kernel sums its inputs in f32, in this order)
+    alpha = 0.5 if res is not None else 1.0
+    ref = ref * alpha + (res.double() if res is not None else 0)
+    rb = _ragged(lens, cuda)
+    c_pad = hip.round_up(c_in, 64)
+    xd = [F.pad(x, (0, c_pad - c_in)).to(cuda).contiguous() for x in xs]
+    kw = dict(dil=dil, bias=b.to(cuda), act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], alpha=alpha,
+              resid=None if res is None else res.to(cuda), out_f32=True, transposed=transposed, pre_lrelu=pre, in_scale=in_scale)
+    y = hip.conv1d(rb, xd, hip.pack_conv_weight_bf16x3(w.to(cuda), 64), c_pad, n_out, k, dtype=hip.F32E, **kw)
+    y32 = hip.conv1d(rb, xd, hip.pack_conv_weight(w.to(cuda), hip.F32), c_pad, n_out, k, dtype=hip.F32, **kw)
+    torch.cuda.synchronize()
+    y, y32 = (y.t(), y32.t()) if transposed else (y, y32)
+    assert torch.isfinite(y).all()
+    e, e32 = relerr(y, ref), relerr(y32, ref)
+    assert e <= max(TOL["fp32"], 2.0 * e32), f"emulated conv1d {case} {xkind}: rel err {e:.3e} (exact f32 {e32:.3e})"
+    m, m32 = _maxerr(y, ref), _maxerr(y32, ref)
+    assert m <= 2.0 * m32 + 1e-30, f"emulated conv1d {case} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
+    # the EmulWeight route of the models (dtype stays F32 at the call site) is the same launch
+    if n_in == 1 and not transposed:
+        y2 = hip.conv1d(rb, xd, hip.EmulWeight(w.to(cuda), 64), c_pad, n_out, k, dtype=hip.F32, **kw)
+        assert torch.equal(y2, y)
+    # a sequence alone == inside the batch, bit for bit
+    if len(lens) > 1 and not transposed:
+        L0 = lens[0]
+        kw0 = dict(kw, resid=None if res is None else res[:L0].to(cuda).contiguous())
+        y0 = hip.conv1d(_ragged([L0], cuda), [x[:L0].contiguous() for x in xd], hip.pack_conv_weight_bf16x3(w.to(cuda), 64), c_pad, n_out, k,
+                        dtype=hip.F32E, **kw0)
+        assert torch.equal(y0, y[:L0])
+
+
+@pytest.mark.parametrize("xkind", ["unit", "tiny", "large", "wide", "single"])
+@pytest.mark.parametrize("C,k,d,lens", [
+    (32, 3, 1, [700, 3, 250]), (32, 11, 5, [600, 31]), (64, 7, 3, [513]), (64, 11, 5, [260, 9]), (128, 3, 5, [300, 40]),
+    (128, 11, 1, [129]), (128, 11, 5, [300]), (128, 7, 3, [140, 139]), (256, 7, 5, [150, 64]), (256, 11, 5, [70]), (256, 3, 1, [200]),
+])
+def test_hifigan_resunit_emul(cuda, lib, C, k, d, lens, xkind):
+    """JATTS_F32E fused dilation unit: the exact-f32 kernel's tolerance against fp64, at most twice its maximum error on the same inputs
+    -- at unit, tiny (1e-6), large (3e3), mixed (8 orders of magnitude between rows) magnitudes and with single-non-zero weight rows."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + d)
+    R = sum(lens)
+    x = torch.randn(R, C, generator=g)
+    if xkind == "tiny":
+        x = x * 1e-6
+    elif xkind == "large":
+        x = x * 3e3
+    elif xkind == "wide":
+        x = x * torch.pow(10.0, torch.rand(R, 1, generator=g) * 8 - 6)
+    w1 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k) * torch.pow(10.0, torch.rand(C, 1, 1, generator=g) * 2 - 1)   # per-channel spread
+    w2 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    sb = {"unit": 0.1, "tiny": 1e-7, "large": 300.0, "wide": 0.1, "single": 0.0}[xkind]
+    b1, b2 = torch.randn(C, generator=g) * sb, torch.randn(C, generator=g) * sb
+    if xkind == "single":
+        from tools.emul_sweep import single_nonzero_
+        single_nonzero_(w1, g).mul_(math.sqrt(C * k))
+        single_nonzero_(w2, g).mul_(math.sqrt(C * k))
+    ref = _ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, False)
+    rb = _ragged(lens, cuda)
+    xd = x.to(cuda)
+    p1, p2 = hip.pack_conv_weight_bf16x3(w1.to(cuda), 32), hip.pack_conv_weight_bf16x3(w2.to(cuda), 32)
+    y = torch.full_like(xd, float("nan"))
+    hip.hifigan_resunit(rb, 1, xd, y, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, hip.F32E)
+    y32 = torch.full_like(xd, float("nan"))
+    hip.hifigan_resunit(rb, 1, xd, y32, hip.pack_conv_weight(w1.to(cuda), hip.F32, 32), b1.to(cuda),
+                        hip.pack_conv_weight(w2.to(cuda), hip.F32, 32), b2.to(cuda), C, k, d, 0.1, hip.F32)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all(), "unwritten / non-finite outputs"
+    e, e32 = relerr(y, ref), relerr(y32, ref)
+    assert e <= TOL["fp32"], f"emulated resunit C={C} k={k} d={d} {xkind}: rel err {e:.3e} (exact f32: {e32:.3e})"
+    m, m32 = _maxerr(y, ref), _maxerr(y32, ref)
+    assert m <= 2.0 * m32 + 1e-30, f"emulated resunit C={C} k={k} d={d} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
+    if len(lens) > 1:      # an utterance alone == inside the batch, bit for bit
+        L0 = lens[0]
+        y0 = torch.empty(L0, C, device=cuda)
+        hip.hifigan_resunit(_ragged([L0], cuda), 1, xd[:L0].contiguous(), y0, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, hip.F32E)
+        assert torch.equal(y0, y[:L0])
+
+
+def test_hifigan_resunit_emul_mrf_mean(cuda, lib):
+    """The fused MRF mean of the unit's output pass ((unit(x) + add0 + add1) * out_scale) and an all-zero input."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(12)
+    lens, C, k, d = [300, 77], 64, 7, 3
+    R = sum(lens)
+    x, a0, a1 = (torch.randn(R, C, generator=g) for _ in range(3))
+    w1, w2 = (torch.randn(C, C, k, generator=g) / math.sqrt(C * k) for _ in range(2))
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    ref = (_ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, False) + a0.double() + a1.double()) / 3.0
+    rb = _ragged(lens, cuda)
+    p1, p2 = hip.pack_conv_weight_bf16x3(w1.to(cuda), 32), hip.pack_conv_weight_bf16x3(w2.to(cuda), 32)
+    y = torch.empty(R, C, device=cuda)
+    hip.hifigan_resunit(rb, 1, x.to(cuda), y, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, hip.F32E, add=[a0.to(cuda), a1.to(cuda)], out_scale=1.0 / 3.0)
+    assert relerr(y, ref) <= TOL["fp32"]
+    z = torch.zeros(R, C, device=cuda)
+    zb = torch.zeros(C, device=cuda)
+    hip.hifigan_resunit(rb, 1, z, y, p1, zb, p2, zb, C, k, d, 0.1, hip.F32E)
+    assert not y.any()
+
+
+def test_emul_sweep_bound(cuda, lib):
+    """A randomised draw of tools/emul_sweep.py (its own seed; the committed 1 100-case table is profiles/r05_emul_sweep.json): in EVERY
+    case the emulated kernel's maximum error against fp64 is at most twice the exact-f32 kernel's, single-non-zero rows included."""
+    from tools import emul_sweep as sw
+    g = torch.Generator().manual_seed(2025)
+    rows = sw.sweep_units(60, g, cuda) + sw.sweep_convs(120, g, cuda)
+    assert all(r["finite"] for r in rows)
+    worst = max(rows, key=sw.ratio_of)
+    assert sw.ratio_of(worst) <= 2.0, f"{worst['case']}: emulated {worst['max_emul']:.3e} vs exact f32 {worst['max_f32']:.3e}"
+    assert sum(r["case"].endswith("single") for r in rows) >= 50
+    assert max(r["rel_emul"] for r in rows if not r["case"].endswith("single")) <= 3e-5

@@ -60,13 +60,19 @@ def stack_split(cuda, lib):
     return _make_stack(cuda, "fp32_split")
 
 
-@pytest.mark.parametrize("prec", ["fp16", "fp32", "fp32_split"])
+@pytest.fixture(scope="module")
+def stack_emul(cuda, lib):
+    """fp32_bf16x3 (round 5): f32 tensors, three exact bf16 terms per operand and six MFMA products in every conv and fused unit."""
+    return _make_stack(cuda, "fp32_bf16x3")
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32", "fp32_split", "fp32_bf16x3"])
 @pytest.mark.parametrize("ragged", [False, True], ids=["64x128", "64xU(64..128)"])
-def test_full_batch_properties(cuda, stack, stack32, stack_split, ragged, prec):
+def test_full_batch_properties(cuda, stack, stack32, stack_split, stack_emul, ragged, prec):
     """fp32 = the arithmetic bench.py's headline measures (register-streamed f32 convs, f32 fused units): determinism, utterance
     independence and permutation equivariance hold bit for bit there too."""
     from jatts_amd.synthetic import synth_texts
-    stack = {"fp32": stack32, "fp32_split": stack_split, "fp16": stack}[prec]
+    stack = {"fp32": stack32, "fp32_split": stack_split, "fp32_bf16x3": stack_emul, "fp16": stack}[prec]
     texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
     if ragged:
         g = torch.Generator().manual_seed(5)

@@ -18,7 +18,7 @@ def _small(params, channels=128):
     return dict(params, channels=channels)
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp32_bf16x3", 2e-4), ("fp16", 2e-2)])
 @pytest.mark.parametrize("params", [_small(HIFIGAN_V1_22K, 512), _small(HIFIGAN_V1_24K, 512),
                                     # narrow generators (HiFi-GAN V3 / V2 widths): 16- and 8-channel stages are zero-padded to 32
                                     _small(HIFIGAN_V1_22K, 256), _small(HIFIGAN_V1_22K, 128),
@@ -57,7 +57,7 @@ def test_generator_matches_oracle(cuda, lib, prec, tol, params):
     assert maxdiff(y1.view(-1), y[lens[0] * hop:]) <= 1e-6
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp32_split", 2e-4), ("fp16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp32_split", 2e-4), ("fp32_bf16x3", 2e-4), ("fp16", 2e-2)])
 @pytest.mark.parametrize("case", ["v1", "w128", "two_blocks", "wn"])
 def test_generator_matches_an_independent_implementation(cuda, lib, case, prec, tol):
     """The HIP generator against waveforms of Hugging Face transformers' FastSpeech2ConformerHifiGan run in fp64 on the same weights and mel

@@ -25,6 +25,8 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     if dtype == hip.F32S:
         (w1, i1), (w2, i2) = hip.pack_conv_weight_split(wa, 32), hip.pack_conv_weight_split(wb, 32)
         kw["ws"] = (i1, i2)
+    elif dtype == hip.F32E:
+        w1, w2 = hip.pack_conv_weight_bf16x3(wa, 32), hip.pack_conv_weight_bf16x3(wb, 32)
     else:
         w1, w2 = hip.pack_conv_weight(wa, dtype, 32), hip.pack_conv_weight(wb, dtype, 32)
     b1 = torch.zeros(C, device=dev)
@@ -100,11 +102,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split", "emul"])
     ap.add_argument("--resblock", action="store_true", help="fused ResBlock launches vs per-unit launches (f16)")
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
-    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S}[a.dtype]
+    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E}[a.dtype]
     if a.resblock:
         for C in ((32, 64, 128) if dt == hip.F16 else (32, 64)):
             for k in ((3, 7) if dt != hip.F32 else (3,)):
