@@ -38,9 +38,10 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TF = 2500.0   # dense f16/bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 (= the f32 vector rate)
 PROFILE_ROUND = "r05"
-# matrix-pipe peak per ALGORITHMIC FLOP of each arithmetic: split = 3 dense f16 MFMAs per product, bf16x3 emulation = 6 dense bf16 MFMAs
-ALG_PEAK_TF = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0, "fp32_bf16x3": MFMA_F16_PEAK_TF / 6.0}
-PRECISIONS = ("fp32", "fp32_bf16x3", "fp32_split", "fp16")
+# matrix-pipe peak per ALGORITHMIC FLOP of each arithmetic: split = 3 dense f16 MFMAs per product, bf16x3 emulation = 7 (6) dense bf16 MFMAs
+ALG_PEAK_TF = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0, "fp32_bf16x3": MFMA_F16_PEAK_TF / 7.0,
+               "fp32_bf16x3_6p": MFMA_F16_PEAK_TF / 6.0}
+PRECISIONS = ("fp32", "fp32_bf16x3", "fp32_bf16x3_6p", "fp32_split", "fp16")
 
 
 def parse():
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--t-text", type=int, default=128)
     ap.add_argument("--frames-per-token", type=int, default=6)
-    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"],
                     help="arithmetic of the headline numbers (the reference computes in f32)")
     ap.add_argument("--vocoder", default="22k", choices=["22k", "24k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,7 +171,10 @@ def committed_traffic():
     return None, f"profiles/{PROFILE_ROUND}_traffic.json not found"
 
 
-UNIT_KERNEL = {"fp32_split": "resunit_split_kernel", "fp32_bf16x3": "resunit_emul_kernel"}
+# fused-unit kernel of each arithmetic as rocprofv3 names it: (mangled, demangled) prefixes up to the channel count
+UNIT_KERNEL = {"fp32_split": ("resunit_split_kernelILi{c}E", "resunit_split_kernel<{c},"),
+               "fp32_bf16x3": ("resunit_emul_kernelI4bf3pILi7EELi{c}E", "resunit_emul_kernel<bf3p<7>, {c},"),
+               "fp32_bf16x3_6p": ("resunit_emul_kernelI4bf3pILi6EELi{c}E", "resunit_emul_kernel<bf3p<6>, {c},")}
 
 
 def lookup_traffic(table, prec, c):
@@ -179,7 +183,7 @@ def lookup_traffic(table, prec, c):
     if not table:
         return None, "no traffic table"
     if prec in UNIT_KERNEL:
-        key, alt = f"{UNIT_KERNEL[prec]}ILi{c}E", f"{UNIT_KERNEL[prec]}<{c},"
+        key, alt = (t.format(c=c) for t in UNIT_KERNEL[prec])
     else:
         key = f"resunit_kernelI{'DF16_' if prec == 'fp16' else 'f'}Li{c}E"
         alt = f"resunit_kernel<{'_Float16' if prec == 'fp16' else 'float'}, {c},"
@@ -388,8 +392,8 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     roof["algorithmic_flops_per_launch"] = dom_flops / n_launch
     roof["kernel"] = (f"resunit_split_kernel<C={dom_c}> (fused HiFi-GAN dilation unit, f32 I/O, split f16 hi/lo MFMA operands: 3 MFMAs per product, "
                       f"peak = dense f16 / 3; 9 launches per step)" if prec == "fp32_split" else
-                      f"resunit_emul_kernel<C={dom_c}> (fused HiFi-GAN dilation unit, f32 I/O, three exact bf16 terms per operand: 6 MFMAs per product, "
-                      f"peak = dense bf16 / 6; 9 launches per step)" if prec == "fp32_bf16x3" else
+                      f"resunit_emul_kernel<C={dom_c}> (fused HiFi-GAN dilation unit, f32 I/O, three exact bf16 terms per operand: {7 if prec == 'fp32_bf16x3' else 6} "
+                      f"MFMAs per product, peak = dense bf16 / {7 if prec == 'fp32_bf16x3' else 6}; 9 launches per step)" if prec.startswith("fp32_bf16x3") else
                       f"resunit_kernel<{'f16' if esz == 2 else 'float'}, C={dom_c}> (fused HiFi-GAN dilation unit, 9 launches per step)")
     roof["avg_launch_ms"] = dom_ms / n_launch
     roof["arith_intensity_flop_per_byte"] = ai
@@ -587,7 +591,8 @@ def compact_line(out, detail_path=None):
         if out.get("cpu_baseline_note"):
             c["cpu_baseline_note"] = out["cpu_baseline_note"]
     for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 tensors, split f16 hi/lo MFMA operands in every conv and fused unit"),
-                       ("f32_emul_mode", "f32 tensors; 3 exact bf16 terms per operand, 6 MFMA products (bound 2^-23), f32 accumulate")):
+                       ("f32_emul_mode", "f32 tensors; 3 exact bf16 terms per operand, 7 MFMA products (1-term contraction within 2^-23), f32 accumulate"),
+                       ("f32_emul6_mode", "as f32_emul_mode with 6 MFMA products (dropped terms <= 2^-23 per product)")):
         fm = out.get(key)
         if fm:
             c[key] = {"dtype": short, "value": fm["value"], "ms_per_step": fm["ms_per_step"],
@@ -603,6 +608,7 @@ def compact_line(out, detail_path=None):
                          "split_ms": (e.get("f32_split_mode") or {}).get("ms_per_step"),
                          "split_err_wave": (e.get("f32_split_mode") or {}).get("max_abs_err_wave"),
                          "emul_ms": (e.get("f32_emul_mode") or {}).get("ms_per_step"),
+                         "emul6_ms": (e.get("f32_emul6_mode") or {}).get("ms_per_step"),
                          "emul_err_wave": (e.get("f32_emul_mode") or {}).get("max_abs_err_wave"),
                          "roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac"),
                          "roofline_kernel": (((e.get("roofline") or {}).get("dominant") or {}).get("kernel") or "")[:24]} for e in out["configs"]}
@@ -616,7 +622,7 @@ def compact_line(out, detail_path=None):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_LIMIT:      # never let the line outgrow the driver's tail again: drop the optional blocks
-        for k in ("executor", "roofline_conv1d", "training", "fast_mode", "configs", "stage_ms", "f32_mode", "f32_split_mode", "ragged", "f32_emul_mode"):
+        for k in ("executor", "roofline_conv1d", "training", "fast_mode", "configs", "stage_ms", "f32_emul6_mode", "f32_mode", "f32_split_mode", "ragged", "f32_emul_mode"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
@@ -644,10 +650,12 @@ def write_detail(out):
     return rel
 
 
-MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode", "fp32_bf16x3": "f32_emul_mode"}
+MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode", "fp32_bf16x3": "f32_emul_mode", "fp32_bf16x3_6p": "f32_emul6_mode"}
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate",
-              "fp32_bf16x3": "f32 tensors; every conv / fused HiFi-GAN unit on f32-equivalent emulated MFMA operands (each value exactly as three bf16 terms, six "
-                             "products per product: per-product error bound 2^-23, no scales), f32 accumulate; attention, normalisations and the duration predictor exact f32",
+              "fp32_bf16x3": "f32 tensors; every conv / fused HiFi-GAN unit on f32-equivalent emulated MFMA operands (each value exactly as three bf16 terms, seven "
+                             "partial products per product: a one-term contraction within 2^-23 = 2 x an f32 FMA's bound for every input, no scales), f32 accumulate; "
+                             "attention, normalisations and the duration predictor exact f32",
+              "fp32_bf16x3_6p": "as fp32_bf16x3 with six partial products per product (dropped terms <= 2^-23 of a product)",
               "fp32_split": "f32 tensors; every conv / fused HiFi-GAN unit on split f16 hi/lo MFMA operands (3 MFMAs per product, power-of-two scales), "
                             "f32 accumulate; attention, normalisations and the duration predictor exact f32"}
 
@@ -872,7 +880,7 @@ def main():
         cb["single_thread"]["rtf"] = c1["seconds"] / (c1["samples"] / job_sr)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_rtf"] = cb["rtf"] / out["rtf"]
-        for k in ("fast_mode", "f32_split_mode", "f32_emul_mode", "f32_mode"):
+        for k in ("fast_mode", "f32_split_mode", "f32_emul_mode", "f32_emul6_mode", "f32_mode"):
             if k in out:
                 out[k]["speedup_vs_cpu_rtf"] = cb["rtf"] / out[k]["rtf"]
     else:

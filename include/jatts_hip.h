@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define JATTS_ABI_VERSION 2   /* 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
+#define JATTS_ABI_VERSION 3   /* 3 (round 5): jatts_ragged + total_rows (in the struct's former tail padding), JATTS_F32E; 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
                                 * bumped whenever a descriptor's layout or an entry point's signature changes: a stale library is refused at load */
 
 #define JATTS_F32 0
@@ -41,11 +41,16 @@ extern "C" {
 #define JATTS_F32S 2
 /* f32 activations in HBM, f32-EQUIVALENT emulated MFMA operands (round 5): every operand value v travels EXACTLY as three
  * bfloat16 terms b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1) (3 x 8 significand bits, f32's exponent range: no
- * scales, no block maxima) and a product keeps the six terms of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 with f32
- * accumulate (6/16 of the matrix-pipe cycles of the exact-f32 chain).  Per-product error bound 2^-23 = 2 x an f32 FMA's for
- * every finite input with |v| >= 2^-110.  Accepted by jatts_hifigan_resunit; weights packed by the host as [b0 x8 | b1 x8 | b2 x8]
- * per lane (jatts_amd.hip.pack_conv_weight_bf16x3), ws1 / ws2 unused. */
+ * scales, no block maxima; exact for |v| >= 2^-110) and a product w v keeps the largest of its nine partial products on
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulate:
+ *   JATTS_F32E  : seven (all of weight >= 2^-16 plus w1 v2).  Dropped <= 2^-24 |w v|: a one-term contraction, product plus its
+ *                 rounding into the f32 result, is within 2^-23 = 2 x an f32 FMA's bound for EVERY input.  7/16 of the pipe cycles
+ *                 of the exact-f32 chain.
+ *   JATTS_F32E6 : six (weight >= 2^-16).  Dropped <= 2^-23 |w v| (3 x 2^-24 with the rounding at one term).  6/16 of the cycles.
+ * Accepted by jatts_hifigan_resunit and jatts_conv1d (x, resid, y f32); weights packed by the host as [b0 x8 | b1 x8 | b2 x8] per lane
+ * (jatts_amd.hip.pack_conv_weight_bf16x3; the same operand serves both), ws1 / ws2 / w_inv unused. */
 #define JATTS_F32E 3
+#define JATTS_F32E6 4
 
 #define JATTS_ACT_NONE 0
 #define JATTS_ACT_RELU 1
@@ -78,6 +83,13 @@ typedef struct jatts_ragged {
   int32_t n_seq;
   int32_t max_len; /* host-known max base length */
   int32_t len_mul; /* rows per base row (HiFi-GAN stage rate); 1 elsewhere */
+  int32_t total_rows; /* (ABI 3) HOST-known sum of the base lengths = cu_rows[n_seq] - cu_rows[0]; 0 with host_lens == NULL */
+  const int32_t* host_lens; /* (ABI 3) HOST memory, n_seq base lengths (= the differences of cu_rows), or NULL.  Non-NULL: the MFMA conv / fused-unit
+                             * kernels launch a 1-D grid over exactly the REAL tiles of a ragged batch (the launcher counts them from these
+                             * lengths for the tile it picks) and every workgroup finds its (sequence, tile) from cu_rows; NULL: the rectangular
+                             * grid n_seq x tiles of the longest sequence, whose workgroups past a shorter sequence's end exit at once (a quarter
+                             * of the grid at T ~ U{64..128}).  Read at launch time only (a captured graph does not keep the pointer).  Results
+                             * are identical either way.  jatts_amd.hip passes it for non-uniform batches only. */
 } jatts_ragged;
 
 /* ---------------------------------------------------------------------------------
@@ -392,7 +404,8 @@ int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, int32_t lda,
  * reference's).  buf: device memory, 16-byte aligned, ZERO-filled by the caller once, owned by the caller and kept
  * alive until replaced (a captured graph bakes its address in); the first 64 KiB hold tickets, the rest slabs.  A launch that needs
  * more fails with JATTS_ERR_ARG naming the size.  Launches of one stream serialise on it; two streams must not run these kernels
- * concurrently.  buf = NULL unregisters. */
+ * concurrently: the scratch is process-wide (jatts_amd.hip records the stream of the last reduction launch and makes any other stream
+ * wait for it with an event before its own).  buf = NULL unregisters. */
 int jatts_set_workspace(void* buf, int64_t bytes);
 
 /* Output stage: y[t] = tanh( b + sum_{tap,c} w[tap][c] * lrelu( in_scale * sum_i x_i[t+tap-pad][c] ) )

@@ -10,8 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
-F32, F16, F32S, F32E = 0, 1, 2, 3      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
-ABI_VERSION = 2      # JATTS_ABI_VERSION of include/jatts_hip.h (tests/test_abi_cpu.py compares the two)
+F32, F16, F32S, F32E, F32E6 = 0, 1, 2, 3, 4      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
+ABI_VERSION = 3      # JATTS_ABI_VERSION of include/jatts_hip.h (tests/test_abi_cpu.py compares the two)
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH, ACT_SNAKEBETA = 0, 1, 2, 3, 4, 5
 PRE_NONE, PRE_LRELU = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -19,7 +19,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 
 class Ragged(C.Structure):
     _fields_ = [("cu_rows", C.c_void_p), ("n_seq", C.c_int32), ("max_len", C.c_int32),
-                ("len_mul", C.c_int32)]
+                ("len_mul", C.c_int32), ("total_rows", C.c_int32), ("host_lens", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):

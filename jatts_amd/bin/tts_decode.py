@@ -158,10 +158,11 @@ def get_parser():
     p.add_argument("--config", default=None, type=str)
     p.add_argument("--verbose", type=int, default=1)
     p.add_argument("--batch-size", type=int, default=64, help="utterances per ragged batch (extension)")
-    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3"],
+    p.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"],
                    help="fp32 = the reference's arithmetic (default); fp16 = fast mode: f16 MFMA operands, f32 accumulate; fp32_split = f32 "
                         "tensors, convs and fused vocoder units on error-corrected split f16 hi/lo MFMA operands; fp32_bf16x3 = f32 tensors, the "
-                        "same kernels on three exact bf16 terms per operand and six MFMA products (per-product error bound 2^-23) (extensions)")
+                        "same kernels on three exact bf16 terms per operand and seven MFMA products (a one-term contraction within 2 x an f32 FMA's error "
+                        "bound for every input); fp32_bf16x3_6p = six products (extensions)")
     p.add_argument("--plot", action="store_true", help="also write <outdir>/outs/<id>.png like the reference")
     p.add_argument("--n_gpus", "--n-gpus", dest="n_gpus", type=int, default=1,
                    help="one process per GPU, every rank decodes its own shard of the csv (extension; the recipes' n_gpus). "

@@ -47,21 +47,27 @@ template <> struct Elem<f16s> {
   static constexpr int kBytes = 4;
 };
 
-// f32-EQUIVALENT emulated operand (round 5, JATTS_F32E): every f32 value v is carried EXACTLY as three bfloat16 terms
+// f32-EQUIVALENT emulated operand (round 5, JATTS_F32E / JATTS_F32E6): every f32 value v is carried EXACTLY as three bfloat16 terms
 //   b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1)      (round-to-nearest-even; both differences are exact in f32)
 // 3 x 8 significand bits = f32's 24 and bf16 has f32's exponent field: v == b0 + b1 + b2 for every finite f32 whose last bit lies at or
 // above bf16's smallest subnormal 2^-133 (|v| >= 2^-110): NO scales, no block maxima, no element-dependent loss of relative precision.
-// A product w v keeps the six terms of weight >= 2^-16: w0 v0 | w0 v1, w1 v0 | w1 v1, w0 v2, w2 v0; dropped: w1 v2 + w2 v1 + w2 v2
-// <= (2^-24 + 2^-24 + 2^-32) |w v| (|b1| <= 2^-8 |v|, |b2| <= 2^-16 |v| under round-to-nearest), i.e. a per-product error bound of
-// 2^-23 = 2 x an f32 FMA's, every bf16 x bf16 product exact in the f32 accumulate.  Six v_mfma_f32_32x32x16_bf16 = 6/16 of the pipe
-// cycles of the exact-f32 chain.  The element TAG is 6 bytes wide; 8 consecutive elements are stored PLANAR (16 B of b0 | b1 | b2).
+// Under round-to-nearest |b1| <= 2^-8 |v| and |b2| <= 2^-16 |v|, so the nine partial products of w v have weights 1 | 2^-8 x2 | 2^-16 x3 |
+// 2^-24 x2 | 2^-32; every bf16 x bf16 product is exact in the f32 accumulate.  NP = the number of partial products kept:
+//   NP = 7 (JATTS_F32E): all of weight >= 2^-16 plus w1 v2 -- dropped: w2 v1 + w2 v2 <= (2^-24 + 2^-32) |w v|.  A contraction with ONE term
+//           is then that product plus the one rounding into the f32 result: <= 2^-24 + 2^-24 = 2^-23 = 2 x an f32 FMA's error bound,
+//           for EVERY input (the acceptance rule of VERDICT r4, K_eff = 1 included).  7/16 of the pipe cycles of the exact-f32 chain;
+//   NP = 6 (JATTS_F32E6): the six of weight >= 2^-16 -- dropped <= 2^-23 |w v| (+ the rounding: 3 x 2^-24 at K_eff = 1).  6/16 of the cycles.
+// With many terms both are MORE accurate than the exact-f32 chain (one rounding per 16-term MFMA instead of one per term).
+// The element TAG is 6 bytes wide; 8 consecutive elements are stored PLANAR (16 B of b0 | b1 | b2).
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct bf3 { bf16 b0, b1, b2; };
-struct bf3x8 { bf16x8 b0, b1, b2; };
-template <> struct Elem<bf3> {
-  typedef bf3x8 vec8;
+template <int NP> struct bf3p { bf16 b0, b1, b2; };
+template <int NP> struct bf3px8 { bf16x8 b0, b1, b2; };
+typedef bf3p<7> bf3;        // JATTS_F32E
+typedef bf3p<6> bf3f;       // JATTS_F32E6
+template <int NP> struct Elem<bf3p<NP>> {
+  typedef bf3px8<NP> vec8;
   static constexpr int kBytes = 6;
 };
 // v -> (b0, b1, b2), exact (see above).  v_cvt_pk_bf16_f32 rounds to nearest even; bf16 -> f32 is a shift.
@@ -92,8 +98,10 @@ __device__ __forceinline__ void mma32(const f16sx8& a, const f16sx8& b, f32x16& 
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
 }
-//  bf3 : the six products of weight >= 2^-16, smallest first, into ONE f32 accumulator
-__device__ __forceinline__ void mma32(const bf3x8& a, const bf3x8& b, f32x16& c) {
+//  bf3p<NP>: the NP partial products, smallest first, into ONE f32 accumulator (a = weights, b = activations)
+template <int NP>
+__device__ __forceinline__ void mma32(const bf3px8<NP>& a, const bf3px8<NP>& b, f32x16& c) {
+  if constexpr (NP >= 7) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b2, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b2, b.b0, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b2, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b1, c, 0, 0, 0);
@@ -176,6 +184,46 @@ __device__ __forceinline__ int find_seq(const int32_t* __restrict__ cu_tiles, in
     if (cu_tiles[mid] <= tile) lo = mid; else hi = mid;
   }
   return lo;
+}
+
+// 1-D grids over the REAL tiles of a ragged batch (jatts_ragged.host_lens != NULL): workgroup `wg` -> (sequence b, tile inside it) with
+// `tt` rows per tile, tiles numbered sequence by sequence.  Every wave of the workgroup computes it redundantly from cu_rows (a 64-lane
+// prefix sum per 64 sequences: no LDS, no barrier; ~1 k cycles against workgroup lifetimes of tens of thousands).  false: a
+// workgroup past the last tile.  All 64 lanes must be active (call it first thing in the kernel).
+__device__ __forceinline__ bool ragged_locate(const jatts_ragged& rg, int tt, unsigned wg, int& b, int& tile) {
+  const int lane = threadIdx.x & 63;
+  unsigned base = 0;
+  for (int b0 = 0; b0 < rg.n_seq; b0 += 64) {
+    const int i = b0 + lane;
+    int tiles = 0;
+    if (i < rg.n_seq) tiles = (int)(((int64_t)(rg.cu_rows[i + 1] - rg.cu_rows[i]) * rg.len_mul + tt - 1) / tt);
+    int incl = tiles;   // inclusive prefix sum over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    const unsigned total = (unsigned)__shfl(incl, 63);
+    if (wg < base + total) {
+      const unsigned long long m = __ballot(base + (unsigned)incl > wg);
+      const int l = __ffsll((long long)m) - 1;
+      b = b0 + l;
+      tile = (int)(wg - base) - (__shfl(incl, l) - __shfl(tiles, l));
+      return true;
+    }
+    base += total;
+  }
+  return false;
+}
+// tiles of `tt` rows a launch over rg covers in the 1-D form: the exact count sum_b ceil(L_b len_mul / tt) from the host lengths, or 0 = the
+// rectangular grid (uniform batches and callers without host lengths).  Exact, not an upper bound: the conv kernels deal the tile range out to
+// the 8 XCDs in contiguous pieces, and spare tiles at the end would leave whole XCDs idle on small launches.
+__host__ __device__ __forceinline__ bool ragged_is_1d(const jatts_ragged& rg) { return rg.host_lens != nullptr && rg.total_rows > 0; }
+static inline int64_t ragged_tiles_1d(const jatts_ragged& rg, int tt) {
+  if (!ragged_is_1d(rg)) return 0;
+  int64_t n = 0;
+  for (int b = 0; b < rg.n_seq; ++b) n += ((int64_t)rg.host_lens[b] * rg.len_mul + tt - 1) / tt;
+  return n;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

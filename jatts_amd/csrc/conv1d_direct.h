@@ -57,7 +57,7 @@ template <int NF, int NT, int WN, int WT, int D, int DIAG = 0, bool PRE = false,
 __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_kernel(jatts_conv_desc d, unsigned long long* trace, unsigned trace_cap, XcdOrder xo) {
   const unsigned wg_lin = blockIdx.x;     // 1-D grid in XCD-aware order (conv1d_impl.h: XcdOrder)
   int bx, by, bz;
-  if (!xo.decode(wg_lin, bx, by, bz)) return;
+  if (!xo.decode(wg_lin, bx, by, bz, d.rg, WT * NT * 32)) return;
   // Phase trace (profiling hook, jatts_debug_trace; tools/trace_conv.py): thread 0 of the first trace_cap workgroups stamps
   // [hw id, start, main loop entered, main loop done, stored, -, -, -, realtime start, realtime end]
   const bool tracing = trace != nullptr && wg_lin < trace_cap && threadIdx.x == 0;
@@ -219,7 +219,7 @@ int launch_conv_direct(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   XcdOrder xo;
-  const int64_t total = xo.plan((int)((maxL + BT - 1) / BT), d.rg.n_seq, (d.n_out + BN - 1) / BN, (int64_t)BN * d.c_in * d.k_w * 4);
+  const int64_t total = xo.plan((int)((maxL + BT - 1) / BT), d.rg.n_seq, (d.n_out + BN - 1) / BN, (int64_t)BN * d.c_in * d.k_w * 4, ragged_tiles_1d(d.rg, BT));
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
   hipLaunchKernelGGL((conv1d_direct_kernel<NF, NT, WN, WT, D, DIAG, PRE, SNAKE>), dim3((unsigned)total), dim3(WN * WT * 64), 0, s, d, jatts_g_trace,
                      jatts_g_trace_cap, xo);

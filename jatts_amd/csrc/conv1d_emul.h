@@ -1,18 +1,19 @@
 // Generic Conv1d / Linear / polyphase ConvTranspose1d with f32 activations in HBM and f32-EQUIVALENT emulated MFMA operands
-// (JATTS_F32E, round 5): every operand value exactly as three bf16 terms, six partial products per product (common.h: bf3, mma32).
+// (JATTS_F32E / JATTS_F32E6, round 5): every operand value exactly as three bf16 terms, seven / six partial products per product
+// (common.h: bf3p<NP>, mma32).
 //
 // Same implicit GEMM as conv1d_impl.h (weights = A operand in fragment order, activation chunks double-buffered in LDS).  There
 // is no scale anywhere (bf16 has f32's exponent range), so -- unlike conv1d_split.h -- the result of a row does not depend on any
 // tile geometry and the accumulators start at the bias like the exact-f32 kernel's.  The chunk is 32 channels: its LDS rows hold
 // 6 bytes per element, and two double-buffered 160-row tiles (66 KB) keep two workgroups on a CU, one committing / storing while
-// the other feeds the matrix pipe; a chunk is k_w x 2 K-steps x 6 NF NT MFMAs, 48 MFMAs per wave between barriers at k = 1.
+// the other feeds the matrix pipe; a chunk is k_w x 2 K-steps x 7 (6) NF NT MFMAs, 56 (48) MFMAs per wave between barriers at k = 1.
 #pragma once
 #include "conv1d_impl.h"
 
 namespace {
 
 // commit of the emulated pipeline: combine the staged f32 inputs (sum, in_scale, LeakyReLU), three bf16 planes, LDS
-template <int MAXU, int NIN, int UPR, int NTHR>
+template <typename T, int MAXU, int NIN, int UPR, int NTHR>
 __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in, float in_scale,
                                             int pre_act, float slope) {
   const int total = rows * UPR;
@@ -22,7 +23,7 @@ __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, cha
     const int u = threadIdx.x + j * NTHR;
     if (u >= total) continue;
     const int r = u / UPR, cu = u % UPR;
-    bf3x8 o;
+    typename Elem<T>::vec8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = sr.v[0][j][e];
@@ -36,18 +37,17 @@ __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, cha
       bf3_split(t, a, b, c);
       o.b0[e] = a; o.b1[e] = b; o.b2[e] = c;
     }
-    Vec8IO<bf3>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
+    Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
   }
 }
 
 // HALO: rows beyond the time tile the staging registers must cover; RD: weight ring depth in K-steps (divides KCHT / 16).
-template <int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2>
+template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2>      // T = bf3 (seven products) / bf3f (six)
 __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_conv_desc d, int f32_tile, XcdOrder xo) {
-  typedef bf3 T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32, NTHR = WN * WT * 64;
   int bx, b, bz;
-  if (!xo.decode(blockIdx.x, bx, b, bz)) return;
+  if (!xo.decode(blockIdx.x, bx, b, bz, d.rg, BT)) return;
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
   const int t0 = bx * BT;
@@ -97,13 +97,13 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
   const size_t buf_bytes = (size_t)rows * pitch;
   StageRegs<float, MAXU, NIN> sr;
   stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0, reflect);
-  emul_commit<MAXU, NIN, UPRC, NTHR>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
+  emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
   __syncthreads();
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
     if (more) stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
     conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
-    if (more) emul_commit<MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
+    if (more) emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     __syncthreads();
   }
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
   }
 }
 
-template <int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2>
+template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2>
 int launch_conv_emul(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   if ((d.k_w - 1) * d.dil > HALO) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (emulated): halo beyond the staging registers");
@@ -147,13 +147,13 @@ int launch_conv_emul(const jatts_conv_desc& d, hipStream_t s) {
     if (lds < (size_t)BT * (BN * 4 + 16)) lds = (size_t)BT * (BN * 4 + 16);
   }
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (emulated): tile exceeds 160 KiB LDS");
-  auto kern = conv1d_emul_kernel<NF, NT, WN, WT, NIN, KCHT, OCC, HALO, RD>;
+  auto kern = conv1d_emul_kernel<T, NF, NT, WN, WT, NIN, KCHT, OCC, HALO, RD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
   XcdOrder xo;
-  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * 6);
+  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * 6, ragged_tiles_1d(d.rg, BT));
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WN * WT * 64), lds, s, d, f32_tile, xo);
   JATTS_CHECK_LAUNCH();

@@ -1,16 +1,20 @@
-// jatts_conv1d, JATTS_F32E: f32 activations in HBM, f32-equivalent emulated MFMA operands (three bf16 terms, six products; conv1d_emul.h).
+// jatts_conv1d, JATTS_F32E / JATTS_F32E6: f32 activations in HBM, f32-equivalent emulated MFMA operands (three bf16 terms, seven / six
+// partial products; conv1d_emul.h).
 #include <stdlib.h>
 
 #include "conv1d_emul.h"
 
 // The arithmetic has no tile-dependent scale, so -- unlike the split kernels -- the tile may follow the launch: every variant gives the
 // same bits for a row.  (variants: JATTS_CONV_EMUL_VARIANT, measured by tools/bench_conv.py --dtype emul)
-int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
+template <typename T>
+static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   static const int variant = [] { const char* e = getenv("JATTS_CONV_EMUL_VARIANT"); return e ? atoi(e) : 0; }();
   if (d.n_in > 1)     // summed inputs (an unfused MRF mean in front of a HiFi-GAN upsampling conv; rare): 3x the staging registers, one workgroup per CU
-    return launch_conv_emul<2, 2, 2, 2, 3, 32, 1>(d, s);
-  if (d.n_out <= 64) return launch_conv_emul<2, 1, 1, 4, 1, 32, 2>(d, s);          // 64 n x 128 t, light on registers: the HBM-bound last upsampling conv
-  if (variant == 1) return launch_conv_emul<2, 2, 2, 2, 1, 64, 1, 32, 4>(d, s);    // 64-channel chunks, one workgroup per CU
-  if (variant == 2) return launch_conv_emul<1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
-  return launch_conv_emul<2, 2, 2, 2, 1, 32, 2>(d, s);                             // 128 n x 128 t, two workgroups per CU
+    return launch_conv_emul<T, 2, 2, 2, 2, 3, 32, 1>(d, s);
+  if (d.n_out <= 64) return launch_conv_emul<T, 2, 1, 1, 4, 1, 32, 2>(d, s);          // 64 n x 128 t, light on registers: the HBM-bound last upsampling conv
+  if (variant == 1) return launch_conv_emul<T, 2, 2, 2, 2, 1, 64, 1, 32, 4>(d, s);    // 64-channel chunks, one workgroup per CU
+  if (variant == 2) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
+  return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 2>(d, s);                             // 128 n x 128 t, two workgroups per CU
 }
+
+int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s) { return d.dtype == JATTS_F32E6 ? conv1d_emul<bf3f>(d, s) : conv1d_emul<bf3>(d, s); }

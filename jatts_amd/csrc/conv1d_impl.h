@@ -14,10 +14,10 @@ namespace {
 // (a workgroup that exits at once still perturbs the placement of the others).  4.6x less fabric traffic, +3-12 % on the wide f32
 // shapes -- on a power-limited kernel fabric bytes are clock (profiles/r03_notes.md).
 struct XcdOrder {
-  int gx, n_tiles, tpx, gz, zc;
-  int64_t plan(int gx_, int n_seq, int gz_, int64_t slice_bytes) {
-    gx = gx_; gz = gz_;
-    n_tiles = gx_ * n_seq;
+  int gx, n_tiles, tpx, gz, zc;   // gx == 0: the tiles are the REAL tiles of a ragged batch (1-D, jatts_ragged.host_lens), located from cu_rows
+  int64_t plan(int gx_, int n_seq, int gz_, int64_t slice_bytes, int64_t tiles_1d = 0) {
+    gx = tiles_1d > 0 ? 0 : gx_; gz = gz_;
+    n_tiles = tiles_1d > 0 ? (int)tiles_1d : gx_ * n_seq;
     tpx = (n_tiles + 7) / 8;
     zc = (int)((2 << 20) / (slice_bytes > 0 ? slice_bytes : 1));
     zc = zc < 1 ? 1 : (zc > gz ? gz : zc);
@@ -25,7 +25,8 @@ struct XcdOrder {
     zc = (gz + n_chunks - 1) / n_chunks;
     return 8 * (int64_t)tpx * zc * n_chunks;     // workgroups of the 1-D grid
   }
-  __device__ __forceinline__ bool decode(unsigned id, int& bx, int& by, int& bz) const {
+  // -> (time tile bx of sequence by, n-block bz); `bt` = rows per time tile.  All 64 lanes active (ragged_locate).
+  __device__ __forceinline__ bool decode(unsigned id, int& bx, int& by, int& bz, const jatts_ragged& rg, int bt) const {
     const int xcd = (int)(id & 7u), m = (int)(id >> 3);
     const int per_chunk = tpx * zc;
     const int c = m / per_chunk, rem = m - c * per_chunk;
@@ -33,6 +34,7 @@ struct XcdOrder {
     const int tile = xcd * tpx + tl;
     bz = c * zc + (rem - tl * zc);
     if (tile >= n_tiles || bz >= gz) return false;
+    if (gx == 0) return ragged_locate(rg, bt, (unsigned)tile, by, bx);
     by = tile / gx;
     bx = tile - by * gx;
     return true;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32;
   int bx, b, bz;
-  if (!xo.decode(blockIdx.x, bx, b, bz)) return;
+  if (!xo.decode(blockIdx.x, bx, b, bz, d.rg, BT)) return;
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
   const int t0 = bx * BT;
@@ -298,7 +300,7 @@ int launch_conv_k(const jatts_conv_desc& d, hipStream_t s) {
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
   XcdOrder xo;
-  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * (int64_t)sizeof(T));
+  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * (int64_t)sizeof(T), ragged_tiles_1d(d.rg, BT));
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WN * WT * 64), lds, s, d, f32_tile, xo);
   JATTS_CHECK_LAUNCH();

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_split_kernel(jatts_co
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32, NTHR = WN * WT * 64;
   int bx, b, bz;
-  if (!xo.decode(blockIdx.x, bx, b, bz)) return;
+  if (!xo.decode(blockIdx.x, bx, b, bz, d.rg, BT)) return;
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
   const int t0 = bx * BT;
@@ -204,7 +204,7 @@ int launch_conv_split(const jatts_conv_desc& d, hipStream_t s) {
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
   }
   XcdOrder xo;
-  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * 4);
+  const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * 4, ragged_tiles_1d(d.rg, BT));
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WN * WT * 64), lds, s, d, f32_tile, xo, slot_off);
   JATTS_CHECK_LAUNCH();

@@ -10,7 +10,7 @@ unsigned jatts_g_trace_cap = 0;
 int jatts_conv1d_f16(const jatts_conv_desc& d, hipStream_t s);
 int jatts_conv1d_f32(const jatts_conv_desc& d, hipStream_t s);
 int jatts_conv1d_split(const jatts_conv_desc& d, hipStream_t s);           // JATTS_F32S
-int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s);            // JATTS_F32E
+int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s);            // JATTS_F32E / JATTS_F32E6
 int jatts_resunit_f16_narrow(const jatts_resunit_desc& d, hipStream_t s);  // C = 32, 64
 int jatts_resunit_f16_wide(const jatts_resunit_desc& d, hipStream_t s);    // C = 128, 256, 512
 int jatts_resunit_f32(const jatts_resunit_desc& d, hipStream_t s);
@@ -19,6 +19,7 @@ int jatts_resunit_emul(const jatts_resunit_desc& d, hipStream_t s);        // JA
 int jatts_resblock_f16(const jatts_resblock_desc& d, hipStream_t s);
 int jatts_resblock_f32(const jatts_resblock_desc& d, hipStream_t s);
 int jatts_resblock_split(const jatts_resblock_desc& d, hipStream_t s);     // JATTS_F32S
+int jatts_resblock_emul(const jatts_resblock_desc& d, hipStream_t s);      // JATTS_F32E / JATTS_F32E6
 
 extern "C" int jatts_debug_trace(void* buf, int64_t n_workgroups) {
   jatts_g_trace = (unsigned long long*)buf;
@@ -50,8 +51,8 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
     if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32S writes f32 (y_is_f32 = 1)");
     return jatts_conv1d_split(*d, s);
   }
-  if (d->dtype == JATTS_F32E) {
-    if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32E writes f32 (y_is_f32 = 1)");
+  if (d->dtype == JATTS_F32E || d->dtype == JATTS_F32E6) {
+    if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32E / JATTS_F32E6 write f32 (y_is_f32 = 1)");
     return jatts_conv1d_emul(*d, s);
   }
   return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: unknown dtype");
@@ -71,7 +72,7 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
     if (!d->ws1 || !d->ws2) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: JATTS_F32S needs ws1 / ws2");
     return jatts_resunit_split(*d, s);
   }
-  if (d->dtype == JATTS_F32E) return jatts_resunit_emul(*d, s);
+  if (d->dtype == JATTS_F32E || d->dtype == JATTS_F32E6) return jatts_resunit_emul(*d, s);
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels/dtype (use jatts_conv1d)");
 }
 
@@ -90,6 +91,10 @@ extern "C" int jatts_hifigan_resblock(const jatts_resblock_desc* d, void* stream
       if (!d->ws1[u] || !d->ws2[u]) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: JATTS_F32S needs ws1 / ws2");
     if (d->rg.max_len <= 0) return JATTS_OK;
     return jatts_resblock_split(*d, (hipStream_t)stream);
+  }
+  if (d->dtype == JATTS_F32E || d->dtype == JATTS_F32E6) {
+    if (d->rg.max_len <= 0) return JATTS_OK;
+    return jatts_resblock_emul(*d, (hipStream_t)stream);
   }
   if (d->dtype != JATTS_F16 && d->dtype != JATTS_F32) return jatts_set_error_msg(JATTS_ERR_ARG, "resblock: unknown dtype");
   if (d->rg.max_len <= 0) return JATTS_OK;

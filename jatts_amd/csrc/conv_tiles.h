@@ -71,15 +71,15 @@ template <> struct Vec8IO<f16s> {   // 32 bytes per 8 elements: [hi x8 | lo x8]
   }
 };
 
-template <> struct Vec8IO<bf3> {    // 48 bytes per 8 elements: [b0 x8 | b1 x8 | b2 x8]
-  static __device__ __forceinline__ bf3x8 ldg(const bf3* p) {
+template <int NP> struct Vec8IO<bf3p<NP>> {    // 48 bytes per 8 elements: [b0 x8 | b1 x8 | b2 x8]
+  static __device__ __forceinline__ bf3px8<NP> ldg(const bf3p<NP>* p) {
     const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
-    return bf3x8{q[0], q[1], q[2]};
+    return bf3px8<NP>{q[0], q[1], q[2]};
   }
-  static __device__ __forceinline__ bf3x8 lds(const char* p) {
-    return bf3x8{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 16), *reinterpret_cast<const bf16x8*>(p + 32)};
+  static __device__ __forceinline__ bf3px8<NP> lds(const char* p) {
+    return bf3px8<NP>{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 16), *reinterpret_cast<const bf16x8*>(p + 32)};
   }
-  static __device__ __forceinline__ void sts(char* p, const bf3x8& v) {
+  static __device__ __forceinline__ void sts(char* p, const bf3px8<NP>& v) {
     *reinterpret_cast<bf16x8*>(p) = v.b0;
     *reinterpret_cast<bf16x8*>(p + 16) = v.b1;
     *reinterpret_cast<bf16x8*>(p + 32) = v.b2;

@@ -32,10 +32,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_sp
     M = max(M, p2 * d.dil[u]);
   }
   const int tt_out = WGCOLS - 2 * H;
-  const int b = blockIdx.y;
+  int b = blockIdx.y, bx = blockIdx.x;
+  if (ragged_is_1d(d.rg) && !ragged_locate(d.rg, tt_out, blockIdx.x, b, bx)) return;   // 1-D grid over the real tiles of a ragged batch
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
-  const int t0 = blockIdx.x * tt_out;
+  const int t0 = bx * tt_out;
   if (t0 >= L) return;
   const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -251,6 +252,7 @@ int launch_resblock_split(const jatts_resblock_desc& d, hipStream_t s) {
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resblock (split): tile exceeds 160 KiB LDS");
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
+  if (const int64_t n1 = ragged_tiles_1d(d.rg, tt_out)) grid = dim3((unsigned)n1);
   auto kern = resblock_split_kernel<C, WGCOLS, WN, NT, KCG, OCC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

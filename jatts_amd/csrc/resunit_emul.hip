@@ -1,36 +1,39 @@
-// Fused HiFi-GAN dilation unit, f32 activations in HBM, f32-EQUIVALENT emulated MFMA operands (three bf16 terms per value,
-// six products): JATTS_F32E.
+// Fused HiFi-GAN dilation unit, f32 activations in HBM, f32-EQUIVALENT emulated MFMA operands (three bf16 terms per value):
+// JATTS_F32E (seven partial products per product) and JATTS_F32E6 (six).
 //
 // The LDS tile holds 6 bytes per element, so the windows are narrower than the f32 / split kernels' at the same channel count;
-// a K-step is 6 x 32 pipe cycles per fragment pair against 48 B of each operand: the loop is matrix-pipe bound with room to spare
+// a K-step is 7 (6) x 32 pipe cycles per fragment pair against 48 B of each operand: the loop is matrix-pipe bound with room to spare
 // on operand delivery, and what the tile choice trades is the halo overhead (tt_out / WGCOLS) against workgroups per CU.
 #include "resunit_emul_impl.h"
 
 // Tile choice measured on the box (profiles/r05_emul_units.txt, 64 x 768 frames): C = 128 / 256 run best as ONE 4-wave workgroup per CU
 // with NF = 2 x NT = 2 fragments per wave (24 MFMAs per K-step between operand fetches), C = 64 as two 4-wave workgroups per CU
 // (one per CU with the 256-column window at k = 11), C = 32 as two 256-column workgroups.
-int jatts_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
+template <typename T>
+static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   static const int variant = [] { const char* e = getenv("JATTS_RESUNIT_EMUL_VARIANT"); return e ? atoi(e) : 0; }();
   const int halo = (d.k_w - 1) * d.dil;   // x-tile rows beyond the workgroup's columns
   switch (d.channels) {
     case 32:
-      if (variant == 1) return launch_resunit_emul<32, 128, 1, 2, 2, 2>(d, s);          // 2 waves per workgroup
-      return launch_resunit_emul<32, 256, 1, 2, 2, 2>(d, s);
+      if (variant == 1) return launch_resunit_emul<T, 32, 128, 1, 2, 2, 2>(d, s);          // 2 waves per workgroup
+      return launch_resunit_emul<T, 32, 256, 1, 2, 2, 2>(d, s);
     case 64:
-      if (variant == 2) return launch_resunit_emul<64, 256, 2, 2, 2, 1>(d, s);          // 8 waves NF = 1 NT = 2
-      if (variant == 1 || d.k_w >= 11) return launch_resunit_emul<64, 256, 1, 2, 2, 1>(d, s);   // 4 waves NF = 2 NT = 2, one workgroup per CU
-      return launch_resunit_emul<64, 128, 2, 2, 2, 2>(d, s);                            // 4 waves NF = 1 NT = 2, two workgroups per CU
+      if (variant == 2) return launch_resunit_emul<T, 64, 256, 2, 2, 2, 1>(d, s);          // 8 waves NF = 1 NT = 2
+      if (variant == 1 || d.k_w >= 11) return launch_resunit_emul<T, 64, 256, 1, 2, 2, 1>(d, s);   // 4 waves NF = 2 NT = 2, one workgroup per CU
+      return launch_resunit_emul<T, 64, 128, 2, 2, 2, 2>(d, s);                            // 4 waves NF = 1 NT = 2, two workgroups per CU
     case 128:
-      if (variant == 1) return launch_resunit_emul<128, 128, 4, 2, 2, 1>(d, s);         // 8 waves NF = 1 NT = 2, one workgroup per CU
-      if (variant == 3) return launch_resunit_emul<128, 128, 2, 1, 2, 1>(d, s);         // 8 waves NF = 2 NT = 1
-      if (variant == 4 && (64 + halo) * 784 + 1024 <= 80 * 1024) return launch_resunit_emul<128, 64, 2, 1, 2, 2>(d, s);   // two per CU
-      return launch_resunit_emul<128, 128, 2, 2, 2, 1>(d, s);                           // 4 waves NF = 2 NT = 2, one workgroup per CU
+      if (variant == 1) return launch_resunit_emul<T, 128, 128, 4, 2, 2, 1>(d, s);         // 8 waves NF = 1 NT = 2, one workgroup per CU
+      if (variant == 3) return launch_resunit_emul<T, 128, 128, 2, 1, 2, 1>(d, s);         // 8 waves NF = 2 NT = 1
+      if (variant == 4 && (64 + halo) * 784 + 1024 <= 80 * 1024) return launch_resunit_emul<T, 128, 64, 2, 1, 2, 2>(d, s);   // two per CU
+      return launch_resunit_emul<T, 128, 128, 2, 2, 2, 1>(d, s);                           // 4 waves NF = 2 NT = 2, one workgroup per CU
     case 256:
       if ((64 + halo) * 1552 + 2048 <= 160 * 1024) {
-        if (variant == 1) return launch_resunit_emul<256, 64, 8, 2, 2, 1>(d, s);        // 8 waves NF = 1 NT = 2
-        return launch_resunit_emul<256, 64, 4, 2, 2, 1>(d, s);                          // 4 waves NF = 2 NT = 2
+        if (variant == 1) return launch_resunit_emul<T, 256, 64, 8, 2, 2, 1>(d, s);        // 8 waves NF = 1 NT = 2
+        return launch_resunit_emul<T, 256, 64, 4, 2, 2, 1>(d, s);                          // 4 waves NF = 2 NT = 2
       }
-      return launch_resunit_emul<256, 32, 4, 1, 2, 1>(d, s);                            // k = 11, dilation 5: 82-row tile
+      return launch_resunit_emul<T, 256, 32, 4, 1, 2, 1>(d, s);                            // k = 11, dilation 5: 82-row tile
   }
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels for JATTS_F32E (32 / 64 / 128 / 256)");
 }
+
+int jatts_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) { return d.dtype == JATTS_F32E6 ? resunit_emul<bf3f>(d, s) : resunit_emul<bf3>(d, s); }

@@ -1,11 +1,11 @@
 // Fused HiFi-GAN dilation unit  y = x + conv_1(lrelu(conv_d(lrelu(x))))  with f32 activations in HBM and
-// f32-EQUIVALENT EMULATED MFMA operands (JATTS_F32E, round 5): every operand value is carried exactly as three bfloat16
-// terms and a product keeps the six partial products of weight >= 2^-16 (common.h: bf3, bf3_split, mma32) --
-// six v_mfma_f32_32x32x16_bf16 with f32 accumulate = 6/16 of the pipe cycles of the exact-f32 chain.
+// f32-EQUIVALENT EMULATED MFMA operands (JATTS_F32E / JATTS_F32E6, round 5): every operand value is carried exactly as three
+// bfloat16 terms and a product keeps the seven (six) largest of its nine partial products (common.h: bf3p<NP>, bf3_split, mma32) --
+// seven (six) v_mfma_f32_32x32x16_bf16 with f32 accumulate = 7/16 (6/16) of the pipe cycles of the exact-f32 chain.
 //
 // Unlike the split-f16 path (resunit_split_impl.h) there is nothing to scale: bf16 has f32's exponent range, so there are no
-// block maxima, no scale barriers and no element whose relative precision depends on its neighbours.  The per-product error
-// bound is 2^-23 (the dropped terms w1 v2 + w2 v1 + w2 v2) for EVERY finite input with |v| >= 2^-110, accumulation is f32.
+// block maxima, no scale barriers and no element whose relative precision depends on its neighbours.  The dropped terms are
+// <= 2^-24 (seven products) / 2^-23 (six) of every product for EVERY finite input with |v| >= 2^-110, accumulation is f32.
 // The LDS tile holds 6 bytes per element (three planes of 16 B per 8 channels), the result tile and the residual / MRF store
 // pass are the f32 kernel's.
 #pragma once
@@ -23,10 +23,10 @@ __device__ __forceinline__ void bf3_split4(const float (&v)[4], bf16x4& p0, bf16
   }
 }
 
-template <int C, int WGCOLS, int WN, int NT, int KCG, int OCC>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCG, int OCC>      // T = bf3 (seven partial products) or bf3f (six)
 __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emul_kernel(jatts_resunit_desc d, unsigned long long* trace,
                                                                                          unsigned trace_cap, unsigned bias_off) {
-  typedef bf3 T;
+  typedef typename Elem<T>::vec8 V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WT = WGCOLS / (NT * 32);
   constexpr int NF = C / (WN * 32);
@@ -50,10 +50,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   const int p2 = (K - 1) / 2, p1 = p2 * dil;
   const int tt_out = WGCOLS - 2 * p2;
 
-  const int b = blockIdx.y;
+  int b = blockIdx.y, bx = blockIdx.x;
+  if (ragged_is_1d(d.rg) && !ragged_locate(d.rg, tt_out, blockIdx.x, b, bx)) return;   // 1-D grid over the real tiles of a ragged batch
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
-  const int t0 = blockIdx.x * tt_out;
+  const int t0 = bx * tt_out;
   if (t0 >= L) return;
   const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
         if (u >= total) continue;
         const int r = u / UPR, cu = u - r * UPR;
         lrelu8(v[j], d.slope);
-        bf3x8 o;
+        V8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           bf16 a, bq, c;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   JATTS_STAMP(10);
   for (int u = threadIdx.x; u < (K - 1) * (C / 8); u += NTHR) {   // rows past the computed columns: read by discarded columns only
     const int r = WGCOLS + u / (C / 8), cu = u % (C / 8);
-    bf3x8 z;
+    V8 z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z.b0[e] = z.b1[e] = z.b2[e] = (bf16)0.f;
     Vec8IO<T>::sts(hs + (size_t)r * pitch + (size_t)cu * 48, z);
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
 #undef JATTS_STAMP
 }
 
-template <int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2>
 int launch_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   constexpr int WT = WGCOLS / (NT * 32);
   const int K = d.k_w, p2 = (K - 1) / 2, p1 = p2 * d.dil;
@@ -215,7 +216,8 @@ int launch_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: tile exceeds 160 KiB LDS");
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
-  auto kern = resunit_emul_kernel<C, WGCOLS, WN, NT, KCG, OCC>;
+  if (const int64_t n1 = ragged_tiles_1d(d.rg, tt_out)) grid = dim3((unsigned)n1);
+  auto kern = resunit_emul_kernel<T, C, WGCOLS, WN, NT, KCG, OCC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);

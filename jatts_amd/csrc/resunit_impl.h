@@ -142,10 +142,11 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC ? OCC : ((C <= 25
   const int p2 = (K - 1) / 2, p1 = p2 * dil;
   const int tt_out = WGCOLS - 2 * p2;
 
-  const int b = blockIdx.y;
+  int b = blockIdx.y, bx = blockIdx.x;
+  if (ragged_is_1d(d.rg) && !ragged_locate(d.rg, tt_out, blockIdx.x, b, bx)) return;   // 1-D grid over the real tiles of a ragged batch
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
-  const int t0 = blockIdx.x * tt_out;
+  const int t0 = bx * tt_out;
   if (t0 >= L) return;
   const int64_t seq_row0 = (int64_t)row_b * d.rg.len_mul;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,6 +345,7 @@ int launch_resunit(const jatts_resunit_desc& d, hipStream_t s) {
   if (pad_lds && lds < (size_t)pad_lds) lds = pad_lds;  // experiment knob: force fewer workgroups per CU
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
+  if (const int64_t n1 = ragged_tiles_1d(d.rg, tt_out)) grid = dim3((unsigned)n1);
   auto kern = resunit_kernel<T, C, WGCOLS, WN, NT, KCGMAX, OCC, RREG>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

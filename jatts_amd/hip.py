@@ -7,13 +7,15 @@ descriptor and launches asynchronously on ``torch.cuda.current_stream()``.
 import collections
 import contextlib
 import ctypes as C
+import os
 
 import torch
 
 from . import _abi
-from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32, F32E, F32S  # noqa: F401
+from ._abi import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, F16, F32, F32E, F32E6, F32S  # noqa: F401
 
-_TORCH = {F32: torch.float32, F16: torch.float16, F32S: torch.float32, F32E: torch.float32}
+_TORCH = {F32: torch.float32, F16: torch.float16, F32S: torch.float32, F32E: torch.float32, F32E6: torch.float32}
+EMUL = (F32E, F32E6)      # f32 tensors, three exact bf16 terms per operand: seven / six partial products per product (include/jatts_hip.h)
 
 
 def torch_dtype(code):
@@ -160,6 +162,7 @@ def _stream():
 
 _WS = {}               # device -> the zero-initialised scratch of the deterministic reductions (include/jatts_hip.h: jatts_set_workspace)
 _WS_CURRENT = [None]
+_WS_OWNER = {}         # device -> (stream handle, event recorded behind that stream's last reduction launch)
 WS_BYTES = 64 * 1024 + 96 * 1024 * 1024
 
 
@@ -168,6 +171,17 @@ def _ws(device):
     parameter gradients, column sums, depthwise-conv weights, the gradient norm): allocated once, outside any graph capture (the trainers'
     first step of a signature runs eagerly), kept alive for the life of the process -- a captured step bakes its address in."""
     key = str(device)
+    # ONE scratch (tickets + slabs) per device: two streams reducing concurrently would corrupt each other's tickets silently (ADVICE r4).
+    # The stream that used it last owns it; another stream first waits for that stream's last reduction (an event, no host sync).  During a
+    # graph capture the scratch belongs to the capturing stream for the graph's whole life (the trainers capture on one stream).
+    if not torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream(device)
+        own = _WS_OWNER.get(key)
+        if own is not None and own[0] != cur.cuda_stream and not own[1].query():
+            cur.wait_event(own[1])
+        ev = own[1] if (own is not None and own[0] == cur.cuda_stream) else torch.cuda.Event()
+        _WS_OWNER[key] = (cur.cuda_stream, ev)
+        _WS_PENDING[0] = (cur, ev)
     if _WS_CURRENT[0] == key:
         return
     buf = _WS.get(key)
@@ -178,6 +192,21 @@ def _ws(device):
         torch.cuda.current_stream(device).synchronize()
     _abi.check(_abi.load().jatts_set_workspace(buf.data_ptr(), buf.numel()), "jatts_set_workspace")
     _WS_CURRENT[0] = key
+
+
+_WS_PENDING = [None]
+
+
+def _ws_done():
+    """Behind a reduction launch: mark how far the owning stream has got with the scratch (what another stream would wait for)."""
+    p, _WS_PENDING[0] = _WS_PENDING[0], None
+    if p is not None:
+        p[1].record(p[0])
+
+
+def _ws_check(rc, name):
+    _abi.check(rc, name)
+    _ws_done()
 
 
 def _ptr(t, col0=0):
@@ -288,7 +317,11 @@ class RaggedBatch:
         self.cu = keep(hit[0])
 
     def struct(self, len_mul=1):
-        return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul)
+        if _RAGGED_1D and self.n_seq > 1 and min(self.lens) != self.max_len:     # a ragged batch: 1-D grids over its real tiles (jatts_ragged.host_lens)
+            if not hasattr(self, "_lens_c"):
+                self._lens_c = (C.c_int32 * self.n_seq)(*self.lens)               # (kept alive with the batch; read by the launchers only)
+            return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul, self.total, C.addressof(self._lens_c))
+        return _abi.Ragged(self.cu.data_ptr(), self.n_seq, self.max_len, len_mul, 0, None)
 
     def vt_layout(self):
         """(col0 int32 device tensor, ld): V^T column layout with every sequence starting on a multiple of 8 columns
@@ -300,6 +333,10 @@ class RaggedBatch:
                 c += round_up(v, 8)
             self._vt = (h2d(col or [0], torch.int32, self.device), c + 8)
         return self._vt
+
+
+# 1-D grids over the real tiles of a ragged batch (jatts_ragged.total_rows); JATTS_RAGGED_1D=0: the rectangular grids (A/B runs)
+_RAGGED_1D = os.environ.get("JATTS_RAGGED_1D", "1") != "0"
 
 
 def round_up(v, m):
@@ -360,7 +397,7 @@ def bf16x3_terms(w):
 
 
 def pack_conv_weight_bf16x3(w, c_mult=32):
-    """(n_out, c_in, k) f32 -> the JATTS_F32E operand: the three bf16 terms of every weight (bf16x3_terms: exact, no scales) in the
+    """(n_out, c_in, k) f32 -> the JATTS_F32E / JATTS_F32E6 operand: the three bf16 terms of every weight (bf16x3_terms: exact, no scales) in the
     fragment order of pack_conv_weight with a lane's 8 elements of each term side by side: [tap][c/16][n/32][lane][b0 x8 | b1 x8 | b2 x8]."""
     planes = [pack_conv_weight(t.float(), F32, c_mult).view(-1, 8).bfloat16() for t in bf16x3_terms(w)]   # bf16 -> f32 -> bf16 is exact
     return torch.stack(planes, dim=1).reshape(-1).contiguous()
@@ -382,11 +419,12 @@ class SplitWeight:
 
 
 class EmulWeight:
-    """A conv weight prepared for JATTS_F32E (pack_conv_weight_bf16x3: the three bf16 terms of every weight, exact).  hip.conv1d recognises
-    it in place of a packed f32 weight -- call sites stay `dtype=hip.F32` -- and takes the emulated kernel; a halo beyond its staging
-    registers (32 rows) takes the exact-f32 kernel on a lazily packed f32 copy of the same weight."""
+    """A conv weight prepared for JATTS_F32E / JATTS_F32E6 (pack_conv_weight_bf16x3: the three bf16 terms of every weight, exact; ``code`` picks
+    seven or six partial products).  hip.conv1d recognises it in place of a packed f32 weight -- call sites stay `dtype=hip.F32` -- and takes the
+    emulated kernel; a halo beyond its staging registers (32 rows) takes the exact-f32 kernel on a lazily packed f32 copy of the same weight."""
 
-    def __init__(self, w, c_mult=64):
+    def __init__(self, w, c_mult=64, code=F32E):
+        self.code = code
         self.packed = pack_conv_weight_bf16x3(w, c_mult)
         self._src, self._c_mult, self._f32 = w.detach(), c_mult, None
 
@@ -396,14 +434,16 @@ class EmulWeight:
         return self._f32
 
 
-_SPLIT_WEIGHTS = [0]     # 0: packed f32 weights; 1: SplitWeight (fp32_split); 2: EmulWeight (fp32_bf16x3)
-WEIGHT_MODE = {"fp16": 0, "fp32": 0, "fp32_split": 1, "fp32_bf16x3": 2}
+_SPLIT_WEIGHTS = [0]     # 0: packed f32 weights; 1: SplitWeight (fp32_split); 2 / 3: EmulWeight, seven / six products (fp32_bf16x3 / fp32_bf16x3_6p)
+WEIGHT_MODE = {"fp16": 0, "fp32": 0, "fp32_split": 1, "fp32_bf16x3": 2, "fp32_bf16x3_6p": 3}
+EMUL_CODE = {2: F32E, 3: F32E6}
+PRECISIONS = tuple(WEIGHT_MODE)
 
 
 @contextlib.contextmanager
 def split_weights(on=True):
-    """Inside: PackedConv(..., dtype=F32) packs SplitWeight operands (the models' set_precision("fp32_split")) or, with on == 2 /
-    "fp32_bf16x3", EmulWeight operands (set_precision("fp32_bf16x3")).  Accepts a bool, a mode number or a precision name.  Nests."""
+    """Inside: PackedConv(..., dtype=F32) packs SplitWeight operands (the models' set_precision("fp32_split")) or, with on == 2 / 3
+    ("fp32_bf16x3" / "fp32_bf16x3_6p"), EmulWeight operands.  Accepts a bool, a mode number or a precision name.  Nests."""
     mode = WEIGHT_MODE[on] if isinstance(on, str) else int(on)
     prev, _SPLIT_WEIGHTS[0] = _SPLIT_WEIGHTS[0], mode
     try:
@@ -415,7 +455,7 @@ def split_weights(on=True):
 def f32_operand(w, c_mult=64):
     """A conv weight for `dtype=F32` call sites in the current weight mode: packed exact f32, SplitWeight or EmulWeight."""
     m = _SPLIT_WEIGHTS[0]
-    return SplitWeight(w, c_mult) if m == 1 else EmulWeight(w, c_mult) if m == 2 else pack_conv_weight(w, F32, c_mult)
+    return SplitWeight(w, c_mult) if m == 1 else EmulWeight(w, c_mult, EMUL_CODE[m]) if m in EMUL_CODE else pack_conv_weight(w, F32, c_mult)
 
 
 def pack_conv_weight_dev(w, dtype_code, c_mult=64, dgrad=False):
@@ -487,7 +527,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
         if dtype != F32:
             raise ValueError("conv1d: an EmulWeight goes with dtype F32 tensors")
         if (k_w - 1) * dil <= 32:
-            dtype, w_packed, out_f32 = F32E, w_packed.packed, True
+            dtype, w_packed, out_f32 = w_packed.code, w_packed.packed, True
         else:
             w_packed = w_packed.f32()
     x0 = _dev(xs[0])
@@ -505,9 +545,9 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     if dtype == F32S:
         if w_packed.dtype != torch.float16 or w_packed.numel() != 2 * n_pad * c_in * k_w or w_inv is None or w_inv.numel() != n_pad:
             raise ValueError("conv1d: F32S takes the (packed, inverse scales) pair of pack_conv_weight_split")
-    elif dtype == F32E:
+    elif dtype in EMUL:
         if w_packed.dtype != torch.bfloat16 or w_packed.numel() != 3 * n_pad * c_in * k_w:
-            raise ValueError("conv1d: F32E takes the packed bf16 terms of pack_conv_weight_bf16x3")
+            raise ValueError("conv1d: F32E / F32E6 take the packed bf16 terms of pack_conv_weight_bf16x3")
         out_f32 = True
     elif w_packed.dtype != tdt or w_packed.numel() != n_pad * c_in * k_w:
         raise ValueError("conv1d: packed weight has wrong dtype/size")
@@ -1045,7 +1085,7 @@ def conv1d_wgrad(rb, x, dy, c_in, n_out, k_w, dil, pad, len_mul=1, want_db=False
     rg = rb.struct(len_mul)
     _count(2.0 * c_in * n_out * k_w * rb.total * len_mul)
     _ws(x.device)
-    _abi.check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
+    _ws_check(lib.jatts_conv1d_wgrad(C.byref(rg), _dev(x).data_ptr(), x.shape[1], dy.data_ptr(), dy.shape[1], c_in, n_out, k_w, dil,
                                       pad, dw.data_ptr(), _ptr(db), ws.data_ptr(), _stream()), "jatts_conv1d_wgrad")
     return (dw, db) if want_db else dw
 
@@ -1055,7 +1095,7 @@ def col_sum(x, dim=None):
     dim = dim or x.shape[1]
     out = _zeros((dim), x.device)
     _ws(x.device)
-    _abi.check(lib.jatts_col_sum(_dev(x).data_ptr(), x.shape[1], x.shape[0], dim, out.data_ptr(), _stream()), "jatts_col_sum")
+    _ws_check(lib.jatts_col_sum(_dev(x).data_ptr(), x.shape[1], x.shape[0], dim, out.data_ptr(), _stream()), "jatts_col_sum")
     return out
 
 
@@ -1078,7 +1118,7 @@ def layernorm_bwd(x, dy, gamma, eps, need_dx=True, need_dparam=True):
     dg = _zeros((dim), x.device) if need_dparam else None
     db = _zeros((dim), x.device) if need_dparam else None
     _ws(x.device)
-    _abi.check(lib.jatts_layernorm_bwd(x.data_ptr(), dim, dy.data_ptr(), dim, _f32c(gamma).data_ptr(), rows, dim, float(eps), _ptr(dx), dim,
+    _ws_check(lib.jatts_layernorm_bwd(x.data_ptr(), dim, dy.data_ptr(), dim, _f32c(gamma).data_ptr(), rows, dim, float(eps), _ptr(dx), dim,
                                        _ptr(dg), _ptr(db), _stream()), "jatts_layernorm_bwd")
     return dx, dg, db
 
@@ -1133,7 +1173,7 @@ def dwconv_wgrad(rb, x, dy, k_w, pad):
     dw = _zeros((x.shape[1], k_w), x.device)
     rg = rb.struct()
     _ws(x.device)
-    _abi.check(lib.jatts_dwconv_wgrad(C.byref(rg), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[1], k_w, pad, _stream()),
+    _ws_check(lib.jatts_dwconv_wgrad(C.byref(rg), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.shape[1], k_w, pad, _stream()),
                "jatts_dwconv_wgrad")
     return dw
 
@@ -1146,7 +1186,7 @@ def col_stats(x, y2=None, shift=None, mul=None):
     o0 = _zeros((dim), x.device)
     o1 = _zeros((dim), x.device)
     _ws(x.device)
-    _abi.check(lib.jatts_col_stats(x.data_ptr(), _ptr(y2), dim, rows, dim, _ptr(shift), _ptr(mul), 0 if y2 is None else 1, o0.data_ptr(),
+    _ws_check(lib.jatts_col_stats(x.data_ptr(), _ptr(y2), dim, rows, dim, _ptr(shift), _ptr(mul), 0 if y2 is None else 1, o0.data_ptr(),
                                    o1.data_ptr(), _stream()), "jatts_col_stats")
     return o0, o1
 
@@ -1270,7 +1310,7 @@ def col_wsum(x, v):
     x, v = _f32c(x), _f32c(v)
     out = _zeros((x.shape[1]), x.device)
     _ws(x.device)
-    _abi.check(lib.jatts_col_wsum(x.data_ptr(), x.shape[1], v.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "jatts_col_wsum")
+    _ws_check(lib.jatts_col_wsum(x.data_ptr(), x.shape[1], v.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "jatts_col_wsum")
     return out
 
 
@@ -1335,7 +1375,7 @@ def qkv_split_bwd(dqu, dqv, dk_, dvv):
         dqv = _f32c(dqv)
         du, dv = _zeros((H * dk), dqu.device), _zeros((H * dk), dqu.device)
     _ws(dqu.device)
-    _abi.check(lib.jatts_qkv_split_bwd(dqu.data_ptr(), _ptr(dqv), dk_.data_ptr(), dvv.data_ptr(), B, T, H, dk, dqkv.data_ptr(), _ptr(du), _ptr(dv),
+    _ws_check(lib.jatts_qkv_split_bwd(dqu.data_ptr(), _ptr(dqv), dk_.data_ptr(), dvv.data_ptr(), B, T, H, dk, dqkv.data_ptr(), _ptr(du), _ptr(dv),
                                        _stream()), "jatts_qkv_split_bwd")
     return dqkv, du, dv
 
@@ -1369,7 +1409,7 @@ def sumsq(x, out):
     lib = _abi.load()
     x = _f32c(x)
     _ws(x.device)
-    _abi.check(lib.jatts_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "jatts_sumsq")
+    _ws_check(lib.jatts_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "jatts_sumsq")
     return out
 
 
@@ -1423,7 +1463,7 @@ def groupnorm_bwd(rb, x, dy, groups, gamma, mean, rstd, need_dx=True, need_dpara
     db = _zeros((dim), x.device) if need_dparam else None
     rg = rb.struct()
     _ws(x.device)
-    _abi.check(lib.jatts_groupnorm_bwd(C.byref(rg), x.data_ptr(), dy.data_ptr(), dim, groups, _f32c(gamma).data_ptr(), mean.data_ptr(),
+    _ws_check(lib.jatts_groupnorm_bwd(C.byref(rg), x.data_ptr(), dy.data_ptr(), dim, groups, _f32c(gamma).data_ptr(), mean.data_ptr(),
                                        rstd.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), _stream()), "jatts_groupnorm_bwd")
     return dx, dg, db
 
@@ -1444,7 +1484,7 @@ def snakebeta_bwd(x, dy, alpha, beta):
     da = _zeros((x.shape[1]), x.device)
     db = _zeros((x.shape[1]), x.device)
     _ws(x.device)
-    _abi.check(lib.jatts_snakebeta_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
+    _ws_check(lib.jatts_snakebeta_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], _f32c(alpha).data_ptr(), _f32c(beta).data_ptr(),
                                        dx.data_ptr(), da.data_ptr(), db.data_ptr(), _stream()), "jatts_snakebeta_bwd")
     return dx, da, db
 
@@ -1474,7 +1514,7 @@ def seq_sum(rb, x):
     out = _zeros((rb.n_seq, x.shape[1]), x.device)
     rg = rb.struct()
     _ws(x.device)
-    _abi.check(lib.jatts_seq_sum(C.byref(rg), x.data_ptr(), x.shape[1], out.data_ptr(), _stream()), "jatts_seq_sum")
+    _ws_check(lib.jatts_seq_sum(C.byref(rg), x.data_ptr(), x.shape[1], out.data_ptr(), _stream()), "jatts_seq_sum")
     return out
 
 
@@ -1504,6 +1544,9 @@ def bgemm(a, b, trans_a=False, trans_b=False, alpha=1.0, out=None):
         raise ValueError("bgemm: contraction sizes differ")
     if out is None:
         out = torch.empty(O, ai, m, n, dtype=torch.float32, device=a.device)
+    elif (not out.is_cuda or out.dtype != torch.float32 or out.dim() != 4 or tuple(out.shape) != (O, ai, m, n) or out.stride(3) != 1
+          or out.device != a.device):
+        raise ValueError(f"bgemm: out must be an f32 device tensor of shape {(O, ai, m, n)} with contiguous rows")
     _count(2.0 * O * ai * m * n * k)
     with _Timed("bgemm", (O * ai, m, n, k)):
         _abi.check(lib.jatts_bgemm(a.data_ptr(), sao, sai, lda, int(trans_a), b.data_ptr(), sbo, sbi, ldb, int(trans_b), out.data_ptr(), out.stride(0),

@@ -174,7 +174,7 @@ class ConformerRunner:
             P = hip.conv1d(rb, pe_t, L["pos"].w, L["pos"].c_in, self.A, 1, dtype=self.dtype)  # (cap, A)
             cv = hip.rowdot(P, self.A, n_pos, self.H, self.dk, L["vb"]).t().contiguous()      # (H, n_pos)
             # per-head weight operand of the BD GEMM (n = position m, contraction d_k): pure re-layout
-            pk = ((lambda w: hip.SplitWeight(w, 64)) if self.wmode == 1 else (lambda w: hip.EmulWeight(w, 64)) if self.wmode == 2
+            pk = ((lambda w: hip.SplitWeight(w, 64)) if self.wmode == 1 else (lambda w: hip.EmulWeight(w, 64, hip.EMUL_CODE[self.wmode])) if self.wmode in hip.EMUL_CODE
                   else (lambda w: hip.pack_conv_weight(w, self.dtype)))
             heads = [pk(P[:, h * self.dk:(h + 1) * self.dk].float().unsqueeze(-1)) for h in range(self.H)]
             per_layer.append((heads, cv))

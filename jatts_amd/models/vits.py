@@ -149,8 +149,9 @@ class VITS(torch.nn.Module):
 
     def set_precision(self, precision):
         # fp32_split: f32 tensors, every Conv1d / Linear but the duration predictor's on split f16 hi/lo MFMA operands (hip.SplitWeight;
-        # csrc/conv1d_split.h); fp32_bf16x3: the same convs on three exact bf16 terms per operand, six products (hip.EmulWeight; csrc/conv1d_emul.h)
-        if precision not in ("fp16", "fp32", "fp32_split", "fp32_bf16x3"):
+        # csrc/conv1d_split.h); fp32_bf16x3 (fp32_bf16x3_6p): the same convs on three exact bf16 terms per operand, seven (six) partial products
+        # per product (hip.EmulWeight; csrc/conv1d_emul.h)
+        if precision not in hip.PRECISIONS:
             raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None

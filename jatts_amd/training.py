@@ -450,7 +450,7 @@ class FastSpeech2Trainer:
                 if dsum != [int(v) for v in batch["olens"].tolist()]:
                     raise ValueError("graph mode needs sum(durations) == olens for every utterance")
             if len(self._graphs) >= 16 * max(1, self.max_graphs):      # signatures seen once and never again (unbucketed data): bounded
-                for k in [k for k, v in self._graphs.items() if v.get("graph") is None][: len(self._graphs) // 2]:
+                for k in [k for k, v in self._graphs.items() if v.get("graph") is None and not v.get("eager_only")][: len(self._graphs) // 2]:   # (eager-only markers stay)
                     del self._graphs[k]
             self._graphs[sig] = {"graph": None}
             return self._train_step(batch)
@@ -509,6 +509,26 @@ class FastSpeech2Trainer:
         # replay: refresh the static inputs and the per-step scalars (all stream-ordered copies; no host wait)
         if self._bad_ids is not None and self._bad_ids():       # out-of-range token ids of an EARLIER replay (zero rows, counted on the
             self._bad_ids = None                                # device by the embedding kernel inside the graph): IndexError, one step late
+        # guard: the gradient norm of every replayed step comes back through the ring.  A finished slot that holds a non-finite
+        # or absurd norm means either a replay that produced garbage (a reduction that does not survive capture on this stack, see _graph_step's
+        # notes) or a genuinely diverged run; either way: refuse to go on silently -- the signature is marked eager-only and the call raises, a
+        # few steps late, without a host sync per step, BEFORE this call has advanced the step counter / learning-rate schedule or touched
+        # the static inputs.  A slot about to be recycled is waited for and checked too, so no step's norm goes unread.
+        nxt = st["ring"][st["ring_pos"] % len(st["ring"])]
+        for sl in st["ring"]:
+            if sl["ev"] is None or not sl["step"]:
+                continue
+            if sl is nxt:
+                sl["ev"].synchronize()       # this slot's copies of SCALAR_RING steps ago have run (normally long since)
+            elif not sl["ev"].query():
+                continue
+            v = float(sl["gn"][0])
+            sl["step"] = 0
+            if not (v == v and abs(v) < self.GRAD_NORM_SANITY):
+                self._graphs[sig] = {"graph": None, "eager_only": True}
+                raise FloatingPointError(f"gradient norm {v} at trainer step {sl['at']} (graph replay): a diverged run or a capture that does not replay "
+                                         "correctly -- replay of this batch signature is disabled, later steps of it run eagerly; the parameters are "
+                                         "suspect: resume from the last checkpoint")
         for k, v in batch.items():
             if torch.is_tensor(v) and torch.is_tensor(st["in"].get(k)) and st["in"][k].is_cuda:
                 st["in"][k].copy_(v, non_blocking=True)
@@ -516,21 +536,10 @@ class FastSpeech2Trainer:
         lr = scheduled_lr(self.scheduler, self.base_lr, self.steps, **self._sched_params())
         self.last_lr = lr
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
-        # guard: the gradient norm of every replayed step comes back through the ring; a finished slot that holds a non-finite or
-        # absurd norm means the replay produced garbage (a reduction that does not survive capture on this stack, see _graph_step's notes):
-        # refuse to go on silently -- the signature is marked eager-only and the step raises, a few steps late, without a host sync per step
-        for sl in st["ring"]:
-            if sl["ev"] is not None and sl["step"] and sl["ev"].query():
-                v = float(sl["gn"][0])
-                sl["step"] = 0
-                if not (v == v and abs(v) < self.GRAD_NORM_SANITY):
-                    self._graphs[sig] = {"graph": None, "eager_only": True}
-                    raise FloatingPointError(f"graph replay produced a gradient norm of {v} (trainer step {sl['at']}): replay of this batch signature is "
-                                             "disabled, later steps of it run eagerly; the parameters are suspect -- resume from the last checkpoint")
         slot = st["ring"][st["ring_pos"] % len(st["ring"])]
         st["ring_pos"] += 1
         if slot["ev"] is not None:
-            slot["ev"].synchronize()         # this slot's copies of SCALAR_RING steps ago have run (normally long since)
+            slot["ev"].synchronize()         # (already waited for by the guard when it held a step's norm)
         slot["seed"][0] = ((self.steps - 1) * self.accumulate + 1) * 4099 * 1000003 + rank * 1000003   # == _Ctx's (seed * 4099 + rank) * 1000003
         slot["hyper"].copy_(torch.tensor(hip.adam_hyper(lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps), dtype=torch.float32))
         st["seed"].copy_(slot["seed"], non_blocking=True)

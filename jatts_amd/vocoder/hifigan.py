@@ -114,9 +114,10 @@ class HiFiGANGenerator(torch.nn.Module):
         upsampling convs on error-corrected split-precision MFMA operands (JATTS_F32S: hi/lo f16 halves, f32 accumulate, power-of-two
         scales) -- measured at or below the exact-f32 path's error against fp64 (tests/test_kernels_gpu.py::test_hifigan_resunit_split,
         test_conv1d_split; tests/test_benchsize_gpu.py::test_hifigan_split_mode_at_bench_size);
-        "fp32_bf16x3" (round 5): f32 activations everywhere, the same kernels' operands carried EXACTLY as three bf16 terms with six MFMA
-        products per product (JATTS_F32E: no scales, per-product error bound 2^-23; csrc/resunit_emul_impl.h, conv1d_emul.h)."""
-        if precision not in ("fp16", "fp32", "fp32_split", "fp32_bf16x3"):
+        "fp32_bf16x3" (round 5): f32 activations everywhere, the same kernels' operands carried EXACTLY as three bf16 terms with seven MFMA
+        products per product (JATTS_F32E: no scales, a one-term contraction within 2^-23 = 2 x an f32 FMA's bound; csrc/resunit_emul_impl.h,
+        conv1d_emul.h); "fp32_bf16x3_6p": six products (JATTS_F32E6: dropped terms <= 2^-23 per product, 1/7 fewer pipe cycles)."""
+        if precision not in hip.PRECISIONS:
             raise ValueError(precision)
         if precision != self.precision:
             self.precision, self._prep = precision, None
@@ -135,11 +136,11 @@ class HiFiGANGenerator(torch.nn.Module):
             return self._prep
         hip._abi.load()
         dt = hip.F16 if self.precision == "fp16" else hip.F32
-        split, emul = self.precision == "fp32_split", self.precision == "fp32_bf16x3"
         wmode = hip.WEIGHT_MODE[self.precision]
+        split, emul = wmode == 1, wmode in hip.EMUL_CODE
         sd = self.state_dict()
         f32 = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
-        P = {"key": key, "dtype": dt, "dev": dev, "unit_dtype": hip.F32S if split else hip.F32E if emul else dt}
+        P = {"key": key, "dtype": dt, "dev": dev, "unit_dtype": hip.F32S if split else hip.EMUL_CODE[wmode] if emul else dt}
         nb = len(self.resblock_kernel_sizes)
         P["ups"], P["blocks"] = [], []
         supported = {hip.F16: (32, 64, 128, 256, 512), hip.F32: (32, 64, 128, 256)}[dt]
@@ -210,6 +211,11 @@ class HiFiGANGenerator(torch.nn.Module):
     fused_blocks_split = (frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE_SPLIT", "1") == "0"
                           else frozenset(tuple(int(v) for v in t.split("x")) for t in os.environ.get("JATTS_HIFIGAN_FUSE_SPLIT_SET", "32x3,32x7,64x3").split(",")))
 
+    # fp32_bf16x3 / fp32_bf16x3_6p (round 5, csrc/resblock_emul_impl.h): only C = 32, k = 3 measured faster fused (3.60 vs 3.93 ms; C = 32 k = 7 0.82x, C = 64 k = 3 0.93-0.96x:
+    # the 6-byte tile leaves one workgroup per CU or a 72 %-useful window; profiles/r05_notes.md); JATTS_HIFIGAN_FUSE_EMUL=0: per-unit launches
+    fused_blocks_emul = (frozenset() if os.environ.get("JATTS_HIFIGAN_FUSE_EMUL", "1") == "0"
+                         else frozenset(tuple(int(v) for v in t.split("x")) for t in os.environ.get("JATTS_HIFIGAN_FUSE_EMUL_SET", "32x3").split(",")))
+
     # tuning knob (profiles/r01_notes.md): run the independent ResBlock chains of a stage on separate HIP streams
     concurrent = os.environ.get("JATTS_HIFIGAN_STREAMS", "0") == "1"
 
@@ -258,10 +264,10 @@ class HiFiGANGenerator(torch.nn.Module):
                 cur = up
                 st = side[j] if j < len(side) else None
                 # HBM-bound shapes: the whole ResBlock in one launch (x read once, y written once; residual in registers)
-                fset = (self.fused_blocks_split if udt == hip.F32S else frozenset() if udt == hip.F32E      # (F32E: per-unit launches only)
+                fset = (self.fused_blocks_split if udt == hip.F32S else self.fused_blocks_emul if udt in hip.EMUL
                         else (self.fused_blocks if dt == hip.F16 else self.fused_blocks_f32))
                 if (c_out, units[0][2]) in fset and len(units) <= 3 and st is None \
-                        and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if (dt == hip.F16 or udt == hip.F32S) else 16):
+                        and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if (dt == hip.F16 or udt == hip.F32S or udt in hip.EMUL) else 16):
                     lastb = fuse_mean and j == len(blocks) - 1
                     hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(c1.w, c1.b, c2.w, c2.b, d) for c1, c2, _, d in units],
                                          c_out, units[0][2], self.slope, udt, add=outs if lastb else None,

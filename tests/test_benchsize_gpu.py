@@ -61,7 +61,7 @@ def test_fs2_bench_utterances_match_the_reference(bench_stack):
 @pytest.mark.parametrize("mode", ["fp32_split", "fp32_bf16x3"])
 def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack, mode):
     """set_precision("fp32_split") on the acoustic model (round 4: every conv but the duration predictor's on split f16 hi/lo MFMA operands;
-    round 5, "fp32_bf16x3": the same convs on three exact bf16 terms per operand, six MFMA products)
+    round 5, "fp32_bf16x3": the same convs on three exact bf16 terms per operand, seven MFMA products)
     against the SAME real-reference golden and tolerance as the exact-f32 path (abs 2e-3, durations exact), alone and inside the batch of 64
     (bit-identical to each other), with its error next to the exact-f32 path's: at most twice as far from the reference."""
     import json
@@ -127,7 +127,7 @@ def test_hifigan_bench_size_matches_the_oracle(bench_stack):
 @pytest.mark.parametrize("mode", ["fp32_split", "fp32_bf16x3"])
 def test_hifigan_split_mode_at_bench_size(bench_stack, mode):
     """The fp32_split vocoder (round 4: ResBlock units on split f16 hi/lo MFMA operands; round 5, "fp32_bf16x3": on three exact bf16 terms per
-    operand, six MFMA products) on the same 768-frame mels: the SAME tolerance as
+    operand, seven MFMA products) on the same 768-frame mels: the SAME tolerance as
     the exact-f32 path against the f32 oracle (abs 2e-4), and against the oracle run in FP64 its maximum error must not exceed twice the
     exact-f32 path's -- the condition under which it is not a narrower arithmetic than the reference's.  Alone and inside the batch of 64,
     bit-identical to each other.  The measured errors go to gpurun_out/r04_split_errors.json (profiles/r04_notes.md quotes them)."""

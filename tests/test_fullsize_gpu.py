@@ -62,7 +62,7 @@ def stack_split(cuda, lib):
 
 @pytest.fixture(scope="module")
 def stack_emul(cuda, lib):
-    """fp32_bf16x3 (round 5): f32 tensors, three exact bf16 terms per operand and six MFMA products in every conv and fused unit."""
+    """fp32_bf16x3 (round 5): f32 tensors, three exact bf16 terms per operand and seven MFMA products in every conv and fused unit."""
     return _make_stack(cuda, "fp32_bf16x3")
 
 

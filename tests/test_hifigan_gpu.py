@@ -57,7 +57,7 @@ def test_generator_matches_oracle(cuda, lib, prec, tol, params):
     assert maxdiff(y1.view(-1), y[lens[0] * hop:]) <= 1e-6
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp32_split", 2e-4), ("fp32_bf16x3", 2e-4), ("fp16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("fp32_split", 2e-4), ("fp32_bf16x3", 2e-4), ("fp32_bf16x3_6p", 2e-4), ("fp16", 2e-2)])
 @pytest.mark.parametrize("case", ["v1", "w128", "two_blocks", "wn"])
 def test_generator_matches_an_independent_implementation(cuda, lib, case, prec, tol):
     """The HIP generator against waveforms of Hugging Face transformers' FastSpeech2ConformerHifiGan run in fp64 on the same weights and mel

@@ -22,14 +22,14 @@ SHAPES = [  # (c_in, n_out, k, frames per utterance, resid f32 out?)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dtype", default="f32", choices=["f16", "f32", "split", "emul"])
+    ap.add_argument("--dtype", default="f32", choices=["f16", "f32", "split", "emul", "emul6"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     ap.add_argument("--variant", type=int, default=0, help="jatts_conv_desc.variant (0 = the product heuristic)")
     ap.add_argument("--pre-lrelu", type=float, default=None, help="LeakyReLU prologue slope (the HiFi-GAN upsampling convs)")
     a = ap.parse_args()
-    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E}[a.dtype]
+    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E, "emul6": hip.F32E6}[a.dtype]
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     for c, n, k, T, res in (SHAPES if a.only < 0 else [SHAPES[a.only]]):
@@ -37,13 +37,13 @@ def main():
         rows = rb.total
         x = (torch.randn(rows, c, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
         wf = (torch.randn(n, c, k, generator=g) / (c * k) ** 0.5).to(dev)
-        w, winv = (hip.pack_conv_weight_split(wf, 64) if dt == hip.F32S else (hip.pack_conv_weight_bf16x3(wf, 64), None) if dt == hip.F32E
+        w, winv = (hip.pack_conv_weight_split(wf, 64) if dt == hip.F32S else (hip.pack_conv_weight_bf16x3(wf, 64), None) if dt in hip.EMUL
                    else (hip.pack_conv_weight(wf, dt), None))
         b = torch.zeros(n, device=dev)
         r = torch.zeros(rows, n, device=dev) if res else None
 
         def run():
-            return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res or dt in (hip.F32S, hip.F32E), variant=a.variant,
+            return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res or dt in (hip.F32S,) + hip.EMUL, variant=a.variant,
                               pre_lrelu=a.pre_lrelu, w_inv=winv)
         for _ in range(2):
             run()

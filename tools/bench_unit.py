@@ -25,7 +25,7 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     if dtype == hip.F32S:
         (w1, i1), (w2, i2) = hip.pack_conv_weight_split(wa, 32), hip.pack_conv_weight_split(wb, 32)
         kw["ws"] = (i1, i2)
-    elif dtype == hip.F32E:
+    elif dtype in hip.EMUL:
         w1, w2 = hip.pack_conv_weight_bf16x3(wa, 32), hip.pack_conv_weight_bf16x3(wb, 32)
     else:
         w1, w2 = hip.pack_conv_weight(wa, dtype, 32), hip.pack_conv_weight(wb, dtype, 32)
@@ -62,6 +62,8 @@ def run_block(C, k, rate, iters, B=64, T=768, dils=(1, 3, 5), dt=hip.F16):
         if dt == hip.F32S:
             (w1, i1), (w2, i2) = hip.pack_conv_weight_split(wa, 32), hip.pack_conv_weight_split(wb, 32)
             invs.append((i1, i2))
+        elif dt in hip.EMUL:
+            w1, w2 = hip.pack_conv_weight_bf16x3(wa, 32), hip.pack_conv_weight_bf16x3(wb, 32)
         else:
             w1, w2 = hip.pack_conv_weight(wa, dt, 32), hip.pack_conv_weight(wb, dt, 32)
         units.append((w1, torch.zeros(C, device=dev), w2, torch.zeros(C, device=dev), d))
@@ -102,15 +104,15 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split", "emul"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split", "emul", "emul6"])
     ap.add_argument("--resblock", action="store_true", help="fused ResBlock launches vs per-unit launches (f16)")
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
-    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E}[a.dtype]
+    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E, "emul6": hip.F32E6}[a.dtype]
     if a.resblock:
         for C in ((32, 64, 128) if dt == hip.F16 else (32, 64)):
             for k in ((3, 7) if dt != hip.F32 else (3,)):
-                if dt == hip.F32S and (C, k) == (64, 7):
+                if dt in (hip.F32S,) + hip.EMUL and (C, k) == (64, 7):
                     continue
                 run_block(C, k, rates[C], a.iters, dt=dt)
         return
