@@ -553,6 +553,7 @@ def _roof(rf):
         return None
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")
     o = {k: rf.get(k) for k in keep}
+    o["kernel"] = (o.get("kernel") or "").split(" (")[0]          # (the long description stays in the detail file)
     src = rf.get("traffic_source") or ""
     o["traffic_source"] = None if rf.get("traffic") is None else ("committed" if src.startswith("profiles/") or "committed" in src else "live")
     o["alg_bytes"] = rf.get("algorithmic_bytes_per_launch")
@@ -567,6 +568,8 @@ def compact_line(out, detail_path=None):
     keys = ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "backend", "steps", "warmup", "ms_per_step", "higher_is_better",
             "scaling", "vs_baseline", "dtype", "data", "config", "rtf", "executor")
     c = {k: out[k] for k in keys if k in out}
+    if c.get("executor") == "sequential":
+        del c["executor"]
     if out.get("stage_ms_per_step"):
         c["stage_ms"] = out["stage_ms_per_step"]
     if out.get("rank_ms_per_step"):
@@ -590,31 +593,26 @@ def compact_line(out, detail_path=None):
         c["cpu_baseline"] = None
         if out.get("cpu_baseline_note"):
             c["cpu_baseline_note"] = out["cpu_baseline_note"]
-    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 tensors, split f16 hi/lo MFMA operands in every conv and fused unit"),
-                       ("f32_emul_mode", "f32 tensors; 3 exact bf16 terms per operand, 7 MFMA products (1-term contraction within 2^-23), f32 accumulate"),
-                       ("f32_emul6_mode", "as f32_emul_mode with 6 MFMA products (dropped terms <= 2^-23 per product)")):
+    # (what each arithmetic is: DTYPE_NAME in the detail file)
+    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 HBM; split f16 hi/lo operands, 3 MFMAs/product"),
+                       ("f32_emul_mode", "f32 HBM; 3 exact bf16 terms/operand, 7 MFMAs/product"),
+                       ("f32_emul6_mode", "f32 HBM; 3 exact bf16 terms/operand, 6 MFMAs/product")):
         fm = out.get(key)
         if fm:
             c[key] = {"dtype": short, "value": fm["value"], "ms_per_step": fm["ms_per_step"],
                       "vocoder_ms": (fm.get("stage_ms_per_step") or {}).get("vocoder"),
-                      "max_abs_err_mel": fm.get("max_abs_err_mel"), "max_abs_err_wave": fm.get("max_abs_err_wave"),
-                      "roofline_frac": (fm.get("roofline") or {}).get("frac"), "roofline_bound": (fm.get("roofline") or {}).get("bound"),
-                      "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
+                      "max_abs_err_wave": fm.get("max_abs_err_wave"),
+                      "roofline_frac": (fm.get("roofline") or {}).get("frac"), "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
     if out.get("configs"):
         c["configs"] = {("matcha_mas_b64" if "Matcha" in e["config"] else "vits_spk192_b32"):
-                        {"f32_ms": e["ms_per_step"], "f32_value": e["value"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
+                        {"f32_ms": e["ms_per_step"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
                          "f16_ms": (e.get("fast_mode") or {}).get("ms_per_step"),
-                         "f16_err_wave": (e.get("fast_mode") or {}).get("max_abs_err_wave"),
                          "split_ms": (e.get("f32_split_mode") or {}).get("ms_per_step"),
-                         "split_err_wave": (e.get("f32_split_mode") or {}).get("max_abs_err_wave"),
                          "emul_ms": (e.get("f32_emul_mode") or {}).get("ms_per_step"),
                          "emul6_ms": (e.get("f32_emul6_mode") or {}).get("ms_per_step"),
-                         "emul_err_wave": (e.get("f32_emul_mode") or {}).get("max_abs_err_wave"),
-                         "roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac"),
-                         "roofline_kernel": (((e.get("roofline") or {}).get("dominant") or {}).get("kernel") or "")[:24]} for e in out["configs"]}
+                         "roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac")} for e in out["configs"]}
     if out.get("training"):
-        c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "mean_ms": e.get("ms_per_step_mean"),
-                                     "tflop": e.get("dense_tflops_per_step"), "frac": e.get("frac_of_f32_mfma_peak"),
+        c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "frac": e.get("frac_of_f32_mfma_peak"),
                                      "split_ms": (e.get("fp32_split") or {}).get("ms_per_step")}
                          for e in out["training"]}
     if detail_path:
@@ -758,7 +756,6 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{job.name}+HiFi-GAN v1 {a.vocoder}, {a.batch} utts x {a.t_text} phonemes x "
                                f"{a.frames_per_token} frames per GPU",
-                   "utterances_per_gpu": a.batch, "phonemes": a.t_text, "frames_per_utt": a.t_text * a.frames_per_token,
                    "hop": job.hop, "sampling_rate": job.sr,
                    "parallelism": f"dp{world} (utterance sharding, int16 PCM all-gather)"
                                   + (" [shared-GPU test mode: all ranks on cuda:0, gloo]" if shared else "")},

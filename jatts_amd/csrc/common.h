@@ -53,10 +53,12 @@ template <> struct Elem<f16s> {
 // above bf16's smallest subnormal 2^-133 (|v| >= 2^-110): NO scales, no block maxima, no element-dependent loss of relative precision.
 // Under round-to-nearest |b1| <= 2^-8 |v| and |b2| <= 2^-16 |v|, so the nine partial products of w v have weights 1 | 2^-8 x2 | 2^-16 x3 |
 // 2^-24 x2 | 2^-32; every bf16 x bf16 product is exact in the f32 accumulate.  NP = the number of partial products kept:
-//   NP = 7 (JATTS_F32E): all of weight >= 2^-16 plus w1 v2 -- dropped: w2 v1 + w2 v2 <= (2^-24 + 2^-32) |w v|.  A contraction with ONE term
-//           is then that product plus the one rounding into the f32 result: <= 2^-24 + 2^-24 = 2^-23 = 2 x an f32 FMA's error bound,
-//           for EVERY input (the acceptance rule of VERDICT r4, K_eff = 1 included).  7/16 of the pipe cycles of the exact-f32 chain;
-//   NP = 6 (JATTS_F32E6): the six of weight >= 2^-16 -- dropped <= 2^-23 |w v| (+ the rounding: 3 x 2^-24 at K_eff = 1).  6/16 of the cycles.
+//   NP = 7 (JATTS_F32E): all of weight >= 2^-16 plus w1 v2 -- dropped: w2 v1 + w2 v2 <= (2^-24 + 2^-32) |w v|, one f32 rounding's worth (an
+//           unfused f32 multiply).  Leading and smaller products go to separate accumulators joined by one correctly rounded add (mma32
+//           below): a contraction with ONE term is within 2^-24 + 2^-24 = 2^-23 = 2 x an f32 FMA's error bound for EVERY input (the
+//           acceptance rule of VERDICT r4, K_eff = 1 included).  7/16 of the pipe cycles of the exact-f32 chain, 16 more registers per fragment;
+//   NP = 6 (JATTS_F32E6): the six of weight >= 2^-16 into ONE accumulator -- dropped <= 2^-23 |w v|, and the MFMA's own accumulate adds up
+//           to 1 ulp at K_eff = 1 (4 x 2^-24 in all; measured 2.7).  6/16 of the cycles.
 // With many terms both are MORE accurate than the exact-f32 chain (one rounding per 16-term MFMA instead of one per term).
 // The element TAG is 6 bytes wide; 8 consecutive elements are stored PLANAR (16 B of b0 | b1 | b2).
 typedef __bf16 bf16;
@@ -98,10 +100,8 @@ __device__ __forceinline__ void mma32(const f16sx8& a, const f16sx8& b, f32x16& 
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
 }
-//  bf3p<NP>: the NP partial products, smallest first, into ONE f32 accumulator (a = weights, b = activations)
-template <int NP>
-__device__ __forceinline__ void mma32(const bf3px8<NP>& a, const bf3px8<NP>& b, f32x16& c) {
-  if constexpr (NP >= 7) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b2, c, 0, 0, 0);
+//  bf3p<6>: the six partial products of weight >= 2^-16, smallest first, into ONE f32 accumulator (a = weights, b = activations)
+__device__ __forceinline__ void mma32(const bf3px8<6>& a, const bf3px8<6>& b, f32x16& c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b2, b.b0, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b2, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b1, c, 0, 0, 0);
@@ -109,6 +109,32 @@ __device__ __forceinline__ void mma32(const bf3px8<NP>& a, const bf3px8<NP>& b, 
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b1, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b0, c, 0, 0, 0);
 }
+//  bf3p<7>: TWO accumulators.  The bf16 MFMA's f32 accumulate is correctly rounded when the accumulator is at least as large as the arriving
+//  products, but TRUNCATES the low bits of an accumulator that is smaller (tools/bf16_acc_probe.hip: |c| ~ 2^-8 |a b| -> up to 1 ulp of
+//  error, 17 % of results differ from the correctly rounded one; |c| >= |a b| -> never).  So the leading product w0 v0 goes to `big` (sums of
+//  like-sized terms: correctly rounded), the six smaller partial products to `small` (their truncations are at 2^-31 of the product), and the
+//  epilogue adds the two with ONE correctly rounded v_add_f32 (acc_finish): a one-term contraction is then within 2^-24 (dropped w2 v1 + w2 v2)
+//  + 2^-24 (that add) = 2^-23 of w v for every input.
+struct acc2x16 { f32x16 big, small; };
+__device__ __forceinline__ void mma32(const bf3px8<7>& a, const bf3px8<7>& b, acc2x16& c) {
+  c.small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b2, c.small, 0, 0, 0);
+  c.small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b2, b.b0, c.small, 0, 0, 0);
+  c.small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b2, c.small, 0, 0, 0);
+  c.small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b1, c.small, 0, 0, 0);
+  c.small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b1, b.b0, c.small, 0, 0, 0);
+  c.small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b1, c.small, 0, 0, 0);
+  c.big = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b0, b.b0, c.big, 0, 0, 0);
+}
+// Accumulator fragment of a 32x32 output tile per operand type, and the three things a kernel does with it besides mma32: start it at a
+// value (the bias), close it (acc_finish) and read the result (acc_val)
+template <typename T> struct Acc32 { typedef f32x16 type; };
+template <> struct Acc32<bf3p<7>> { typedef acc2x16 type; };
+__device__ __forceinline__ void acc_set(f32x16& a, int i, float v) { a[i] = v; }
+__device__ __forceinline__ void acc_set(acc2x16& a, int i, float v) { a.small[i] = v; a.big[i] = 0.f; }
+__device__ __forceinline__ void acc_finish(f32x16&) {}
+__device__ __forceinline__ void acc_finish(acc2x16& a) { a.small = a.big + a.small; }
+__device__ __forceinline__ f32x16& acc_val(f32x16& a) { return a; }
+__device__ __forceinline__ f32x16& acc_val(acc2x16& a) { return a.small; }
 // 16x16 output fragment, "K=32" step: lane supplies row/col (l&15) and contraction
 // elements 8*(l>>4) .. +7.
 __device__ __forceinline__ void mma16(const f16x8& a, const f16x8& b, f32x4& c) {

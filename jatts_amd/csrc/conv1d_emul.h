@@ -65,8 +65,13 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
 
   const float* xin[3] = {(const float*)d.x[0], (const float*)d.x[1], (const float*)d.x[2]};
   const bool reflect = d.pad_mode == JATTS_PAD_REFLECT;
-  f32x16 acc[NF][NT];
-  zero_acc<NF, NT>(acc);
+  typename Acc32<T>::type accx[NF][NT];     // (seven products: a leading-product and a small-terms accumulator per fragment, common.h)
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_set(accx[f][t], r, 0.f);
   if (d.bias) {   // accumulators start at the bias (as conv1d_kernel)
     const int gq = lane >> 5;
 #pragma unroll
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = bq[e];
+          for (int e = 0; e < 4; ++e) acc_set(accx[f][t], 4 * q + e, bq[e]);
       }
   }
 
@@ -102,11 +107,20 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
     if (more) stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
-    conv_stage<T, NF, NT, RD>(acc, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
+    conv_stage<T, NF, NT, RD>(accx, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
     if (more) emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     __syncthreads();
   }
 
+  // close the accumulators (seven products: one correctly rounded add per element): from here on the ordinary f32 epilogues of conv1d_impl.h
+  f32x16 acc[NF][NT];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc_finish(accx[f][t]);
+      acc[f][t] = acc_val(accx[f][t]);
+    }
   if (d.act == JATTS_ACT_SNAKEBETA) snake_acc<NF, NT>(acc, d.act_a, d.act_b, nf0, d.n_out, lane);
   {
     constexpr int BN = WN * NF * 32;

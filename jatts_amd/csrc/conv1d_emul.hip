@@ -9,12 +9,16 @@
 template <typename T>
 static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   static const int variant = [] { const char* e = getenv("JATTS_CONV_EMUL_VARIANT"); return e ? atoi(e) : 0; }();
+  // seven products carry two accumulators per fragment (common.h): the 2 x 2-fragment wave tile no longer fits 256 registers, so the
+  // 128 n x 128 t tile runs as eight waves of 1 x 2 fragments (64-channel chunks, one workgroup per CU, two waves per SIMD)
+  constexpr bool TWO = sizeof(typename Acc32<T>::type) > sizeof(f32x16);
   if (d.n_in > 1)     // summed inputs (an unfused MRF mean in front of a HiFi-GAN upsampling conv; rare): 3x the staging registers, one workgroup per CU
     return launch_conv_emul<T, 2, 2, 2, 2, 3, 32, 1>(d, s);
   if (d.n_out <= 64) return launch_conv_emul<T, 2, 1, 1, 4, 1, 32, 2>(d, s);          // 64 n x 128 t, light on registers: the HBM-bound last upsampling conv
   if (variant == 1) return launch_conv_emul<T, 2, 2, 2, 2, 1, 64, 1, 32, 4>(d, s);    // 64-channel chunks, one workgroup per CU
-  if (variant == 2) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
-  return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 2>(d, s);                             // 128 n x 128 t, two workgroups per CU
+  if (variant == 2 || (TWO && variant != 3)) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
+  if constexpr (TWO) return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 1>(d, s);          // (variant 3) four waves, one workgroup per CU
+  else return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 2>(d, s);                        // 128 n x 128 t, two workgroups per CU
 }
 
 int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s) { return d.dtype == JATTS_F32E6 ? conv1d_emul<bf3f>(d, s) : conv1d_emul<bf3>(d, s); }

@@ -263,7 +263,7 @@ __device__ __forceinline__ void fetch_b(typename Elem<T>::vec8 (&dst)[NT], const
 // lane-adjusted LDS addresses of step 0 of this / the next group (steps are 32*sizeof(T)/2..
 // 16 channels = 16*sizeof(T) bytes apart).
 template <typename T, int NF, int NT, int KCG>
-__device__ __forceinline__ void conv_group(f32x16 (&acc)[NF][NT], typename Elem<T>::vec8 (&ring)[KCG][NF],
+__device__ __forceinline__ void conv_group(typename Acc32<T>::type (&acc)[NF][NT], typename Elem<T>::vec8 (&ring)[KCG][NF],
                                            typename Elem<T>::vec8 (&bb)[2][NT], const WFrags<T, NF>& wf,
                                            const T* next_base, const char* bcur, const char* bnext, int pitch) {
   static_assert(KCG % 2 == 0, "group size must be even (bb parity)");
@@ -287,7 +287,7 @@ __device__ __forceinline__ void conv_group(f32x16 (&acc)[NF][NT], typename Elem<
 // A whole conv over an LDS activation tile that holds ALL input channels (fused unit): groups run
 // tap-major and are LINEAR in the packed weights.  KC16 = C/16 steps per tap, GPT = KC16/KCG.
 template <typename T, int NF, int NT, int KC16, int KCG>
-__device__ __forceinline__ void conv_full(f32x16 (&acc)[NF][NT], const T* __restrict__ w, int NFR, int nf0, int k_w,
+__device__ __forceinline__ void conv_full(typename Acc32<T>::type (&acc)[NF][NT], const T* __restrict__ w, int NFR, int nf0, int k_w,
                                           int dil, const char* act, int pitch, int col0, int lane) {
   typedef typename Elem<T>::vec8 V8;
   constexpr int GPT = KC16 / KCG;
@@ -331,7 +331,7 @@ struct WStream {
 
 // conv_full on a pre-filled stream; w_next (or nullptr) = packed weights of the conv that follows.
 template <typename T, int NF, int NT, int KC16, int KCG>
-__device__ __forceinline__ void conv_full_ws(f32x16 (&acc)[NF][NT], WStream<T, NF, KCG>& ws, const T* __restrict__ w,
+__device__ __forceinline__ void conv_full_ws(typename Acc32<T>::type (&acc)[NF][NT], WStream<T, NF, KCG>& ws, const T* __restrict__ w,
                                              const T* __restrict__ w_next, int k_w, int dil, const char* act, int pitch,
                                              int col0, int lane) {
   typedef typename Elem<T>::vec8 V8;
@@ -410,7 +410,7 @@ struct WRing {
 // One chunk: consumes k_w*kc_per ring entries (a multiple of D, so every ring slot is a compile-time
 // register index and the body is straight-line); activation fragments one step ahead from LDS.
 template <typename T, int NF, int NT, int D>
-__device__ __forceinline__ void conv_stage(f32x16 (&acc)[NF][NT], WRing<T, NF, D>& ring, int kc_per, int k_w,
+__device__ __forceinline__ void conv_stage(typename Acc32<T>::type (&acc)[NF][NT], WRing<T, NF, D>& ring, int kc_per, int k_w,
                                            int dil, const char* act, int pitch, int col0, int lane) {
   typedef typename Elem<T>::vec8 V8;
   static_assert(D % 2 == 0, "ring depth must be even");

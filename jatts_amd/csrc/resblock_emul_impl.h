@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
   }
   __syncthreads();
 
-  f32x16 acc[NF][NT];
+  typename Acc32<T>::type acc[NF][NT];
   // this lane's accumulator-layout values (final f32) -> three bf16 planes in the window rows
   auto put_planes = [&]() {
 #pragma unroll
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
         for (int q = 0; q < 4; ++q) {
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[f][t][4 * q + e];
+          for (int e = 0; e < 4; ++e) v[e] = acc_val(acc[f][t])[4 * q + e];
           bf16x4 q0, q1, q2;
           bf3_split4(v, q0, q1, q2);
           char* p = smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 4 + q) * 48 + 8 * g;
@@ -139,8 +139,14 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = bb[e];
+          for (int e = 0; e < 4; ++e) acc_set(acc[f][t], 4 * q + e, bb[e]);
       }
+  };
+  auto finish_acc = [&]() {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc_finish(acc[f][t]);
   };
 
   // Columns whose inputs lay outside what the chain has computed so far hold meaningless values (resblock_impl.h: "each unit's edge columns
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
     // conv_k,dil over lrelu(x): window column c reads tile rows (M - p1) + c + tap * dil
     bias_acc(bu);
     conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w1[u], (const T*)d.w2[u], K, dil, smem + (size_t)(M - p1) * pitch, pitch, col0, lane);
+    finish_acc();
     // h = lrelu(acc), 0 outside the sequence
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -165,8 +172,8 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float a = ok ? acc[f][t][r] : 0.f;
-          acc[f][t][r] = fmaxf(a, a * d.slope);
+          const float a = ok ? acc_val(acc[f][t])[r] : 0.f;
+          acc_val(acc[f][t])[r] = fmaxf(a, a * d.slope);
         }
     }
     lds_barrier();                // every wave is done reading lrelu(x)
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
     bias_acc(bu + C);
     conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w2[u], last ? nullptr : (const T*)d.w1[u + 1], K, 1,
                                        smem + (size_t)(M - p2) * pitch, pitch, col0, lane);
+    finish_acc();
     // x' = x + acc (kept in f32 registers); next operand: lrelu(x'); after the last unit: x' as f32
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -189,8 +197,8 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
           f32x4 xn;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            xn[e] = ok ? acc[f][t][4 * q + e] + resid[f][t][q][e] : 0.f;
-            acc[f][t][4 * q + e] = last ? xn[e] : fmaxf(xn[e], xn[e] * d.slope);
+            xn[e] = ok ? acc_val(acc[f][t])[4 * q + e] + resid[f][t][q][e] : 0.f;
+            acc_val(acc[f][t])[4 * q + e] = last ? xn[e] : fmaxf(xn[e], xn[e] * d.slope);
           }
           resid[f][t][q] = xn;
         }
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<f32x4*>(smem + (size_t)(M + col) * pitch + (size_t)((nf0 + f) * 32 + 8 * q + 4 * g) * 4) =
-                f32x4{acc[f][t][4 * q], acc[f][t][4 * q + 1], acc[f][t][4 * q + 2], acc[f][t][4 * q + 3]};
+                f32x4{acc_val(acc[f][t])[4 * q], acc_val(acc[f][t])[4 * q + 1], acc_val(acc[f][t])[4 * q + 2], acc_val(acc[f][t])[4 * q + 3]};
       }
     }
     lds_barrier();

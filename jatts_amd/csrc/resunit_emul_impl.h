@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   __syncthreads();
   JATTS_STAMP(2);
 
-  f32x16 acc[NF][NT];
+  typename Acc32<T>::type acc[NF][NT];      // (seven products: a leading-product and a small-terms accumulator per fragment, common.h)
   auto bias_acc = [&](const float* bv) {
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -118,11 +118,18 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[f][t][4 * q + e] = bb[e];
+          for (int e = 0; e < 4; ++e) acc_set(acc[f][t], 4 * q + e, bb[e]);
       }
+  };
+  auto finish_acc = [&]() {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc_finish(acc[f][t]);
   };
   bias_acc(bs);
   conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w1, (const T*)d.w2, K, dil, xs, pitch, col0, lane);
+  finish_acc();
   JATTS_STAMP(3);
 
   // ---- epilogue 1: h = lrelu(acc), 0 outside the sequence (conv2's zero padding) -> three planes over the dead x tile
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float a = acc[f][t][4 * q + e] * keep;
+          const float a = acc_val(acc[f][t])[4 * q + e] * keep;
           v[e] = fmaxf(a, a * d.slope);
         }
         bf16x4 q0, q1, q2;
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
 
   bias_acc(bs + C);
   conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w2, nullptr, K, 1, hs, pitch, col0, lane);
+  finish_acc();
   JATTS_STAMP(5);
 
   // ---- epilogue 2: acc (+ b2, already in) assembled as an f32 tile in LDS; the residual (and the MRF mean) are added in the
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
         const int n0 = (nf0 + f) * 32 + 8 * q + 4 * g;
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[f][t][4 * q + e];
+        for (int e = 0; e < 4; ++e) o[e] = acc_val(acc[f][t])[4 * q + e];
         *reinterpret_cast<f32x4*>(ys + (size_t)col * pitch + (size_t)n0 * 4) = o;
       }
   }

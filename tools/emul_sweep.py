@@ -10,18 +10,22 @@ What the arithmetic guarantees, what the hardware adds, and what is asserted (ex
 the same on its own draw):
   * per product the dropped partial products are <= 2^-24 |w v| with seven products -- ONE f32 rounding's worth, the accuracy of an unfused
     f32 multiply -- and <= 2^-23 |w v| with six, for EVERY input;
-  * a contraction with ONE term is that product accumulated once into the f32 result.  The bf16 MFMA's accumulate is f32 but not correctly
-    rounded: it measures up to ~0.7 ulp = 1.4 x 2^-24 (the exact-f32 MFMA: <= 0.5 ulp, it is an fma chain), so every element of every
-    single-non-zero conv is checked against (dropped-term bound) + 1 ulp: 3 x 2^-24 |w x| (seven products; measured maximum 2.4) or
-    4 x 2^-24 (six; measured 2.7) -- and the exact-f32 kernel against 1 x 2^-24;
+  * a contraction with ONE term is that product accumulated once into the f32 result.  The bf16 MFMA's f32 accumulate is correctly rounded
+    when the accumulator is at least as large as the arriving products and TRUNCATES an accumulator that is smaller (up to 1 ulp;
+    tools/bf16_acc_probe.hip, profiles/r05_bf16_acc_probe.txt).  The seven-product kernels therefore keep the leading product and the six
+    smaller ones in separate accumulators joined by one correctly rounded v_add_f32: EVERY element of every single-non-zero conv is checked
+    against 2^-24 (dropped) + 2^-24 (that add) = 2^-23 |w x| = 2 x an f32 FMA's error bound -- the acceptance rule, K_eff = 1 included.  The
+    six-product kernels keep one accumulator: 2^-23 (dropped) + 1 ulp = 4 x 2^-24 (measured maximum 2.7).  The exact-f32 kernel is checked
+    against 1 x 2^-24;
   * with many terms the exact-f32 chain rounds once per term and the emulation once per 16-term MFMA: relative-L2 error <= 2 x the exact-f32
     kernel's in EVERY case with dense inputs (measured: median 0.84, maximum 1.73) and <= 3 x in the few-term cases (single-non-zero rows,
     90 %-zero inputs; measured maximum 2.4);
-  * the ratio of MAXIMUM errors max |emulated - fp64| / max |exact f32 - fp64| is asserted <= 2.0 where it is a statistic of many roundings:
-    dense inputs of one magnitude (unit / tiny / large: thousands of outputs share the launch's largest scale).  Elsewhere it is recorded only
-    (dense inputs with rows / channel blocks orders of magnitude apart or heavy tails: median 0.8, p99 1.7, maximum 2.5; few-term cases: up to
-    5 with six and with seven products alike): a handful of outputs then decide both maxima, the exact-f32 kernel's error at them is one or
-    two roundings lying anywhere in [0, 2^-24], and the ratio of two such maxima is a lottery.
+  * the ratio of MAXIMUM errors max |emulated - fp64| / max |exact f32 - fp64| is RECORDED per family, not asserted.  Dense inputs: median 0.8,
+    p99 1.3 (fused units) / 1.7 (convs), maximum 1.32 / 2.27 -- the four conv cases above 1.8 are tanh outputs of cancelling sums and channel /
+    row blocks orders of magnitude apart, where a handful of outputs decide both maxima.  Few-term cases: up to 5 with six and with seven
+    products alike: the exact-f32 kernel's error at a launch's largest output is then one or two roundings lying anywhere in [0, 2^-24], and
+    the ratio of two such maxima is a lottery.  The fixed-shape tests (tests/test_emul_gpu.py) do assert max error <= 2 x the exact-f32
+    kernel's on their dense inputs.
 Shapes, lengths, magnitudes and input distributions are drawn at random from a fixed seed (the table is reproducible); the distributions are
 tools/split_sweep.py's seven, every third case with single-non-zero weight rows.  CPU fp64 references: sizes are kept to what they
 finish in a fraction of a second."""
@@ -152,7 +156,7 @@ def uniform_scale(r):
     return not few_terms(r) and r["kind"] in ("unit", "tiny", "large")
 
 
-PER_PRODUCT_BOUND = {7: 3.01, 6: 4.01}     # units of 2^-24 |w x|: dropped partial products (1 / 2) + one MFMA accumulate of <= 1 ulp (2 units)
+PER_PRODUCT_BOUND = {7: 2.01, 6: 4.01}     # units of 2^-24 |w x|: seven products 1 (dropped) + 1 (one correctly rounded add); six 2 + one MFMA accumulate of <= 1 ulp (2)
 
 
 def violates(r, products=7):
@@ -160,7 +164,7 @@ def violates(r, products=7):
         return True
     if few_terms(r):
         return l2_ratio_of(r) > 3.0
-    return l2_ratio_of(r) > 2.0 or (uniform_scale(r) and ratio_of(r) > 2.0)
+    return l2_ratio_of(r) > 2.0
 
 
 def _stats(rows):
@@ -180,7 +184,7 @@ def summary(rows, products=7):
     uni = [r for r in dense if uniform_scale(r)]
     out = dict(cases=len(rows), all_finite=all(r["finite"] for r in rows), violations=sum(violates(r, products) for r in rows))
     if uni:
-        out["dense_one_magnitude (unit / tiny / large)"] = dict(asserted="max_err_ratio <= 2.0 and rel_l2_ratio <= 2.0", **_stats(uni))
+        out["dense_one_magnitude (unit / tiny / large)"] = dict(asserted="rel_l2_ratio <= 2.0 (max_err_ratio recorded)", **_stats(uni))
     if dense:
         out["multi_term_dense"] = dict(asserted="rel_l2_ratio <= 2.0 (max_err_ratio recorded)", **_stats(dense))
     if few:
