@@ -3,16 +3,15 @@
 Every operand value travels exactly as three bf16 terms (b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1): 3 x 8 significand
 bits, f32's exponent range, no scales) and a product keeps the SEVEN (JATTS_F32E; JATTS_F32E6: six) largest of its nine partial products
 on v_mfma_f32_32x32x16_bf16 with f32 accumulate.  The bound argument (include/jatts_hip.h, csrc/common.h): dropped terms <= 2^-24 |w v|
--- one f32 rounding's worth -- (six products: 2^-23) for EVERY input, accumulation in f32.  What is asserted here (tools/emul_sweep.py's
-docstring has the measured distributions and why a ratio of two maximum errors cannot be held to 2 in few-term cases):
+-- one f32 rounding's worth -- (six products: 2^-23) for EVERY input; the seven-product kernels keep the leading and the smaller partial
+products in separate accumulators joined by ONE correctly rounded add (the bf16 MFMA truncates an accumulator that is smaller than the
+arriving product: tools/bf16_acc_probe.hip).  What is asserted here (tools/emul_sweep.py's docstring has the measured distributions):
   * the operands round-trip exactly through the device split (identity contraction returns the input bit for bit);
-  * single-non-zero contractions (K_eff = 1: one product, accumulated once): EVERY element within 2^-23 |w x| = 2 x an f32 FMA's error bound
-    with seven products (leading and smaller partial products in separate accumulators joined by one correctly rounded add: the bf16 MFMA
-    truncates an accumulator that is smaller than the arriving product, tools/bf16_acc_probe.hip), 4 x 2^-24 with six (one accumulator;
-    measured 2.7); the exact-f32 kernel, checked too: 1 x 2^-24;
-  * dense inputs: relative L2 <= 2e-5 against fp64 (the exact-f32 kernels' tolerance) and max error <= 2 x the exact-f32 kernel's on the
-    same inputs over the fixed shapes; on the randomised draw relative L2 <= 2 x the exact-f32 kernel's;
-  * few-term cases (single-non-zero rows, 90 %-zero inputs): relative-L2 error <= 3 x the exact-f32 kernel's;
+  * SEVEN products: in every case -- dense, sparse and single-non-zero (K_eff = 1) alike -- maximum error <= 2 x and relative L2 <= 2 x the
+    exact-f32 kernel's against fp64 on the same inputs, and EVERY element of a single-non-zero conv within 2^-23 |w x| = 2 x an f32 FMA's
+    error bound (the exact-f32 kernel, checked too: 2^-24); relative L2 <= 2e-5 against fp64 (the exact-f32 kernels' tolerance);
+  * SIX products (one accumulator): maximum error <= 2 x the exact-f32 kernel's on dense inputs over the fixed shapes, relative L2 <= 2 x
+    (dense) / 3 x (few-term cases), every element of a single-non-zero conv within 4 x 2^-24 |w x| (measured 2.7);
   * a row's result does not depend on its batch (bit-identical alone / inside a batch) -- there is no tile-dependent scale at all.
 """
 import math
@@ -134,7 +133,9 @@ def test_conv1d_emul(cuda, lib, case, xkind, np_):
             den = ref.abs() * 2.0 ** -24                                  # (six: 4 x; the exact-f32 kernel: 1 x)
             assert ((y.double().cpu() - ref).abs() <= PER_PRODUCT[np_] * den).all(), float(((y.double().cpu() - ref).abs() / den.clamp_min(1e-300)).max())
             assert ((y32.double().cpu() - ref).abs() <= 1.0001 * den).all()
-        assert e <= 3.0 * e32 + 1e-30, f"emulated conv1d {case} single: rel L2 {e:.3e} vs exact f32 {e32:.3e}"
+        assert e <= (2.0 if np_ == "7" else 3.0) * e32 + 1e-30, f"emulated conv1d {case} single: rel L2 {e:.3e} vs exact f32 {e32:.3e}"
+        if np_ == "7":
+            assert m <= 2.0 * m32 + 1e-30, f"emulated conv1d {case} single: max err {m:.3e} vs exact f32 {m32:.3e}"
     else:
         assert m <= 2.0 * m32 + 1e-30, f"emulated conv1d {case} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
     # the EmulWeight route of the models (dtype stays F32 at the call site) is the same launch
@@ -196,7 +197,9 @@ def test_hifigan_resunit_emul(cuda, lib, C, k, d, lens, xkind, np_):
     assert e <= TOL["fp32"], f"emulated resunit C={C} k={k} d={d} {xkind}: rel err {e:.3e} (exact f32: {e32:.3e})"
     m, m32 = _maxerr(y, ref), _maxerr(y32, ref)
     if xkind == "single":
-        assert e <= 3.0 * e32 + 1e-30, f"emulated resunit C={C} k={k} d={d} single: rel L2 {e:.3e} vs exact f32 {e32:.3e}"
+        assert e <= (2.0 if np_ == "7" else 3.0) * e32 + 1e-30, f"emulated resunit C={C} k={k} d={d} single: rel L2 {e:.3e} vs exact f32 {e32:.3e}"
+        if np_ == "7":
+            assert m <= 2.0 * m32 + 1e-30, f"emulated resunit C={C} k={k} d={d} single: max err {m:.3e} vs exact f32 {m32:.3e}"
     else:
         assert m <= 2.0 * m32 + 1e-30, f"emulated resunit C={C} k={k} d={d} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
     if len(lens) > 1:      # an utterance alone == inside the batch, bit for bit
@@ -229,10 +232,10 @@ def test_hifigan_resunit_emul_mrf_mean(cuda, lib):
 
 @pytest.mark.parametrize("products", [7, 6])
 def test_emul_sweep_bound(cuda, lib, products):
-    """A randomised draw of tools/emul_sweep.py (its own seed; the committed 1 100-case tables are profiles/r05_emul_sweep*.json): every case
-    with dense inputs has a relative-L2 error against fp64 of at most twice the exact-f32 kernel's; every
-    few-term case (single-non-zero rows, 90 %-zero inputs) a relative-L2 error of at most 3 x; every element of every single-non-zero conv lies
-    within 2 x 2^-24 |w x| (six products: 4 x) -- tools/emul_sweep.violates."""
+    """A randomised draw of tools/emul_sweep.py (its own seed; the committed 1 100-case tables are profiles/r05_emul_sweep*.json).  Seven products:
+    in EVERY case, single-non-zero rows included, the maximum error against fp64 is at most twice the exact-f32 kernel's (VERDICT r4's acceptance
+    test), so is the relative-L2 error, and every element of every single-non-zero conv lies within 2 x 2^-24 |w x|.  Six products: relative L2 at
+    most twice (dense inputs) / three times (few-term cases), elements within 4 x 2^-24 -- tools/emul_sweep.violates."""
     from jatts_amd import hip
     from tools import emul_sweep as sw
     g = torch.Generator().manual_seed(2025)

@@ -5,27 +5,24 @@ products per product; --products 6: JATTS_F32E6) against the exact-f32 kernels, 
     python tools/emul_sweep.py [--products 7] [--units 400] [--convs 700] [--seed 0] [--out profiles/r05_emul_sweep.json]
 
 VERDICT r4 next #1 asked for >= 1 000 cases including single-non-zero contractions (K_eff = 1: every dot product has ONE term, so the
-accumulation error both paths share vanishes and what is left is the representation of the product plus its one rounding into the result).
-What the arithmetic guarantees, what the hardware adds, and what is asserted (exit code 1 on any violation; tests/test_emul_gpu.py asserts
-the same on its own draw):
+accumulation error both paths share vanishes and what is left is the representation of the product plus its one rounding into the result),
+with  ratio = max |emulated - fp64| / max |exact f32 - fp64|  <= 2.0 in every case.  What the arithmetic guarantees, and what is asserted
+(exit code 1 on any violation; tests/test_emul_gpu.py asserts the same on its own draw):
   * per product the dropped partial products are <= 2^-24 |w v| with seven products -- ONE f32 rounding's worth, the accuracy of an unfused
     f32 multiply -- and <= 2^-23 |w v| with six, for EVERY input;
-  * a contraction with ONE term is that product accumulated once into the f32 result.  The bf16 MFMA's f32 accumulate is correctly rounded
-    when the accumulator is at least as large as the arriving products and TRUNCATES an accumulator that is smaller (up to 1 ulp;
-    tools/bf16_acc_probe.hip, profiles/r05_bf16_acc_probe.txt).  The seven-product kernels therefore keep the leading product and the six
-    smaller ones in separate accumulators joined by one correctly rounded v_add_f32: EVERY element of every single-non-zero conv is checked
-    against 2^-24 (dropped) + 2^-24 (that add) = 2^-23 |w x| = 2 x an f32 FMA's error bound -- the acceptance rule, K_eff = 1 included.  The
-    six-product kernels keep one accumulator: 2^-23 (dropped) + 1 ulp = 4 x 2^-24 (measured maximum 2.7).  The exact-f32 kernel is checked
-    against 1 x 2^-24;
-  * with many terms the exact-f32 chain rounds once per term and the emulation once per 16-term MFMA: relative-L2 error <= 2 x the exact-f32
-    kernel's in EVERY case with dense inputs (measured: median 0.84, maximum 1.73) and <= 3 x in the few-term cases (single-non-zero rows,
-    90 %-zero inputs; measured maximum 2.4);
-  * the ratio of MAXIMUM errors max |emulated - fp64| / max |exact f32 - fp64| is RECORDED per family, not asserted.  Dense inputs: median 0.8,
-    p99 1.3 (fused units) / 1.7 (convs), maximum 1.32 / 2.27 -- the four conv cases above 1.8 are tanh outputs of cancelling sums and channel /
-    row blocks orders of magnitude apart, where a handful of outputs decide both maxima.  Few-term cases: up to 5 with six and with seven
-    products alike: the exact-f32 kernel's error at a launch's largest output is then one or two roundings lying anywhere in [0, 2^-24], and
-    the ratio of two such maxima is a lottery.  The fixed-shape tests (tests/test_emul_gpu.py) do assert max error <= 2 x the exact-f32
-    kernel's on their dense inputs.
+  * the bf16 MFMA's f32 accumulate is correctly rounded when the accumulator is at least as large as the arriving products and TRUNCATES an
+    accumulator that is smaller (up to 1 ulp; tools/bf16_acc_probe.hip, profiles/r05_bf16_acc_probe.txt).  The SEVEN-product kernels
+    (JATTS_F32E) therefore keep the leading product and the six smaller ones in separate accumulators joined by one correctly rounded
+    v_add_f32.  Asserted for them, in EVERY case (dense, sparse, single-non-zero alike):
+        max-error ratio <= 2.0 and relative-L2 ratio <= 2.0 against the exact-f32 kernel, and EVERY element of every single-non-zero conv
+        within 2^-24 (dropped) + 2^-24 (that add) = 2^-23 |w x| = 2 x an f32 FMA's error bound (the exact-f32 kernel: 1 x 2^-24, checked too).
+    Measured over the 1 100 cases: max-error ratio median 0.36-0.39 on dense inputs (never above 1.00: the emulation is the MORE accurate of
+    the two whenever terms are summed), 1.00 median / 1.82 maximum on few-term cases; per-element maximum 1.43 x 2^-24;
+  * the SIX-product kernels (JATTS_F32E6) keep one accumulator: 2^-23 (dropped) + 1 ulp = 4 x 2^-24 per element at K_eff = 1 (measured
+    2.7).  Asserted for them: relative-L2 ratio <= 2.0 on dense inputs and <= 3.0 on few-term cases (single-non-zero rows, 90 %-zero
+    inputs), the per-element bound.  Their max-error ratio is RECORDED only (dense: median 0.8, p99 1.3-1.7, maximum 2.3; few-term: up to 5
+    -- the exact-f32 kernel's error at a launch's largest output is then one or two roundings anywhere in [0, 2^-24], so the ratio of two
+    such maxima is a lottery once the emulation's own error reaches 2-3 x 2^-24).
 Shapes, lengths, magnitudes and input distributions are drawn at random from a fixed seed (the table is reproducible); the distributions are
 tools/split_sweep.py's seven, every third case with single-non-zero weight rows.  CPU fp64 references: sizes are kept to what they
 finish in a fraction of a second."""
@@ -162,6 +159,8 @@ PER_PRODUCT_BOUND = {7: 2.01, 6: 4.01}     # units of 2^-24 |w x|: seven product
 def violates(r, products=7):
     if not r["finite"] or r.get("per_product_emul", 0.0) > PER_PRODUCT_BOUND[products] or r.get("per_product_f32", 0.0) > 1.0001:
         return True
+    if products == 7:      # the acceptance rule as written: every case, maximum error and relative L2
+        return ratio_of(r) > 2.0 or l2_ratio_of(r) > 2.0
     if few_terms(r):
         return l2_ratio_of(r) > 3.0
     return l2_ratio_of(r) > 2.0
@@ -184,11 +183,13 @@ def summary(rows, products=7):
     uni = [r for r in dense if uniform_scale(r)]
     out = dict(cases=len(rows), all_finite=all(r["finite"] for r in rows), violations=sum(violates(r, products) for r in rows))
     if uni:
-        out["dense_one_magnitude (unit / tiny / large)"] = dict(asserted="rel_l2_ratio <= 2.0 (max_err_ratio recorded)", **_stats(uni))
+        out["dense_one_magnitude (unit / tiny / large)"] = dict(**_stats(uni))
+    a7 = "max_err_ratio <= 2.0 and rel_l2_ratio <= 2.0"
     if dense:
-        out["multi_term_dense"] = dict(asserted="rel_l2_ratio <= 2.0 (max_err_ratio recorded)", **_stats(dense))
+        out["multi_term_dense"] = dict(asserted=a7 if products == 7 else "rel_l2_ratio <= 2.0 (max_err_ratio recorded)", **_stats(dense))
     if few:
-        out["few_terms (single-non-zero rows, 90 %-zero inputs)"] = dict(asserted="rel_l2_ratio <= 3.0; per-element bound on the single-non-zero convs", **_stats(few))
+        out["few_terms (single-non-zero rows, 90 %-zero inputs)"] = dict(
+            asserted=(a7 if products == 7 else "rel_l2_ratio <= 3.0 (max_err_ratio recorded)") + "; per-element bound on the single-non-zero convs", **_stats(few))
         pp = [r for r in few if "per_product_emul" in r]
         if pp:
             out["single_nonzero_conv_per_product_error_in_units_of_2^-24"] = dict(
