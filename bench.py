@@ -346,7 +346,7 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     MRF mean its epilogue carries (n_add more reads of C sizeof bytes per row)."""
     esz = 2 if prec == "fp16" else 4                      # bytes per activation element in HBM
     # matrix-pipe peak per ALGORITHMIC FLOP: the split mode spends three dense f16 MFMAs per product
-    # ... the emulated mode six dense bf16 MFMAs
+    # ... the emulated modes seven / six dense bf16 MFMAs
     unit_peak = conv_peak = ALG_PEAK_TF[prec]
     fam = {}
     for tag, meta, ms in recs:

@@ -16,6 +16,10 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
     return launch_conv_emul<T, 2, 2, 2, 2, 3, 32, 1>(d, s);
   if (d.n_out <= 64) return launch_conv_emul<T, 2, 1, 1, 4, 1, 32, 2>(d, s);          // 64 n x 128 t, light on registers: the HBM-bound last upsampling conv
   if (variant == 1) return launch_conv_emul<T, 2, 2, 2, 2, 1, 64, 1, 32, 4>(d, s);    // 64-channel chunks, one workgroup per CU
+  // k = 1 with two accumulators: 128 n x 64 t, four waves of 2 x 1 fragments, two workgroups per CU (+3-8 % on the large launches, +20-35 % at
+  // 4 096 / 8 192 rows against the eight-wave tile; at k = 3 the eight-wave tile is 3-4 % ahead: profiles/r05_notes.md)
+  if (variant == 4 || (TWO && variant == 0 && d.k_w == 1)) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);
+  if (variant == 5) return launch_conv_emul<T, 1, 2, 2, 2, 1, 64, 2, 32, 4>(d, s);    // 64 n x 128 t, four waves of 1 x 2 fragments, two workgroups per CU
   if (variant == 2 || (TWO && variant != 3)) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
   if constexpr (TWO) return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 1>(d, s);          // (variant 3) four waves, one workgroup per CU
   else return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 2>(d, s);                        // 128 n x 128 t, two workgroups per CU

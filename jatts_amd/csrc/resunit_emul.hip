@@ -31,7 +31,8 @@ static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
         if (variant == 1) return launch_resunit_emul<T, 256, 64, 8, 2, 2, 1>(d, s);        // 8 waves NF = 1 NT = 2
         return launch_resunit_emul<T, 256, 64, 4, 2, 2, 1>(d, s);                          // 4 waves NF = 2 NT = 2
       }
-      return launch_resunit_emul<T, 256, 32, 4, 1, 2, 1>(d, s);                            // k = 11, dilation 5: 82-row tile
+      if (variant == 2) return launch_resunit_emul<T, 256, 32, 4, 1, 2, 1>(d, s);          // 32-column window, 82-row tile
+      return launch_resunit_emul<T, 256, 64, 4, 2, 2, 1, true>(d, s);                      // k = 11, dilation 5: the 114-row x tile one channel half at a time
   }
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels for JATTS_F32E (32 / 64 / 128 / 256)");
 }

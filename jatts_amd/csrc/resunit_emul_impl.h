@@ -23,7 +23,38 @@ __device__ __forceinline__ void bf3_split4(const float (&v)[4], bf16x4& p0, bf16
   }
 }
 
-template <typename T, int C, int WGCOLS, int WN, int NT, int KCG, int OCC>      // T = bf3 (seven partial products) or bf3f (six)
+// conv_full_ws over ONE HALF of the input channels (KSPLIT kernels: the x tile holds C / 2 channels at a time).  KC16 = the FULL steps per tap of the
+// packed weights; the tile holds KC16 / 2 of them per row.  On entry the ring holds this half's first group; on exit the first group at `w_after`
+// (the other half's, or the next conv's).
+template <typename T, int NF, int NT, int KC16, int KCG>
+__device__ __forceinline__ void conv_khalf_ws(typename Acc32<T>::type (&acc)[NF][NT], WStream<T, NF, KCG>& ws, const T* __restrict__ w, const T* __restrict__ w_after,
+                                              int half, int k_w, int dil, const char* act, int pitch_half, int col0, int lane) {
+  typedef typename Elem<T>::vec8 V8;
+  constexpr int GPT = KC16 / KCG, GPH = GPT / 2;
+  static_assert(GPH * 2 * KCG == KC16, "group size must divide half the steps per tap");
+  const T* wl = w + (size_t)lane * 8;
+  const size_t gstride = (size_t)KCG * ws.wf.stride;
+  const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch_half + (size_t)(8 * (lane >> 5)) * sizeof(T);
+  V8 bb[2][NT];
+  fetch_b<T, NT>(bb[0], bbase, pitch_half);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int tap = 0; tap < k_w; ++tap) {
+#pragma unroll
+    for (int h = 0; h < GPH; ++h) {
+      const bool wrap = h + 1 == GPH;
+      const int nt = wrap ? tap + 1 : tap, nh = wrap ? 0 : h + 1;
+      const T* nb = nt < k_w ? wl + (size_t)(nt * GPT + half * GPH + nh) * gstride : w_after + (size_t)lane * 8;
+      const char* bcur = bbase + (size_t)(tap * dil) * pitch_half + (size_t)(h * KCG) * 16 * sizeof(T);
+      const char* bnext = bbase + (size_t)(min(nt, k_w - 1) * dil) * pitch_half + (size_t)(nh * KCG) * 16 * sizeof(T);
+      conv_group<T, NF, NT, KCG>(acc, ws.ring, bb, ws.wf, nb, bcur, bnext, pitch_half);
+    }
+  }
+}
+
+// KSPLIT: the x tile of conv1 is staged one channel half at a time (the second half's global loads are in flight under the first half's MFMAs).  For
+// shapes whose full x tile does not fit LDS beside nothing else -- C = 256, k = 11, dilation 5: 114 rows x 1 552 B = 177 KB -- where the alternative was a
+// 32-column window (9.2 ms against 6.8 ms for the other dilations).
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCG, int OCC, bool KSPLIT = false>      // T = bf3 (seven partial products) or bf3f (six)
 __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emul_kernel(jatts_resunit_desc d, unsigned long long* trace,
                                                                                          unsigned trace_cap, unsigned bias_off) {
   typedef typename Elem<T>::vec8 V8;
@@ -32,6 +63,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   constexpr int NF = C / (WN * 32);
   constexpr int KC16 = C / 16, NFR = C / 32;
   constexpr int pitch = C * 6 + 16;
+  constexpr int pitch_x = KSPLIT ? (C / 2) * 6 + 16 : pitch;      // x tile row: all channels, or one half
   constexpr int NTHR = WN * WT * 64;
   static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
   static_assert(sizeof(T) == 6, "bf3 is three packed bf16");
@@ -73,41 +105,6 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   ws.prefetch((const T*)d.w1, NFR, nf0, lane);
 
   // ---- stage: lrelu(x) tile -> registers -> three bf16 planes in LDS (all loads of a batch in flight before the first is used)
-  {
-    constexpr int UPR = C / 8;
-    constexpr int UB = 8;
-    const float* x = (const float*)d.x;
-    const int total = rx * UPR, pos0 = t0 - p2 - p1;
-    for (int base = threadIdx.x; base < total; base += NTHR * UB) {
-      f32x8 v[UB];
-#pragma unroll
-      for (int j = 0; j < UB; ++j) {
-        const int u = base + j * NTHR;
-        const int r = u / UPR, cu = u - r * UPR;
-        const int pos = pos0 + r;
-        if (u < total && pos >= 0 && pos < L) v[j] = Vec8IO<float>::ldg(x + (seq_row0 + pos) * (int64_t)C + cu * 8);
-        else v[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-#pragma unroll
-      for (int j = 0; j < UB; ++j) {
-        const int u = base + j * NTHR;
-        if (u >= total) continue;
-        const int r = u / UPR, cu = u - r * UPR;
-        lrelu8(v[j], d.slope);
-        V8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          bf16 a, bq, c;
-          bf3_split(v[j][e], a, bq, c);
-          o.b0[e] = a; o.b1[e] = bq; o.b2[e] = c;
-        }
-        Vec8IO<T>::sts(xs + (size_t)r * pitch + (size_t)cu * 48, o);
-      }
-    }
-  }
-  __syncthreads();
-  JATTS_STAMP(2);
-
   typename Acc32<T>::type acc[NF][NT];      // (seven products: a leading-product and a small-terms accumulator per fragment, common.h)
   auto bias_acc = [&](const float* bv) {
 #pragma unroll
@@ -127,8 +124,80 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc_finish(acc[f][t]);
   };
-  bias_acc(bs);
-  conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w1, (const T*)d.w2, K, dil, xs, pitch, col0, lane);
+  auto to_planes = [&](f32x8 v) {
+    lrelu8(v, d.slope);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bf16 a, bq, c;
+      bf3_split(v[e], a, bq, c);
+      o.b0[e] = a; o.b1[e] = bq; o.b2[e] = c;
+    }
+    return o;
+  };
+  const float* x = (const float*)d.x;
+  const int pos0 = t0 - p2 - p1;
+  if constexpr (!KSPLIT) {
+    constexpr int UPR = C / 8;
+    constexpr int UB = 8;
+    const int total = rx * UPR;
+    for (int base = threadIdx.x; base < total; base += NTHR * UB) {
+      f32x8 v[UB];
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int u = base + j * NTHR;
+        const int r = u / UPR, cu = u - r * UPR;
+        const int pos = pos0 + r;
+        if (u < total && pos >= 0 && pos < L) v[j] = Vec8IO<float>::ldg(x + (seq_row0 + pos) * (int64_t)C + cu * 8);
+        else v[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int u = base + j * NTHR;
+        if (u >= total) continue;
+        const int r = u / UPR, cu = u - r * UPR;
+        Vec8IO<T>::sts(xs + (size_t)r * pitch + (size_t)cu * 48, to_planes(v[j]));
+      }
+    }
+    __syncthreads();
+    JATTS_STAMP(2);
+    bias_acc(bs);
+    conv_full_ws<T, NF, NT, KC16, KCG>(acc, ws, (const T*)d.w1, (const T*)d.w2, K, dil, xs, pitch, col0, lane);
+  } else {
+    constexpr int UPR = C / 16;                                            // 8-element units per row of one channel half
+    constexpr int MAXU = ((WGCOLS + 64) * UPR + NTHR - 1) / NTHR;         // halos up to 32 rows a side (the launcher refuses more)
+    const int total = rx * UPR;
+    f32x8 xv[MAXU];
+    auto load_half = [&](int half) {
+#pragma unroll
+      for (int j = 0; j < MAXU; ++j) {
+        const int u = threadIdx.x + j * NTHR;
+        const int r = u / UPR, cu = u - r * UPR;
+        const int pos = pos0 + r;
+        if (u < total && pos >= 0 && pos < L) xv[j] = Vec8IO<float>::ldg(x + (seq_row0 + pos) * (int64_t)C + half * (C / 2) + cu * 8);
+        else xv[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    };
+    auto store_half = [&]() {
+#pragma unroll
+      for (int j = 0; j < MAXU; ++j) {
+        const int u = threadIdx.x + j * NTHR;
+        if (u < total) Vec8IO<T>::sts(xs + (size_t)(u / UPR) * pitch_x + (size_t)(u % UPR) * 48, to_planes(xv[j]));
+      }
+    };
+    load_half(0);
+    store_half();
+    load_half(1);                 // in flight under the first half's MFMAs
+    __syncthreads();
+    JATTS_STAMP(2);
+    bias_acc(bs);
+    const T* w1 = (const T*)d.w1;
+    conv_khalf_ws<T, NF, NT, KC16, KCG>(acc, ws, w1, w1 + (size_t)(KC16 / KCG / 2) * KCG * ws.wf.stride, 0, K, dil, xs, pitch_x, col0, lane);
+    lds_barrier();                // every wave is done reading the first half
+    store_half();
+    lds_barrier();
+    conv_khalf_ws<T, NF, NT, KC16, KCG>(acc, ws, w1, (const T*)d.w2, 1, K, dil, xs, pitch_x, col0, lane);
+  }
   finish_acc();
   JATTS_STAMP(3);
 
@@ -210,22 +279,23 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
 #undef JATTS_STAMP
 }
 
-template <typename T, int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2, bool KSPLIT = false>
 int launch_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   constexpr int WT = WGCOLS / (NT * 32);
   const int K = d.k_w, p2 = (K - 1) / 2, p1 = p2 * d.dil;
   const int tt_out = WGCOLS - 2 * p2;
   if (tt_out < 8) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: kernel too wide for tile");
-  const size_t pitch = C * 6 + 16;
+  const size_t pitch = C * 6 + 16, pitch_x = KSPLIT ? (C / 2) * 6 + 16 : pitch;
   const size_t rows_x = WGCOLS + 2 * p1, rows_h = WGCOLS + K - 1;
-  size_t lds = (rows_x > rows_h ? rows_x : rows_h) * pitch;
+  if (KSPLIT && 2 * p1 > 64) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit (emulated, channel halves): halo beyond 32 rows a side");
+  size_t lds = rows_x * pitch_x > rows_h * pitch ? rows_x * pitch_x : rows_h * pitch;
   const unsigned bias_off = (unsigned)lds;
   lds += 2 * C * sizeof(float);                                // b1 | b2
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: tile exceeds 160 KiB LDS");
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
   if (const int64_t n1 = ragged_tiles_1d(d.rg, tt_out)) grid = dim3((unsigned)n1);
-  auto kern = resunit_emul_kernel<T, C, WGCOLS, WN, NT, KCG, OCC>;
+  auto kern = resunit_emul_kernel<T, C, WGCOLS, WN, NT, KCG, OCC, KSPLIT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);

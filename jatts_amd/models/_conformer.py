@@ -56,7 +56,7 @@ class PackedConv:
         self.n_out, c, self.k = w.shape
         self.c_in = hip.round_up(c, c_mult)
         # set_precision("fp32_split"): f32 tensors, split f16 hi/lo MFMA operands (hip.split_weights is on while the model prepares)
-        # set_precision("fp32_bf16x3"): f32 tensors, three exact bf16 terms per operand, six MFMA products (hip.EmulWeight)
+        # set_precision("fp32_bf16x3"): f32 tensors, three exact bf16 terms per operand, seven (fp32_bf16x3_6p: six) MFMA products (hip.EmulWeight)
         self.w = hip.f32_operand(w.to(device), c_mult) if dtype == hip.F32 else hip.pack_conv_weight(w.to(device), dtype, c_mult)
         self.b = None if b is None else b.to(device).contiguous()
 

@@ -904,3 +904,49 @@ def test_conv1d_snakebeta_epilogue(cuda, lib, mode):
         hip.conv1d(rb, xd, wp, c_in, n_out - 2, 1, snake=(ad[:-2].contiguous(), ibd[:-2].contiguous()), dtype=dt, bias=b.to(cuda))
     with pytest.raises(ValueError):
         hip.conv1d(rb, xd, wp, c_in, n_out, 1, snake=(ad, ibd), act=hip.ACT_RELU, **kw)
+
+
+@pytest.mark.parametrize("n_seq", [3, 70, 150])
+def test_ragged_1d_grids_equal_rectangular(cuda, lib, n_seq):
+    """Round 5: for a non-uniform batch the MFMA conv / fused-unit kernels launch a 1-D grid over exactly the real tiles (jatts_ragged.host_lens;
+    csrc/common.h: ragged_locate) instead of n_seq x tiles-of-the-longest.  Same tile geometry inside every sequence => bit-identical outputs, for more
+    than 64 sequences (the lookup scans 64 at a time), with empty sequences, in every arithmetic; uniform batches never take the 1-D form."""
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(n_seq)
+    lens = [int(v) for v in torch.randint(0, 400, (n_seq,), generator=g)]
+    lens[1] = 0
+    lens[-1] = 777
+    rb = _ragged(lens, cuda)
+    assert rb.struct().host_lens and not _ragged([5] * n_seq, cuda).struct().host_lens
+    R, C, k, d = sum(lens), 64, 7, 3
+    x = torch.randn(R, C, generator=g).to(cuda)
+    w1, w2 = (torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).to(cuda), (torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).to(cuda)
+    b = torch.zeros(C, device=cuda)
+    wc = (torch.randn(192, C, 3, generator=g) / math.sqrt(3 * C)).to(cuda)
+
+    def run():
+        outs = []
+        for dt, pack in ((hip.F32, lambda w: hip.pack_conv_weight(w, hip.F32, 32)), (hip.F32E, lambda w: hip.pack_conv_weight_bf16x3(w, 32)),
+                         (hip.F32E6, lambda w: hip.pack_conv_weight_bf16x3(w, 32))):
+            y = torch.full_like(x, float("nan"))
+            hip.hifigan_resunit(rb, 1, x, y, pack(w1), b, pack(w2), b, C, k, d, 0.1, dt)
+            outs.append(y)
+        ws1, is1 = hip.pack_conv_weight_split(w1, 32)
+        ws2, is2 = hip.pack_conv_weight_split(w2, 32)
+        y = torch.full_like(x, float("nan"))
+        hip.hifigan_resunit(rb, 1, x, y, ws1, b, ws2, b, C, k, d, 0.1, hip.F32S, ws=(is1, is2))
+        outs.append(y)
+        outs.append(hip.conv1d(rb, x, hip.pack_conv_weight(wc, hip.F32), C, 192, 3, dtype=hip.F32, act=hip.ACT_RELU))
+        outs.append(hip.conv1d(rb, x, hip.pack_conv_weight_bf16x3(wc, 64), C, 192, 3, dtype=hip.F32E, act=hip.ACT_RELU))
+        outs.append(hip.conv1d(rb, x.half(), hip.pack_conv_weight(wc, hip.F16), C, 192, 3, dtype=hip.F16, act=hip.ACT_RELU).float())
+        torch.cuda.synchronize()
+        return outs
+    one_d = run()
+    prev, hip._RAGGED_1D = hip._RAGGED_1D, False
+    try:
+        assert not rb.struct().host_lens
+        rect = run()
+    finally:
+        hip._RAGGED_1D = prev
+    for a, c in zip(one_d, rect):
+        assert torch.isfinite(a).all() and torch.equal(a, c)
