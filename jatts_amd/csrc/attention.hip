@@ -115,14 +115,14 @@ struct TileRegs {
 };
 
 // WHICH: 1 = the K tile (+ the u . k bias of its keys), 2 = the V^T tile, 3 = both
-template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4>
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true>      // KU = false: no u . k bias (bias-free attention: REL = false)
 __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
                                           const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec,
                                           __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv) {
   typedef typename G<T>::vec8 Vec;
   typedef typename G<T>::type TG;
   constexpr int UPR = DK / 8;
-  if constexpr (WHICH & 1) {   // (first: anything the compiler reloads from scratch for this address must not sit behind the tile's loads --
+  if constexpr ((WHICH & 1) && KU) {   // (first: anything the compiler reloads from scratch for this address must not sit behind the tile's loads --
     tr.ku = 0.f;               //  a scratch reload waits on vmcnt(0), i.e. on every global load issued before it)
     if (d.ku && threadIdx.x < KBT) {
       const int j = j0 + (int)threadIdx.x;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const ja
   }
 }
 
-template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4>
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true>
 __device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT, NW>& tr, char* ks, char* vs, float* kus, int KP, int VP, float sk = 1.f,
                                            float sv = 1.f) {
   constexpr int UPR = DK / 8;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT, NW>& tr, c
     if constexpr (WHICH & 1) store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i], sk);
     if constexpr (WHICH & 2) store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i], sv);
   }
-  if constexpr (WHICH & 1) {
+  if constexpr ((WHICH & 1) && KU) {
     if (threadIdx.x < KBT) kus[threadIdx.x] = tr.ku;
   }
 }
@@ -271,16 +271,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   // every tile before: matrix pipe 54 % busy).
   constexpr bool HALFPF = JATTS_ATTN_HALFPF && !PREFETCH && !SPLIT && sizeof(T) == 4;   // (f16 d_k 256 keeps its 64-key tiles: the half pipeline spilled 80 bytes there)
   TileRegs<T, DK, KBT, NW> tr;
-  if (PREFETCH) tile_load<T, DK, KBT, 3, NW>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
+  if (PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
   if constexpr (HALFPF) {
-    tile_load<T, DK, KBT, 1, NW>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
-    tile_store<T, DK, KBT, 1, NW>(tr, ks, vs, kus, KP, VP);
+    tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
+    tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
     __syncthreads();
   }
   int ev_prev = 0;
   for (int j0 = j_start; j0 < Tk; j0 += KBT) {
-    if constexpr (HALFPF) tile_load<T, DK, KBT, 2, NW>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
-    else if (!PREFETCH) tile_load<T, DK, KBT, 3, NW>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
+    if constexpr (HALFPF) tile_load<T, DK, KBT, 2, NW, REL>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
+    else if (!PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
     int ek = 0, ev = 0;
     if constexpr (HALFPF) {
       // (K(t) is in LDS since the previous iteration's last barrier)
@@ -300,12 +300,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       for (int w = 1; w < NW; ++w) { sk = fmaxf(sk, slots[2 * w]); sv = fmaxf(sv, slots[2 * w + 1]); }
       ek = attn_split_exp(sk);
       ev = attn_split_exp(sv);
-      tile_store<T, DK, KBT, 3, NW>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev));
+      tile_store<T, DK, KBT, 3, NW, REL>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev));
     } else {
-      tile_store<T, DK, KBT, 3, NW>(tr, ks, vs, kus, KP, VP);
+      tile_store<T, DK, KBT, 3, NW, REL>(tr, ks, vs, kus, KP, VP);
     }
     if constexpr (!HALFPF) __syncthreads();
-    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT, 3, NW>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
+    if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
 
     // ---- rel-pos bias gather, issued before the score MFMAs so that its latency hides behind them ----
     float bd[NF][4];
@@ -357,7 +357,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
     const float inv_qk = SPLIT ? attn_exp2i(-(eq + ek)) : 1.f;     // exact un-scale of q . k
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const f32x4 kq = *reinterpret_cast<const f32x4*>(kus + 16 * f + 4 * g);
+      f32x4 kq = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (REL) kq = *reinterpret_cast<const f32x4*>(kus + 16 * f + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * f + 4 * g + r;
@@ -391,9 +392,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       for (int r = 0; r < 4; ++r) ot[f][r] *= oscale;
 
     if constexpr (HALFPF) {
-      tile_store<T, DK, KBT, 2, NW>(tr, ks, vs, kus, KP, VP);
+      tile_store<T, DK, KBT, 2, NW, REL>(tr, ks, vs, kus, KP, VP);
       __syncthreads();            // V^T(t) visible; every wave is past its score MFMAs and its u . k reads: the K buffer is free
-      if (j0 + KBT < Tk) tile_load<T, DK, KBT, 1, NW>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
+      if (j0 + KBT < Tk) tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
     }
     // ---- O^T += V^T P^T over two 32-key blocks.  Contraction slots of k-group g in block kb:
     //      keys {32kb + 4g + r} (from st[2kb]) then {32kb + 16 + 4g + r} (from st[2kb+1]) ----
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       }
     }
     if constexpr (HALFPF) {
-      if (j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW>(tr, ks, vs, kus, KP, VP);
+      if (j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
     }
     __syncthreads();
   }
@@ -475,7 +476,7 @@ int launch_attn(const jatts_relattn_desc& d, hipStream_t s) {
       if (half && (wide >= 0 ? wide != 0 : G<T>::split)) return launch_attn_kb<T, DK, 32, true, 8>(d, s);
     }
     if constexpr (DK == 256 && sizeof(typename G<T>::type) == 4 && !G<T>::split) {
-      if (half && !d.g) return launch_attn_kb<T, DK, 32, false>(d, s);
+      if (half && !d.g && !d.ku) return launch_attn_kb<T, DK, 32, false>(d, s);
     }
     if (half) return launch_attn_kb<T, DK, 32>(d, s);
   }

@@ -50,7 +50,9 @@ template <> struct Elem<f16s> {
 // f32-EQUIVALENT emulated operand (round 5, JATTS_F32E / JATTS_F32E6): every f32 value v is carried EXACTLY as three bfloat16 terms
 //   b0 = bf16(v), b1 = bf16(v - b0), b2 = bf16(v - b0 - b1)      (round-to-nearest-even; both differences are exact in f32)
 // 3 x 8 significand bits = f32's 24 and bf16 has f32's exponent field: v == b0 + b1 + b2 for every finite f32 whose last bit lies at or
-// above bf16's smallest subnormal 2^-133 (|v| >= 2^-110): NO scales, no block maxima, no element-dependent loss of relative precision.
+// above bf16's smallest subnormal 2^-133 (|v| >= 2^-110) and which does not round up past bf16's largest finite value (|v| < 3.3895e38 =
+// (2 - 2^-8) 2^127, a hair under FLT_MAX; beyond it b0 becomes infinity): NO scales, no block maxima, no element-dependent loss of
+// relative precision.  Infinities and NaNs give NaN (inf - inf in the split), where the exact-f32 path would propagate an infinity.
 // Under round-to-nearest |b1| <= 2^-8 |v| and |b2| <= 2^-16 |v|, so the nine partial products of w v have weights 1 | 2^-8 x2 | 2^-16 x3 |
 // 2^-24 x2 | 2^-32; every bf16 x bf16 product is exact in the f32 accumulate.  NP = the number of partial products kept:
 //   NP = 7 (JATTS_F32E): all of weight >= 2^-16 plus w1 v2 -- dropped: w2 v1 + w2 v2 <= (2^-24 + 2^-32) |w v|, one f32 rounding's worth (an

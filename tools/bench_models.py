@@ -48,7 +48,7 @@ def timed(fn, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "fp32_split"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"])
     ap.add_argument("--model", default="both", choices=["both", "matcha", "vits"])
     ap.add_argument("--no-vocoder", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="per-shape conv1d / attention table from HIP-event records")

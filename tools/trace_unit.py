@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--k", type=int, default=11)
     ap.add_argument("--dil", type=int, default=1)
     ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split", "emul", "emul6"])
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}
     dev = torch.device("cuda:0")
@@ -31,7 +31,7 @@ def main():
     rb = hip.RaggedBatch([T] * B, dev)
     rows = B * T * rate
     g = torch.Generator(device="cpu").manual_seed(0)
-    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S}[a.dtype]
+    dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E, "emul6": hip.F32E6}[a.dtype]
     x = (torch.randn(rows, a.C, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
     y = torch.empty_like(x)
     wf = [(torch.randn(a.C, a.C, a.k, generator=g) / (a.C * a.k) ** 0.5).to(dev) for _ in range(2)]
@@ -39,6 +39,9 @@ def main():
     if dt == hip.F32S:
         (w0, i0), (w1, i1) = (hip.pack_conv_weight_split(v, 32) for v in wf)
         run = lambda: hip.hifigan_resunit(rb, rate, x, y, w0, b, w1, b, a.C, a.k, a.dil, 0.1, dt, ws=(i0, i1))
+    elif dt in hip.EMUL:
+        w = [hip.pack_conv_weight_bf16x3(v, 32) for v in wf]
+        run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, dt)
     else:
         w = [hip.pack_conv_weight(v, dt, 32) for v in wf]
         run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, dt)
