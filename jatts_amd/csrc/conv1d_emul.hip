@@ -18,7 +18,11 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   if (variant == 1) return launch_conv_emul<T, 2, 2, 2, 2, 1, 64, 1, 32, 4>(d, s);    // 64-channel chunks, one workgroup per CU
   // k = 1 with two accumulators: 128 n x 64 t, four waves of 2 x 1 fragments, two workgroups per CU (+3-8 % on the large launches, +20-35 % at
   // 4 096 / 8 192 rows against the eight-wave tile; at k = 3 the eight-wave tile is 3-4 % ahead: profiles/r05_notes.md)
-  if (variant == 4 || (TWO && variant == 0 && d.k_w == 1)) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);
+  // (six products: the same tile for SMALL k = 1 launches -- <= 768 workgroups of 128 x 128, i.e. one round of the two-per-CU slots: 40-72 -> 58-79 TFLOP/s at
+  //  4 096 / 8 192 rows.  Nothing in this arithmetic depends on the tile, so the choice may follow the launch.)
+  const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
+  const bool small_k1 = d.k_w == 1 && ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128) <= 768;
+  if (variant == 4 || (variant == 0 && d.k_w == 1 && (TWO || small_k1))) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);
   if (variant == 5) return launch_conv_emul<T, 1, 2, 2, 2, 1, 64, 2, 32, 4>(d, s);    // 64 n x 128 t, four waves of 1 x 2 fragments, two workgroups per CU
   if (variant == 2 || (TWO && variant != 3)) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
   if constexpr (TWO) return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 1>(d, s);          // (variant 3) four waves, one workgroup per CU

@@ -65,3 +65,28 @@ def test_compact_line_without_optional_blocks():
     out["cpu_baseline"] = None
     d = json.loads(bench.compact_line(out))
     assert d["cpu_baseline"] is None and "detail" not in d and "training" not in d
+
+
+def test_compact_line_carries_every_block_of_a_round5_result():
+    """A real round-5 result (profiles/r05_bench_detail.json: five arithmetics, the ragged leg, two configs, four training lines, the CPU
+    baseline) must fit the line WITHOUT any optional block being dropped."""
+    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+    line = bench.compact_line(out, "bench_detail.json")
+    assert len(line) <= bench.LINE_LIMIT
+    d = check_line(line)
+    for k in ("ragged", "f32_emul_mode", "f32_emul6_mode", "f32_split_mode", "fast_mode", "configs", "training", "roofline_conv1d"):
+        assert k in d, k
+    assert set(d["ragged"]) >= {"t_text", "seed", "value", "ms_per_step", "per_sample_efficiency"}
+    assert d["roofline"]["traffic"] and d["roofline"]["traffic_source"] in ("live", "committed")
+
+
+def test_traffic_lookup_answers_null_with_a_reason():
+    """roofline.traffic never comes from a table that lacks the kernel asked about, and the committed table of this round
+    holds the fused-unit kernels of every arithmetic."""
+    table = json.load(open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_ROUND}_traffic.json")))["kernels"]
+    for prec in bench.PRECISIONS:
+        v, why = bench.lookup_traffic(table, prec, 128)
+        assert v and v > 1e9 and why is None, (prec, why)
+    v, why = bench.lookup_traffic({"some_other_kernel": {"hbm_bytes": 1.0, "launches": 1}}, "fp32_bf16x3", 128)
+    assert v is None and "resunit_emul_kernel" in why
+    assert bench.lookup_traffic(None, "fp32", 128) == (None, "no traffic table")

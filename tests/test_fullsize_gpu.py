@@ -66,13 +66,19 @@ def stack_emul(cuda, lib):
     return _make_stack(cuda, "fp32_bf16x3")
 
 
-@pytest.mark.parametrize("prec", ["fp16", "fp32", "fp32_split", "fp32_bf16x3"])
+@pytest.fixture(scope="module")
+def stack_emul6(cuda, lib):
+    """fp32_bf16x3_6p: six MFMA products, one accumulator; its k = 1 convs pick their tile by launch size (csrc/conv1d_emul.hip), which must not change a bit."""
+    return _make_stack(cuda, "fp32_bf16x3_6p")
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"])
 @pytest.mark.parametrize("ragged", [False, True], ids=["64x128", "64xU(64..128)"])
-def test_full_batch_properties(cuda, stack, stack32, stack_split, stack_emul, ragged, prec):
+def test_full_batch_properties(cuda, stack, stack32, stack_split, stack_emul, stack_emul6, ragged, prec):
     """fp32 = the arithmetic bench.py's headline measures (register-streamed f32 convs, f32 fused units): determinism, utterance
     independence and permutation equivariance hold bit for bit there too."""
     from jatts_amd.synthetic import synth_texts
-    stack = {"fp32": stack32, "fp32_split": stack_split, "fp32_bf16x3": stack_emul, "fp16": stack}[prec]
+    stack = {"fp32": stack32, "fp32_split": stack_split, "fp32_bf16x3": stack_emul, "fp32_bf16x3_6p": stack_emul6, "fp16": stack}[prec]
     texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
     if ragged:
         g = torch.Generator().manual_seed(5)
