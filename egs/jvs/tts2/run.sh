@@ -40,7 +40,8 @@ expdir=""      # exp/<expname>; derived from conf / tag like the reference when 
 # decoding related setting
 outdir=
 checkpoint=""  # checkpoint path to be used for decoding; if not provided, the latest one will be used
-precision=fp32        # fp32 = the reference's arithmetic; fp32_split = f32 tensors + split-precision MFMA operands (2.5x, same error); fp16 = fast mode
+precision=fp32        # fp32 = the reference's arithmetic; fp32_bf16x3 = f32 tensors, f32-equivalent emulated MFMA operands (1.35x; fp32_bf16x3_6p: 1.5x);
+                      # fp32_split = f32 tensors + split-precision MFMA operands (2.5x); fp16 = fast mode
 decode_batch_size=64  # utterances per ragged batch
 master_port=29517
 
