@@ -24,6 +24,8 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   const bool small_k1 = d.k_w == 1 && ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128) <= 768;
   if (variant == 4 || (variant == 0 && d.k_w == 1 && (TWO || small_k1))) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);
   if (variant == 5) return launch_conv_emul<T, 1, 2, 2, 2, 1, 64, 2, 32, 4>(d, s);    // 64 n x 128 t, four waves of 1 x 2 fragments, two workgroups per CU
+  // (measured and dropped: 256 n x 64 t and 256 n x 128 t eight-wave tiles -- more output channels per staged tile -- were 5-25 % slower on most shapes and
+  //  +3-12 % only on 512 -> 2048 / 2048 -> 512 k1 in the six-product mode; profiles/r05_notes.md)
   if (variant == 2 || (TWO && variant != 3)) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4>(d, s);    // 8 waves, 64-channel chunks, one workgroup per CU
   if constexpr (TWO) return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 1>(d, s);          // (variant 3) four waves, one workgroup per CU
   else return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 2>(d, s);                        // 128 n x 128 t, two workgroups per CU
