@@ -150,3 +150,33 @@ def test_split_weight_packing_is_an_exact_scaled_hi_lo_pair():
         assert abs(hi + lo - ws) <= max(amax, 1.0) * 2.0 ** -22, (nn, tap, cc, hi, lo, ws)
         assert hi == float(torch.tensor(ws).half())                                            # hi = f16(ws), round to nearest
     assert math.isfinite(float(packed.float().abs().max())) and float(packed.float().abs().max()) < 65504.0
+
+
+def test_bf16x3_weight_packing_is_exact():
+    """hip.bf16x3_terms / hip.pack_conv_weight_bf16x3 (the JATTS_F32E / JATTS_F32E6 operand, CPU-checkable: pure torch): b0 + b1 + b2 == w EXACTLY
+    for every f32 in 2^-110 <= |w| < 3.39e38 (no scale anywhere), |b1| <= 2^-8 |w|, |b2| <= 2^-16 |w| (what bounds the dropped partial products),
+    zeros stay zeros, and elements sit where jatts_conv_weight_index says with the three planes of a lane side by side."""
+    import torch
+
+    from jatts_amd import hip
+    g = torch.Generator().manual_seed(4)
+    n, c, k = 40, 64, 3
+    w = torch.randn(n, c, k, generator=g) * torch.pow(10.0, torch.rand(n, c, k, generator=g) * 60 - 30)    # 60 decades, element by element
+    w[7] = 0.0
+    b0, b1, b2 = hip.bf16x3_terms(w)
+    assert torch.equal((b0.double() + b1.double() + b2.double()).float(), w)
+    nz = w != 0
+    assert float((b1.float().abs()[nz] / w.abs()[nz]).max()) <= 2.0 ** -8 and float((b2.float().abs()[nz] / w.abs()[nz]).max()) <= 2.0 ** -16
+    m = torch.arange(1 << 23, 1 << 24, 4099, dtype=torch.int32).float() * 2.0 ** -23              # a comb of mantissas in one binade
+    t0, t1, t2 = hip.bf16x3_terms(-m)
+    assert torch.equal((t0.double() + t1.double() + t2.double()).float(), -m)
+    packed = hip.pack_conv_weight_bf16x3(w, 64)
+    n_pad = 64
+    assert packed.dtype == torch.bfloat16 and packed.numel() == 3 * n_pad * c * k
+    pk = packed.view(-1, 3, 8).double()             # [fragment lane slot][b0 | b1 | b2][8]
+    for (nn, tap, cc) in [(0, 0, 0), (5, 2, 17), (39, 1, 63), (7, 0, 3), (33, 2, 40), (63, 1, 9)]:
+        idx = ((tap * (c // 16) + cc // 16) * (n_pad // 32) + nn // 32) * 64 + 32 * ((cc % 16) // 8) + nn % 32
+        want = float(w[nn, cc, tap]) if nn < n else 0.0
+        assert float(pk[idx, :, cc % 8].sum()) == want, (nn, tap, cc)
+        if nn < n:
+            assert float(pk[idx, 0, cc % 8]) == float(torch.tensor(want).bfloat16())            # b0 = bf16(w), round to nearest even
