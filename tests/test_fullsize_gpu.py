@@ -132,6 +132,30 @@ def test_zero_length_sequences_are_skipped(cuda, lib):
     assert torch.equal(a1, a2) and torch.isfinite(a1).all()
 
 
+@pytest.mark.parametrize("mode", ["F32", "F32E", "F32E6"])
+def test_zero_and_one_row_sequences_f32_and_emulated(cuda, lib, mode):
+    """Empty sequences and one-row sequences in the exact-f32 and emulated unit / conv kernels (1-D ragged grids: a zero-length sequence owns no
+    tile; a one-row sequence is all halo): finite, identical to the batch without the empty ones."""
+    from jatts_amd import hip
+    dt = getattr(hip, mode)
+    pack = (lambda w, cm: hip.pack_conv_weight_bf16x3(w, cm)) if dt in hip.EMUL else (lambda w, cm: hip.pack_conv_weight(w, hip.F32, cm))
+    g = torch.Generator().manual_seed(1)
+    lens, C = [0, 1, 37, 0, 1, 130, 0], 128
+    R = sum(lens)
+    rb, rb2 = hip.RaggedBatch(lens, cuda), hip.RaggedBatch([1, 37, 1, 130], cuda)
+    x = (torch.randn(R, C, generator=g) * 0.3).to(cuda)
+    w = [pack((torch.randn(C, C, 7, generator=g) / (7 * C) ** 0.5).to(cuda), 32) for _ in range(2)]
+    b = torch.randn(C, generator=g).to(cuda) * 0.1
+    y, y2 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    hip.hifigan_resunit(rb, 1, x, y, w[0], b, w[1], b, C, 7, 3, 0.1, dt)
+    hip.hifigan_resunit(rb2, 1, x, y2, w[0], b, w[1], b, C, 7, 3, 0.1, dt)
+    assert torch.isfinite(y).all() and torch.equal(y, y2)
+    wc = pack((torch.randn(192, C, 3, generator=g) / (3 * C) ** 0.5).to(cuda), 64)
+    o1 = hip.conv1d(rb, x, wc, C, 192, 3, dtype=dt, bias=torch.zeros(192, device=cuda))
+    o2 = hip.conv1d(rb2, x, wc, C, 192, 3, dtype=dt, bias=torch.zeros(192, device=cuda))
+    assert torch.isfinite(o1).all() and torch.equal(o1, o2)
+
+
 def test_two_stream_pipeline_is_bit_identical(cuda, stack):
     """jatts_amd.pipeline.Stage4Pipeline (text2mel of batch k+1 overlapping the vocoder of batch k) == sequential loop."""
     from jatts_amd.pipeline import Stage4Pipeline
