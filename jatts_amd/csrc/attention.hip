@@ -45,6 +45,12 @@ __device__ __forceinline__ typename G<T>::vec8 load8_buf(__amdgpu_buffer_rsrc_t 
   }
   return v;
 }
+// one element through the descriptor (V^T rows whose first column is not 16-byte aligned)
+template <typename TG>
+__device__ __forceinline__ TG load1_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(TG) == 2) return __builtin_bit_cast(TG, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+  else return __builtin_bit_cast(TG, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
 // LDS fragment read: 8 contraction elements of arithmetic T at `p` (f16s: one planar unit, 16 B of hi then 16 B of lo)
 template <typename T>
 __device__ __forceinline__ typename Elem<T>::vec8 lds8(const char* p) {
@@ -77,6 +83,12 @@ __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((uns
 
 #ifndef JATTS_ATTN_HALFPF
 #define JATTS_ATTN_HALFPF 1
+#endif
+#ifndef JATTS_ATTN_PIPE
+#define JATTS_ATTN_PIPE 3
+#endif
+#ifndef JATTS_ATTN_DIAG
+#define JATTS_ATTN_DIAG 0   // timing probes only (wrong results): 1 = no softmax arithmetic, 2 = no barriers in the key loop, 4 = no tile loads / stores in it
 #endif
 constexpr int KB = 64;  // keys per tile
 
@@ -115,7 +127,9 @@ struct TileRegs {
 };
 
 // WHICH: 1 = the K tile (+ the u . k bias of its keys), 2 = the V^T tile, 3 = both
-template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true>      // KU = false: no u . k bias (bias-free attention: REL = false)
+// LATE_MASK: the columns of a V^T chunk past the sequence are zeroed by tile_store, not here -- anything that touches a loaded register
+// before the store lets the scheduler pull it (and an `s_waitcnt vmcnt`) up into the MFMA loop the load is meant to hide behind.
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true, bool LATE_MASK = false>   // KU = false: no u . k bias (bias-free attention: REL = false)
 __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
                                           const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec,
                                           __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv) {
@@ -138,19 +152,18 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const ja
     }
     if constexpr (WHICH & 2) {  // V^T rows: channels, 8 keys per chunk
       const int r = u / (KBT / 8), jc = j0 + 8 * (u % (KBT / 8));
+      const unsigned voff = (unsigned)(r * d.ldvt + 8 * (u % (KBT / 8))) * (unsigned)sizeof(TG), soff = (unsigned)j0 * (unsigned)sizeof(TG);
       Vec z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = from_f32<TG>(0.f);
-      const TG* src = vtg + (int64_t)r * d.ldvt + jc;
       if (vt_vec) {   // aligned: (row0 + j0) % 8 == 0, ldvt % 8 == 0; chunks at or past round_up(Tn, 8) lie past the descriptor
-        z = load8_buf<T>(rv, (unsigned)(r * d.ldvt + 8 * (u % (KBT / 8))) * (unsigned)sizeof(TG), (unsigned)j0 * (unsigned)sizeof(TG));
+        z = load8_buf<T>(rv, voff, soff);
+      } else {        // element-aligned only: one load per element through the same descriptor (cut at Tn columns of the last row then)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = load1_buf<TG>(rv, voff + (unsigned)(e * sizeof(TG)), soff);
+      }
+      if constexpr (!LATE_MASK) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (jc + e < 0 || jc + e >= Tn) z[e] = from_f32<TG>(0.f);   // never multiply P = 0 by stray bits
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (jc + e >= 0 && jc + e < Tn) z[e] = src[e];
       }
       tr.v[i] = z;
     }
@@ -159,14 +172,24 @@ __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const ja
 
 template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true>
 __device__ __forceinline__ void tile_store(const TileRegs<T, DK, KBT, NW>& tr, char* ks, char* vs, float* kus, int KP, int VP, float sk = 1.f,
-                                           float sv = 1.f) {
+                                           float sv = 1.f, int mask_from = -1) {    // mask_from >= 0 (LATE_MASK loads): zero the tile's columns >= mask_from
   constexpr int UPR = DK / 8;
+  typedef typename G<T>::type TG;
 #pragma unroll
   for (int i = 0; i < TileRegs<T, DK, KBT, NW>::N; ++i) {
     const int u = threadIdx.x + 64 * NW * i;
     const int r = u / UPR, cu = u - r * UPR;
     if constexpr (WHICH & 1) store8<T>(ks + (size_t)r * KP + (size_t)cu * 8 * sizeof(T), tr.k[i], sk);
-    if constexpr (WHICH & 2) store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), tr.v[i], sv);
+    if constexpr (WHICH & 2) {
+      typename G<T>::vec8 z = tr.v[i];
+      if (mask_from >= 0) {
+        const int c0 = 8 * (u % (KBT / 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e >= mask_from) z[e] = from_f32<TG>(0.f);
+      }
+      store8<T>(vs + (size_t)(u / (KBT / 8)) * VP + (size_t)(u % (KBT / 8)) * 8 * sizeof(T), z, sv);
+    }
   }
   if constexpr ((WHICH & 1) && KU) {
     if (threadIdx.x < KBT) kus[threadIdx.x] = tr.ku;
@@ -197,10 +220,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   float* kus = reinterpret_cast<float*>(smem + KBT * KP + DK * VP);
   float* slots = kus + KBT;                // split arithmetic: per-wave block maxima [4 waves][K | V] (+ Q at start)
 
-  const int b = blockIdx.y, h = blockIdx.z;
+  // XCD-aware order of the 1-D grid (launch_attn_kb): the dispatcher places workgroup id on XCD id % 8, each with its own L2; in the natural
+  // (query block, sequence, head) order the query blocks of one (sequence, head) land on all eight and each XCD pulls that head's K and V^T
+  // through its own L2 misses (T = 768, d_k 256: 1.6 GB from the fabric per launch for 200 MB of K / V, and the tile loads -- not the MFMAs --
+  // set the pace: 730 us against 510 us with the loads compiled out).  XCD x takes the contiguous range [x * per, (x + 1) * per) of
+  // (head, sequence, query block) triples, query block fastest: one head's query blocks run side by side on one XCD and share its tiles.
+  const int gx = (d.rg.max_len + 16 * NW - 1) / (16 * NW);
+  const int total = gx * d.rg.n_seq * d.n_heads, per = (total + 7) >> 3;
+  const int wg = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if (wg >= total) return;
+  const int bh = wg / gx;
+  const int h = bh / d.rg.n_seq, b = bh - h * d.rg.n_seq;
   const int row0 = d.rg.cu_rows[b];
   const int Tn = d.rg.cu_rows[b + 1] - row0;
-  const int i0 = blockIdx.x * (16 * NW);
+  const int i0 = (wg - bh * gx) * (16 * NW);
   if (i0 >= Tn) return;
   // keys >= Tk are masked out of the softmax (a PADDED batch, the reference's training-time forward(): Tn is then the padded
   // length, which the rel-shift geometry keeps using, and Tk the utterance's own length; attention.py:80-88)
@@ -220,10 +253,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   const bool vt_vec = (d.ldvt & 7) == 0 && (vcol0 & 7) == 0 && (reinterpret_cast<uintptr_t>(d.vt) & 31) == 0;
   constexpr int j_start = 0;
   // buffer descriptors of this (utterance, head)'s K rows and V^T rows (tile_load): K = Tn rows of ldk elements from kg; V^T = d_k rows
-  // of ldvt elements from vtg, the last one cut at round_up(Tn, 8) columns
+  // of ldvt elements from vtg, the last one cut at round_up(Tn, 8) columns (aligned rows: whole 16-byte chunks) or at Tn (element loads)
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, (unsigned)((int64_t)Tn * d.ldk * sizeof(TG)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv =
-      __builtin_amdgcn_make_buffer_rsrc((void*)vtg, 0, (unsigned)(((int64_t)(DK - 1) * d.ldvt + ((Tn + 7) & ~7)) * sizeof(TG)), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)vtg, 0, (unsigned)(((int64_t)(DK - 1) * d.ldvt + (vt_vec ? ((Tn + 7) & ~7) : Tn)) * sizeof(TG)), 0x00020000);
 
   Vec qf[NKS];
   int eq = 0;                               // split arithmetic: Q lives at scale 2^eq (one scale per workgroup = 64 queries of one head)
@@ -270,6 +303,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   // MFMA phase, the same two barriers per tile, 32 staging registers instead of 64 (f32 d_k 256 at two workgroups per CU waited on
   // every tile before: matrix pipe 54 % busy).
   constexpr bool HALFPF = JATTS_ATTN_HALFPF && !PREFETCH && !SPLIT && sizeof(T) == 4;   // (f16 d_k 256 keeps its 64-key tiles: the half pipeline spilled 80 bytes there)
+  // PIPE_S / PIPE_V (exact f32, half-tile pipeline): the compiler issues each MFMA group's ds_read_b128 right in front of it (read, wait, 4 MFMA) and
+  // the LDS round trip shows in every group; reading fragment i + 1 before fragment i's MFMAs, pinned with sched_barrier, takes 8 registers.
+  constexpr bool PIPE_S = (JATTS_ATTN_PIPE & 1) && HALFPF, PIPE_V = (JATTS_ATTN_PIPE & 2) && HALFPF;
+  constexpr int DIAG = HALFPF ? JATTS_ATTN_DIAG : 0;
   TileRegs<T, DK, KBT, NW> tr;
   if (PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
   if constexpr (HALFPF) {
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   }
   int ev_prev = 0;
   for (int j0 = j_start; j0 < Tk; j0 += KBT) {
-    if constexpr (HALFPF) tile_load<T, DK, KBT, 2, NW, REL>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
+    if constexpr (HALFPF) { if (!(DIAG & 4)) tile_load<T, DK, KBT, 2, NW, REL, true>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv); }
     else if (!PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
     int ek = 0, ev = 0;
     if constexpr (HALFPF) {
@@ -344,16 +381,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
     f32x4 st[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) st[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PIPE_S) {           // fragment i + 1 is read while fragment i's MFMAs issue (see PIPE_S above)
+      auto kfrag = [&](int i) { return lds8<T>(ks + (size_t)(16 * (i % NF) + qc) * KP + (size_t)(32 * (i / NF) + 8 * g) * sizeof(T)); };
+      Vec a0 = kfrag(0);
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {   // NF independent accumulator chains per contraction step
+      for (int i = 0; i < NKS * NF; ++i) {
+        Vec a1 = a0;
+        if (i + 1 < NKS * NF) a1 = kfrag(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(a0, qf[i / NF], st[i % NF]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a1;
+      }
+    } else {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const Vec a = lds8<T>(ks + (size_t)(16 * f + qc) * KP + (size_t)(32 * s + 8 * g) * sizeof(T));
-        mma16(a, qf[s], st[f]);
+      for (int s = 0; s < NKS; ++s) {   // NF independent accumulator chains per contraction step
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const Vec a = lds8<T>(ks + (size_t)(16 * f + qc) * KP + (size_t)(32 * s + 8 * g) * sizeof(T));
+          mma16(a, qf[s], st[f]);
+        }
       }
     }
     // ---- bias terms, scale, mask, online softmax ----
     float mx = -INFINITY;
+    if constexpr (!(DIAG & 1)) {
     const float inv_qk = SPLIT ? attn_exp2i(-(eq + ek)) : 1.f;     // exact un-scale of q . k
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -362,7 +414,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * f + 4 * g + r;
-        float s = (j >= 0 && j < Tk) ? ((SPLIT ? st[f][r] * inv_qk : st[f][r]) + kq[r] + bd[f][r]) * d.scale : -INFINITY;
+        float sv = SPLIT ? st[f][r] * inv_qk : st[f][r];
+        if constexpr (REL) sv = sv + kq[r] + bd[f][r];      // (x + 0 is not a no-op the compiler may drop: -0)
+        float s = (j >= 0 && j < Tk) ? sv * d.scale : -INFINITY;
         st[f][r] = s;
         mx = fmaxf(mx, s);
       }
@@ -390,11 +444,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
     for (int f = 0; f < NDF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ot[f][r] *= oscale;
+    }
 
     if constexpr (HALFPF) {
-      tile_store<T, DK, KBT, 2, NW, REL>(tr, ks, vs, kus, KP, VP);
-      __syncthreads();            // V^T(t) visible; every wave is past its score MFMAs and its u . k reads: the K buffer is free
-      if (j0 + KBT < Tk) tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
+      __builtin_amdgcn_sched_barrier(0);   // nothing of the store (its waits on the loads) moves up into the score MFMAs
+      if (!(DIAG & 4)) tile_store<T, DK, KBT, 2, NW, REL>(tr, ks, vs, kus, KP, VP, 1.f, 1.f, j0 + KBT > Tn ? Tn - j0 : -1);
+      if (!(DIAG & 2)) __syncthreads();            // V^T(t) visible; every wave is past its score MFMAs and its u . k reads: the K buffer is free
+      if (!(DIAG & 4) && j0 + KBT < Tk) tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);
     }
     // ---- O^T += V^T P^T over two 32-key blocks.  Contraction slots of k-group g in block kb:
     //      keys {32kb + 4g + r} (from st[2kb]) then {32kb + 16 + 4g + r} (from st[2kb+1]) ----
@@ -413,6 +469,25 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
           pb[4 + r] = from_f32<T>(st[2 * kb + 1][r]);
         }
       }
+      if constexpr (PIPE_V) {
+        auto vfrag = [&](int f) {
+          const T* vr = reinterpret_cast<const T*>(vs + (size_t)(16 * f + qc) * VP) + 32 * kb + 4 * g;
+          Vec a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] = vr[r]; a[4 + r] = vr[16 + r]; }
+          return a;
+        };
+        Vec a0 = vfrag(0);
+#pragma unroll
+        for (int f = 0; f < NDF; ++f) {
+          Vec a1 = a0;
+          if (f + 1 < NDF) a1 = vfrag(f + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma16(a0, pb, ot[f]);
+          __builtin_amdgcn_sched_barrier(0);
+          a0 = a1;
+        }
+      } else
 #pragma unroll
       for (int f = 0; f < NDF; ++f) {
         Vec a;
@@ -434,9 +509,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       }
     }
     if constexpr (HALFPF) {
-      if (j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
+      __builtin_amdgcn_sched_barrier(0);   // (the same for K(t + 1) and the P V MFMAs)
+      if (!(DIAG & 4) && j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
     }
-    __syncthreads();
+    if (!(DIAG & 2) || !HALFPF) __syncthreads();
   }
 
   l_run += __shfl_xor(l_run, 16);
@@ -454,7 +530,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
 template <typename T, int DK, int KBT = KB, bool REL = true, int NW = 4>
 int launch_attn_kb(const jatts_relattn_desc& d, hipStream_t s) {
   const size_t lds = (size_t)KBT * (DK * sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) + (size_t)DK * (KBT * sizeof(T) + 16) + KBT * sizeof(float) + 64;
-  dim3 grid((unsigned)((d.rg.max_len + 16 * NW - 1) / (16 * NW)), (unsigned)d.rg.n_seq, (unsigned)d.n_heads);
+  const int64_t total = (int64_t)((d.rg.max_len + 16 * NW - 1) / (16 * NW)) * d.rg.n_seq * d.n_heads;
+  if (total >= ((int64_t)1 << 31) - 8) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "relpos_attention: more than 2^31 query blocks (split the batch)");
+  dim3 grid((unsigned)(8 * ((total + 7) / 8)));    // 1-D, decoded in XCD-aware order by the kernel
   auto kern = relattn_kernel<T, DK, KBT, REL, NW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
