@@ -87,6 +87,9 @@ __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((uns
 #ifndef JATTS_ATTN_PIPE
 #define JATTS_ATTN_PIPE 3
 #endif
+#ifndef JATTS_ATTN_PIPE_PF
+#define JATTS_ATTN_PIPE_PF 1
+#endif
 #ifndef JATTS_ATTN_DIAG
 #define JATTS_ATTN_DIAG 0   // timing probes only (wrong results): 1 = no softmax arithmetic, 2 = no barriers in the key loop, 4 = no tile loads / stores in it
 #endif
@@ -129,7 +132,7 @@ struct TileRegs {
 // WHICH: 1 = the K tile (+ the u . k bias of its keys), 2 = the V^T tile, 3 = both
 // LATE_MASK: the columns of a V^T chunk past the sequence are zeroed by tile_store, not here -- anything that touches a loaded register
 // before the store lets the scheduler pull it (and an `s_waitcnt vmcnt`) up into the MFMA loop the load is meant to hide behind.
-template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true, bool LATE_MASK = false>   // KU = false: no u . k bias (bias-free attention: REL = false)
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true, bool LATE_MASK = !G<T>::split>   // (the split arithmetic takes block maxima of the registers: masked at load)  KU = false: no u . k bias (bias-free attention: REL = false)
 __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
                                           const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec,
                                           __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv) {
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   constexpr bool HALFPF = JATTS_ATTN_HALFPF && !PREFETCH && !SPLIT && sizeof(T) == 4;   // (f16 d_k 256 keeps its 64-key tiles: the half pipeline spilled 80 bytes there)
   // PIPE_S / PIPE_V (exact f32, half-tile pipeline): the compiler issues each MFMA group's ds_read_b128 right in front of it (read, wait, 4 MFMA) and
   // the LDS round trip shows in every group; reading fragment i + 1 before fragment i's MFMAs, pinned with sched_barrier, takes 8 registers.
-  constexpr bool PIPE_S = (JATTS_ATTN_PIPE & 1) && HALFPF, PIPE_V = (JATTS_ATTN_PIPE & 2) && HALFPF;
+  constexpr bool PIPE_OK = HALFPF || (JATTS_ATTN_PIPE_PF && sizeof(T) == 4 && !SPLIT && KBT == 32 && NW == 4);
+  constexpr bool PIPE_S = (JATTS_ATTN_PIPE & 1) && PIPE_OK, PIPE_V = (JATTS_ATTN_PIPE & 2) && PIPE_OK;
   constexpr int DIAG = HALFPF ? JATTS_ATTN_DIAG : 0;
   TileRegs<T, DK, KBT, NW> tr;
   if (PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
@@ -337,9 +341,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       for (int w = 1; w < NW; ++w) { sk = fmaxf(sk, slots[2 * w]); sv = fmaxf(sv, slots[2 * w + 1]); }
       ek = attn_split_exp(sk);
       ev = attn_split_exp(sv);
-      tile_store<T, DK, KBT, 3, NW, REL>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev));
+      tile_store<T, DK, KBT, 3, NW, REL>(tr, ks, vs, kus, KP, VP, attn_exp2i(ek), attn_exp2i(ev), j0 + KBT > Tn ? Tn - j0 : -1);
     } else {
-      tile_store<T, DK, KBT, 3, NW, REL>(tr, ks, vs, kus, KP, VP);
+      tile_store<T, DK, KBT, 3, NW, REL>(tr, ks, vs, kus, KP, VP, 1.f, 1.f, j0 + KBT > Tn ? Tn - j0 : -1);
     }
     if constexpr (!HALFPF) __syncthreads();
     if (PREFETCH && j0 + KBT < Tk) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j0 + KBT, Tn, vt_vec, rk, rv);

@@ -554,6 +554,38 @@ def test_relpos_attention(cuda, lib, prec, pad_vt, H, dk, lens, rel):
             assert torch.equal(o0, out[:T0])
 
 
+@pytest.mark.parametrize("pad_vt", [False, True])
+@pytest.mark.parametrize("lens", [[300, 77, 130], [64, 1, 33, 768], [31]])
+def test_relpos_attention_bias_free_dk256(cuda, lib, pad_vt, lens):
+    """Matcha's plain attention (no rel-pos bias, no u . k term): the exact-f32 d_k 256 instantiation with the half-tile pipeline, the
+    pipelined LDS fragment reads and the store-time V^T mask -- partial last tiles, one-row sequences, both V^T alignments, NaN in every
+    slack column, against float64 softmax attention."""
+    from jatts_amd import hip
+    H, dk = 2, 256
+    g = torch.Generator().manual_seed(len(lens) + sum(lens))
+    A, R = H * dk, sum(lens)
+    q, k, v = (torch.randn(R, A, generator=g) for _ in range(3))
+    scale = 1.0 / math.sqrt(dk)
+    outs, o = [], 0
+    for T in lens:
+        qs, ks, vs = (t[o:o + T].view(T, H, dk).transpose(0, 1).double() for t in (q, k, v))
+        outs.append((torch.softmax(qs @ ks.transpose(1, 2) * scale, -1) @ vs).transpose(0, 1).reshape(T, A))
+        o += T
+    ref = torch.cat(outs)
+    rb = _ragged(lens, cuda)
+    vcol, ldvt = rb.vt_layout() if pad_vt else (None, R)
+    vt = torch.full((A, ldvt), float("nan"), device=cuda)
+    o = 0
+    for b, T in enumerate(lens):
+        c0 = int(vcol[b]) if pad_vt else o
+        vt[:, c0:c0 + T] = v[o:o + T].t().to(cuda)
+        o += T
+    out = hip.relpos_attention(rb, q.to(cuda), A, k.to(cuda), A, vt, ldvt, None, 0, None, scale, H, dk, hip.F32, vt_col0=vcol)
+    assert torch.isfinite(out).all()
+    e = relerr(out, ref)
+    assert e <= 5e-6, f"bias-free d_k 256 attention: rel err {e:.3e}"
+
+
 def test_relpos_attention_refuses_offsets_beyond_32_bits(cuda, lib):
     """The tile loads use 32-bit buffer offsets per (utterance, head): a V^T row stride that would overflow them is refused loudly
     (JATTS_ERR_UNSUPPORTED) before any memory is touched."""
