@@ -9,6 +9,9 @@
 // the other feeds the matrix pipe; a chunk is k_w x 2 K-steps x 7 (6) NF NT MFMAs, 56 (48) MFMAs per wave between barriers at k = 1.
 #pragma once
 #include "conv1d_impl.h"
+#ifndef JATTS_CEMUL_DIAG
+#define JATTS_CEMUL_DIAG 0   // timing probes only (wrong results): 1 = no split arithmetic in the commit, 2 = no activation loads in the chunk loop, 4 = no barriers in it
+#endif
 
 namespace {
 
@@ -34,7 +37,11 @@ __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, cha
         if (pre_act == JATTS_PRE_LRELU) t = fmaxf(t, t * slope);     // 0 <= slope <= 1
       }
       bf16 a, b, c;
+#if JATTS_CEMUL_DIAG & 1
+      a = b = c = __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(t) >> 16));
+#else
       bf3_split(t, a, b, c);
+#endif
       o.b0[e] = a; o.b1[e] = b; o.b2[e] = c;
     }
     Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
@@ -106,11 +113,12 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
   __syncthreads();
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
-    if (more) stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
+    if (more && !(JATTS_CEMUL_DIAG & 2)) stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
     conv_stage<T, NF, NT, RD>(accx, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
     if (more) emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
-    __syncthreads();
+    if (!(JATTS_CEMUL_DIAG & 4)) __syncthreads();
   }
+  if (JATTS_CEMUL_DIAG & 4) __syncthreads();
 
   // close the accumulators (seven products: one correctly rounded add per element): from here on the ordinary f32 epilogues of conv1d_impl.h
   f32x16 acc[NF][NT];

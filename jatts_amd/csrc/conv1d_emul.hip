@@ -22,7 +22,11 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   //  4 096 / 8 192 rows.  Nothing in this arithmetic depends on the tile, so the choice may follow the launch.)
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   const bool small_k1 = d.k_w == 1 && ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128) <= 768;
-  if (variant == 4 || (variant == 0 && d.k_w == 1 && (TWO || small_k1))) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);
+  // The same 128 n x 64 t tile as four waves of 1 x 2 fragments SIDE BY SIDE IN n (each wave 32 n x 64 t): half the weight fragments fetched per
+  // MFMA (a 2 x 1 wave pulls 6 KB of weights per 14 MFMAs through the vector memory path, eight waves ~110 B / clk / CU): another +4-9 % on every
+  // k = 1 shape, +20 % at 4 096 rows (profiles/r05_notes.md); 64 n x 128 t (variant 5) stages twice the activations per MFMA and loses 30 %.
+  if (variant == 6 || (variant == 0 && d.k_w == 1 && (TWO || small_k1))) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4>(d, s);
+  if (variant == 4) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);    // (2 x 1 fragments per wave, 2 x 2 waves: the first k = 1 tile)
   if (variant == 5) return launch_conv_emul<T, 1, 2, 2, 2, 1, 64, 2, 32, 4>(d, s);    // 64 n x 128 t, four waves of 1 x 2 fragments, two workgroups per CU
   // (measured and dropped: 256 n x 64 t and 256 n x 128 t eight-wave tiles -- more output channels per staged tile -- were 5-25 % slower on most shapes and
   //  +3-12 % only on 512 -> 2048 / 2048 -> 512 k1 in the six-product mode; profiles/r05_notes.md)
