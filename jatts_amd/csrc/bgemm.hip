@@ -7,11 +7,14 @@
 // One workgroup = 4 waves = a 128 x 128 (or 128 x 64) tile of C (each wave 64 x 64 = 2 x 2 fragments, or 64 x 32); K runs in chunks of 32
 // through a double-buffered LDS pair As[k][m], Bs[k][n] (pitch 132: the transposing store of a K-contiguous operand hits 64 distinct
 // banks); the loads of chunk i + 1 are issued before the MFMAs of chunk i.  A fragment operand is one ds_read_b32 per lane and K-pair.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BP = BM + 4;   // LDS pitch of the A tile in floats.  BN = 64 / 128 / 192 and the chunk depth BK are template parameters
+// Tile rows BM = 64 MF (MF = 32-row fragments per wave along m: 2 -> 128 rows, 1 -> 64), LDS pitch of the A tile BP = BM + 4 floats; BN = 64 / 128 / 192 and
+// the chunk depth BK are template parameters too
 
 struct BgemmArgs {
   const float* a;
@@ -61,33 +64,42 @@ struct Chunk {                                               // run-time flag ma
         for (int e = 0; e < 4; ++e) v[j][e] = at[j] + e < lim[j] ? v[j][e] : 0.f;
       return;
     }
+    // element loads (a matrix that starts off a 16-byte boundary or ld % 4 != 0: a padded batch length T with T % 4 != 0 puts P v and its
+    // gradients here): the same discipline -- every load unconditional from a clamped address, masks afterwards.  (The first version loaded
+    // inside per-element branches: one exec-masked load and one L2 round trip per element.)
+    // Element (j, e) of a thread is element tid + 256 (4 j + e) of the chunk counted along the CONTIGUOUS dimension first, so one wave
+    // instruction reads 64 consecutive floats of a row (or 64 / BK rows of BK): the 4-consecutive-elements-per-lane map of the 16-byte
+    // path would touch four times the cache lines per instruction here.
+    bool ok[NL][4];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int u = (int)threadIdx.x + 256 * j;
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      if (TOTAL % 256 != 0 && u >= TOTAL) { v[j] = o; continue; }
-      if (k_contig) {
-        const int r = r0 + u / (BK / 4), k = k0 + 4 * (u % (BK / 4));
-        if (r < R) {
-          const float* p = base + (int64_t)r * ld + k;
+    for (int j = 0; j < NL; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < K) o[e] = p[e];
-        }
-      } else {
-        const int k = k0 + u / (RW / 4), r = r0 + 4 * (u % (RW / 4));
-        if (k < K) {
-          const float* p = base + (int64_t)k * ld + r;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (r + e < R) o[e] = p[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int idx = (int)threadIdx.x + 256 * (4 * j + e);
+        const int re = r0 + (k_contig ? idx / BK : idx % RW), ke = k0 + (k_contig ? idx % BK : idx / RW);
+        ok[j][e] = (RW * BK % 1024 == 0 || idx < RW * BK) && re < R && ke < K;
+        const int rc = re < R ? re : R - 1, kc = ke < K ? ke : K - 1;
+        v[j][e] = base[k_contig ? (int64_t)rc * ld + kc : (int64_t)kc * ld + rc];
       }
-      v[j] = o;
-    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] = ok[j][e] ? v[j][e] : 0.f;
   }
   __device__ __forceinline__ void store(float* s) const {
     constexpr bool k_contig = KC;
+    if constexpr (!VEC) {      // (the element map of load(): consecutive lanes = consecutive k at pitch 132 = 64 distinct banks, or consecutive r)
+#pragma unroll
+      for (int j = 0; j < NL; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = (int)threadIdx.x + 256 * (4 * j + e);
+          if (RW * BK % 1024 != 0 && idx >= RW * BK) continue;
+          const int r = k_contig ? idx / BK : idx % RW, k = k_contig ? idx % BK : idx / RW;
+          s[k * PITCH + r] = v[j][e];
+        }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int u = (int)threadIdx.x + 256 * j;
@@ -109,9 +121,11 @@ struct Chunk {                                               // run-time flag ma
 // 1-D grid in XCD-aware order: workgroup id lands on XCD id % 8 (each with its own L2), so matrix b = 8 (m / tiles) + id % 8 with m = id / 8 --
 // all tiles of a matrix run on ONE XCD, back to back, and its operands are fetched from HBM once instead of once per XCD that happens to
 // hold one of its tiles (the first version, a 3-D grid, ran at 45-65 TFLOP/s against rocBLAS' 100-110).
-template <int WNF, int BK, bool AK, bool BKC, bool VEC>      // AK / BKC: K contiguous in A (trans_a == 0) / in B (trans_b != 0)
+// MF = 1: 64-row tiles for launches whose 128-row tiles would not fill the two-per-CU slots evenly (P v and the key / value gradients at T = 768: 384
+// workgroups of 128 x 192 on 512 slots = half the CUs carrying two and half one; 768 of 64 x 192 = three each)
+template <int WNF, int BK, bool AK, bool BKC, bool VEC, int MF = 2>      // AK / BKC: K contiguous in A (trans_a == 0) / in B (trans_b != 0)
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
-  constexpr int BN = 64 * WNF, BPN = BN + 4;
+  constexpr int BN = 64 * WNF, BPN = BN + 4, BM = 64 * MF, BP = BM + 4;
   extern __shared__ __attribute__((aligned(16))) float sm_raw[];      // [buffer][A: BK x BP | B: BK x BPN]
   constexpr int BUF = BK * (BP + BPN);
   const int xcd = (int)(blockIdx.x & 7u), mloc = (int)(blockIdx.x >> 3);
@@ -124,12 +138,12 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
   float* C = g.c + bo * g.sc_o + bi * g.sc_i;
   const int m0 = (tile / g.gx) * BM, n0 = (tile % g.gx) * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32 * WNF;
+  const int wm = (wave >> 1) * 32 * MF, wn = (wave & 1) * 32 * WNF;
   const int lo = lane & 31, hi = lane >> 5;
 
-  f32x16 acc[2][WNF];
+  f32x16 acc[MF][WNF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
     for (int j = 0; j < WNF; ++j)
 #pragma unroll
@@ -155,11 +169,11 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
     // per chunk (the first version ran at 55-63 TFLOP/s)
 #pragma unroll
     for (int k8 = 0; k8 < BK / 2; k8 += 8) {
-      float av[8][2], bv[8][WNF];
+      float av[8][MF], bv[8][WNF];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        av[q][0] = as[2 * (k8 + q) * BP];
-        av[q][1] = as[2 * (k8 + q) * BP + 32];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) av[q][i] = as[2 * (k8 + q) * BP + 32 * i];
 #pragma unroll
         for (int j = 0; j < WNF; ++j) bv[q][j] = bs[2 * (k8 + q) * BPN + 32 * j];
       }
@@ -168,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
       for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int j = 0; j < WNF; ++j) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], bv[q][j], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], bv[q][j], acc[1][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], bv[q][j], acc[i][j], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
   }
   // C/D map: column (lane & 31) = n, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = m
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MF; ++i)
 #pragma unroll
     for (int j = 0; j < WNF; ++j) {
       const int n = n0 + wn + 32 * j + lo;
@@ -208,13 +222,13 @@ extern "C" int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, i
   BgemmArgs g{a, b, c, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner, lda, ldb, ldc, trans_a, trans_b, n_inner, m, n, k, alpha, accumulate, 0, 0, 0};
   // n tile: 192 in one piece (n = d_k = 192), else 64-wide where a 128-wide tile would be more than a quarter empty
   const int n_batch = n_outer * n_inner;
-  auto launch = [&](auto kern, int bn, int bk) -> int {
-    const int lds = 2 * bk * (BP + bn + 4) * (int)sizeof(float);
+  auto launch = [&](auto kern, int bn, int bk, int bm) -> int {
+    const int lds = 2 * bk * (bm + 4 + bn + 4) * (int)sizeof(float);
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return jatts_set_error_msg(JATTS_ERR_HIP, "bgemm: could not raise the dynamic LDS limit");
     g.n_batch = n_batch;
     g.gx = (n + bn - 1) / bn;
-    g.gy = (m + BM - 1) / BM;
+    g.gy = (m + bm - 1) / bm;
     const int64_t total = (int64_t)8 * ((n_batch + 7) / 8) * g.gx * g.gy;
     if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "bgemm: launch too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, (hipStream_t)stream, g);
@@ -226,18 +240,24 @@ extern "C" int jatts_bgemm(const float* a, int64_t sa_outer, int64_t sa_inner, i
                    ((sa_outer | sa_inner | sb_outer | sb_inner | (int64_t)lda | (int64_t)ldb) & 3) == 0;
   const int tile = (n > 128 && n <= 192) ? 3 : (n64 * 4 <= n128 * 3 ? 1 : 2);
   int rc = JATTS_ERR_UNSUPPORTED;
-#define JATTS_BGEMM_CASE(WNF, BKC_, AKv, BKv, VECv) rc = launch(bgemm_kernel<WNF, BKC_, AKv, BKv, VECv>, 64 * WNF, BKC_)
-#define JATTS_BGEMM_ORIENT(WNF, BKC_, VECv)                                         \
-  do {                                                                              \
-    if (!trans_a && trans_b) JATTS_BGEMM_CASE(WNF, BKC_, true, true, VECv);         \
-    else if (!trans_a && !trans_b) JATTS_BGEMM_CASE(WNF, BKC_, true, false, VECv);  \
-    else if (trans_a && !trans_b) JATTS_BGEMM_CASE(WNF, BKC_, false, false, VECv);  \
-    else JATTS_BGEMM_CASE(WNF, BKC_, false, true, VECv);                            \
+#define JATTS_BGEMM_CASE(WNF, BKC_, AKv, BKv, VECv, MFv) rc = launch(bgemm_kernel<WNF, BKC_, AKv, BKv, VECv, MFv>, 64 * WNF, BKC_, 64 * MFv)
+#define JATTS_BGEMM_ORIENT(WNF, BKC_, VECv, MFv)                                         \
+  do {                                                                                   \
+    if (!trans_a && trans_b) JATTS_BGEMM_CASE(WNF, BKC_, true, true, VECv, MFv);         \
+    else if (!trans_a && !trans_b) JATTS_BGEMM_CASE(WNF, BKC_, true, false, VECv, MFv);  \
+    else if (trans_a && !trans_b) JATTS_BGEMM_CASE(WNF, BKC_, false, false, VECv, MFv);  \
+    else JATTS_BGEMM_CASE(WNF, BKC_, false, true, VECv, MFv);                            \
   } while (0)
-  if (!vec) JATTS_BGEMM_ORIENT(2, 16, false);            // element loads: any alignment (nothing on the training path takes it)
-  else if (tile == 3) JATTS_BGEMM_ORIENT(3, 16, true);
-  else if (tile == 1) JATTS_BGEMM_ORIENT(1, 32, true);
-  else JATTS_BGEMM_ORIENT(2, 32, true);
+  // 64-row tiles when the 128-row tiling leaves fewer than two rounds of the 512 two-per-CU slots (see bgemm_kernel); JATTS_BGEMM_MF = 1 / 2 forces either
+  static const int mf_env = [] { const char* e = getenv("JATTS_BGEMM_MF"); return e ? atoi(e) : 0; }();
+  const int64_t wg128 = (int64_t)n_batch * ((m + 127) / 128) * ((n + 191) / 192);
+  const bool half_m = mf_env ? mf_env == 1 : (m > 64 && wg128 < 1024);
+  if (!vec && tile == 3) JATTS_BGEMM_ORIENT(3, 16, false, 1);     // (n = d_k = 192 in one 64 x 192 tile here too: the T x T operand is read once)
+  else if (!vec) JATTS_BGEMM_ORIENT(2, 16, false, 2);            // element loads: any alignment (a padded batch length T % 4 != 0 takes it for P v and its gradients)
+  else if (tile == 3 && half_m) JATTS_BGEMM_ORIENT(3, 16, true, 1);
+  else if (tile == 3) JATTS_BGEMM_ORIENT(3, 16, true, 2);
+  else if (tile == 1) JATTS_BGEMM_ORIENT(1, 32, true, 2);
+  else JATTS_BGEMM_ORIENT(2, 32, true, 2);
 #undef JATTS_BGEMM_ORIENT
 #undef JATTS_BGEMM_CASE
   if (rc != JATTS_OK) return rc;

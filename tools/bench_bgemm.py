@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """jatts_bgemm against torch.matmul (rocBLAS) on the attention products of the FastSpeech2 training step (batch 32 x 2 heads, T = 768, d_k = 192).
-    python tools/bench_bgemm.py"""
+    python tools/bench_bgemm.py [--T 770]      (T % 4 != 0: the T x T operand takes the element-load path)"""
+import argparse
 import os
 import sys
 
@@ -25,15 +26,17 @@ def t(fn, it=10):
 
 def main():
     dev = torch.device("cuda:0")
-    B, H, T, dk = 32, 2, 768, 192
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--T", type=int, default=768)
+    B, H, T, dk = 32, 2, ap.parse_args().T, 192
     g = torch.Generator().manual_seed(0)
     q = torch.randn(B, H, T, dk, generator=g).to(dev)
     k = torch.randn(B, H, T, dk, generator=g).to(dev)
     p = torch.randn(B, H, T, T, generator=g).to(dev)
-    cases = [("q k^T   (m n k = 768 768 192, NT)", lambda: hip.bgemm(q, k, trans_b=True), lambda: torch.matmul(q, k.transpose(-1, -2)), 2.0 * B * H * T * T * dk),
-             ("P v     (768 192 768, NN)", lambda: hip.bgemm(p, k), lambda: torch.matmul(p, k), 2.0 * B * H * T * T * dk),
-             ("dS^T q  (768 192 768, TN)", lambda: hip.bgemm(p, q, trans_a=True), lambda: torch.matmul(p.transpose(-1, -2), q), 2.0 * B * H * T * T * dk),
-             ("dO v^T  (768 768 192, NT)", lambda: hip.bgemm(q, k, trans_b=True), lambda: torch.matmul(q, k.transpose(-1, -2)), 2.0 * B * H * T * T * dk)]
+    cases = [("q k^T   (T x T x d_k, NT)", lambda: hip.bgemm(q, k, trans_b=True), lambda: torch.matmul(q, k.transpose(-1, -2)), 2.0 * B * H * T * T * dk),
+             ("P v     (T x d_k x T, NN)", lambda: hip.bgemm(p, k), lambda: torch.matmul(p, k), 2.0 * B * H * T * T * dk),
+             ("dS^T q  (T x d_k x T, TN)", lambda: hip.bgemm(p, q, trans_a=True), lambda: torch.matmul(p.transpose(-1, -2), q), 2.0 * B * H * T * T * dk),
+             ("dO v^T  (T x T x d_k, NT)", lambda: hip.bgemm(q, k, trans_b=True), lambda: torch.matmul(q, k.transpose(-1, -2)), 2.0 * B * H * T * T * dk)]
     for name, f1, f2, fl in cases:
         a, b = t(f1), t(f2)
         print(f"{name:40s} jatts_bgemm {a * 1e3:7.1f} us {fl / a / 1e9:6.1f} TFLOP/s   torch.matmul {b * 1e3:7.1f} us {fl / b / 1e9:6.1f} TFLOP/s")
