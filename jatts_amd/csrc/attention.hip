@@ -85,10 +85,10 @@ __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((uns
 #define JATTS_ATTN_HALFPF 1
 #endif
 #ifndef JATTS_ATTN_PIPE
-#define JATTS_ATTN_PIPE 3
+#define JATTS_ATTN_PIPE 3      // exact f32, 32-key tiles: LDS operand fragments read one step ahead of their MFMAs (1 = scores, 2 = P V; relattn_kernel: PIPE_S / PIPE_V)
 #endif
 #ifndef JATTS_ATTN_PIPE_PF
-#define JATTS_ATTN_PIPE_PF 1
+#define JATTS_ATTN_PIPE_PF 1   // ... in the fully prefetched kernels too (d_k 128 / 192), not only the half-tile pipeline of d_k 256
 #endif
 #ifndef JATTS_ATTN_DIAG
 #define JATTS_ATTN_DIAG 0   // timing probes only (wrong results): 1 = no softmax arithmetic, 2 = no barriers in the key loop, 4 = no tile loads / stores in it
@@ -132,7 +132,8 @@ struct TileRegs {
 // WHICH: 1 = the K tile (+ the u . k bias of its keys), 2 = the V^T tile, 3 = both
 // LATE_MASK: the columns of a V^T chunk past the sequence are zeroed by tile_store, not here -- anything that touches a loaded register
 // before the store lets the scheduler pull it (and an `s_waitcnt vmcnt`) up into the MFMA loop the load is meant to hide behind.
-template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true, bool LATE_MASK = !G<T>::split>   // (the split arithmetic takes block maxima of the registers: masked at load)  KU = false: no u . k bias (bias-free attention: REL = false)
+// (The split arithmetic takes block maxima of the registers it loaded: it masks at load.)  KU = false: no u . k bias (bias-free attention: REL = false).
+template <typename T, int DK, int KBT, int WHICH = 3, int NW = 4, bool KU = true, bool LATE_MASK = !G<T>::split>
 __device__ __forceinline__ void tile_load(TileRegs<T, DK, KBT, NW>& tr, const jatts_relattn_desc& d, const typename G<T>::type* kg,
                                           const typename G<T>::type* vtg, int row0, int h, int j0, int Tn, bool vt_vec,
                                           __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv) {
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
 
   // XCD-aware order of the 1-D grid (launch_attn_kb): the dispatcher places workgroup id on XCD id % 8, each with its own L2; in the natural
   // (query block, sequence, head) order the query blocks of one (sequence, head) land on all eight and each XCD pulls that head's K and V^T
-  // through its own L2 misses (T = 768, d_k 256: 1.6 GB from the fabric per launch for 200 MB of K / V, and the tile loads -- not the MFMAs --
-  // set the pace: 730 us against 510 us with the loads compiled out).  XCD x takes the contiguous range [x * per, (x + 1) * per) of
-  // (head, sequence, query block) triples, query block fastest: one head's query blocks run side by side on one XCD and share its tiles.
+  // through its own L2.  XCD x takes the contiguous range [x * per, (x + 1) * per) of (head, sequence, query block) triples, query block
+  // fastest: one head's query blocks run side by side on one XCD and share its tiles (f32 d_k 256: T = 384 214 -> 201 us, T = 768 unchanged --
+  // there the waits on the tile loads inside the MFMA loops were the limit, see LATE_MASK; profiles/r05_notes.md section 7).
   const int gx = (d.rg.max_len + 16 * NW - 1) / (16 * NW);
   const int total = gx * d.rg.n_seq * d.n_heads, per = (total + 7) >> 3;
   const int wg = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
