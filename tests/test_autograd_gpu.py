@@ -503,7 +503,9 @@ def test_qkv_split_backward(cuda, lib):
         _check([(f"p{i}", o, r) for i, (o, r) in enumerate(zip(outs, ref))] + [("dqkv", qd.grad, qr.grad)])
 
 
-@pytest.mark.parametrize("shape", [(3, 2, 70, 50, 33), (2, 2, 257, 192, 300), (1, 1, 128, 128, 16), (4, 1, 5, 81, 7)])
+# (2, 2, 257, 192, 300): the 64 x 192 tile; (2, 3, 130, 190, 66): the same tile on the element-load path (no leading dimension is a multiple of 4);
+# (2, 2, 770, 192, 770) / T x T operands of a padded batch length with T % 4 != 0 are timed by tools/bench_bgemm.py --T 770
+@pytest.mark.parametrize("shape", [(3, 2, 70, 50, 33), (2, 2, 257, 192, 300), (1, 1, 128, 128, 16), (4, 1, 5, 81, 7), (2, 3, 130, 190, 66)])
 def test_bgemm_and_bmm_function(cuda, lib, shape):
     """jatts_bgemm (exact-f32 MFMA batched GEMM: the training step's attention products, rocBLAS before round 4) in all four transpose forms
     against fp64 matmul, with strided batch dims and an operand shared over the outer batch index; autograd.BMM forward and gradients
