@@ -11,6 +11,10 @@
 
 #include "common.h"
 
+#ifndef JATTS_BGEMM_DIAG
+#define JATTS_BGEMM_DIAG 0   // timing probes only (wrong results): 1 = no operand loads in the chunk loop, 2 = no LDS stores in it, 4 = no barriers in it
+#endif
+
 namespace {
 
 // Tile rows BM = 64 MF (MF = 32-row fragments per wave along m: 2 -> 128 rows, 1 -> 64), LDS pitch of the A tile BP = BM + 4 floats; BN = 64 / 128 / 192 and
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
   const int n_chunks = (g.K + BK - 1) / BK;
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
-    if (more) {
+    if (more && !(JATTS_BGEMM_DIAG & 1)) {
       ra.load(A, g.lda, m0, g.M, (ci + 1) * BK, g.K);
       rb.load(B, g.ldb, n0, g.N, (ci + 1) * BK, g.K);
     }
@@ -187,11 +191,11 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs g) {
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
+    if (more && !(JATTS_BGEMM_DIAG & 2)) {
       ra.store(sm_raw + ((ci + 1) & 1) * BUF);
       rb.store(sm_raw + ((ci + 1) & 1) * BUF + BK * BPN * 0 + BK * BP);
     }
-    __syncthreads();
+    if (!(JATTS_BGEMM_DIAG & 4)) __syncthreads();
   }
   // C/D map: column (lane & 31) = n, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = m
 #pragma unroll
