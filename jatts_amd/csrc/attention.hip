@@ -90,6 +90,9 @@ __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((uns
 #ifndef JATTS_ATTN_PIPE_PF
 #define JATTS_ATTN_PIPE_PF 1   // ... in the fully prefetched kernels too (d_k 128 / 192), not only the half-tile pipeline of d_k 256
 #endif
+#ifndef JATTS_ATTN_DMA
+#define JATTS_ATTN_DMA 1       // K / V^T tiles of the bias-free f32 d_k 256 kernel by LDS-direct buffer loads (no staging registers, no ds_write); 0: through registers
+#endif
 #ifndef JATTS_ATTN_DIAG
 #define JATTS_ATTN_DIAG 0   // timing probes only (wrong results): 1 = no softmax arithmetic, 2 = no barriers in the key loop, 4 = no tile loads / stores in it
 #endif
@@ -312,16 +315,52 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   constexpr bool PIPE_OK = HALFPF || (JATTS_ATTN_PIPE_PF && sizeof(T) == 4 && !SPLIT && KBT == 32 && NW == 4);
   constexpr bool PIPE_S = (JATTS_ATTN_PIPE & 1) && PIPE_OK, PIPE_V = (JATTS_ATTN_PIPE & 2) && PIPE_OK;
   constexpr int DIAG = HALFPF ? JATTS_ATTN_DIAG : 0;
+  // DMA: the tiles go global -> LDS directly (buffer_load_dwordx4 ... lds: 64 lanes x 16 B = 1 KB of consecutive LDS per wave instruction).
+  // K: one key row (1 024 B) per instruction at the usual pitch.  V^T: eight 128-byte channel rows per instruction, so its image has NO row padding; bank
+  // conflicts are avoided by an XOR swizzle of the 16-byte unit index with (row >> 1) & 7, applied to the SOURCE address here and to the fragment reads.
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr bool DMA = JATTS_ATTN_DMA && HALFPF && !REL && DK == 256 && NW == 4 && KBT == 32;
+  constexpr int VPD = KBT * 4;     // V^T pitch in the DMA image (bytes)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_k = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < KBT / NW; ++i) {
+      const int row = i * NW + wave_s;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(ks + row * KP), 16, lane * 16, (j0 + row) * d.ldk * 4, 0, 0);
+    }
+  };
+  auto dma_v = [&](int j0) {
+    if (vt_vec) {
+#pragma unroll
+      for (int i = 0; i < DK / 8 / NW; ++i) {
+        const int r8 = i * NW + wave_s;
+        const int row = r8 * 8 + (lane >> 3);
+        const int lu = (lane & 7) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(vs + r8 * 8 * VPD), 16, (row * d.ldvt + lu * 4) * 4, j0 * 4, 0, 0);
+      }
+    } else {     // element-aligned V^T rows: 4 bytes per lane, two channel rows per instruction
+      for (int i = 0; i < DK / 2 / NW; ++i) {
+        const int r2 = i * NW + wave_s;
+        const int row = r2 * 2 + (lane >> 5), fl = lane & 31;
+        const int lu = (fl >> 2) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(vs + r2 * 2 * VPD), 4, (row * d.ldvt + lu * 4 + (fl & 3)) * 4, j0 * 4, 0, 0);
+      }
+    }
+  };
   TileRegs<T, DK, KBT, NW> tr;
   if (PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
-  if constexpr (HALFPF) {
+  if constexpr (DMA) {
+    dma_k(j_start);
+    __syncthreads();
+  } else if constexpr (HALFPF) {
     tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
     tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
     __syncthreads();
   }
   int ev_prev = 0;
   for (int j0 = j_start; j0 < Tk; j0 += KBT) {
-    if constexpr (HALFPF) { if (!(DIAG & 4)) tile_load<T, DK, KBT, 2, NW, REL, true>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv); }
+    if constexpr (DMA) dma_v(j0);
+    else if constexpr (HALFPF) { if (!(DIAG & 4)) tile_load<T, DK, KBT, 2, NW, REL, true>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv); }
     else if (!PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j0, Tn, vt_vec, rk, rv);
     int ek = 0, ev = 0;
     if constexpr (HALFPF) {
@@ -451,7 +490,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       for (int r = 0; r < 4; ++r) ot[f][r] *= oscale;
     }
 
-    if constexpr (HALFPF) {
+    if constexpr (DMA) {
+      __syncthreads();            // V^T(t) landed (vmcnt(0) in front of the barrier) and visible; the K buffer is free
+      if (j0 + KBT > Tn) {        // the sequence's last, partial tile: zero the columns past its end (never multiply P = 0 by stray bits)
+        const int mf = Tn - j0;
+        for (int row = (int)threadIdx.x; row < DK; row += 64 * NW)
+          for (int c = mf; c < KBT; ++c)
+            *reinterpret_cast<float*>(vs + row * VPD + (((c >> 2) ^ ((row >> 1) & 7)) << 4) + ((c & 3) << 2)) = 0.f;
+        __syncthreads();
+      }
+      if (j0 + KBT < Tk) dma_k(j0 + KBT);
+    } else if constexpr (HALFPF) {
       __builtin_amdgcn_sched_barrier(0);   // nothing of the store (its waits on the loads) moves up into the score MFMAs
       if (!(DIAG & 4)) tile_store<T, DK, KBT, 2, NW, REL>(tr, ks, vs, kus, KP, VP, 1.f, 1.f, j0 + KBT > Tn ? Tn - j0 : -1);
       if (!(DIAG & 2)) __syncthreads();            // V^T(t) visible; every wave is past its score MFMAs and its u . k reads: the K buffer is free
@@ -476,10 +525,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       }
       if constexpr (PIPE_V) {
         auto vfrag = [&](int f) {
-          const T* vr = reinterpret_cast<const T*>(vs + (size_t)(16 * f + qc) * VP) + 32 * kb + 4 * g;
           Vec a;
+          if constexpr (DMA) {      // swizzled image: unit u of row r sits at unit u ^ ((r >> 1) & 7); (16 f + qc) >> 1 = 8 f + (qc >> 1)
+            const char* vrow = vs + (16 * f + qc) * VPD;
+            const int sw = (qc >> 1) & 7;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(vrow + ((g ^ sw) << 4)), hi = *reinterpret_cast<const f32x4*>(vrow + (((g + 4) ^ sw) << 4));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { a[r] = vr[r]; a[4 + r] = vr[16 + r]; }
+            for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+          } else {
+            const T* vr = reinterpret_cast<const T*>(vs + (size_t)(16 * f + qc) * VP) + 32 * kb + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = vr[r]; a[4 + r] = vr[16 + r]; }
+          }
           return a;
         };
         Vec a0 = vfrag(0);
@@ -513,7 +570,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
         mma16(a, pb, ot[f]);
       }
     }
-    if constexpr (HALFPF) {
+    if constexpr (HALFPF && !DMA) {
       __builtin_amdgcn_sched_barrier(0);   // (the same for K(t + 1) and the P V MFMAs)
       if (!(DIAG & 4) && j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
     }
