@@ -91,7 +91,7 @@ __device__ __forceinline__ float attn_exp2i(int s) { return __uint_as_float((uns
 #define JATTS_ATTN_PIPE_PF 1   // ... in the fully prefetched kernels too (d_k 128 / 192), not only the half-tile pipeline of d_k 256
 #endif
 #ifndef JATTS_ATTN_DMA
-#define JATTS_ATTN_DMA 1       // K / V^T tiles of the bias-free f32 d_k 256 kernel by LDS-direct buffer loads (no staging registers, no ds_write); 0: through registers
+#define JATTS_ATTN_DMA 2       // K / V^T tiles by LDS-direct buffer loads (no staging registers, no ds_write): 2 = every exact-f32 32-key-tile kernel (d_k 128 / 192 / 256), 1 = the bias-free d_k 256 one only, 0 = through registers
 #endif
 #ifndef JATTS_ATTN_DIAG
 #define JATTS_ATTN_DIAG 0   // timing probes only (wrong results): 1 = no softmax arithmetic, 2 = no barriers in the key loop, 4 = no tile loads / stores in it
@@ -304,7 +304,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   // d_k <= 192: the next tile is prefetched into registers during the current tile's MFMAs.  d_k = 256 does not
   // have the registers for that at 2 waves/SIMD: it loads and stores the tile back to back (still 16-byte batched)
   // and relies on the second resident workgroup to cover the round trip.
-  constexpr bool PREFETCH = NW == 8 || ((DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192));   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
+  // DMA_OK (JATTS_ATTN_DMA >= 2: every exact-f32 32-key-tile kernel, not only the bias-free d_k 256 one): tiles by LDS-direct loads in the half-tile
+  // schedule below; nothing is staged in registers, so there is nothing to prefetch into
+  constexpr bool DMA_OK = sizeof(T) == 4 && !SPLIT && KBT == 32 && NW == 4 && DK % 64 == 0 && (JATTS_ATTN_DMA >= 2 || (JATTS_ATTN_DMA == 1 && !REL && DK == 256));
+  constexpr bool PREFETCH = !DMA_OK && (NW == 8 || ((DK <= 192 || sizeof(T) != 2) && !(KBT == 32 && DK > 192)));   // (f32 d_k 256 at two workgroups per CU: no registers for it either)
   // Without the registers for a whole tile pair (plain operands only): HALF a tile in flight at a time.  V^T(t) is loaded under the score
   // MFMAs of tile t and lands in LDS before P V; K(t+1) is loaded under P V(t) and lands after it -- each global round trip behind one
   // MFMA phase, the same two barriers per tile, 32 staging registers instead of 64 (f32 d_k 256 at two workgroups per CU waited on
@@ -319,14 +322,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   // K: one key row (1 024 B) per instruction at the usual pitch.  V^T: eight 128-byte channel rows per instruction, so its image has NO row padding; bank
   // conflicts are avoided by an XOR swizzle of the 16-byte unit index with (row >> 1) & 7, applied to the SOURCE address here and to the fragment reads.
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  constexpr bool DMA = JATTS_ATTN_DMA && HALFPF && !REL && DK == 256 && NW == 4 && KBT == 32;
+  constexpr bool DMA = DMA_OK && HALFPF;
   constexpr int VPD = KBT * 4;     // V^T pitch in the DMA image (bytes)
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  float ku_next = 0.f;            // (rel-pos kernels: the u . k bias of the next tile's keys, one per thread < KBT, goes through a register as before)
   auto dma_k = [&](int j0) {
+    if constexpr (REL) {
+      ku_next = 0.f;
+      if (d.ku && threadIdx.x < KBT && j0 + (int)threadIdx.x < Tn) ku_next = d.ku[(int64_t)(row0 + j0 + (int)threadIdx.x) * d.n_heads + h];
+    }
+    if (DK == 256 || lane < DK / 4) {     // a key row of d_k floats = d_k / 4 lanes of 16 bytes
 #pragma unroll
-    for (int i = 0; i < KBT / NW; ++i) {
-      const int row = i * NW + wave_s;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(ks + row * KP), 16, lane * 16, (j0 + row) * d.ldk * 4, 0, 0);
+      for (int i = 0; i < KBT / NW; ++i) {
+        const int row = i * NW + wave_s;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(ks + row * KP), 16, lane * 16, (j0 + row) * d.ldk * 4, 0, 0);
+      }
+    }
+  };
+  auto ku_commit = [&]() {
+    if constexpr (REL) {
+      if (threadIdx.x < KBT) kus[threadIdx.x] = ku_next;
     }
   };
   auto dma_v = [&](int j0) {
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
   if (PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
   if constexpr (DMA) {
     dma_k(j_start);
+    ku_commit();
     __syncthreads();
   } else if constexpr (HALFPF) {
     tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
@@ -570,6 +586,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
         mma16(a, pb, ot[f]);
       }
     }
+    if constexpr (DMA) ku_commit();          // (every wave is past this tile's softmax since the barrier in front of the P V MFMAs)
     if constexpr (HALFPF && !DMA) {
       __builtin_amdgcn_sched_barrier(0);   // (the same for K(t + 1) and the P V MFMAs)
       if (!(DIAG & 4) && j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);
