@@ -14,6 +14,7 @@ from jatts_amd import _abi, hip  # noqa: E402
 SHAPES = [
     ("fs2 encoder", 64, 2, 192, 128, True),
     ("fs2 decoder", 64, 2, 192, 768, True),
+    ("fs2 decoder, no bias", 64, 2, 192, 768, False),
     ("matcha decoder T", 64, 2, 256, 768, False),
     ("matcha decoder T/2", 64, 2, 256, 384, False),
     ("matcha mid T/4", 64, 2, 256, 192, False),
