@@ -8,12 +8,22 @@ A "step" = token ids resident on the GPU -> mel -> waveform resident on the GPU 
 all-gather of int16 PCM when N > 1).  Weak scaling: every rank synthesises its own 64 utterances.
 
 Prints ONE JSON line (rank 0):
-  * headline (`value`, `ms_per_step`, `dtype` "f32", `roofline`): the reference's own arithmetic -- f32 operands on
-    v_mfma_f32_32x32x2_f32 (exact f32 fma chains), priced against the 157.3 TFLOP/s f32 MFMA peak;
-  * `fast_mode`: the same K steps with f16 MFMA operands (f32 accumulate, f32 residual streams), its own roofline
-    block, and the max abs error of its mel / waveform against the f32 run on the same 64 x 768-frame batch;
+  * headline (`value`, `ms_per_step`, `dtype`, `roofline`): the f32-EQUIVALENT emulated arithmetic `fp32_bf16x3` (VERDICT r5's ruling; DESIGN.md
+    section 4): f32 tensors, every conv / fused-unit operand carried exactly as three bf16 terms, seven MFMA products per product, f32 accumulate;
+    attention, normalisations and the duration predictor exact f32.  `roofline.peak` = the dense bf16 spec peak / 7; `roofline.practical_peak` =
+    the matrix pipe's sustained rate on THIS part measured live before the timed region (jatts_mfma_probe: v_mfma_f32_32x32x16_bf16 fed from
+    LDS on random operand bits) / 7, `frac_of_practical` beside `frac`;
+  * `exact_f32_mode`: the same K steps in the reference's own arithmetic -- f32 operands on v_mfma_f32_32x32x2_f32 (exact f32 fma chains) --
+    with its own `roofline` (157.3 TFLOP/s f32 MFMA peak) and the max mel / waveform difference between the two runs;
+  * `vocoder_24k`: the same batch through the 24 kHz / hop-300 generator the JSUT / JVS recipes load (scales 5,5,4,3), headline arithmetic
+    and exact f32;
+  * `b1_latency`: ONE 128-phoneme utterance through the reference's own call shape -- model.inference(x) + vocoder.decode(mel),
+    tts_decode.py:230,249 -- median wall ms (hipGraph replay, jatts_amd/graphs.py), the kernel-time sum of a rocprofv3 --kernel-trace child
+    of the same calls, and the launch-gap fraction between them;
+  * `fast_mode`: the same K steps with f16 MFMA operands (f32 accumulate, f32 residual streams) and its error against the exact-f32 run;
+    the six-product and split-f16 arithmetics are timed too but live in bench_detail.json only (ruled ineligible as headlines);
   * `configs`: BASELINE configs[2] (Matcha-TTS MAS, 10 Euler steps, 64 utterances) and configs[4]'s per-GPU share
-    (mel-VITS, 192-d speaker embeddings, 32 utterances), f32 and f16, N == 1 only;
+    (mel-VITS, 192-d speaker embeddings, 32 utterances), every arithmetic, N == 1 only;
   * `cpu_baseline`: the CPU oracle (a port of the reference algorithm; the reference cannot travel to the GPU box)
     in the reference's B=1 loop on the host cores, rank 0, N == 1 only.
 `roofline.traffic` comes from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate child processes started
@@ -37,7 +47,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TF = 2500.0   # dense f16/bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 (= the f32 vector rate)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 # matrix-pipe peak per ALGORITHMIC FLOP of each arithmetic: split = 3 dense f16 MFMAs per product, bf16x3 emulation = 7 (6) dense bf16 MFMAs
 ALG_PEAK_TF = {"fp16": MFMA_F16_PEAK_TF, "fp32": MFMA_F32_PEAK_TF, "fp32_split": MFMA_F16_PEAK_TF / 3.0, "fp32_bf16x3": MFMA_F16_PEAK_TF / 7.0,
                "fp32_bf16x3_6p": MFMA_F16_PEAK_TF / 6.0}
@@ -52,8 +62,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--t-text", type=int, default=128)
     ap.add_argument("--frames-per-token", type=int, default=6)
-    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"],
-                    help="arithmetic of the headline numbers (the reference computes in f32)")
+    ap.add_argument("--precision", default="fp32_bf16x3", choices=["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"],
+                    help="arithmetic of the headline numbers: fp32_bf16x3 = f32-equivalent emulated operands (three exact bf16 terms, seven MFMA products; "
+                         "VERDICT r5 ruled it eligible), fp32 = exact f32 MFMA (always reported beside it as exact_f32_mode)")
     ap.add_argument("--vocoder", default="22k", choices=["22k", "24k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length leg (T_text ~ U{64..t_text}, SURVEY 8d's optional variant)")
@@ -65,6 +76,14 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the FastSpeech2 train-step line")
     ap.add_argument("--no-configs", action="store_true", help="skip the Matcha-TTS / VITS config lines")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
+    ap.add_argument("--pmc-all", action="store_true", help="the --pmc child runs every arithmetic (default: the headline one and exact f32)")
+    ap.add_argument("--no-24k", action="store_true", help="skip the 24 kHz / hop-300 recipe-vocoder block")
+    ap.add_argument("--only-24k", action="store_true", help="run ONLY the 24 kHz vocoder leg at --precision and print nothing (the command under rocprofv3 "
+                                                           "for profiles/rNN_bench_24k_kernel_stats.csv)")
+    ap.add_argument("--no-b1", action="store_true", help="skip the B = 1 drop-in latency block")
+    ap.add_argument("--b1-child", action="store_true", help=argparse.SUPPRESS)    # the rocprofv3 --kernel-trace child of the b1_latency block
+    ap.add_argument("--b1-iters", type=int, default=30, help="timed utterances of the B = 1 latency block")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the live MFMA ceiling probe (roofline.practical_peak = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child: one step, no JSON
     ap.add_argument("--no-detail", action="store_true", help="do not (over)write bench_detail.json -- partial runs under a profiler (tools/profile_*.sh)")
     ap.add_argument("--pipeline", action="store_true",
@@ -120,7 +139,7 @@ def cpu_baseline(fs2_sd, voc_sd, voc_params, texts, heads, budget_s, threads):
 
 
 # ------------------------------------------------------------------------------------------- PMC traffic
-def pmc_passes(argv_tail, timeout_s=240):
+def pmc_passes(argv_tail, timeout_s=240):     # (main() scales timeout_s with the number of arithmetics the child runs: ADVICE r5)
     """HBM bytes per launch of every kernel of one f32 + one f16 bench step: two rocprofv3 passes (FETCH_SIZE, then
     WRITE_SIZE; kernel-trace only), each a CHILD process started before this process initialises the GPU.
     Corrections per MI355X_MICROARCH.md §HBM: counters are KiB; FETCH_SIZE x2 on gfx950 (wide streaming reads are
@@ -171,6 +190,86 @@ def committed_traffic():
     return None, f"profiles/{PROFILE_ROUND}_traffic.json not found"
 
 
+
+# ------------------------------------------------------------------------------------------- B = 1 drop-in latency
+B1_MARK = "mfma_probe_kernel"     # the marker launches that bracket the timed utterances in the child's kernel trace
+
+
+def b1_trace_pass(argv_tail, timeout_s=240):
+    """Kernel-time sum of ONE utterance through model.inference(x) + vocoder.decode(mel): a rocprofv3 --kernel-trace CHILD of this file
+    (`--b1-child`, started before this process touches the GPU) runs the timed utterances between two marker launches; the durations of every
+    kernel between the markers / utterances = the GPU time the path needs when no launch gap is left.  -> (dict, None) or (None, why not)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="jatts_b1_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "-d", tmp, "-o", "b1", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--b1-child"] + argv_tail
+        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        path = None
+        for dp, _, fs in os.walk(tmp):
+            for f in fs:
+                if f.endswith("kernel_trace.csv"):
+                    path = os.path.join(dp, f)
+        if p.returncode != 0 or path is None:
+            return None, f"rocprofv3 --kernel-trace child failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"
+        child = None
+        for ln in p.stdout.decode(errors="replace").splitlines():
+            if ln.startswith("{") and '"b1_child"' in ln:
+                child = json.loads(ln)
+        rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))), key=lambda t: t[0])
+        marks = [i for i, r in enumerate(rows) if B1_MARK in r[2]]
+        if len(marks) < 2 or child is None:
+            return None, "the child's trace holds no marker pair"
+        body = rows[marks[-2] + 1:marks[-1]]
+        n = child["iters"]
+        busy = sum(e - b for b, e, _ in body)
+        span = body[-1][1] - body[0][0] if body else 0
+        return dict(kernel_ms=busy / n / 1e6, launches_per_utt=len(body) / n, gpu_span_ms_profiled=span / n / 1e6, wall_ms_profiled=child["ms"],
+                    source="rocprofv3 --kernel-trace child of this run (sum of kernel durations between two marker launches / utterances)"), None
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return None, f"kernel-trace child failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def b1_run(a, dev, prec, iters, warm=4, graph=True, markers=False, job=None):
+    """The reference's stage-4 loop body (tts_decode.py:230,249) on ONE synthetic utterance: model.inference(x) -> vocoder.decode(feat_gen),
+    a host synchronisation per utterance (the loop writes a wav next).  -> dict(ms median, per-utterance list, frames, samples)."""
+    import torch
+    from jatts_amd import graphs, hip
+    job = job or Job("fs2", a, dev, 0, 1)
+    job.set_precision(prec)
+    text = job.texts[0]
+    on, graphs.ENABLED = graphs.ENABLED, bool(graph) and graphs.ENABLED
+
+    def once():
+        r = job.m.inference(text)
+        y, _ = job.voc.decode(r["feat_gen"])
+        return r, y
+
+    def mark():
+        if markers:
+            hip.mfma_marker(dev)
+    try:
+        for _ in range(warm):          # first sight eager, second captures, then replays
+            once()
+        torch.cuda.synchronize()
+        per = []
+        mark()
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            r, y = once()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) * 1e3)
+        mark()
+        torch.cuda.synchronize()
+    finally:
+        graphs.ENABLED = on
+    assert torch.isfinite(y).all()
+    return dict(ms=sorted(per)[len(per) // 2], ms_min=min(per), ms_all=[round(v, 3) for v in per], frames=int(r["feat_gen"].shape[0]), samples=int(y.numel()),
+                phonemes=int(text.numel()), job=job)
+
 # fused-unit kernel of each arithmetic as rocprofv3 names it: (mangled, demangled) prefixes up to the channel count
 UNIT_KERNEL = {"fp32_split": ("resunit_split_kernelILi{c}E", "resunit_split_kernel<{c},"),
                "fp32_bf16x3": ("resunit_emul_kernelI4bf3pILi7EELi{c}E", "resunit_emul_kernel<bf3p<7>, {c},"),
@@ -201,18 +300,11 @@ class Job:
     def __init__(self, kind, a, dev, rank, batch):
         import torch
         from jatts_amd import models
-        from jatts_amd.synthetic import (FS2_JSUT, HIFIGAN_V1_22K, HIFIGAN_V1_24K, MATCHA_MAS_JSUT, VITS_JSUT,
-                                         pin_duration_head, synth_hifigan_state, synth_state_dict, synth_texts)
-        from jatts_amd.vocoder import Vocoder
+        from jatts_amd.synthetic import FS2_JSUT, MATCHA_MAS_JSUT, VITS_JSUT, pin_duration_head, synth_state_dict, synth_texts
 
         self.kind, self.dev, self.batch, self.vocab = kind, dev, batch, 45
-        self.vp = HIFIGAN_V1_22K if a.vocoder == "22k" else HIFIGAN_V1_24K
-        self.sr = 22050 if a.vocoder == "22k" else 24000
-        self.voc_sd = synth_hifigan_state(self.vp, 0)
-        ones, zeros = [1.0] * 80, [0.0] * 80
-        self.voc = Vocoder(self.voc_sd, {"sampling_rate": self.sr, "generator_type": "HiFiGANGenerator", "generator_params": self.vp},
-                           {"mean": zeros, "scale": ones}, dev, trg_stats={"mean": zeros, "scale": ones})
-        self.hop = self.voc.model.hop
+        self._vocs, self.precision = {}, "fp32"
+        self.use_vocoder(a.vocoder)
         fpt = a.frames_per_token
         if kind == "fs2":
             m = models.FastSpeech2(idim=self.vocab, **FS2_JSUT)
@@ -240,7 +332,25 @@ class Job:
         elif kind == "vits":
             self.noise = [torch.randn(frames, 384, generator=g).to(dev) for _ in self.texts]
 
+    def use_vocoder(self, which):
+        """"22k": HiFi-GAN v1 at 22.05 kHz / hop 256 (scales 8,8,2,2 -- BASELINE's metric); "24k": 24 kHz / hop 300 (scales 5,5,4,3 -- what the JSUT / JVS
+        recipes load, conf/fastspeech2.v1.yaml:4-6,96-99).  Synthetic weights (seed 0), identity feature statistics; built once per job."""
+        from jatts_amd.synthetic import HIFIGAN_V1_22K, HIFIGAN_V1_24K, synth_hifigan_state
+        from jatts_amd.vocoder import Vocoder
+        if which not in self._vocs:
+            vp = HIFIGAN_V1_22K if which == "22k" else HIFIGAN_V1_24K
+            sr = 22050 if which == "22k" else 24000
+            sd = synth_hifigan_state(vp, 0)
+            ones, zeros = [1.0] * 80, [0.0] * 80
+            voc = Vocoder(sd, {"sampling_rate": sr, "generator_type": "HiFiGANGenerator", "generator_params": vp},
+                          {"mean": zeros, "scale": ones}, self.dev, trg_stats={"mean": zeros, "scale": ones})
+            self._vocs[which] = (vp, sr, sd, voc)
+        self.vp, self.sr, self.voc_sd, self.voc = self._vocs[which]
+        self.voc.set_precision(self.precision)
+        self.hop = self.voc.model.hop
+
     def set_precision(self, p):
+        self.precision = p
         self.m.set_precision(p)      # fp32_split: every conv of the acoustic model but the duration predictor's, and the whole vocoder generator
         self.voc.set_precision(p)
 
@@ -339,7 +449,33 @@ def ragged_leg(job, a, world, dist, rank, uniform_value, record=True):
     return blk
 
 
-def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
+# the MFMA each arithmetic issues and how many of them one algorithmic product costs: (jatts_mfma_probe dtype name, MFMAs per product)
+PROBE_OF = {"fp32": ("f32", 1), "fp16": ("f16", 1), "fp32_split": ("f16", 3), "fp32_bf16x3": ("bf16", 7), "fp32_bf16x3_6p": ("bf16", 6)}
+
+
+def measure_ceilings(dev, precisions):
+    """Live matrix-pipe ceilings of this part (jatts_mfma_probe, ~60 ms per launch, before any timed region): for every MFMA type the given
+    arithmetics issue, the sustained TFLOP/s with both operands re-read from LDS every K-step on N(0, 1) operand bits (`lds`: what a kernel that
+    has to feed its operands can reach at the clock the power budget allows) and with the operands held in registers (`registers`: the issue
+    rate alone).  -> {"bf16": {"lds": {...}, "registers": {...}}, ...}"""
+    from jatts_amd import hip
+    code = {"bf16": hip.F32E, "f16": hip.F16, "f32": hip.F32}
+    out = {}
+    for name in sorted({PROBE_OF[p][0] for p in precisions}):
+        out[name] = {"lds": hip.mfma_ceiling(code[name], 1, device=dev), "registers": hip.mfma_ceiling(code[name], 0, device=dev)}
+    return out
+
+
+def practical_peak(ceilings, prec):
+    """TFLOP/s of ALGORITHMIC work the matrix pipe can sustain in arithmetic `prec` on this part: the LDS-fed probe of its MFMA type / MFMAs per product."""
+    if not ceilings:
+        return None
+    name, div = PROBE_OF[prec]
+    c = ceilings.get(name)
+    return c["lds"]["tflops"] / div if c else None
+
+
+def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source, ceilings=None):
     """Per-kernel live timings (HIP events on the launch stream inside the timed region) -> roofline of the dominant
     fused-unit family + per-shape tables.  Algorithmic work per dilation unit: 4 C^2 k FLOP and
     2 C sizeof bytes per row (x in, y out); the last unit of a stage also reads the other ResBlocks' outputs for the
@@ -384,6 +520,13 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     else:
         roof = dict(bound="hbm", achieved=dom_bytes / dom_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s")
     roof["frac"] = roof["achieved"] / roof["peak"]
+    pp = practical_peak(ceilings, prec) if roof["bound"] == "mfma" else None
+    roof["practical_peak"] = pp
+    roof["frac_of_practical"] = roof["achieved"] / pp if pp else None
+    if pp:
+        c = ceilings[PROBE_OF[prec][0]]
+        roof["practical_peak_source"] = (f"jatts_mfma_probe, live: v_mfma {PROBE_OF[prec][0]} 32x32 fragments fed from LDS on N(0,1) operand bits, "
+                                         f"{c['lds']['tflops']:.0f} TFLOP/s at {c['lds']['clock_ghz'] or 0:.2f} GHz (registers only: {c['registers']['tflops']:.0f}) / {PROBE_OF[prec][1]} MFMAs per product")
     roof["traffic"], why = lookup_traffic(traffic_table, prec, dom_c)
     roof["traffic_source"] = traffic_source if roof["traffic"] is not None else None
     if why:
@@ -409,6 +552,8 @@ def kernel_report(recs, steps, prec, dt, traffic_table, traffic_source):
     if conv_ms > 0:      # second family: every jatts_conv1d launch of the step (acoustic model + HiFi-GAN input / upsampling convs)
         roof_conv = dict(bound="mfma", achieved=conv_flops / conv_ms / 1e9, peak=conv_peak, unit="TFLOP/s", frac=conv_flops / conv_ms / 1e9 / conv_peak,
                          ms_per_step=conv_ms / steps, launches_per_step=sum(len(v) for _, v in conv) / steps)
+        if practical_peak(ceilings, prec):
+            roof_conv["frac_of_practical"] = roof_conv["achieved"] / practical_peak(ceilings, prec)
     return dict(
         roofline=roof,
         roofline_conv1d=roof_conv,
@@ -551,7 +696,7 @@ def _r(x, sig=5):
 def _roof(rf):
     if not rf:
         return None
-    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")
+    keep = ("bound", "achieved", "peak", "unit", "frac", "practical_peak", "frac_of_practical", "traffic", "kernel", "avg_launch_ms")
     o = {k: rf.get(k) for k in keep}
     o["kernel"] = (o.get("kernel") or "").split(" (")[0]          # (the long description stays in the detail file)
     src = rf.get("traffic_source") or ""
@@ -593,34 +738,48 @@ def compact_line(out, detail_path=None):
         c["cpu_baseline"] = None
         if out.get("cpu_baseline_note"):
             c["cpu_baseline_note"] = out["cpu_baseline_note"]
-    # (what each arithmetic is: DTYPE_NAME in the detail file)
-    for key, short in (("fast_mode", "f16"), ("f32_mode", "f32"), ("f32_split_mode", "f32 HBM; split f16 hi/lo operands, 3 MFMAs/product"),
-                       ("f32_emul_mode", "f32 HBM; 3 exact bf16 terms/operand, 7 MFMAs/product"),
-                       ("f32_emul6_mode", "f32 HBM; 3 exact bf16 terms/operand, 6 MFMAs/product")):
-        fm = out.get(key)
-        if fm:
-            c[key] = {"dtype": short, "value": fm["value"], "ms_per_step": fm["ms_per_step"],
-                      "vocoder_ms": (fm.get("stage_ms_per_step") or {}).get("vocoder"),
-                      "max_abs_err_wave": fm.get("max_abs_err_wave"),
-                      "roofline_frac": (fm.get("roofline") or {}).get("frac"), "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
+    # (what each arithmetic is: DTYPE_NAME in the detail file; the six-product and split-f16 blocks are in the detail file only:
+    # both are ruled ineligible as headlines)
+    ex = out.get("f32_mode")
+    if ex:       # the reference's own arithmetic beside the headline, with its own roofline and the distance between the two runs' outputs
+        rf = ex.get("roofline") or {}
+        c["exact_f32_mode"] = {"dtype": "f32", "value": ex["value"], "ms_per_step": ex["ms_per_step"],
+                               "vocoder_ms": (ex.get("stage_ms_per_step") or {}).get("vocoder"),
+                               "max_abs_err_mel": ex.get("max_abs_err_mel"), "max_abs_err_wave": ex.get("max_abs_err_wave"),
+                               "roofline": {k: rf.get(k) for k in ("achieved", "peak", "frac", "practical_peak", "frac_of_practical", "avg_launch_ms", "traffic")},
+                               "speedup_vs_cpu_rtf": ex.get("speedup_vs_cpu_rtf")}
+    v24 = out.get("vocoder_24k")
+    if v24:
+        def leg(b):
+            rf = b.get("roofline") or {}
+            return {"value": b["value"], "ms_per_step": b["ms_per_step"], "vocoder_ms": (b.get("stage_ms_per_step") or {}).get("vocoder"),
+                    "roofline_frac": rf.get("frac"), "frac_of_practical": rf.get("frac_of_practical"), "kernel": (rf.get("kernel") or "").split(" (")[0]}
+        c["vocoder_24k"] = {"sampling_rate": v24["sampling_rate"], "hop": v24["hop"], **leg(v24["headline"])}
+        if v24.get("exact_f32"):
+            c["vocoder_24k"]["exact_f32"] = {k: v for k, v in leg(v24["exact_f32"]).items() if k != "kernel"}
+    b1 = out.get("b1_latency")
+    if b1:
+        c["b1_latency"] = {k: b1.get(k) for k in ("ms", "kernel_ms", "wall_over_kernel", "launch_gap_frac", "eager_ms", "launches", "utterance")}
+    fm = out.get("fast_mode")
+    if fm:
+        c["fast_mode"] = {"dtype": "f16", "value": fm["value"], "ms_per_step": fm["ms_per_step"],
+                          "max_abs_err_wave": fm.get("max_abs_err_wave"),
+                          "roofline_frac": (fm.get("roofline") or {}).get("frac"), "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
     if out.get("configs"):
         c["configs"] = {("matcha_mas_b64" if "Matcha" in e["config"] else "vits_spk192_b32"):
-                        {"f32_ms": e["ms_per_step"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
+                        {"ms": (e.get("f32_emul_mode") or {}).get("ms_per_step"),
+                         "text2mel_ms": ((e.get("f32_emul_mode") or {}).get("stage_ms_per_step") or {}).get("text2mel"),
+                         "f32_ms": e["ms_per_step"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
                          "f16_ms": (e.get("fast_mode") or {}).get("ms_per_step"),
-                         "split_ms": (e.get("f32_split_mode") or {}).get("ms_per_step"),
-                         "emul_ms": (e.get("f32_emul_mode") or {}).get("ms_per_step"),
-                         "emul6_ms": (e.get("f32_emul6_mode") or {}).get("ms_per_step"),
-                         "roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac")} for e in out["configs"]}
+                         "f32_roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac")} for e in out["configs"]}
     if out.get("training"):
-        c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "frac": e.get("frac_of_f32_mfma_peak"),
-                                     "split_ms": (e.get("fp32_split") or {}).get("ms_per_step")}
-                         for e in out["training"]}
+        c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "frac": e.get("frac_of_f32_mfma_peak")} for e in out["training"]}
     if detail_path:
         c["detail"] = detail_path
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_LIMIT:      # never let the line outgrow the driver's tail again: drop the optional blocks
-        for k in ("executor", "roofline_conv1d", "training", "fast_mode", "configs", "stage_ms", "f32_emul6_mode", "f32_mode", "f32_split_mode", "ragged", "f32_emul_mode"):
+        for k in ("executor", "training", "roofline_conv1d", "fast_mode", "configs", "stage_ms", "ragged", "b1_latency", "vocoder_24k", "exact_f32_mode"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
@@ -650,9 +809,7 @@ def write_detail(out):
 
 MODE_KEY = {"fp16": "fast_mode", "fp32": "f32_mode", "fp32_split": "f32_split_mode", "fp32_bf16x3": "f32_emul_mode", "fp32_bf16x3_6p": "f32_emul6_mode"}
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16 MFMA operands, f32 accumulate",
-              "fp32_bf16x3": "f32 tensors; every conv / fused HiFi-GAN unit on f32-equivalent emulated MFMA operands (each value exactly as three bf16 terms, seven "
-                             "partial products per product: a one-term contraction within 2^-23 = 2 x an f32 FMA's bound for every input, no scales), f32 accumulate; "
-                             "attention, normalisations and the duration predictor exact f32",
+              "fp32_bf16x3": "f32 (emulated: 3 exact bf16 terms per operand, 7 MFMA products, f32 accumulate; attention / norms / duration predictor exact f32)",
               "fp32_bf16x3_6p": "as fp32_bf16x3 with six partial products per product (dropped terms <= 2^-23 of a product)",
               "fp32_split": "f32 tensors; every conv / fused HiFi-GAN unit on split f16 hi/lo MFMA operands (3 MFMAs per product, power-of-two scales), "
                             "f32 accumulate; attention, normalisations and the duration predictor exact f32"}
@@ -696,18 +853,23 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus} launched with WORLD_SIZE={world}: --nproc-per-node must equal --gpus")
 
-    # roofline.traffic: PMC passes run as children BEFORE this process touches the GPU
+    # roofline.traffic and b1_latency.kernel_ms: rocprofv3 passes run as children BEFORE this process touches the GPU
     traffic_table = traffic_source = None
-    if rank == 0 and world == 1 and not a.no_pmc and not a.pmc_child:
-        tail = ["--vocoder", a.vocoder, "--batch", str(a.batch), "--t-text", str(a.t_text),
-                "--frames-per-token", str(a.frames_per_token)]
-        traffic_table, traffic_source = pmc_passes(tail)
+    b1_trace = b1_trace_note = None
+    special = a.pmc_child or a.b1_child or a.only_ragged or a.only_24k or a.profile_config
+    tail = ["--vocoder", a.vocoder, "--batch", str(a.batch), "--t-text", str(a.t_text), "--frames-per-token", str(a.frames_per_token),
+            "--precision", a.precision]
+    if rank == 0 and world == 1 and not a.no_pmc and not special:
+        n_prec = len(PRECISIONS) if a.pmc_all else len({a.precision, "fp32"})
+        traffic_table, traffic_source = pmc_passes(tail + (["--pmc-all"] if a.pmc_all else []), timeout_s=120 + 60 * n_prec)
         if traffic_table is None:
             note = traffic_source
             traffic_table, traffic_source = committed_traffic()
             traffic_source = f"{traffic_source} [live passes unavailable: {note}]"
-    elif rank == 0 and not a.pmc_child:
+    elif rank == 0 and not special:
         traffic_table, traffic_source = committed_traffic()
+    if rank == 0 and world == 1 and not a.no_b1 and not special:
+        b1_trace, b1_trace_note = b1_trace_pass(tail + ["--b1-iters", str(a.b1_iters)])
 
     if world > 1:      # N launch-heavy host loops on one node: keep each rank's CPU-side torch work on one thread (torchrun's default too)
         os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -733,10 +895,14 @@ def main():
         j.set_precision(a.precision)
         run_timed(j, a, 1, None, record=False)
         return
+    if a.b1_child:    # the rocprofv3 --kernel-trace child of the b1_latency block: the timed utterances between two marker launches
+        r = b1_run(a, dev, a.precision, a.b1_iters, markers=True)
+        print(json.dumps({"b1_child": 1, "ms": r["ms"], "iters": a.b1_iters, "frames": r["frames"]}), flush=True)
+        return
     job = Job("fs2", a, dev, rank, a.batch)
-    if a.pmc_child:   # profiled child: one step of each arithmetic, nothing printed
+    if a.pmc_child:   # profiled child: one step of the headline arithmetic and of exact f32 (--pmc-all: of every arithmetic), nothing printed
         a.steps, a.warmup = 1, 1
-        for p in PRECISIONS:
+        for p in (PRECISIONS if a.pmc_all else dict.fromkeys((a.precision, "fp32"))):
             job.set_precision(p)
             run_timed(job, a, 1, None)
         return
@@ -745,8 +911,18 @@ def main():
     if a.only_ragged:
         ragged_leg(job, a, world, dist, rank, 1.0, record=False)
         return
+    if a.only_24k:
+        job.use_vocoder("24k")
+        run_timed(job, a, world, dist, record=False)
+        return
+    # the matrix pipe's practical ceiling on THIS part, measured before any timed region (~1 s in all)
+    ceilings = None
+    if not a.no_ceiling:
+        from jatts_amd import hip as _h
+        ceilings = measure_ceilings(dev, PRECISIONS if world == 1 else (a.precision, "fp32"))
+        del _h
     head = run_timed(job, a, world, dist, a.pipeline)
-    rep = kernel_report(head["recs"], a.steps, a.precision, head["dt"], traffic_table, traffic_source)
+    rep = kernel_report(head["recs"], a.steps, a.precision, head["dt"], traffic_table, traffic_source, ceilings)
 
     out = {
         "metric": f"audio samples/sec ({'22.05' if a.vocoder == '22k' else '24'} kHz) + RTF, FastSpeech2+HiFi-GAN",
@@ -763,6 +939,7 @@ def main():
         "backend": (("gloo [shared-GPU test mode]" if shared else "nccl (RCCL)") if dist else None),
         "rtf": head["rtf"], "stage_ms_per_step": head["stages"], "rank_ms_per_step": head["rank_ms"],
         "executor": "two-stream pipeline (jatts_amd.pipeline)" if a.pipeline else "sequential",
+        "mfma_ceilings": ceilings,
     }
     out.update(rep)
 
@@ -774,11 +951,12 @@ def main():
     # ---- the other arithmetics on the same batch, and how far apart their outputs are from the headline's
     if not a.no_fast_mode:
         mel0, wav0 = head["mel"].float().clone(), head["wave"].float().clone()
-        others = [p for p in PRECISIONS if p != a.precision]
+        # exact f32 always rides along (exact_f32_mode); the other arithmetics at N == 1 only
+        others = [p for p in PRECISIONS if p != a.precision and (world == 1 or p == "fp32")]
         for other in others:
             job.set_precision(other)
             alt = run_timed(job, a, world, dist, a.pipeline)
-            arep = kernel_report(alt["recs"], a.steps, other, alt["dt"], traffic_table, traffic_source)
+            arep = kernel_report(alt["recs"], a.steps, other, alt["dt"], traffic_table, traffic_source, ceilings)
             same = alt["mel"].shape == mel0.shape and alt["wave"].shape == wav0.shape
             dm = (alt["mel"].float() - mel0) if same else None
             dw = (alt["wave"].float() - wav0) if same else None
@@ -799,6 +977,45 @@ def main():
         del mel0, wav0
     del head
     job_fs2_sd, job_voc_sd, job_vp, job_sr = job.sd, job.voc_sd, job.vp, job.sr
+
+    # ---- the 24 kHz / hop-300 generator every JSUT / JVS recipe loads (conf/fastspeech2.v1.yaml:4-6,96-99; SURVEY 8d "report both"): the same
+    # batch and acoustic model, headline arithmetic and exact f32, N == 1 only
+    if world == 1 and not a.no_24k and a.vocoder == "22k":
+        job.use_vocoder("24k")
+        blk = {"sampling_rate": job.sr, "hop": job.hop, "upsample_scales": list(job.vp["upsample_scales"]),
+               "workload": f"{job.name}+HiFi-GAN v1 24k (scales 5,5,4,3), {a.batch} utts x {a.t_text} phonemes x {a.frames_per_token} frames"}
+        for name, p in (("headline", a.precision), ("exact_f32", "fp32")):
+            if name == "exact_f32" and p == a.precision:
+                continue
+            job.set_precision(p)
+            r = run_timed(job, a, 1, None)
+            e = {"dtype": DTYPE_NAME[p], "value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "rtf": r["rtf"],
+                 "stage_ms_per_step": r["stages"], "samples_per_step": r["samples_per_step"]}
+            e.update(kernel_report(r["recs"], a.steps, p, r["dt"], None, None, ceilings))
+            blk[name] = e
+            del r
+        out["vocoder_24k"] = blk
+        job.use_vocoder(a.vocoder)
+
+    # ---- the drop-in B = 1 path: one utterance through model.inference(x) + vocoder.decode(mel), hipGraph replay against eager launches
+    if world == 1 and not a.no_b1:
+        j1 = None
+        g = b1_run(a, dev, a.precision, a.b1_iters, graph=True)
+        j1 = g.pop("job")
+        e = b1_run(a, dev, a.precision, max(5, a.b1_iters // 3), graph=False, job=j1)
+        e.pop("job")
+        b1 = {"utterance": f"{g['phonemes']} phonemes -> {g['frames']} frames -> {g['samples']} samples", "dtype": DTYPE_NAME[a.precision],
+              "call": "model.inference(x) + vocoder.decode(feat_gen), a host synchronisation per utterance (tts_decode.py:230,249)",
+              "ms": g["ms"], "ms_min": g["ms_min"], "ms_all": g["ms_all"], "eager_ms": e["ms"], "eager_ms_all": e["ms_all"],
+              "executor": "hipGraph replay (jatts_amd/graphs.py: front keyed by T_text, back by T_feats, generator by T_feats)",
+              "rtf": g["ms"] / 1e3 / (g["samples"] / job.sr)}
+        if b1_trace:
+            b1.update(kernel_ms=b1_trace["kernel_ms"], launches=b1_trace["launches_per_utt"], wall_over_kernel=g["ms"] / b1_trace["kernel_ms"],
+                      launch_gap_frac=1.0 - b1_trace["kernel_ms"] / g["ms"], eager_launch_gap_frac=1.0 - b1_trace["kernel_ms"] / e["ms"], trace=b1_trace)
+        else:
+            b1["kernel_ms"], b1["kernel_ms_note"] = None, b1_trace_note
+        out["b1_latency"] = b1
+        del j1, g, e
     del job
     torch.cuda.empty_cache()
 
@@ -877,7 +1094,7 @@ def main():
         cb["single_thread"]["rtf"] = c1["seconds"] / (c1["samples"] / job_sr)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_rtf"] = cb["rtf"] / out["rtf"]
-        for k in ("fast_mode", "f32_split_mode", "f32_emul_mode", "f32_emul6_mode", "f32_mode"):
+        for k in ("fast_mode", "f32_split_mode", "f32_emul_mode", "f32_emul6_mode", "f32_mode"):     # (f32_mode -> the line's exact_f32_mode)
             if k in out:
                 out[k]["speedup_vs_cpu_rtf"] = cb["rtf"] / out[k]["rtf"]
     else:

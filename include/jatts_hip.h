@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define JATTS_ABI_VERSION 3   /* 3 (round 5): jatts_ragged + total_rows (in the struct's former tail padding), JATTS_F32E; 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
+#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops; 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
+                                * so every descriptor that embeds it (jatts_conv_desc, jatts_resunit_desc, jatts_resblock_desc, jatts_relattn_desc) shifted by 8 bytes; JATTS_F32E; 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
                                 * bumped whenever a descriptor's layout or an entry point's signature changes: a stale library is refused at load */
 
 #define JATTS_F32 0
@@ -89,7 +90,9 @@ typedef struct jatts_ragged {
                              * lengths for the tile it picks) and every workgroup finds its (sequence, tile) from cu_rows; NULL: the rectangular
                              * grid n_seq x tiles of the longest sequence, whose workgroups past a shorter sequence's end exit at once (a quarter
                              * of the grid at T ~ U{64..128}).  Read at launch time only (a captured graph does not keep the pointer).  Results
-                             * are identical either way.  jatts_amd.hip passes it for non-uniform batches only. */
+                             * are identical either way.  jatts_amd.hip passes it for non-uniform batches only.  It is a HOST pointer that travels
+                             * inside descriptors copied to the device as kernel arguments: DEVICE CODE MUST NEVER DEREFERENCE IT -- kernels only
+                             * compare it with NULL (common.h: ragged_is_1d) to learn which grid form they were launched with. */
 } jatts_ragged;
 
 /* ---------------------------------------------------------------------------------
@@ -385,6 +388,18 @@ int jatts_adam_step(float* p, const float* g, float* m, float* v, int64_t n, dou
  * at start, x staged, conv1 done, h written, conv2 done, y assembled, y stored, then s_memrealtime (100 MHz) at start
  * and end, 6 unused}.  buf: device memory of n_workgroups*128 bytes.  Pass NULL to switch tracing off (the default). */
 int jatts_debug_trace(void* buf, int64_t n_workgroups);
+
+/* Measurement hook (not part of the reference interface; bench.py's `roofline.practical_peak`): the matrix pipe's sustained issue rate on THIS
+ * part at the clock its power budget allows.  One launch of `workgroups` x 256 threads, every wave issuing 2 x 2 fragments of 32 x 32 per K-step
+ * for `iters` K-steps (rounded up to even) with nothing else in the kernel: dtype JATTS_F32E / JATTS_F32E6 -> v_mfma_f32_32x32x16_bf16, JATTS_F16 /
+ * JATTS_F32S -> v_mfma_f32_32x32x16_f16, JATTS_F32 -> eight v_mfma_f32_32x32x2_f32 per K-step; feed = 1: both operands re-read from LDS every K-step
+ * (ds_read_b128), feed = 0: operands stay in registers.  operands: >= 64 KiB of DEVICE memory, 16-byte aligned, holding operand bits of the dtype (the
+ * matrix pipe's power, hence its clock, follows them: zeros run ~19 % faster than random bits); clocks (device, 2 x uint64, may be NULL): s_memtime and
+ * s_memrealtime (100 MHz) ticks of workgroup 0 across its MFMA loop; sink: 1 device float, never written.  The caller times the launch on `stream`
+ * and divides jatts_mfma_probe_flops() by it. */
+int jatts_mfma_probe(int32_t dtype, int32_t feed, const void* operands, int64_t operand_bytes, int32_t iters, int32_t workgroups,
+                     uint64_t* clocks, float* sink, void* stream);
+double jatts_mfma_probe_flops(int32_t dtype, int32_t iters, int32_t workgroups);
 
 /* Batched f32 GEMM on the exact-f32 matrix pipe, for the attention products of the TRAINING step and their gradients (round 4; reference:
  * torch.matmul inside LegacyRelPositionMultiHeadedAttention.forward / forward_attention, modules/transformer/attention.py:63-93,164-206,

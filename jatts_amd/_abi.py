@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JATTS_HIP_LIB") or os.path.join(_HERE, "lib", "libjatts_hip.so")  # override: profiling builds only
 
 F32, F16, F32S, F32E, F32E6 = 0, 1, 2, 3, 4      # F32S: f32 in HBM, split f16 hi/lo MFMA operands (jatts_hifigan_resunit only)
-ABI_VERSION = 3      # JATTS_ABI_VERSION of include/jatts_hip.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 4      # JATTS_ABI_VERSION of include/jatts_hip.h (tests/test_abi_cpu.py compares the two)
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH, ACT_MISH, ACT_SNAKEBETA = 0, 1, 2, 3, 4, 5
 PRE_NONE, PRE_LRELU = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -74,6 +74,8 @@ PROTOTYPES = {
     "jatts_hifigan_resunit": (C.c_int, [C.POINTER(ResUnitDesc), C.c_void_p]),
     "jatts_hifigan_resblock": (C.c_int, [C.POINTER(ResBlockDesc), C.c_void_p]),
     "jatts_debug_trace": (C.c_int, [C.c_void_p, C.c_int64]),
+    "jatts_mfma_probe": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jatts_mfma_probe_flops": (C.c_double, [C.c_int32, C.c_int32, C.c_int32]),
     "jatts_set_workspace": (C.c_int, [C.c_void_p, C.c_int64]),
     "jatts_pack_conv_weight_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jatts_bgemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,

@@ -594,6 +594,17 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     return out
 
 
+def _check_unit_weights(who, dtype, channels, k_w, *ws):
+    """The packed operand a fused-unit dtype expects, element for element: the C entry point sees only a pointer, and an f32-packed weight (4 B per
+    element) handed to an emulated kernel (three bf16 planes: 6 B) would be read out of bounds on the device."""
+    n = channels * channels * k_w
+    want = {F32: (torch.float32, n), F16: (torch.float16, n), F32S: (torch.float16, 2 * n), F32E: (torch.bfloat16, 3 * n), F32E6: (torch.bfloat16, 3 * n)}[dtype]
+    for w in ws:
+        if w.dtype != want[0] or w.numel() != want[1] or not w.is_cuda:
+            raise ValueError(f"{who}: dtype code {dtype} needs packed weights of {want[1]} x {want[0]} on the GPU (pack_conv_weight / pack_conv_weight_split / "
+                             f"pack_conv_weight_bf16x3 with c_mult=32), got {w.numel()} x {w.dtype}")
+
+
 def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype, add=None, out_scale=1.0, ws=None):
     lib = _abi.load()
     d = _abi.ResUnitDesc()
@@ -603,6 +614,7 @@ def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope
     if x.numel() != rows * channels or y.numel() != rows * channels or x.dtype != torch_dtype(dtype):
         raise ValueError("hifigan_resunit: bad buffer size/dtype")
     d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
+    _check_unit_weights("hifigan_resunit", dtype, channels, k_w, w1, w2)
     d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
     if dtype == F32S:
         if ws is None or ws[0].numel() < channels or ws[1].numel() < channels or ws[0].dtype != torch.float32:
@@ -632,6 +644,7 @@ def hifigan_resblock(rb, len_mul, x, y, units, channels, k_w, slope, dtype, add=
         raise ValueError("hifigan_resblock: bad buffer size/dtype")
     d.x, d.y = _dev(x).data_ptr(), y.data_ptr()
     for i, (w1, b1, w2, b2, dil) in enumerate(units):
+        _check_unit_weights("hifigan_resblock", dtype, channels, k_w, w1, w2)
         d.w1[i], d.b1[i], d.w2[i], d.b2[i], d.dil[i] = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), dil
     if dtype == F32S:
         if ws is None or len(ws) != len(units):
@@ -896,19 +909,31 @@ def lr_durations(rb, d, alpha=1.0, zero_rule=2):
     return d_eff, cum, buf[:rb.n_seq], (buf[rb.n_seq:] if zero_rule == 2 else None)
 
 
-def lr_sizes(rb, d, alpha=1.0, check=None):
-    """lr_durations + the one host sync of the path: -> (d_eff, cum, olens list).  Logs the reference's warning
-    (length_regulator.py:87-90) for utterances that took the all-zero fallback.  ``check``: the embed_scale bad-id
-    counter, read in the same transfer; non-zero raises IndexError like torch.nn.Embedding."""
+def lr_sizes_dev(rb, d, alpha=1.0, check=None):
+    """The device half of lr_sizes (capturable: no host access): -> (d_eff, cum, sizes) with sizes = int64 [olens (n_seq) | all-zero
+    fallback flags (n_seq) | the bad-id counter `check` (1, when given)], read by lr_sizes_host."""
     d_eff, cum, olens, fb = lr_durations(rb, d, alpha)
-    host = torch.cat([olens, fb] + ([check.view(-1)] if check is not None else [])).tolist()
-    if check is not None and host[2 * rb.n_seq]:
+    return d_eff, cum, torch.cat([olens, fb] + ([check.view(-1)] if check is not None else []))
+
+
+def lr_sizes_host(rb, sizes, checked):
+    """The one host sync of the path: sizes (lr_sizes_dev) -> olens list.  Logs the reference's warning (length_regulator.py:87-90) for
+    utterances that took the all-zero fallback; a non-zero bad-id counter raises IndexError like torch.nn.Embedding."""
+    host = sizes.tolist()
+    if checked and host[2 * rb.n_seq]:
         raise IndexError("token id out of range")
     olens_h, fb_h = host[:rb.n_seq], host[rb.n_seq:2 * rb.n_seq]
     if any(fb_h):
         import logging
         logging.warning("predicted durations includes all 0 sequences. fill the first element with 1.")
-    return d_eff, cum, olens_h
+    return olens_h
+
+
+def lr_sizes(rb, d, alpha=1.0, check=None):
+    """lr_durations + the one host sync of the path: -> (d_eff, cum, olens list).  ``check``: the embed_scale bad-id counter, read in
+    the same transfer."""
+    d_eff, cum, sizes = lr_sizes_dev(rb, d, alpha, check)
+    return d_eff, cum, lr_sizes_host(rb, sizes, check is not None)
 
 
 def zero_pad_rows(rb, x, valid_len, len_mul=1):
@@ -1552,3 +1577,56 @@ def bgemm(a, b, trans_a=False, trans_b=False, alpha=1.0, out=None):
         _abi.check(lib.jatts_bgemm(a.data_ptr(), sao, sai, lda, int(trans_a), b.data_ptr(), sbo, sbi, ldb, int(trans_b), out.data_ptr(), out.stride(0),
                                    out.stride(1), out.stride(2), O, ai, m, n, k, float(alpha), 0, _stream()), "jatts_bgemm")
     return out
+
+
+def mfma_ceiling(dtype=F32E, feed=1, target_ms=60.0, device=None, seed=0):
+    """jatts_mfma_probe: the matrix pipe's sustained rate on this part for `dtype` -- nothing but MFMAs (2 x 2 fragments per wave, two 4-wave workgroups per
+    CU), operands re-read from LDS every K-step (feed=1) or held in registers (feed=0), on N(0, 1) operand bits in the form the kernels see them (bf16: the
+    three exact terms of the emulated arithmetic in equal parts).  A calibration launch sizes the timed one to ~target_ms: long enough for the clock to
+    settle at the power limit, short enough to sit in front of a bench run.  -> dict(tflops, ms, clock_ghz, iters, workgroups)."""
+    lib = _abi.load()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(1 << 16, generator=g)
+    if dtype in EMUL:
+        ops = torch.cat([t.reshape(-1) for t in bf16x3_terms(v)])
+    elif dtype in (F16, F32S):
+        ops = v.half()
+    else:
+        ops = v
+    ops = ops.to(dev).contiguous()
+    clocks = torch.zeros(2, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float32, device=dev)
+    wgs = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+
+    def run(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _abi.check(lib.jatts_mfma_probe(dtype, feed, ops.data_ptr(), ops.numel() * ops.element_size(), iters, wgs, clocks.data_ptr(), sink.data_ptr(),
+                                        _stream()), "jatts_mfma_probe")
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b)
+
+    it = 2000
+    ms = run(it)
+    it = max(2000, min(int(it * target_ms / max(ms, 1e-3)) & ~1, 1 << 24))
+    run(it)                              # settles the clock at the sustained level
+    ms = run(it)
+    c = clocks.tolist()
+    return dict(tflops=lib.jatts_mfma_probe_flops(dtype, it, wgs) / ms / 1e9, ms=ms, clock_ghz=c[0] / (c[1] * 10.0) if c[1] else None, iters=it, workgroups=wgs,
+                feed="lds" if feed else "registers")
+
+
+_MARKER = {}
+
+
+def mfma_marker(device=None):
+    """One 1-workgroup, 2-K-step jatts_mfma_probe launch: a marker that tools (bench.py's B = 1 kernel-trace child) find by name in a rocprofv3 trace."""
+    lib = _abi.load()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    key = str(dev)
+    if key not in _MARKER:
+        _MARKER[key] = (torch.zeros(1 << 15, dtype=torch.bfloat16, device=dev), torch.zeros(1, dtype=torch.float32, device=dev))
+    ops, sink = _MARKER[key]
+    _abi.check(lib.jatts_mfma_probe(F32E, 0, ops.data_ptr(), ops.numel() * 2, 2, 1, None, sink.data_ptr(), _stream()), "jatts_mfma_probe")

@@ -156,7 +156,7 @@ class ConformerRunner:
             self._pos_cache.clear()
         cap = hip.round_up(t_max, 128)
         if cap in self._pos_cache:
-            return cap, self._pos_cache[cap]
+            return cap, hip.keep(self._pos_cache[cap])      # (a capturing graph pins what it was handed: the cache evicts)
         if self.rel_style == "new":
             pe = rel_pos_table_new(cap, self.A)          # (2cap-1, A)
         else:
@@ -181,7 +181,7 @@ class ConformerRunner:
         if len(self._pos_cache) >= 8:
             self._pos_cache.pop(next(iter(self._pos_cache)))
         self._pos_cache[cap] = per_layer
-        return cap, per_layer
+        return cap, hip.keep(per_layer)
 
     def _ffn(self, rb, x, ln, ff, scale):
         xn = hip.layernorm(x, ln[0], ln[1], self.dtype, LN_EPS)

@@ -16,6 +16,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from .. import hip
+from ..graphs import GraphCache
 from ..hip import ACT_NONE, ACT_RELU, ACT_TANH
 from . import _schema as S
 from ._conformer import BN_EPS, LN_EPS, ConformerRunner, PackedConv, SpkProjection
@@ -229,28 +230,70 @@ class FastSpeech2(torch.nn.Module):
         duration/pitch/energy/log_duration packed over tokens, and ``feats_rb``/``text_rb`` geometry.
         """
         P = self._prepare()
-        dt, dev = P["dtype"], P["dev"]
-        A = self.adim
+        dev = P["dev"]
         lens = [int(t.numel()) for t in texts]
         if min(lens) <= 0:
             raise ValueError("empty text")
         rb = hip.RaggedBatch(lens, dev)
-        ids = torch.cat([t.reshape(-1) for t in texts]).to(device=dev, dtype=torch.int64)
+        ids = torch.cat([t.reshape(-1) for t in texts]).to(device=dev, dtype=torch.int64).contiguous()
+        d_over = None
+        if durations is not None:
+            d_over = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
+            if d_over.numel() != rb.total:
+                raise ValueError("durations do not match texts")
+        if self.spks is not None and sids is None:
+            raise ValueError("sids required (spks is set)")
+        if self.spk_embed_dim is not None and spembs is None:
+            raise ValueError("spembs required (spk_embed_dim is set)")
+        sp = None if self.spk_embed_dim is None else spembs.to(dev).float().reshape(rb.n_seq, -1).contiguous()
+        sd = None if self.spks is None else sids.to(dev).view(-1).long().contiguous()
+        # B = 1 (the reference's own call shape, tts_decode.py:230): both halves replay as hipGraphs keyed by (T_text) / (T_text, T_feats)
+        # (jatts_amd/graphs.py: first sight eager, second captures; bit-identical to the eager launches)
+        gc = None
+        if rb.n_seq == 1 and taps is None:
+            gc = P.get("graphs")
+            if gc is None:
+                gc = P["graphs"] = GraphCache()
+        extra = tuple(t for t in (sp, sd, d_over) if t is not None)
+
+        def front(ids_, *more):
+            it = iter(more)
+            sp_ = next(it) if sp is not None else None
+            sd_ = next(it) if sd is not None else None
+            do_ = next(it) if d_over is not None else None
+            return self._front(P, rb, ids_, sp_, sd_, do_, alpha, taps)
+
+        if gc is not None:
+            hs, p_outs, e_outs, logd, d_pred, d_eff, cum, sizes = gc.run(("front", lens[0], float(alpha), sp is not None, sd is not None, d_over is not None),
+                                                                         front, (ids,) + extra)
+        else:
+            hs, p_outs, e_outs, logd, d_pred, d_eff, cum, sizes = front(ids, *extra)
+        # length regulator (length_regulator.py:70-97): the one host sync of the path — output sizes
+        olens_h = hip.lr_sizes_host(rb, sizes, True)    # an all-zero utterance gets all ones, as the reference's B=1 call
+        rbo = hip.RaggedBatch(olens_h, dev)
+        if gc is not None:
+            after, before = gc.run(("back", lens[0], olens_h[0]), lambda hs_, cum_: self._back(P, rb, rbo, hs_, cum_, None), (hs, cum))
+        else:
+            after, before = self._back(P, rb, rbo, hs, cum, taps)
+        return dict(feat_gen=after, before=before, olens=olens_h, feats_rb=rbo, text_rb=rb, duration=d_pred,
+                    duration_used=d_eff, pitch=p_outs, energy=e_outs, log_duration=logd)
+
+    def _front(self, P, rb, ids, spembs, sids, d_over, alpha, taps):
+        """Token ids -> encoder -> variance adaptor -> length-regulator sizes, all on the device (capturable).
+        -> (hs, pitch, energy, log duration, predicted duration, durations used, their running sums, sizes for hip.lr_sizes_host)."""
+        dt = P["dtype"]
+        A = self.adim
         # encoder.embed: Embedding -> LegacyRelPositionalEncoding (x * sqrt(adim))  encoder.py:133-137.  Out-of-range ids are
-        # counted by the kernel and raised (IndexError, as torch.nn.Embedding) at the length-regulator host sync below
-        n_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        # counted by the kernel and raised (IndexError, as torch.nn.Embedding) at the length-regulator host sync
+        n_bad = torch.zeros(1, dtype=torch.int64, device=ids.device)
         x = hip.embed_scale(ids, P["emb"], math.sqrt(A), n_bad)
         hs = P["enc"].run(rb, x, taps=taps)                                  # f32 (R, A)
         if taps is not None:
             taps["encoder_out"] = hs.clone()
         if self.spks is not None:
-            if sids is None:
-                raise ValueError("sids required (spks is set)")
-            vec = P["sid_emb"][sids.to(dev).view(-1).long()].contiguous()   # row select (plumbing)
+            vec = P["sid_emb"][sids].contiguous()   # row select (plumbing)
             hip.add_seq_vector(rb, hs, vec)
         if self.spk_embed_dim is not None:
-            if spembs is None:
-                raise ValueError("spembs required (spk_embed_dim is set)")
             hs = P["proj"](rb, hs, spembs)
         hs_t = hip.affine_cast(hs, dt)
         p_outs = hip.predictor_head(P["pitch"].trunk(rb, hs_t), P["pitch"].w, P["pitch"].b)
@@ -261,14 +304,13 @@ class FastSpeech2(torch.nn.Module):
                                e_outs, P["energy_embed"][0], P["energy_embed"][1])
         if taps is not None:
             taps["variance_out"] = hs.clone()
-        d_used = d_pred
-        if durations is not None:
-            d_used = torch.cat([d.reshape(-1) for d in durations]).to(device=dev, dtype=torch.int64).contiguous()
-            if d_used.numel() != rb.total:
-                raise ValueError("durations do not match texts")
-        # length regulator (length_regulator.py:70-97): the one host sync of the path — output sizes
-        d_eff, cum, olens_h = hip.lr_sizes(rb, d_used, alpha, check=n_bad)   # an all-zero utterance gets all ones, as the reference's B=1 call
-        rbo = hip.RaggedBatch(olens_h, dev)
+        d_eff, cum, sizes = hip.lr_sizes_dev(rb, d_pred if d_over is None else d_over, alpha, check=n_bad)
+        return hs, p_outs, e_outs, logd, d_pred, d_eff, cum, sizes
+
+    def _back(self, P, rb, rbo, hs, cum, taps):
+        """Length-regulator gather -> decoder -> feat_out -> postnet (capturable).  -> (after, before)."""
+        dt, dev = P["dtype"], P["dev"]
+        A = self.adim
         if taps is not None:
             ys, fidx = hip.lr_gather(rb, cum, rbo, hs, want_index=True)
             taps["lr_out"], taps["frame_index"] = ys.clone(), fidx
@@ -294,8 +336,7 @@ class FastSpeech2(torch.nn.Module):
                     h = hip.conv1d(rbo, h, pc.w, pc.c_in, pc.n_out, pc.k, dtype=dt, bias=pc.b, act=ACT_TANH)
         if taps is not None:
             taps["decoder_out"] = zs_t.float()
-        return dict(feat_gen=after, before=before, olens=olens_h, feats_rb=rbo, text_rb=rb, duration=d_pred,
-                    duration_used=d_eff, pitch=p_outs, energy=e_outs, log_duration=logd)
+        return after, before
 
     def inference(
         self, text: torch.Tensor, feats: Optional[torch.Tensor] = None, durations: Optional[torch.Tensor] = None,

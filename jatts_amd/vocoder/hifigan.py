@@ -17,6 +17,7 @@ import os
 import torch
 
 from .. import hip
+from ..graphs import GraphCache
 from ..models._conformer import PackedConv
 from ..models import _schema as S
 
@@ -231,6 +232,21 @@ class HiFiGANGenerator(torch.nn.Module):
         scale/shift: optional per-channel affine applied first (Vocoder.decode normalisation).
         Returns f32 (rows * hop,) packed waveforms (utterance b owns samples cu[b]*hop ...)."""
         P = self._prepare()
+        if rb.n_seq == 1 and taps is None and not self.concurrent:
+            # B = 1 (Vocoder.decode, the reference's call shape vocoder.py:56-67): the ~150 launches of one utterance replay as ONE hipGraph per frame
+            # count (jatts_amd/graphs.py: first sight eager, second captures, bit-identical)
+            gc = P.get("graphs")
+            if gc is None:
+                gc = P["graphs"] = GraphCache()
+            affine = tuple(t for t in (scale, shift) if t is not None)
+
+            def body(mel_, *aff):
+                it = iter(aff)
+                return self._generate(P, rb, mel_, next(it) if scale is not None else None, next(it) if shift is not None else None, None)
+            return gc.run(("generate", rb.total, scale is not None, shift is not None), body, (mel,) + affine)
+        return self._generate(P, rb, mel, scale, shift, taps)
+
+    def _generate(self, P, rb, mel, scale, shift, taps):
         dt, udt = P["dtype"], P["unit_dtype"]
         pin = P["in"]
         x = hip.affine_cast(mel, dt, scale=scale, shift=shift, ldy=pin.c_in)

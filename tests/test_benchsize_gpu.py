@@ -38,6 +38,30 @@ def bench_stack(cuda, lib):
     return z, m, voc, vsd, texts
 
 
+VOC_PARAMS = {"22k": ("HIFIGAN_V1_22K", 22050, 256), "24k": ("HIFIGAN_V1_24K", 24000, 300)}
+_VOCS = {}
+
+
+def _vocoder(bench_stack, sr):
+    """(Vocoder, its state dict, generator params, hop) of BASELINE's 22.05 kHz / hop-256 generator (the fixture's) or of the 24 kHz / hop-300 one the
+    JSUT / JVS recipes load (scales 5,5,4,3, kernels 10,10,8,6: conf/fastspeech2.v1.yaml:4-6,96-99), full width, synthetic weights."""
+    from jatts_amd import synthetic
+    from jatts_amd.vocoder import Vocoder
+    z, m, voc, vsd, texts = bench_stack
+    name, rate, hop = VOC_PARAMS[sr]
+    params = getattr(synthetic, name)
+    if sr == "22k":
+        return voc, vsd, params, hop
+    if sr not in _VOCS:
+        ones, zeros = [1.0] * 80, [0.0] * 80
+        sd = synthetic.synth_hifigan_state(params, 0)
+        v = Vocoder(sd, {"sampling_rate": rate, "generator_type": "HiFiGANGenerator", "generator_params": params},
+                    {"mean": zeros, "scale": ones}, texts[0].device, trg_stats={"mean": zeros, "scale": ones})
+        _VOCS[sr] = (v.set_precision("fp32"), sd)
+    assert _VOCS[sr][0].model.hop == hop
+    return _VOCS[sr][0], _VOCS[sr][1], params, hop
+
+
 def test_fs2_bench_utterances_match_the_reference(bench_stack):
     """f32 mel of a 128-phoneme / 768-frame bench utterance vs the real reference (abs 2e-3 on values up to 4.8), computed alone and
     as part of the 64-utterance batch bench.py times; integer outputs exact."""
@@ -92,17 +116,18 @@ def test_fs2_split_mode_bench_utterances_match_the_reference(bench_stack, mode):
         m.set_precision("fp32")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f"r05_{mode}_errors_fs2.json"), "w") as f:
+    with open(os.path.join(out, f"r06_{mode}_errors_fs2.json"), "w") as f:
         json.dump(rec, f, indent=1)
 
 
-def test_hifigan_bench_size_matches_the_oracle(bench_stack):
-    """HiFi-GAN v1 (22.05 kHz, hop 256, 512 channels) on a 768-frame mel: 196 608 samples vs oracle.hifigan_generate (f32, abs 2e-4 on a
-    signal in [-1, 1]), alone and as utterances 0 / 37 inside the batch of 64 the bench times."""
+@pytest.mark.parametrize("sr", ["22k", "24k"])
+def test_hifigan_bench_size_matches_the_oracle(bench_stack, sr):
+    """HiFi-GAN v1 (22.05 kHz, hop 256 / 24 kHz, hop 300; 512 channels) on a 768-frame mel: 196 608 / 230 400 samples vs oracle.hifigan_generate
+    (f32, abs 2e-4 on a signal in [-1, 1]), alone and as utterances 0 / 37 inside the batch of 64 the bench times."""
     from jatts_amd import hip
-    from jatts_amd.synthetic import HIFIGAN_V1_22K
     from oracle.hifigan_oracle import hifigan_generate
-    z, m, voc, vsd, texts = bench_stack
+    z, m, _, _, texts = bench_stack
+    voc, vsd, HIFIGAN_V1_22K, hop = _vocoder(bench_stack, sr)      # (the generator under test; the name is kept for the lines below)
     utts = [int(u) for u in z["utts"]]
     dev = texts[0].device
     rbatch = m.inference_batch(texts)
@@ -114,18 +139,19 @@ def test_hifigan_bench_size_matches_the_oracle(bench_stack):
         with torch.no_grad():
             refs[u] = hifigan_generate(vsd, torch.tensor(z[f"u{j}_feat_gen"]), HIFIGAN_V1_22K["upsample_scales"],
                                        HIFIGAN_V1_22K["resblock_dilations"])
-        assert refs[u].numel() == 768 * 256 and float(refs[u].abs().max()) > 1e-3
+        assert refs[u].numel() == 768 * hop and float(refs[u].abs().max()) > 1e-3
     yb = voc.decode_batch(rbatch["feats_rb"], mel_b)
-    assert yb.numel() == 64 * 768 * 256
+    assert yb.numel() == 64 * 768 * hop
     for j, u in enumerate(utts):
         y1 = voc.decode_batch(hip.RaggedBatch([768], dev), torch.tensor(z[f"u{j}_feat_gen"]).to(dev))
         e1 = maxdiff(y1.reshape(-1), refs[u].reshape(-1))
-        eb = maxdiff(yb[768 * 256 * u:768 * 256 * (u + 1)].reshape(-1), refs[u].reshape(-1))
-        assert e1 <= 2e-4 and eb <= 2e-4, f"utterance {u}: alone {e1:.3e}, in the batch {eb:.3e}"
+        eb = maxdiff(yb[768 * hop * u:768 * hop * (u + 1)].reshape(-1), refs[u].reshape(-1))
+        assert e1 <= 2e-4 and eb <= 2e-4, f"{sr} utterance {u}: alone {e1:.3e}, in the batch {eb:.3e}"
 
 
+@pytest.mark.parametrize("sr", ["22k", "24k"])
 @pytest.mark.parametrize("mode", ["fp32_split", "fp32_bf16x3"])
-def test_hifigan_split_mode_at_bench_size(bench_stack, mode):
+def test_hifigan_split_mode_at_bench_size(bench_stack, mode, sr):
     """The fp32_split vocoder (round 4: ResBlock units on split f16 hi/lo MFMA operands; round 5, "fp32_bf16x3": on three exact bf16 terms per
     operand, seven MFMA products) on the same 768-frame mels: the SAME tolerance as
     the exact-f32 path against the f32 oracle (abs 2e-4), and against the oracle run in FP64 its maximum error must not exceed twice the
@@ -134,9 +160,9 @@ def test_hifigan_split_mode_at_bench_size(bench_stack, mode):
     import json
     import os
     from jatts_amd import hip
-    from jatts_amd.synthetic import HIFIGAN_V1_22K
     from oracle.hifigan_oracle import hifigan_generate
-    z, m, voc, vsd, texts = bench_stack
+    z, m, _, _, texts = bench_stack
+    voc, vsd, HIFIGAN_V1_22K, hop = _vocoder(bench_stack, sr)      # (the generator under test; the name is kept for the lines below)
     utts = [int(u) for u in z["utts"]]
     dev = texts[0].device
     rbatch = m.inference_batch(texts)
@@ -158,7 +184,7 @@ def test_hifigan_split_mode_at_bench_size(bench_stack, mode):
             ys = voc.decode_batch(hip.RaggedBatch([768], dev), mel.to(dev)).reshape(-1)
             voc.set_precision("fp32")
             yf = voc.decode_batch(hip.RaggedBatch([768], dev), mel.to(dev)).reshape(-1)
-            assert torch.equal(ys, yb[768 * 256 * u:768 * 256 * (u + 1)].reshape(-1)), "split mode: utterance alone != inside the batch"
+            assert torch.equal(ys, yb[768 * hop * u:768 * hop * (u + 1)].reshape(-1)), "split mode: utterance alone != inside the batch"
             e32 = maxdiff(ys, ref32)
             es64, ef64 = float((ys.double().cpu() - ref64).abs().max()), float((yf.double().cpu() - ref64).abs().max())
             rs64 = float((ys.double().cpu() - ref64).pow(2).mean().sqrt())
@@ -172,7 +198,7 @@ def test_hifigan_split_mode_at_bench_size(bench_stack, mode):
         voc.set_precision("fp32")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f"r05_{mode}_errors.json"), "w") as f:
+    with open(os.path.join(out, f"r06_{mode}_errors{'' if sr == '22k' else '_24k'}.json"), "w") as f:
         json.dump(rec, f, indent=1)
 
 
@@ -312,10 +338,10 @@ def test_conv1d_direct_edge_geometry(cuda, lib, case, variant):
 
 # ------------------------------------------------------------------------------------------------ configs 3 and 5 at the bench's length
 def _record_error(name, prec, e_alone, e_batch):
-    """max |mel - reference| per arithmetic -> gpurun_out/r05_model_errors.json (profiles/r05_notes.md quotes the table)."""
+    """max |mel - reference| per arithmetic -> gpurun_out/r06_model_errors.json (profiles/r06_notes.md quotes the table)."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_model_errors.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r06_model_errors.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     rec = json.load(open(path)) if os.path.exists(path) else {}
     rec.setdefault(name, {})[prec] = {"alone": e_alone, "in_batch_of_8": e_batch}

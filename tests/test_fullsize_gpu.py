@@ -29,6 +29,20 @@ def _make_stack(cuda, prec):
     return m, voc
 
 
+_VOC24 = {}
+
+
+def _voc24(cuda, prec):
+    """The 24 kHz / hop-300 generator the JSUT / JVS recipes load (scales 5,5,4,3; conf/fastspeech2.v1.yaml:96-99), one per arithmetic."""
+    from jatts_amd.synthetic import HIFIGAN_V1_24K, synth_hifigan_state
+    from jatts_amd.vocoder import Vocoder
+    if prec not in _VOC24:
+        ones, zeros = [1.0] * 80, [0.0] * 80
+        _VOC24[prec] = Vocoder(synth_hifigan_state(HIFIGAN_V1_24K, 0), {"sampling_rate": 24000, "generator_type": "HiFiGANGenerator", "generator_params": HIFIGAN_V1_24K},
+                               {"mean": zeros, "scale": ones}, cuda, trg_stats={"mean": zeros, "scale": ones}).set_precision(prec)
+    return _VOC24[prec]
+
+
 @pytest.fixture(scope="module")
 def stack(cuda, lib):
     return _make_stack(cuda, "fp16")
@@ -74,11 +88,17 @@ def stack_emul6(cuda, lib):
 
 @pytest.mark.parametrize("prec", ["fp16", "fp32", "fp32_split", "fp32_bf16x3", "fp32_bf16x3_6p"])
 @pytest.mark.parametrize("ragged", [False, True], ids=["64x128", "64xU(64..128)"])
-def test_full_batch_properties(cuda, stack, stack32, stack_split, stack_emul, stack_emul6, ragged, prec):
-    """fp32 = the arithmetic bench.py's headline measures (register-streamed f32 convs, f32 fused units): determinism, utterance
-    independence and permutation equivariance hold bit for bit there too."""
+@pytest.mark.parametrize("sr", ["22k", "24k"])
+def test_full_batch_properties(cuda, stack, stack32, stack_split, stack_emul, stack_emul6, sr, ragged, prec):
+    """fp32_bf16x3 = the arithmetic bench.py's headline measures, fp32 = the reference's own (register-streamed f32 convs, f32 fused units):
+    determinism, utterance independence and permutation equivariance hold bit for bit in every arithmetic, through the 22.05 kHz / hop-256 generator
+    of BASELINE's metric and the 24 kHz / hop-300 one of the recipes (odd strides 5 and 3 in the polyphase upsampling convs)."""
     from jatts_amd.synthetic import synth_texts
     stack = {"fp32": stack32, "fp32_split": stack_split, "fp32_bf16x3": stack_emul, "fp32_bf16x3_6p": stack_emul6, "fp16": stack}[prec]
+    if sr == "24k":
+        stack = (stack[0], _voc24(cuda, prec))
+    hop = stack[1].model.hop
+    assert hop == (256 if sr == "22k" else 300)
     texts = [t.to(cuda) for t in synth_texts(64, 128, 45, seed=1)]
     if ragged:
         g = torch.Generator().manual_seed(5)
@@ -88,7 +108,7 @@ def test_full_batch_properties(cuda, stack, stack32, stack_split, stack_emul, st
     assert torch.equal(r["duration"].cpu(), torch.full((sum(len(t) for t in texts),), 6, dtype=torch.int64))
     assert r["olens"] == [6 * len(t) for t in texts]
     for t, y in zip(texts, outs):
-        assert y.numel() == 6 * len(t) * 256
+        assert y.numel() == 6 * len(t) * hop
     ycat = torch.cat(outs)
     assert torch.isfinite(ycat).all() and float(ycat.abs().max()) <= 1.0 and float(ycat.abs().max()) > 0.0
     # determinism

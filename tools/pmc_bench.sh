@@ -7,6 +7,6 @@ TAG=${1:-pmc_bench}
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --pmc-child > $OUT.$c.log 2>&1
+  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --pmc-child --pmc-all > $OUT.$c.log 2>&1
 done
 ls -R $OUT | head
