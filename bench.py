@@ -131,7 +131,7 @@ def cpu_baseline(fs2_sd, voc_sd, voc_params, texts, heads, budget_s, threads):
                 break
     secs = t_fs2 + t_voc
     return dict(value=samples / secs, unit="samples/s", cores=threads, kind="port",
-                sample_short=f"{n}/{len(texts)} utts x {texts[0].numel()} phonemes, B=1 loop, torch CPU f32 oracle, {threads} thr",
+                sample_short=f"{n}/{len(texts)} utts x {texts[0].numel()} phonemes, B=1 loop, torch CPU f32 oracle",
                 sample=f"{n} of the bench's {len(texts)} utterances x {texts[0].numel()} phonemes, one at a time (the reference "
                        f"loop is B=1) -> {frames} frames -> {samples} samples, torch CPU fp32 oracle, {threads} threads, "
                        f"text2mel {t_fs2:.2f}s + vocoder {t_voc:.2f}s",
@@ -362,8 +362,9 @@ class Job:
         return self.m.inference_batch(self.texts, self.spk, noise_scale=0.667, durations=self.dur, noise=self.noise)
 
 
-def run_timed(job, a, world, dist, pipeline=False, record=True):
-    """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks.  -> dict"""
+def run_timed(job, a, world, dist, pipeline=False, record=True, job_samples=None):
+    """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks.  -> dict.  job_samples: samples ALL ranks produce per step when
+    the ranks' shares differ (the sharded ragged leg); default: this rank's x world (weak scaling, equal shares)."""
     import torch
     from jatts_amd import hip
 
@@ -417,12 +418,12 @@ def run_timed(job, a, world, dist, pipeline=False, record=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
         rank_ms = {"min": -float(t[2]) / a.steps * 1e3, "max": float(t[1]) / a.steps * 1e3}
-    total_samples = sum(lens) * world * a.steps
+    total_samples = (job_samples if job_samples is not None else sum(lens) * world) * a.steps
     assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
     stages = ({nme: sum(e[i].elapsed_time(e[i + 1]) for e in stage_ev) / len(stage_ev)
                for i, nme in enumerate(["text2mel", "vocoder", "audio_all_gather"])} if stage_ev else None)
     return dict(dt=dt, value=total_samples / dt, ms_per_step=dt / a.steps * 1e3, rtf=dt / (total_samples / job.sr),
-                stages=stages, recs=recs, rank_ms=rank_ms, mel=r["feat_gen"], wave=y, frames=sum(r["olens"]), samples_per_step=sum(lens) * world)
+                stages=stages, recs=recs, rank_ms=rank_ms, mel=r["feat_gen"], wave=y, frames=sum(r["olens"]), samples_per_step=total_samples // a.steps)
 
 
 def ragged_leg(job, a, world, dist, rank, uniform_value, record=True):
@@ -430,12 +431,26 @@ def ragged_leg(job, a, world, dist, rank, uniform_value, record=True):
     utterances with T_text ~ U{ragged_min..t_text}, same frames per phoneme, in the job's current arithmetic.  per_sample_efficiency =
     ragged samples/s / uniform samples/s: 1.0 when a sample costs the same in a ragged batch (tile tails, early-exit workgroups of a grid
     sized for the longest utterance and, at N > 1, the ranks' unequal shares all push it below 1)."""
+    from jatts_amd.hostlogic import shard_load, shard_utterances
     from jatts_amd.synthetic import synth_texts
     uniform = job.texts
-    job.texts = [t.to(job.dev) for t in synth_texts(job.batch, a.t_text, job.vocab, seed=a.ragged_seed + rank, ragged_min=a.ragged_min)]
+    job_samples = imbalance = None
+    if world > 1:
+        # BASELINE configs[3]'s shape: ONE ragged batch of world x batch utterances (the same draw on every rank), dealt to the ranks by
+        # shard_utterances -- what tts_decode --n_gpus N does with a csv -- instead of every rank drawing its own lengths (whose sums differ by
+        # ~3 % between ranks at 64 x U{64..128}: that would measure the draw, not the path)
+        every = synth_texts(job.batch * world, a.t_text, job.vocab, seed=a.ragged_seed, ragged_min=a.ragged_min)
+        tl = [int(t.numel()) for t in every]
+        parts = shard_utterances(tl, world)
+        mx, mean = shard_load(tl, parts)
+        imbalance = mx / mean
+        job.texts = [every[i].to(job.dev) for i in parts[rank]]
+        job_samples = sum(tl) * a.frames_per_token * job.hop
+    else:
+        job.texts = [t.to(job.dev) for t in synth_texts(job.batch, a.t_text, job.vocab, seed=a.ragged_seed + rank, ragged_min=a.ragged_min)]
     lens = [int(t.numel()) for t in job.texts]
     try:
-        r = run_timed(job, a, world, dist, record=record)
+        r = run_timed(job, a, world, dist, record=record, job_samples=job_samples)
     finally:
         job.texts = uniform
     blk = {"t_text": f"U{{{a.ragged_min}..{a.t_text}}}", "seed": a.ragged_seed, "utterances_per_gpu": job.batch,
@@ -443,6 +458,9 @@ def ragged_leg(job, a, world, dist, rank, uniform_value, record=True):
            "value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "samples_per_step": r["samples_per_step"],
            "stage_ms_per_step": r["stages"], "rank_ms_per_step": r["rank_ms"],
            "per_sample_efficiency": r["value"] / uniform_value}
+    if imbalance is not None:
+        blk["sharding"] = f"one batch of {job.batch * world} utterances dealt by jatts_amd.hostlogic.shard_utterances (longest first to the least-loaded rank)"
+        blk["predicted_slowest_over_mean_load"] = imbalance
     if r["recs"]:
         units = [ms for tag, _, ms in r["recs"] if tag in ("resunit", "resblock")]
         blk["resunit_ms_per_step"] = sum(units) / a.steps
@@ -725,11 +743,13 @@ def compact_line(out, detail_path=None):
         c["ragged"] = {k: rg.get(k) for k in ("t_text", "seed", "value", "ms_per_step", "per_sample_efficiency")}
         if rg.get("rank_ms_per_step"):
             c["ragged"]["rank_ms"] = rg["rank_ms_per_step"]
+        if rg.get("predicted_slowest_over_mean_load"):
+            c["ragged"]["predicted_imbalance"] = rg["predicted_slowest_over_mean_load"]
     if out.get("roofline_conv1d"):
-        c["roofline_conv1d"] = out["roofline_conv1d"]
+        c["roofline_conv1d"] = {k: out["roofline_conv1d"].get(k) for k in ("achieved", "peak", "frac", "frac_of_practical", "ms_per_step")}
     cb = out.get("cpu_baseline")
     if cb:
-        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "rtf", "cpu_model", "host_logical_cores", "seconds")}
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "rtf", "cpu_model")}
         c["cpu_baseline"]["sample"] = cb.get("sample_short") or cb.get("sample")
         if cb.get("single_thread"):
             c["cpu_baseline"]["single_thread_rtf"] = cb["single_thread"]["rtf"]
@@ -753,10 +773,10 @@ def compact_line(out, detail_path=None):
         def leg(b):
             rf = b.get("roofline") or {}
             return {"value": b["value"], "ms_per_step": b["ms_per_step"], "vocoder_ms": (b.get("stage_ms_per_step") or {}).get("vocoder"),
-                    "roofline_frac": rf.get("frac"), "frac_of_practical": rf.get("frac_of_practical"), "kernel": (rf.get("kernel") or "").split(" (")[0]}
+                    "roofline_frac": rf.get("frac"), "frac_of_practical": rf.get("frac_of_practical")}
         c["vocoder_24k"] = {"sampling_rate": v24["sampling_rate"], "hop": v24["hop"], **leg(v24["headline"])}
         if v24.get("exact_f32"):
-            c["vocoder_24k"]["exact_f32"] = {k: v for k, v in leg(v24["exact_f32"]).items() if k != "kernel"}
+            c["vocoder_24k"]["exact_f32"] = leg(v24["exact_f32"])
     b1 = out.get("b1_latency")
     if b1:
         c["b1_latency"] = {k: b1.get(k) for k in ("ms", "kernel_ms", "wall_over_kernel", "launch_gap_frac", "eager_ms", "launches", "utterance")}
@@ -764,14 +784,13 @@ def compact_line(out, detail_path=None):
     if fm:
         c["fast_mode"] = {"dtype": "f16", "value": fm["value"], "ms_per_step": fm["ms_per_step"],
                           "max_abs_err_wave": fm.get("max_abs_err_wave"),
-                          "roofline_frac": (fm.get("roofline") or {}).get("frac"), "speedup_vs_cpu_rtf": fm.get("speedup_vs_cpu_rtf")}
+                          "roofline_frac": (fm.get("roofline") or {}).get("frac")}
     if out.get("configs"):
         c["configs"] = {("matcha_mas_b64" if "Matcha" in e["config"] else "vits_spk192_b32"):
                         {"ms": (e.get("f32_emul_mode") or {}).get("ms_per_step"),
                          "text2mel_ms": ((e.get("f32_emul_mode") or {}).get("stage_ms_per_step") or {}).get("text2mel"),
                          "f32_ms": e["ms_per_step"], "f32_text2mel_ms": (e.get("stage_ms_per_step") or {}).get("text2mel"),
-                         "f16_ms": (e.get("fast_mode") or {}).get("ms_per_step"),
-                         "f32_roofline_frac": ((e.get("roofline") or {}).get("dominant") or {}).get("frac")} for e in out["configs"]}
+                         "f16_ms": (e.get("fast_mode") or {}).get("ms_per_step")} for e in out["configs"]}
     if out.get("training"):
         c["training"] = {e["kind"]: {"ms": e["ms_per_step"], "frac": e.get("frac_of_f32_mfma_peak")} for e in out["training"]}
     if detail_path:
