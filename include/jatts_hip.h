@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops; 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
+#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops, jatts_conv_desc + n_split / ldy2 / y2 / y2_seq_col0 (appended); 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
                                 * so every descriptor that embeds it (jatts_conv_desc, jatts_resunit_desc, jatts_resblock_desc, jatts_relattn_desc) shifted by 8 bytes; JATTS_F32E; 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
                                 * bumped whenever a descriptor's layout or an entry point's signature changes: a stale library is refused at load */
 
@@ -147,6 +147,15 @@ typedef struct jatts_conv_desc {
                         * W[n] * 2^s[n] (jatts_amd.hip.pack_conv_weight_split); x_i, resid and y are f32 */
   const float* act_a;  /* JATTS_ACT_SNAKEBETA only (NULL otherwise): [n_out] exp(alpha) and ... */
   const float* act_b;  /* ... [n_out] 1 / (exp(beta) + 1e-9), the two per-channel vectors jatts_snakebeta takes */
+  /* (ABI 4) TWO outputs from one launch -- the Q | K | V projection of an attention block (modules/transformer/attention.py:39-61 forward_qkv; Matcha's
+   * attn1.to_q / to_k / to_v, modules/matchatts/transformer.py:222-260) as ONE conv over the concatenated weights: output channels n < n_split go to y as
+   * described above (row-major), channels n >= n_split go to y2 TRANSPOSED, y2[(n - n_split) * ldy2 + column] with the column rule of y_seq_col0 taken
+   * from y2_seq_col0 (V^T in the attention kernel's layout).  n_split = 0: one output.  Requires n_split % 256 == 0 (a workgroup's channel slab lies on
+   * one side), y_transposed = 0, resid = NULL; y2 has y's element type.  Same arithmetic as two launches: every output element is the same contraction. */
+  int32_t n_split;
+  int32_t ldy2;
+  void* y2;
+  const int32_t* y2_seq_col0;
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);

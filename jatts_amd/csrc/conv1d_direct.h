@@ -85,6 +85,7 @@ __global__ __launch_bounds__(WN* WT * 64, (D <= 2 ? 3 : 2)) void conv1d_direct_k
   const int nf0 = (bz * WN + wn) * NF;
   const int col0 = wt * NT * 32;
   const int g = lane >> 5;
+  conv_second_output(d, bz * WN * NF * 32);
 
   // accumulators start at the bias through the matrix pipe: acc = [bias | 0] (A, k = 0 / 1) x [1 | 1] (B) + 0 -- four MFMAs with an
   // inline-zero C operand instead of 64 v_mov + 8 loads per lane

@@ -21,11 +21,20 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   // (six products: the same tile for SMALL k = 1 launches -- <= 768 workgroups of 128 x 128, i.e. one round of the two-per-CU slots: 40-72 -> 58-79 TFLOP/s at
   //  4 096 / 8 192 rows.  Nothing in this arithmetic depends on the tile, so the choice may follow the launch.)
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
-  const bool small_k1 = d.k_w == 1 && ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128) <= 768;
+  const int64_t wgs128 = ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128);
+  const bool small_k1 = d.k_w == 1 && wgs128 <= 768;
+  // round 6, the B = 1 drop-in path (one utterance: 768 rows): a k = 3 feed-forward conv is 72 (384 -> 1536) or 18 (1536 -> 384) workgroups of 128 x 128 on 256
+  // CUs, each walking the whole contraction -- 44 % of the utterance's GPU time.  Launches that cannot give every CU one such workgroup take the 128 n x 64 t
+  // tile (twice the workgroups, two per CU).  Nothing in this arithmetic depends on the tile.
+  if (variant == 0 && d.k_w > 1 && wgs128 <= 128 && (d.k_w - 1) * d.dil <= 32) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4>(d, s);
   // The same 128 n x 64 t tile as four waves of 1 x 2 fragments SIDE BY SIDE IN n (each wave 32 n x 64 t): half the weight fragments fetched per
   // MFMA (a 2 x 1 wave pulls 6 KB of weights per 14 MFMAs through the vector memory path, eight waves ~110 B / clk / CU): another +4-9 % on every
   // k = 1 shape, +20 % at 4 096 rows (profiles/r05_notes.md); 64 n x 128 t (variant 5) stages twice the activations per MFMA and loses 30 %.
   if (variant == 6 || (variant == 0 && d.k_w == 1 && (TWO || small_k1))) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4>(d, s);
+  // round-6 candidates with the next chunk's commit INSIDE the MFMA loop (conv1d_emul.h: conv_stage_commit)
+  if (variant == 20 && d.k_w == 1) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 0, 4, true>(d, s);      // the k = 1 product tile, interleaved
+  if (variant == 20 || variant == 21) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4, true>(d, s);  // the k >= 2 product tile (seven products), interleaved
+  if (variant == 22) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4, true>(d, s);                   // 128 n x 64 t for every k, interleaved
   // round-6 k = 1 candidates (HALO = 0: no halo rows in the staging registers): fewer barriers per MFMA through wider chunks / 2 x 2-fragment waves
   if (d.k_w == 1 && variant == 8) return launch_conv_emul<T, 2, 2, 4, 1, 1, 128, 1, 0, 4>(d, s);   // 256 n x 64 t, four waves of 2 x 2, 128-channel chunks, one workgroup per CU
   if (d.k_w == 1 && variant == 9) return launch_conv_emul<T, 2, 2, 2, 2, 1, 64, 1, 0, 4>(d, s);    // 128 n x 128 t, four waves of 2 x 2, 64-channel chunks

@@ -41,6 +41,19 @@ struct XcdOrder {
   }
 };
 
+// Two outputs from one launch (jatts_conv_desc.n_split > 0: the Q | K | V projection): a workgroup whose channel slab starts at or beyond n_split
+// writes the SECOND output -- transposed, through the generic fragment-order epilogue -- by pointing its private copy of the descriptor at it, shifted
+// so that the absolute channel index n addresses row n - n_split.  n_split is a multiple of every kernel's slab (256), so a slab never straddles it.
+__device__ __forceinline__ void conv_second_output(jatts_conv_desc& d, int n_first) {
+  if (d.n_split > 0 && n_first >= d.n_split) {
+    const size_t esz = (d.y_is_f32 || d.dtype != JATTS_F16) ? 4 : 2;
+    d.y = (char*)d.y2 - (size_t)d.n_split * (size_t)d.ldy2 * esz;
+    d.ldy = d.ldy2;
+    d.y_transposed = 1;
+    d.y_seq_col0 = d.y2_seq_col0;
+  }
+}
+
 // ------------------------------------------------------------------ generic conv kernel
 constexpr int KCH = 64;  // channels staged per LDS chunk
 
@@ -168,6 +181,7 @@ __global__ __launch_bounds__(WN* WT * 64, (KCHT == 128 || (sizeof(T) == 4 && NIN
   const int NFR = n_pad >> 5;
   const int nf0 = (bz * WN + wn) * NF;
   const int col0 = wt * NT * 32;
+  conv_second_output(d, bz * WN * NF * 32);
 
   const T* xin[3] = {(const T*)d.x[0], (const T*)d.x[1], (const T*)d.x[2]};
   const bool reflect = d.pad_mode == JATTS_PAD_REFLECT;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_split_kernel(jatts_co
   const int NFR = n_pad >> 5;
   const int nf0 = (bz * WN + wn) * NF;
   const int col0 = wt * NT * 32;
+  conv_second_output(d, bz * WN * NF * 32);
   float* slots = reinterpret_cast<float*>(smem + slot_off);
 
   const float* xin[3] = {(const float*)d.x[0], (const float*)d.x[1], (const float*)d.x[2]};

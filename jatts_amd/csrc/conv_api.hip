@@ -42,6 +42,8 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: bad geometry");
   if (d->act == JATTS_ACT_SNAKEBETA && (!d->act_a || !d->act_b || (d->n_out & 3) || ((uintptr_t)d->act_a & 15) || ((uintptr_t)d->act_b & 15)))
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_ACT_SNAKEBETA needs 16-byte aligned act_a / act_b and n_out % 4 == 0");
+  if (d->n_split != 0 && (d->n_split < 0 || d->n_split % 256 || d->n_split >= d->n_out || !d->y2 || d->y_transposed || d->resid || d->ldy2 <= 0))
+    return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: n_split must be a multiple of 256 below n_out, with y2 / ldy2 set, y row-major and no residual");
   if (d->rg.max_len <= 0) return JATTS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return jatts_conv1d_f16(*d, s);

@@ -13,6 +13,13 @@ template <typename T>
 static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   static const int variant = [] { const char* e = getenv("JATTS_RESUNIT_EMUL_VARIANT"); return e ? atoi(e) : 0; }();
   const int halo = (d.k_w - 1) * d.dil;   // x-tile rows beyond the workgroup's columns
+  // Round 6, the B = 1 drop-in path: ONE utterance is 6 144 rows at C = 256 and 49 152 at C = 128 -- 114 and 417 workgroups of the throughput windows on 256
+  // CUs, each walking both convs' whole contraction (100-180 us).  A launch that cannot hand every CU a workgroup (C = 256) or ends in a half-empty
+  // second round (C = 128) takes the next narrower window: more halo recomputation, twice the workgroups, ~0.6x the time.  Bit-identical (nothing in this
+  // arithmetic depends on the tile).
+  const int64_t cols = (int64_t)d.rg.max_len * d.rg.len_mul;
+  auto wgs = [&](int window) { const int64_t tt = window - (d.k_w - 1); return tt > 0 ? ((cols + tt - 1) / tt) * d.rg.n_seq : (int64_t)1 << 40; };
+  const bool auto_tile = variant == 0;
   switch (d.channels) {
     case 32:
       if (variant == 1) return launch_resunit_emul<T, 32, 128, 1, 2, 2, 2>(d, s);          // 2 waves per workgroup
@@ -24,9 +31,10 @@ static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
     case 128:
       if (variant == 1) return launch_resunit_emul<T, 128, 128, 4, 2, 2, 1>(d, s);         // 8 waves NF = 1 NT = 2, one workgroup per CU
       if (variant == 3) return launch_resunit_emul<T, 128, 128, 2, 1, 2, 1>(d, s);         // 8 waves NF = 2 NT = 1
-      if (variant == 4 && (64 + halo) * 784 + 1024 <= 80 * 1024) return launch_resunit_emul<T, 128, 64, 2, 1, 2, 2>(d, s);   // two per CU
+      if ((variant == 4 || (auto_tile && wgs(128) <= 448)) && (64 + halo) * 784 + 1024 <= 80 * 1024) return launch_resunit_emul<T, 128, 64, 2, 1, 2, 2>(d, s);   // two per CU
       return launch_resunit_emul<T, 128, 128, 2, 2, 2, 1>(d, s);                           // 4 waves NF = 2 NT = 2, one workgroup per CU
     case 256:
+      if (auto_tile && wgs(64) <= 160) return launch_resunit_emul<T, 256, 32, 4, 1, 2, 1>(d, s);   // small launch: 32-column window
       if ((64 + halo) * 1552 + 2048 <= 160 * 1024) {
         if (variant == 1) return launch_resunit_emul<T, 256, 64, 8, 2, 2, 1>(d, s);        // 8 waves NF = 1 NT = 2
         return launch_resunit_emul<T, 256, 64, 4, 2, 2, 1>(d, s);                          // 4 waves NF = 2 NT = 2

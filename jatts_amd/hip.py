@@ -509,10 +509,12 @@ def convtranspose_as_conv(w, stride, padding):
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
            in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
-           y_seq_col0=None, reflect=False, variant=0, w_inv=None, snake=None):
+           y_seq_col0=None, reflect=False, variant=0, w_inv=None, snake=None, split=None):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors.  dtype F32S: f32 tensors, ``w_packed`` / ``w_inv``
     from pack_conv_weight_split (c_mult 64).  ``snake`` = (exp(alpha), 1 / (exp(beta) + 1e-9)) f32 vectors of n_out: the SnakeBeta
-    activation (the ``snakebeta`` op) applied in the epilogue instead of ``act``."""
+    activation (the ``snakebeta`` op) applied in the epilogue instead of ``act``.  ``split`` = (n_split, ld2, seq_col0): TWO outputs from one launch
+    (the Q | K | V projection): channels < n_split row-major as usual, channels >= n_split transposed into a (n_out - n_split, ld2) matrix with the V^T
+    column layout ``seq_col0`` (RaggedBatch.vt_layout); returns (out, out2)."""
     lib = _abi.load()
     if isinstance(xs, torch.Tensor):
         xs = [xs]
@@ -552,6 +554,13 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     elif w_packed.dtype != tdt or w_packed.numel() != n_pad * c_in * k_w:
         raise ValueError("conv1d: packed weight has wrong dtype/size")
     odt = torch.float32 if out_f32 else tdt
+    out2 = None
+    if split is not None:
+        n_split, ld2, col2 = split
+        if transposed or out is not None or resid is not None or n_split % 256 or not 0 < n_split < n_out:
+            raise ValueError("conv1d: split takes a fresh row-major output, no residual, n_split a multiple of 256 below n_out")
+        out = torch.empty(rows, out_ld or n_split, dtype=odt, device=x0.device)
+        out2 = torch.empty(n_out - n_split, ld2, dtype=odt, device=x0.device)
     if out is None:
         if transposed:
             # slack columns of an aligned V^T layout stay uninitialised: the attention kernel masks every element
@@ -588,10 +597,12 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
     d.y_seq_col0 = _ptr(y_seq_col0) if transposed else None
     d.w_inv = _ptr(w_inv) if dtype == F32S else None
+    if out2 is not None:
+        d.n_split, d.ldy2, d.y2, d.y2_seq_col0 = split[0], split[1], out2.data_ptr(), _ptr(split[2])
     _count(2.0 * c_in * n_out * k_w * rows)
     with _Timed("conv1d", (c_in, n_out, k_w, rows)):
         _abi.check(lib.jatts_conv1d(C.byref(d), _stream()), "jatts_conv1d")
-    return out
+    return out if out2 is None else (out, out2)
 
 
 def _check_unit_weights(who, dtype, channels, k_w, *ws):

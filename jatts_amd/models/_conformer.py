@@ -8,12 +8,14 @@ processed exactly as the reference's B=1 ``inference()`` does (no pad leakage; S
 and sequences kernel launches.
 """
 import math
+import os
 
 import torch
 
 from .. import hip
 from ..hip import ACT_NONE, ACT_RELU
 
+QKV_ONE_LAUNCH = os.environ.get("JATTS_QKV_ONE_LAUNCH", "1") != "0"     # A/B switch (tools/); the two forms are bit-identical (tests/test_kernels_gpu.py)
 LN_EPS = 1e-12  # modules/transformer/layer_norm.py:23
 BN_EPS = 1e-5   # torch.nn.BatchNorm1d default
 PE_TABLE_LEN = 5000  # modules/positional_encoding.py:26
@@ -126,6 +128,9 @@ class ConformerRunner:
             L["qk"] = PackedConv(torch.cat([wq, wk], 0), torch.cat([g(a + "linear_q.bias"), g(a + "linear_k.bias")], 0),
                                  dtype, device)
             L["v"] = PackedConv(g(a + "linear_v.weight"), g(a + "linear_v.bias"), dtype, device)
+            if (2 * self.A) % 256 == 0:     # Q | K | V as ONE launch (jatts_conv_desc.n_split): Q | K row-major, V transposed
+                L["qkv"] = PackedConv(torch.cat([wq, wk, g(a + "linear_v.weight")], 0),
+                                      torch.cat([g(a + "linear_q.bias"), g(a + "linear_k.bias"), g(a + "linear_v.bias")], 0), dtype, device)
             L["o"] = PackedConv(g(a + "linear_out.weight"), g(a + "linear_out.bias"), dtype, device)
             L["rel"] = has("self_attn.linear_pos.weight")
             if L["rel"]:
@@ -193,10 +198,13 @@ class ConformerRunner:
     def _mha(self, rb, x, L, pos, kv_len=None):
         A, H, dk = self.A, self.H, self.dk
         xn = hip.layernorm(x, L["norm_mha"][0], L["norm_mha"][1], self.dtype, LN_EPS)
-        qk = hip.conv1d(rb, xn, L["qk"].w, A, 2 * A, 1, dtype=self.dtype, bias=L["qk"].b)       # (R, 2A)
         vcol, ldvt = rb.vt_layout()
-        vt = hip.conv1d(rb, xn, L["v"].w, A, A, 1, dtype=self.dtype, bias=L["v"].b, transposed=True,
-                        out_ld=ldvt, y_seq_col0=vcol)                                            # (A, ldvt)
+        if "qkv" in L and QKV_ONE_LAUNCH:
+            qk, vt = hip.conv1d(rb, xn, L["qkv"].w, A, 3 * A, 1, dtype=self.dtype, bias=L["qkv"].b, split=(2 * A, ldvt, vcol))   # (R, 2A), (A, ldvt)
+        else:
+            qk = hip.conv1d(rb, xn, L["qk"].w, A, 2 * A, 1, dtype=self.dtype, bias=L["qk"].b)       # (R, 2A)
+            vt = hip.conv1d(rb, xn, L["v"].w, A, A, 1, dtype=self.dtype, bias=L["v"].b, transposed=True,
+                            out_ld=ldvt, y_seq_col0=vcol)                                            # (A, ldvt)
         g = ku = None
         ldg = 0
         rel_mode, rel_center = 1, 0

@@ -22,7 +22,7 @@ import torch
 from .. import hip
 from ..hip import ACT_MISH, ACT_NONE, ACT_RELU, ACT_SWISH
 from . import _schema as S
-from ._conformer import ConformerRunner, PackedConv, SpkProjection
+from ._conformer import QKV_ONE_LAUNCH, ConformerRunner, PackedConv, SpkProjection
 from .fastspeech2 import _Predictor
 
 GN_EPS = 1e-5  # torch.nn.GroupNorm / LayerNorm defaults (decoder.py:71, transformer.py:213)
@@ -98,6 +98,8 @@ class _TBlock:
             raise NotImplementedError("attention head dim must be a multiple of 32")
         self.qk = PackedConv(torch.cat([wq, wk], 0), None, dt, dev)
         self.v = PackedConv(sd[p + "attn1.to_v.weight"], None, dt, dev)
+        # Q | K | V as ONE launch (jatts_conv_desc.n_split; transformer.py:222-260 issues three Linear calls): Q | K row-major, V transposed
+        self.qkv = PackedConv(torch.cat([wq, wk, sd[p + "attn1.to_v.weight"]], 0), None, dt, dev) if (2 * self.inner) % 256 == 0 else None
         self.o = PackedConv(sd[p + "attn1.to_out.0.weight"], sd[p + "attn1.to_out.0.bias"], dt, dev)
         self.ff1 = PackedConv(sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"], dt, dev)
         self.ff2 = PackedConv(sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"], dt, dev)
@@ -109,9 +111,12 @@ class _TBlock:
         1/sqrt(d) scaling -- diffusers adds `attention_mask` to the scores [recalled]; Matcha passes its 1/0 frame mask."""
         C, I = x.shape[1], self.inner
         n = hip.layernorm(x, self.n1[0], self.n1[1], dt, GN_EPS)
-        qk = hip.conv1d(rb, n, self.qk.w, self.qk.c_in, 2 * I, 1, dtype=dt)
         vcol, ldvt = rb.vt_layout()
-        vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt, y_seq_col0=vcol)
+        if self.qkv is not None and QKV_ONE_LAUNCH:
+            qk, vt = hip.conv1d(rb, n, self.qkv.w, self.qkv.c_in, 3 * I, 1, dtype=dt, split=(2 * I, ldvt, vcol))
+        else:
+            qk = hip.conv1d(rb, n, self.qk.w, self.qk.c_in, 2 * I, 1, dtype=dt)
+            vt = hip.conv1d(rb, n, self.v.w, self.v.c_in, I, 1, dtype=dt, transposed=True, out_ld=ldvt, y_seq_col0=vcol)
         a = hip.relpos_attention(rb, qk, 2 * I, qk, 2 * I, vt, ldvt, None, 0, key_bias, self.dh ** -0.5, self.heads,
                                  self.dh, hip.F32S if self.split else dt, q_col0=0, k_col0=I, rel_mode=0, vt_col0=vcol)
         hip.conv1d(rb, a, self.o.w, self.o.c_in, C, 1, dtype=dt, bias=self.o.b, resid=x, out=x, out_f32=True)

@@ -118,7 +118,10 @@ def test_shard_utterances_is_a_balanced_partition():
     lens = [5, 100, 7, 64, 64, 3, 90, 12, 1]
     parts = shard_utterances(lens, 4)
     assert sorted(i for p in parts for i in p) == list(range(len(lens)))
-    assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert max(len(p) for p in parts) <= -(-len(lens) // 4)          # never more than ceil(n / W) per rank: the exchange step's slot count
+    load = [sum(lens[i] for i in p) for p in parts]
+    order = sorted(range(len(lens)), key=lambda i: (-lens[i], i))
+    assert max(load) <= max(sum(lens[i] for i in order[r::4]) for r in range(4))      # no worse than round-robin over the sorted list
     assert parts == shard_utterances(lens, 4)
 
 

@@ -8,7 +8,7 @@ import bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
-ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "alg_bytes", "alg_flops")
+ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "practical_peak", "frac_of_practical", "traffic", "kernel", "avg_launch_ms", "alg_bytes", "alg_flops")
 CPU = ("value", "unit", "cores", "kind", "sample", "rtf", "cpu_model")
 
 
@@ -18,7 +18,7 @@ def check_line(line, n_gpus=1):
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == n_gpus and d["unit"] == "samples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["dtype"] in ("f32", "f16")
+    assert d["vs_baseline"] is None and (d["dtype"] in ("f32", "f16") or d["dtype"].startswith("f32 (emulated: 3 exact bf16 terms per operand, 7 MFMA products"))
     assert isinstance(d["config"]["workload"], str) and "model" not in d["config"]
     for k in ROOFLINE:
         assert k in d["roofline"], k
@@ -67,17 +67,30 @@ def test_compact_line_without_optional_blocks():
     assert d["cpu_baseline"] is None and "detail" not in d and "training" not in d
 
 
-def test_compact_line_carries_every_block_of_a_round5_result():
-    """A real round-5 result (profiles/r05_bench_detail.json: five arithmetics, the ragged leg, two configs, four training lines, the CPU
-    baseline) must fit the line WITHOUT any optional block being dropped."""
-    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+def test_compact_line_carries_every_block_of_a_round6_result():
+    """A real round-6 result (profiles/r06_bench_detail.json: the emulated headline with its live practical ceiling, exact f32 beside it, the 24 kHz
+    recipe vocoder, the B = 1 latency block, the ragged leg, two configs, four training lines, the CPU baseline) must fit the line WITHOUT any optional
+    block being dropped; the ineligible arithmetics (six products, split f16) stay in the detail file."""
+    out = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")))
     line = bench.compact_line(out, "bench_detail.json")
     assert len(line) <= bench.LINE_LIMIT
     d = check_line(line)
-    for k in ("ragged", "f32_emul_mode", "f32_emul6_mode", "f32_split_mode", "fast_mode", "configs", "training", "roofline_conv1d"):
+    for k in ("ragged", "exact_f32_mode", "vocoder_24k", "b1_latency", "fast_mode", "configs", "training", "roofline_conv1d"):
         assert k in d, k
+    assert "f32_emul6_mode" not in d and "f32_split_mode" not in d and "f32_emul6_mode" in out and "f32_split_mode" in out
     assert set(d["ragged"]) >= {"t_text", "seed", "value", "ms_per_step", "per_sample_efficiency"}
     assert d["roofline"]["traffic"] and d["roofline"]["traffic_source"] in ("live", "committed")
+    # the headline is the emulated arithmetic, priced against the spec peak / 7 AND the live ceiling / 7
+    rf = d["roofline"]
+    assert d["dtype"].startswith("f32 (emulated") and abs(rf["peak"] - 2500.0 / 7) < 0.01
+    assert rf["frac"] < rf["frac_of_practical"] < 1.05 and abs(rf["frac_of_practical"] - rf["achieved"] / rf["practical_peak"]) < 1e-3
+    ex = d["exact_f32_mode"]
+    assert ex["dtype"] == "f32" and ex["roofline"]["peak"] == 157.3 and 0 < ex["roofline"]["frac"] < 1 and ex["ms_per_step"] > d["ms_per_step"]
+    assert 0 <= ex["max_abs_err_wave"] < 1e-5 and 0 <= ex["max_abs_err_mel"] < 1e-4
+    v = d["vocoder_24k"]
+    assert v["sampling_rate"] == 24000 and v["hop"] == 300 and v["value"] > 0 and v["exact_f32"]["ms_per_step"] > v["ms_per_step"]
+    b1 = d["b1_latency"]
+    assert b1["ms"] > 0 and b1["kernel_ms"] > 0 and abs(b1["wall_over_kernel"] - b1["ms"] / b1["kernel_ms"]) < 1e-2
 
 
 def test_traffic_lookup_answers_null_with_a_reason():

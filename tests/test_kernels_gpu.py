@@ -982,3 +982,63 @@ def test_ragged_1d_grids_equal_rectangular(cuda, lib, n_seq):
         hip._RAGGED_1D = prev
     for a, c in zip(one_d, rect):
         assert torch.isfinite(a).all() and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("mode", ["F32", "F16", "F32S", "F32E", "F32E6"])
+@pytest.mark.parametrize("geom", [(384, 768, 384, [130, 1, 77, 768]), (512, 1024, 512, [300, 64]), (256, 256, 128, [40, 200, 5])],
+                         ids=["fs2-384", "matcha-512", "small-256"])
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_conv1d_two_outputs_equal_two_launches(cuda, lib, mode, geom, variant):
+    """jatts_conv_desc.n_split (round 6): the Q | K | V projection as ONE launch -- channels < n_split row-major, the rest transposed into the attention
+    kernel's V^T layout -- against the two launches it replaces (reference: three Linear calls, modules/transformer/attention.py:39-61;
+    modules/matchatts/transformer.py:222-260): every element is the same contraction, so the outputs are BIT-IDENTICAL in every arithmetic and
+    kernel variant; V^T slack columns stay untouched."""
+    from jatts_amd import hip
+    c_in, n_split, n_v, lens = geom
+    dt = getattr(hip, mode)
+    g = torch.Generator().manual_seed(c_in + n_v)
+    R = sum(lens)
+    tdt = hip.torch_dtype(dt)
+    x = (torch.randn(R, c_in, generator=g) * 0.7).to(cuda).to(tdt)
+    w = (torch.randn(n_split + n_v, c_in, 1, generator=g) / c_in ** 0.5).to(cuda)
+    b = torch.randn(n_split + n_v, generator=g).to(cuda)
+    kw = {}
+
+    def pack(wt):
+        if dt == hip.F32S:
+            p, inv = hip.pack_conv_weight_split(wt, 64)
+            return p, {"w_inv": inv}
+        if dt in hip.EMUL:
+            return hip.pack_conv_weight_bf16x3(wt, 64), {}
+        return hip.pack_conv_weight(wt, dt), {}
+    rb = _ragged(lens, cuda)
+    vcol, ldvt = rb.vt_layout()
+    f32o = dt != hip.F16
+    (wa, ka), (wq, kq), (wv, kv) = pack(w), pack(w[:n_split]), pack(w[n_split:])
+    qk1 = hip.conv1d(rb, x, wq, c_in, n_split, 1, dtype=dt, bias=b[:n_split].contiguous(), out_f32=f32o, variant=variant, **kq)
+    vt1 = torch.full((n_v, ldvt), 7.0, dtype=qk1.dtype, device=cuda)
+    hip.conv1d(rb, x, wv, c_in, n_v, 1, dtype=dt, bias=b[n_split:].contiguous(), transposed=True, out=vt1, out_ld=ldvt, y_seq_col0=vcol, out_f32=f32o,
+               variant=variant, **kv)
+    qk2, vt2 = hip.conv1d(rb, x, wa, c_in, n_split + n_v, 1, dtype=dt, bias=b, out_f32=f32o, variant=variant, split=(n_split, ldvt, vcol), **ka)
+    # (the split-f16 arithmetic scales its activation tiles by the block maximum, and the tile may follow the launch's channel count: same values to
+    # within its own rounding there, bit-identical everywhere else)
+    same = (lambda a, c: relerr(a.float(), c.float()) <= 2e-6) if dt == hip.F32S else torch.equal
+    assert qk2.shape == qk1.shape and same(qk1, qk2), f"{mode}: Q | K of the one-launch form differs"
+    o = 0
+    for i, T in enumerate(lens):
+        c0 = int(vcol[i])
+        assert same(vt1[:, c0:c0 + T], vt2[:, c0:c0 + T]), f"{mode}: V^T of sequence {i} differs"
+        ref = (x[o:o + T].double() @ w[n_split:, :, 0].double().t() + b[n_split:].double()).t()
+        assert relerr(vt2[:, c0:c0 + T].float(), ref) <= (3e-3 if dt == hip.F16 else 1e-5)
+        o += T
+
+
+def test_conv1d_two_outputs_argument_checks(cuda, lib):
+    from jatts_amd import hip
+    rb = _ragged([10], cuda)
+    x = torch.zeros(10, 64, device=cuda)
+    w = hip.pack_conv_weight(torch.zeros(384, 64, 1, device=cuda), hip.F32)
+    with pytest.raises(ValueError):
+        hip.conv1d(rb, x, w, 64, 384, 1, dtype=hip.F32, split=(128, 16, None))        # not a multiple of 256
+    with pytest.raises(ValueError):
+        hip.conv1d(rb, x, w, 64, 384, 1, dtype=hip.F32, split=(512, 16, None))        # beyond n_out
