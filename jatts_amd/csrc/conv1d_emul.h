@@ -8,8 +8,6 @@
 // 6 bytes per element, and two double-buffered 160-row tiles (66 KB) keep two workgroups on a CU, one committing / storing while
 // the other feeds the matrix pipe; a chunk is k_w x 2 K-steps x 7 (6) NF NT MFMAs, 56 (48) MFMAs per wave between barriers at k = 1.
 #pragma once
-#include <type_traits>
-
 #include "conv1d_impl.h"
 #ifndef JATTS_CEMUL_DIAG
 #define JATTS_CEMUL_DIAG 0   // timing probes only (wrong results): 1 = no split arithmetic in the commit, 2 = no activation loads in the chunk loop, 4 = no barriers in it
@@ -17,131 +15,41 @@
 
 namespace {
 
-// commit of the emulated pipeline: combine the staged f32 inputs (sum, in_scale, LeakyReLU), three bf16 planes, LDS.  One staged unit (8 channels of a row):
-template <typename T, int MAXU, int NIN, int UPR, int NTHR>
-__device__ __forceinline__ void emul_commit_unit(StageRegs<float, MAXU, NIN>& sr, int j, char* lds, int pitch, int total, int n_in, float in_scale,
-                                                 int pre_act, float slope, bool plain) {
-  // (the conversions run for every lane -- stage_issue zero-fills the units past the tile -- and only the LDS store is predicated: a guard around the
-  //  whole unit would put the conversions into a basic block of their own, out of reach of the MFMA interleave of conv_stage_commit)
-  const int u = threadIdx.x + j * NTHR;
-  const int r = u / UPR, cu = u % UPR;
-  typename Elem<T>::vec8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float t = sr.v[0][j][e];
-    if (!plain) {
-      if (NIN > 1 && n_in > 1) t += sr.v[NIN > 1 ? 1 : 0][j][e];
-      if (NIN > 2 && n_in > 2) t += sr.v[NIN > 2 ? 2 : 0][j][e];
-      t *= in_scale;
-      if (pre_act == JATTS_PRE_LRELU) t = fmaxf(t, t * slope);     // 0 <= slope <= 1
-    }
-    bf16 a, b, c;
-#if JATTS_CEMUL_DIAG & 1
-    a = b = c = __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(t) >> 16));
-#else
-    bf3_split(t, a, b, c);
-#endif
-    o.b0[e] = a; o.b1[e] = b; o.b2[e] = c;
-  }
-  // pin the planes in front of the predicated store (the optimiser otherwise sinks the whole conversion into the store's exec-masked block)
-  asm volatile("" : "+v"(o.b0), "+v"(o.b1), "+v"(o.b2));
-  if (u < total) Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
-}
-
+// commit of the emulated pipeline: combine the staged f32 inputs (sum, in_scale, LeakyReLU), three bf16 planes, LDS
 template <typename T, int MAXU, int NIN, int UPR, int NTHR>
 __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in, float in_scale,
                                             int pre_act, float slope) {
   const int total = rows * UPR;
   const bool plain = n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE;
 #pragma unroll
-  for (int j = 0; j < MAXU; ++j) emul_commit_unit<T, MAXU, NIN, UPR, NTHR>(sr, j, lds, pitch, total, n_in, in_scale, pre_act, slope, plain);
-}
-
-// The commit of the NEXT chunk riding inside the MFMA loop of the current one (round 6).  With the commit behind the loop every wave of the workgroup
-// leaves the matrix pipe idle while it converts and stores its units and then waits at the barrier -- at k = 1 that happens every 56 MFMAs.  Here the
-// LAST `D` K-steps of a chunk each carry 1 / D of the staged units: their conversions (VALU) and LDS stores are dealt out between that step's MFMAs
-// (sched_group_barrier), the other LDS buffer is the target, so nothing is read that is being written.  Same values, same order: bit-identical.
-template <typename T, int MAXU, int NIN, int UPR, int NTHR>
-struct EmulCommit {
-  StageRegs<float, MAXU, NIN>& sr;
-  char* lds;
-  int pitch, total, n_in, pre_act;
-  float in_scale, slope;
-  bool plain;
-  template <int J, int D> __device__ __forceinline__ void part() {
-    constexpr int U0 = J * MAXU / D, U1 = (J + 1) * MAXU / D;
+  for (int j = 0; j < MAXU; ++j) {
+    const int u = threadIdx.x + j * NTHR;
+    if (u >= total) continue;
+    const int r = u / UPR, cu = u % UPR;
+    typename Elem<T>::vec8 o;
 #pragma unroll
-    for (int j = U0; j < U1; ++j) emul_commit_unit<T, MAXU, NIN, UPR, NTHR>(sr, j, lds, pitch, total, n_in, in_scale, pre_act, slope, plain);
-  }
-};
-
-// conv_stage (conv_tiles.h) whose last D K-steps carry the commit parts.  MPS = MFMAs of one K-step per wave (for the interleave hint).
-template <typename T, int NF, int NT, int D, typename Commit>
-__device__ __forceinline__ void conv_stage_commit(typename Acc32<T>::type (&acc)[NF][NT], WRing<T, NF, D>& ring, int kc_per, int k_w,
-                                                  int dil, const char* act, int pitch, int col0, int lane, Commit& cm) {
-  typedef typename Elem<T>::vec8 V8;
-  static_assert(D == 2 || D == 4, "ring depth 2 or 4");
-  const int g = lane >> 5;
-  const int n_it = k_w * kc_per;
-  const char* bbase = act + (size_t)(col0 + (lane & 31)) * pitch + (size_t)(8 * g) * sizeof(T);
-  const int last_tap = k_w - 1;
-  int bp_tap = 0, bp_kk = 0;
-  auto fetch_bb = [&](V8(&dst)[NT]) {
-    const char* p = bbase + (size_t)(bp_tap * dil) * pitch + (size_t)(bp_kk * 16) * sizeof(T);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) dst[t] = Vec8IO<T>::lds(p + (size_t)(t * 32) * pitch);
-    const int nk = bp_kk + 1;
-    const bool wrap = nk == kc_per;
-    bp_kk = wrap ? 0 : nk;
-    bp_tap = min(bp_tap + (wrap ? 1 : 0), last_tap);
-  };
-  V8 bb[2][NT];
-  fetch_bb(bb[0]);
-  __builtin_amdgcn_sched_barrier(0);
-  int it0 = 0;
-  for (; it0 + D < n_it; it0 += D) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      fetch_bb(bb[(j + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mma32(ring.r[j][f], bb[j & 1][t], acc[f][t]);
-      ring.fetch(ring.r[j]);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int e = 0; e < 8; ++e) {
+      float t = sr.v[0][j][e];
+      if (!plain) {
+        if (NIN > 1 && n_in > 1) t += sr.v[NIN > 1 ? 1 : 0][j][e];
+        if (NIN > 2 && n_in > 2) t += sr.v[NIN > 2 ? 2 : 0][j][e];
+        t *= in_scale;
+        if (pre_act == JATTS_PRE_LRELU) t = fmaxf(t, t * slope);     // 0 <= slope <= 1
+      }
+      bf16 a, b, c;
+#if JATTS_CEMUL_DIAG & 1
+      a = b = c = __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(t) >> 16));
+#else
+      bf3_split(t, a, b, c);
+#endif
+      o.b0[e] = a; o.b1[e] = b; o.b2[e] = c;
     }
-  }
-  constexpr int MPS = NF * NT * (sizeof(typename Acc32<T>::type) > sizeof(f32x16) ? 7 : 6);
-  auto step = [&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    fetch_bb(bb[(j + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) mma32(ring.r[j][f], bb[j & 1][t], acc[f][t]);
-    cm.template part<j, D>();
-    // one MFMA, then a handful of the conversions' VALU instructions, ... ; the LDS stores and what is left follow in program order
-#pragma unroll
-    for (int m = 0; m < MPS; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    ring.fetch(ring.r[j]);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  step(std::integral_constant<int, 0>{});
-  step(std::integral_constant<int, 1>{});
-  if constexpr (D == 4) {
-    step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{});
+    Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
   }
 }
 
 // HALO: rows beyond the time tile the staging registers must cover; RD: weight ring depth in K-steps (divides KCHT / 16).
-template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2, bool IL = false>      // T = bf3 (seven products) / bf3f (six)
+template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2>      // T = bf3 (seven products) / bf3f (six)
 __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_conv_desc d, int f32_tile, XcdOrder xo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 32, NTHR = WN * WT * 64;
@@ -207,14 +115,8 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
     if (more && !(JATTS_CEMUL_DIAG & 2)) stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
-    if (more && IL) {     // the next chunk's commit rides inside this chunk's last RD K-steps
-      EmulCommit<T, MAXU, NIN, UPRC, NTHR> cm{sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows * UPRC, d.n_in, d.pre_act, d.in_scale, d.pre_slope,
-                                              d.n_in == 1 && d.in_scale == 1.f && d.pre_act == JATTS_PRE_NONE};
-      conv_stage_commit<T, NF, NT, RD>(accx, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane, cm);
-    } else {
-      conv_stage<T, NF, NT, RD>(accx, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
-      if (more) emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
-    }
+    conv_stage<T, NF, NT, RD>(accx, ring, KCHT / 16, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
+    if (more) emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
     if (!(JATTS_CEMUL_DIAG & 4)) __syncthreads();
   }
   if (JATTS_CEMUL_DIAG & 4) __syncthreads();
@@ -253,7 +155,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul_kernel(jatts_con
   }
 }
 
-template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2, bool IL = false>
+template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int RD = 2>
 int launch_conv_emul(const jatts_conv_desc& d, hipStream_t s) {
   constexpr int BT = WT * NT * 32, BN = WN * NF * 32;
   if ((d.k_w - 1) * d.dil > HALO) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (emulated): halo beyond the staging registers");
@@ -268,7 +170,7 @@ int launch_conv_emul(const jatts_conv_desc& d, hipStream_t s) {
     if (lds < (size_t)BT * (BN * 4 + 16)) lds = (size_t)BT * (BN * 4 + 16);
   }
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (emulated): tile exceeds 160 KiB LDS");
-  auto kern = conv1d_emul_kernel<T, NF, NT, WN, WT, NIN, KCHT, OCC, HALO, RD, IL>;
+  auto kern = conv1d_emul_kernel<T, NF, NT, WN, WT, NIN, KCHT, OCC, HALO, RD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);

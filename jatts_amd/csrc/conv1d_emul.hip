@@ -31,16 +31,10 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   // MFMA (a 2 x 1 wave pulls 6 KB of weights per 14 MFMAs through the vector memory path, eight waves ~110 B / clk / CU): another +4-9 % on every
   // k = 1 shape, +20 % at 4 096 rows (profiles/r05_notes.md); 64 n x 128 t (variant 5) stages twice the activations per MFMA and loses 30 %.
   if (variant == 6 || (variant == 0 && d.k_w == 1 && (TWO || small_k1))) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4>(d, s);
-  // round-6 candidates with the next chunk's commit INSIDE the MFMA loop (conv1d_emul.h: conv_stage_commit)
-  if (variant == 20 && d.k_w == 1) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 0, 4, true>(d, s);      // the k = 1 product tile, interleaved
-  if (variant == 20 || variant == 21) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 32, 4, true>(d, s);  // the k >= 2 product tile (seven products), interleaved
-  if (variant == 22) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4, true>(d, s);                   // 128 n x 64 t for every k, interleaved
-  // round-6 k = 1 candidates (HALO = 0: no halo rows in the staging registers): fewer barriers per MFMA through wider chunks / 2 x 2-fragment waves
-  if (d.k_w == 1 && variant == 8) return launch_conv_emul<T, 2, 2, 4, 1, 1, 128, 1, 0, 4>(d, s);   // 256 n x 64 t, four waves of 2 x 2, 128-channel chunks, one workgroup per CU
-  if (d.k_w == 1 && variant == 9) return launch_conv_emul<T, 2, 2, 2, 2, 1, 64, 1, 0, 4>(d, s);    // 128 n x 128 t, four waves of 2 x 2, 64-channel chunks
-  if (d.k_w == 1 && variant == 10) return launch_conv_emul<T, 1, 2, 4, 2, 1, 64, 1, 0, 4>(d, s);   // 128 n x 128 t, eight waves of 1 x 2
-  if (d.k_w == 1 && variant == 11) return launch_conv_emul<T, 2, 2, 4, 1, 1, 64, 1, 0, 4>(d, s);   // 256 n x 64 t, four waves of 2 x 2, 64-channel chunks
-  if (d.k_w == 1 && variant == 12) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 0, 4>(d, s);   // the product tile (128 n x 64 t, 1 x 2) with HALO = 0
+  // (round 6, measured and dropped -- profiles/r06_notes.md: 256 n x 64 t / 128 n x 128 t tiles of 2 x 2-fragment waves with 64- and 128-channel chunks and
+  //  HALO = 0 staging for k = 1: +-3 % except 2048 -> 512 (+14 % with 128-channel chunks), -10..-25 % on the 384-wide shapes; the next chunk's commit dealt out
+  //  between the MFMAs of the current one with sched_group_barrier: spills at 256 registers, -20 % at k = 1, -6 % at k = 3; starting the CUs' second
+  //  workgroup slot half a K-loop late: +-1 %)
   if (variant == 4) return launch_conv_emul<T, 2, 1, 2, 2, 1, 64, 2, 32, 4>(d, s);    // (2 x 1 fragments per wave, 2 x 2 waves: the first k = 1 tile)
   if (variant == 5) return launch_conv_emul<T, 1, 2, 2, 2, 1, 64, 2, 32, 4>(d, s);    // 64 n x 128 t, four waves of 1 x 2 fragments, two workgroups per CU
   // (measured and dropped: 256 n x 64 t and 256 n x 128 t eight-wave tiles -- more output channels per staged tile -- were 5-25 % slower on most shapes and

@@ -51,7 +51,9 @@ __device__ __forceinline__ void conv_second_output(jatts_conv_desc& d, int n_fir
     d.ldy = d.ldy2;
     d.y_transposed = 1;
     d.y_seq_col0 = d.y2_seq_col0;
-  }
+  } else if (d.n_split > 0) {
+    d.n_out = d.n_split;      // the first output's rows are n_split wide: the row-major epilogues bound their stores (and the buffer range check that drops
+  }                           // the rows past a sequence's end) by n_out.  Callers have taken the packed-weight geometry (NFR) from the full n_out BEFORE this.
 }
 
 // ------------------------------------------------------------------ generic conv kernel
