@@ -21,13 +21,16 @@ static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   auto wgs = [&](int window) { const int64_t tt = window - (d.k_w - 1); return tt > 0 ? ((cols + tt - 1) / tt) * d.rg.n_seq : (int64_t)1 << 40; };
   const bool auto_tile = variant == 0;
   switch (d.channels) {
+    // C <= 64: the residual from registers (RREG; variant 9 = the round-5 form that re-reads x in the store pass, for A/B)
     case 32:
       if (variant == 1) return launch_resunit_emul<T, 32, 128, 1, 2, 2, 2>(d, s);          // 2 waves per workgroup
-      return launch_resunit_emul<T, 32, 256, 1, 2, 2, 2>(d, s);
+      if (variant == 9) return launch_resunit_emul<T, 32, 256, 1, 2, 2, 2>(d, s);
+      return launch_resunit_emul<T, 32, 256, 1, 2, 2, 2, false, true>(d, s);
     case 64:
       if (variant == 2) return launch_resunit_emul<T, 64, 256, 2, 2, 2, 1>(d, s);          // 8 waves NF = 1 NT = 2
-      if (variant == 1 || d.k_w >= 11) return launch_resunit_emul<T, 64, 256, 1, 2, 2, 1>(d, s);   // 4 waves NF = 2 NT = 2, one workgroup per CU
-      return launch_resunit_emul<T, 64, 128, 2, 2, 2, 2>(d, s);                            // 4 waves NF = 1 NT = 2, two workgroups per CU
+      if (variant == 9) return d.k_w >= 11 ? launch_resunit_emul<T, 64, 256, 1, 2, 2, 1>(d, s) : launch_resunit_emul<T, 64, 128, 2, 2, 2, 2>(d, s);
+      if (variant == 1 || d.k_w >= 11) return launch_resunit_emul<T, 64, 256, 1, 2, 2, 1, false, true>(d, s);   // 4 waves NF = 2 NT = 2, one workgroup per CU
+      return launch_resunit_emul<T, 64, 128, 2, 2, 2, 2, false, true>(d, s);               // 4 waves NF = 1 NT = 2, two workgroups per CU
     case 128:
       if (variant == 1) return launch_resunit_emul<T, 128, 128, 4, 2, 2, 1>(d, s);         // 8 waves NF = 1 NT = 2, one workgroup per CU
       if (variant == 3) return launch_resunit_emul<T, 128, 128, 2, 1, 2, 1>(d, s);         // 8 waves NF = 2 NT = 1

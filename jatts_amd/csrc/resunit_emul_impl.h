@@ -54,7 +54,10 @@ __device__ __forceinline__ void conv_khalf_ws(typename Acc32<T>::type (&acc)[NF]
 // KSPLIT: the x tile of conv1 is staged one channel half at a time (the second half's global loads are in flight under the first half's MFMAs).  For
 // shapes whose full x tile does not fit LDS beside nothing else -- C = 256, k = 11, dilation 5: 114 rows x 1 552 B = 177 KB -- where the alternative was a
 // 32-column window (9.2 ms against 6.8 ms for the other dilations).
-template <typename T, int C, int WGCOLS, int WN, int NT, int KCG, int OCC, bool KSPLIT = false>      // T = bf3 (seven partial products) or bf3f (six)
+// RREG (round 6, C <= 64): the residual comes from REGISTERS.  The rows of the x tile that are this workgroup's output rows are staged with the store
+// pass's own unit -> thread map and kept (4-8 units of 8 floats per thread), so the store pass adds them without reading x a second time: the re-read was
+// the larger half of these shapes' wasted traffic (1.5-1.9 x the algorithmic bytes: halo + re-read), and on a power-limited part fabric bytes are clock.
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCG, int OCC, bool KSPLIT = false, bool RREG = false>      // T = bf3 (seven partial products) or bf3f (six)
 __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emul_kernel(jatts_resunit_desc d, unsigned long long* trace,
                                                                                          unsigned trace_cap, unsigned bias_off) {
   typedef typename Elem<T>::vec8 V8;
@@ -67,6 +70,9 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   constexpr int NTHR = WN * WT * 64;
   static_assert(WT * NT * 32 == WGCOLS && NF * WN * 32 == C, "tile shape");
   static_assert(sizeof(T) == 6, "bf3 is three packed bf16");
+  static_assert(!(KSPLIT && RREG), "the residual registers go with the one-piece x tile");
+  constexpr int MAXI = RREG ? (WGCOLS * (C / 8) + NTHR - 1) / NTHR : 1;      // interior units per thread
+  f32x8 xk[MAXI];
   const unsigned wg_lin = blockIdx.x + blockIdx.y * gridDim.x;
   const bool tracing = trace != nullptr && wg_lin < trace_cap && threadIdx.x == 0;
 #define JATTS_STAMP(i) do { if (tracing) trace[(size_t)wg_lin * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -141,6 +147,49 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
     constexpr int UPR = C / 8;
     constexpr int UB = 8;
     const int total = rx * UPR;
+    if constexpr (RREG) {
+      // interior rows (the output rows: x-tile rows p1 + p2 .. + tt_out) first, unit v = thread + j NTHR <-> output row v / UPR: the map of the store pass
+      const int r_in = p1 + p2, n_in = tt_out * UPR;
+#pragma unroll
+      for (int j = 0; j < MAXI; ++j) {
+        const int v = threadIdx.x + j * NTHR;
+        const int ro = v / UPR, cu = v - ro * UPR;
+        const int pos = t0 + ro;
+        if (v < n_in && pos < L) xk[j] = Vec8IO<float>::ldg(x + (seq_row0 + pos) * (int64_t)C + cu * 8);
+        else xk[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      // the halo rows above and below, batched like the one-piece staging
+      const int n_halo = (rx - tt_out) * UPR;
+      for (int base = threadIdx.x; base < n_halo; base += NTHR * UB) {
+        f32x8 v[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          const int u = base + j * NTHR;
+          int r = u / UPR;
+          const int cu = u - r * UPR;
+          if (r >= r_in) r += tt_out;
+          const int pos = pos0 + r;
+          if (u < n_halo && pos >= 0 && pos < L) v[j] = Vec8IO<float>::ldg(x + (seq_row0 + pos) * (int64_t)C + cu * 8);
+          else v[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          const int u = base + j * NTHR;
+          if (u >= n_halo) continue;
+          int r = u / UPR;
+          const int cu = u - r * UPR;
+          if (r >= r_in) r += tt_out;
+          Vec8IO<T>::sts(xs + (size_t)r * pitch + (size_t)cu * 48, to_planes(v[j]));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MAXI; ++j) {
+        const int v = threadIdx.x + j * NTHR;
+        if (v >= n_in) continue;
+        const int ro = v / UPR, cu = v - ro * UPR;
+        Vec8IO<T>::sts(xs + (size_t)(r_in + ro) * pitch + (size_t)cu * 48, to_planes(xk[j]));
+      }
+    } else {
     for (int base = threadIdx.x; base < total; base += NTHR * UB) {
       f32x8 v[UB];
 #pragma unroll
@@ -158,6 +207,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
         const int r = u / UPR, cu = u - r * UPR;
         Vec8IO<T>::sts(xs + (size_t)r * pitch + (size_t)cu * 48, to_planes(v[j]));
       }
+    }
     }
     __syncthreads();
     JATTS_STAMP(2);
@@ -271,15 +321,49 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
     constexpr bool keep_small = C <= 64;
     const float* xg = (const float*)d.x;
     float* yg = (float*)d.y;
+    if constexpr (RREG) {
+      // y = (acc + b2 tile in LDS) + x FROM REGISTERS [+ MRF partners] (unit_store_pass with the staged interior units)
+      constexpr int UPR = C / 8;
+      const int n_out = vrows * UPR;
+      const bool has_add1 = d.add0 != nullptr && d.add1 != nullptr;
+      f32x8 a0[MAXI], a1[MAXI];
+      if (d.add0) {
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+          const int v = threadIdx.x + j * NTHR;
+          if (v < n_out) {
+            a0[j] = Vec8IO<float>::ldg((const float*)d.add0 + g0 + (int64_t)v * 8);
+            if (has_add1) a1[j] = Vec8IO<float>::ldg((const float*)d.add1 + g0 + (int64_t)v * 8);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MAXI; ++j) {
+        const int v = threadIdx.x + j * NTHR;
+        if (v >= n_out) continue;
+        const int ro = v / UPR, cu = v - ro * UPR;
+        f32x8 o = Vec8IO<float>::lds(ys + (size_t)ro * pitch + (size_t)cu * 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] + xk[j][e];          // residual
+        if (d.add0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (o[e] + a0[j][e] + (has_add1 ? a1[j][e] : 0.f)) * d.out_scale;
+        }
+        float* dst = yg + g0 + (int64_t)v * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+    } else {
     if (d.add0) unit_store_pass<float, C, keep_small ? 2 : 4, true, NTHR>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
     else unit_store_pass<float, C, keep_small ? 4 : 8, false, NTHR>(d.add0, d.add1, d.out_scale, ys, pitch, vrows, xg, yg, g0);
+    }
   }
   JATTS_STAMP(7);
   if (tracing) trace[(size_t)wg_lin * 16 + 9] = __builtin_amdgcn_s_memrealtime();
 #undef JATTS_STAMP
 }
 
-template <typename T, int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2, bool KSPLIT = false>
+template <typename T, int C, int WGCOLS, int WN, int NT, int KCG = 2, int OCC = 2, bool KSPLIT = false, bool RREG = false>
 int launch_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   constexpr int WT = WGCOLS / (NT * 32);
   const int K = d.k_w, p2 = (K - 1) / 2, p1 = p2 * d.dil;
@@ -295,7 +379,7 @@ int launch_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
   if (const int64_t n1 = ragged_tiles_1d(d.rg, tt_out)) grid = dim3((unsigned)n1);
-  auto kern = resunit_emul_kernel<T, C, WGCOLS, WN, NT, KCG, OCC, KSPLIT>;
+  auto kern = resunit_emul_kernel<T, C, WGCOLS, WN, NT, KCG, OCC, KSPLIT, RREG>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
