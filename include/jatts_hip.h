@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops, jatts_conv_desc + n_split / ldy2 / y2 / y2_seq_col0 (appended); 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
+#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops, jatts_conv_desc + n_split / ldy2 / y2 / y2_seq_col0 and jatts_resunit_desc + w_layout (appended), jatts_unit_weight_index_k32; 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
                                 * so every descriptor that embeds it (jatts_conv_desc, jatts_resunit_desc, jatts_resblock_desc, jatts_relattn_desc) shifted by 8 bytes; JATTS_F32E; 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
                                 * bumped whenever a descriptor's layout or an entry point's signature changes: a stale library is refused at load */
 
@@ -195,9 +195,16 @@ typedef struct jatts_resunit_desc {
   /* JATTS_F32S only: channels floats each, 2^-s[n] where w1 / w2 were packed as hi/lo of w[n] * 2^s[n] (NULL otherwise) */
   const float* ws1;
   const float* ws2;
+  /* (ABI 4) JATTS_F32E / JATTS_F32E6 only: fragment order of w1 / w2.  0: [tap][c / 16][n / 32][lane = 32 ((c % 16) / 8) + n % 32][c % 8] x (b0 | b1 | b2), the
+   * order of jatts_conv_weight_index (v_mfma_f32_32x32x16_bf16 kernels).  1: [tap][c / 32][n / 16][lane = 16 ((c % 32) / 8) + n % 16][c % 8] x (b0 | b1 | b2)
+   * (v_mfma_f32_16x16x32_bf16 kernels, csrc/resunit_emul16_impl.h: the form the power-limited matrix pipe sustains 14 % more of; jatts_unit_weight_index_k32). */
+  int32_t w_layout;
 } jatts_resunit_desc;
 
 int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream);
+
+/* Index of W[n][tap][c] (one of the three bf16 planes' 8-element groups counted as one element) inside a w_layout = 1 buffer (HOST helper, pure function). */
+int64_t jatts_unit_weight_index_k32(int32_t n, int32_t tap, int32_t c, int32_t channels);
 
 /* ---------------------------------------------------------------------------------
  * HiFi-GAN ResBlock, all dilation units fused in one launch (f16 operands; f32 for the small-channel k = 3 blocks):
@@ -401,7 +408,8 @@ int jatts_debug_trace(void* buf, int64_t n_workgroups);
 /* Measurement hook (not part of the reference interface; bench.py's `roofline.practical_peak`): the matrix pipe's sustained issue rate on THIS
  * part at the clock its power budget allows.  One launch of `workgroups` x 256 threads, every wave issuing 2 x 2 fragments of 32 x 32 per K-step
  * for `iters` K-steps (rounded up to even) with nothing else in the kernel: dtype JATTS_F32E / JATTS_F32E6 -> v_mfma_f32_32x32x16_bf16, JATTS_F16 /
- * JATTS_F32S -> v_mfma_f32_32x32x16_f16, JATTS_F32 -> eight v_mfma_f32_32x32x2_f32 per K-step; feed = 1: both operands re-read from LDS every K-step
+ * JATTS_F32S -> v_mfma_f32_32x32x16_f16, JATTS_F32 -> eight v_mfma_f32_32x32x2_f32 per K-step, 16 + JATTS_F32E -> 4 x 4 fragments of v_mfma_f32_16x16x32_bf16 (the
+ * same operand bytes per flop; a comparison of the two bf16 forms under the power limit); feed = 1: both operands re-read from LDS every K-step
  * (ds_read_b128), feed = 0: operands stay in registers.  operands: >= 64 KiB of DEVICE memory, 16-byte aligned, holding operand bits of the dtype (the
  * matrix pipe's power, hence its clock, follows them: zeros run ~19 % faster than random bits); clocks (device, 2 x uint64, may be NULL): s_memtime and
  * s_memrealtime (100 MHz) ticks of workgroup 0 across its MFMA loop; sink: 1 device float, never written.  The caller times the launch on `stream`

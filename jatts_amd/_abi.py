@@ -41,7 +41,7 @@ class ResUnitDesc(C.Structure):
         ("dil", C.c_int32), ("slope", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
         ("add0", C.c_void_p), ("add1", C.c_void_p), ("out_scale", C.c_float),
-        ("ws1", C.c_void_p), ("ws2", C.c_void_p),
+        ("ws1", C.c_void_p), ("ws2", C.c_void_p), ("w_layout", C.c_int32),
     ]
 
 
@@ -73,6 +73,7 @@ PROTOTYPES = {
     "jatts_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "jatts_conv_weight_index": (C.c_int64, [C.c_int32] * 5),
     "jatts_hifigan_resunit": (C.c_int, [C.POINTER(ResUnitDesc), C.c_void_p]),
+    "jatts_unit_weight_index_k32": (C.c_int64, [C.c_int32] * 4),
     "jatts_hifigan_resblock": (C.c_int, [C.POINTER(ResBlockDesc), C.c_void_p]),
     "jatts_debug_trace": (C.c_int, [C.c_void_p, C.c_int64]),
     "jatts_mfma_probe": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

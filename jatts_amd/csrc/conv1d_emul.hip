@@ -25,8 +25,9 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   const bool small_k1 = d.k_w == 1 && wgs128 <= 768;
   // round 6, the B = 1 drop-in path (one utterance: 768 rows): a k = 3 feed-forward conv is 72 (384 -> 1536) or 18 (1536 -> 384) workgroups of 128 x 128 on 256
   // CUs, each walking the whole contraction -- 44 % of the utterance's GPU time.  Launches that cannot give every CU one such workgroup take the 128 n x 64 t
-  // tile (twice the workgroups, two per CU).  Nothing in this arithmetic depends on the tile.
-  if (variant == 0 && d.k_w > 1 && wgs128 <= 128 && (d.k_w - 1) * d.dil <= 32) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4>(d, s);
+  // tile (twice the workgroups, two per CU).  Seven products only: their k > 1 product tile walks the contraction in the same 64-channel chunks, so a row's
+  // bits do not change (the six-product k > 1 tile uses 32-channel chunks: another summation order at k > 1).
+  if (variant == 0 && TWO && d.k_w > 1 && wgs128 <= 128 && (d.k_w - 1) * d.dil <= 32) return launch_conv_emul<T, 1, 2, 4, 1, 1, 64, 2, 32, 4>(d, s);
   // The same 128 n x 64 t tile as four waves of 1 x 2 fragments SIDE BY SIDE IN n (each wave 32 n x 64 t): half the weight fragments fetched per
   // MFMA (a 2 x 1 wave pulls 6 KB of weights per 14 MFMAs through the vector memory path, eight waves ~110 B / clk / CU): another +4-9 % on every
   // k = 1 shape, +20 % at 4 096 rows (profiles/r05_notes.md); 64 n x 128 t (variant 5) stages twice the activations per MFMA and loses 30 %.

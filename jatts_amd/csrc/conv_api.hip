@@ -34,6 +34,13 @@ extern "C" int64_t jatts_conv_weight_index(int32_t n, int32_t tap, int32_t c, in
   return ((((int64_t)tap * KC16 + kc) * NFR + nf) * 64 + lane) * 8 + (c % 8);
 }
 
+extern "C" int64_t jatts_unit_weight_index_k32(int32_t n, int32_t tap, int32_t c, int32_t channels) {
+  const int64_t KC32 = channels / 32, NFR16 = channels / 16;
+  const int64_t kc = c / 32, nf = n / 16;
+  const int64_t lane = 16 * ((c % 32) / 8) + (n % 16);
+  return ((((int64_t)tap * KC32 + kc) * NFR16 + nf) * 64 + lane) * 8 + (c % 8);
+}
+
 extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   if (!d || !d->x[0] || !d->w || !d->y || !d->rg.cu_rows) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: null pointer");
   if (d->c_in <= 0 || d->c_in % 64) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: c_in must be a positive multiple of 64");
@@ -74,7 +81,11 @@ extern "C" int jatts_hifigan_resunit(const jatts_resunit_desc* d, void* stream) 
     if (!d->ws1 || !d->ws2) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: JATTS_F32S needs ws1 / ws2");
     return jatts_resunit_split(*d, s);
   }
-  if (d->dtype == JATTS_F32E || d->dtype == JATTS_F32E6) return jatts_resunit_emul(*d, s);
+  if (d->dtype == JATTS_F32E || d->dtype == JATTS_F32E6) {
+    if (d->w_layout != 0 && d->w_layout != 1) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: w_layout must be 0 or 1");
+    return jatts_resunit_emul(*d, s);
+  }
+  if (d->w_layout != 0) return jatts_set_error_msg(JATTS_ERR_ARG, "resunit: w_layout = 1 goes with JATTS_F32E / JATTS_F32E6 only");
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels/dtype (use jatts_conv1d)");
 }
 

@@ -96,6 +96,65 @@ __global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe_kernel(const c
   if (blockIdx.x == 0 && threadIdx.x == 0 && clocks) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
 }
 
+// The same probe on v_mfma_f32_16x16x32_bf16: 4 x 4 fragments of 16 x 16 per wave (the operand bytes per flop of the 2 x 2 x 32 x 32 form), K = 32 per step.
+// Half the accumulator elements written per flop of the 32 x 32 x 16 form: does the power-limited pipe sustain more with it?  (dtype code 16 + JATTS_F32E)
+template <bool LDSFED>
+__global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe16_kernel(const char* __restrict__ src, int64_t src_bytes, int iters,
+                                                                            unsigned long long* clocks, float* sink) {
+  constexpr int PITCH = PROBE_PITCH;
+  __shared__ __attribute__((aligned(16))) char lds[PROBE_ROWS * PITCH];
+  for (int u = threadIdx.x; u < PROBE_ROWS * PITCH / 16; u += PROBE_WAVES * 64)
+    *reinterpret_cast<f32x4*>(lds + (size_t)u * 16) =
+        *reinterpret_cast<const f32x4*>(src + (((size_t)blockIdx.x * 4096 + (size_t)u * 16) % (size_t)(src_bytes - 16) & ~(size_t)15));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment (row block r of 16 rows, K-step s): row r * 16 + (lane & 15), bytes ((s & 1) * 4 + (lane >> 4)) * 16 ..
+  auto frag = [&](int rblk, int s) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(lds + (size_t)(rblk * 16 + (lane & 15)) * PITCH + (size_t)(((s & 1) * 4 + (lane >> 4)) * 16));
+  };
+  bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) a0[f] = frag(f, wave), a1[f] = frag(f, wave + 1), b0[f] = frag(4 + f, wave), b1[f] = frag(4 + f, wave + 1);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it += 2) {
+    if constexpr (LDSFED) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) a1[f] = frag(f, it + 1), b1[f] = frag(4 + f, it + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[f], b0[t], acc[f][t], 0, 0, 0);
+    if constexpr (LDSFED) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) a0[f] = frag(f, it + 2), b0[f] = frag(4 + f, it + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[f], b1[t], acc[f][t], 0, 0, 0);
+    if constexpr (LDSFED) __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[f][t][j];
+  if (s == 12345.678f) sink[0] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && clocks) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
+}
+
 template <int KIND>
 int probe_launch(int feed, const void* src, int64_t src_bytes, int iters, int wgs, unsigned long long* clocks, float* sink, hipStream_t s) {
   if (feed) hipLaunchKernelGGL((mfma_probe_kernel<KIND, true>), dim3(wgs), dim3(PROBE_WAVES * 64), 0, s, (const char*)src, src_bytes, iters, clocks, sink);
@@ -107,7 +166,8 @@ int probe_launch(int feed, const void* src, int64_t src_bytes, int iters, int wg
 }  // namespace
 
 extern "C" double jatts_mfma_probe_flops(int32_t dtype, int32_t iters, int32_t workgroups) {
-  (void)dtype;      // one K-step = 32 x 32 x 16 multiply-adds per fragment in every dtype (f32: eight 32x32x2 MFMAs)
+  // one K-step = 32 x 32 x 16 multiply-adds per fragment in every dtype (f32: eight 32x32x2 MFMAs); the 16 x 16 x 32 form: 16 fragments of 16 x 16 x 32
+  if (dtype >= 16) return (double)workgroups * PROBE_WAVES * (double)(iters + (iters & 1)) * 16 * (2.0 * 16 * 16 * 32);
   return (double)workgroups * PROBE_WAVES * (double)(iters + (iters & 1)) * PROBE_NF * PROBE_NT * (2.0 * 32 * 32 * 16);
 }
 
@@ -117,6 +177,12 @@ extern "C" int jatts_mfma_probe(int32_t dtype, int32_t feed, const void* operand
     return jatts_set_error_msg(JATTS_ERR_ARG, "mfma_probe: operands (>= 64 KiB, 16-byte aligned), iters >= 2, workgroups >= 1, sink required");
   hipStream_t s = (hipStream_t)stream;
   unsigned long long* c = (unsigned long long*)clocks;
+  if (dtype == 16 + JATTS_F32E) {
+    if (feed) hipLaunchKernelGGL((mfma_probe16_kernel<true>), dim3(workgroups), dim3(PROBE_WAVES * 64), 0, s, (const char*)operands, operand_bytes, iters, c, sink);
+    else hipLaunchKernelGGL((mfma_probe16_kernel<false>), dim3(workgroups), dim3(PROBE_WAVES * 64), 0, s, (const char*)operands, operand_bytes, iters, c, sink);
+    JATTS_CHECK_LAUNCH();
+    return JATTS_OK;
+  }
   switch (dtype) {
     case JATTS_F32E: case JATTS_F32E6: return probe_launch<0>(feed, operands, operand_bytes, iters, workgroups, c, sink, s);
     case JATTS_F16: case JATTS_F32S: return probe_launch<1>(feed, operands, operand_bytes, iters, workgroups, c, sink, s);

@@ -4,7 +4,7 @@
 // The LDS tile holds 6 bytes per element, so the windows are narrower than the f32 / split kernels' at the same channel count;
 // a K-step is 7 (6) x 32 pipe cycles per fragment pair against 48 B of each operand: the loop is matrix-pipe bound with room to spare
 // on operand delivery, and what the tile choice trades is the halo overhead (tt_out / WGCOLS) against workgroups per CU.
-#include "resunit_emul_impl.h"
+#include "resunit_emul16_impl.h"
 
 // Tile choice measured on the box (profiles/r05_emul_units.txt, 64 x 768 frames): C = 128 / 256 run best as ONE 4-wave workgroup per CU
 // with NF = 2 x NT = 2 fragments per wave (24 MFMAs per K-step between operand fetches), C = 64 as two 4-wave workgroups per CU
@@ -48,4 +48,25 @@ static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
   return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels for JATTS_F32E (32 / 64 / 128 / 256)");
 }
 
-int jatts_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) { return d.dtype == JATTS_F32E6 ? resunit_emul<bf3f>(d, s) : resunit_emul<bf3>(d, s); }
+// The same tiles on v_mfma_f32_16x16x32_bf16 (w_layout = 1; resunit_emul16_impl.h): waves as (WN, WT), a wave's tile 64 channels x 64 columns wherever the
+// channel count allows (C = 32: 32 x 64, C = 64 with two workgroups per CU: 32 x 64).
+template <typename T>
+static int resunit_emul16(const jatts_resunit_desc& d, hipStream_t s) {
+  const int halo = (d.k_w - 1) * d.dil;
+  switch (d.channels) {
+    case 32: return launch_resunit_emul16<T, 32, 256, 1, 4, 2, false, true>(d, s);
+    case 64:
+      if (d.k_w >= 11) return launch_resunit_emul16<T, 64, 256, 1, 4, 1, false, true>(d, s);
+      return launch_resunit_emul16<T, 64, 128, 2, 2, 2, false, true>(d, s);
+    case 128: return launch_resunit_emul16<T, 128, 128, 2, 2, 1>(d, s);
+    case 256:
+      if ((64 + halo) * 1552 + 2048 <= 160 * 1024) return launch_resunit_emul16<T, 256, 64, 4, 1, 1>(d, s);
+      return launch_resunit_emul16<T, 256, 64, 4, 1, 1, true>(d, s);
+  }
+  return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "resunit: unsupported channels for JATTS_F32E (32 / 64 / 128 / 256)");
+}
+
+int jatts_resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
+  if (d.w_layout == 1) return d.dtype == JATTS_F32E6 ? resunit_emul16<bf3f>(d, s) : resunit_emul16<bf3>(d, s);
+  return d.dtype == JATTS_F32E6 ? resunit_emul<bf3f>(d, s) : resunit_emul<bf3>(d, s);
+}

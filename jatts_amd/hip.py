@@ -403,6 +403,20 @@ def pack_conv_weight_bf16x3(w, c_mult=32):
     return torch.stack(planes, dim=1).reshape(-1).contiguous()
 
 
+def pack_unit_weight_bf16x3_k32(w):
+    """(C, C, k) f32 -> the JATTS_F32E / JATTS_F32E6 fused-unit operand in the fragment order of the v_mfma_f32_16x16x32_bf16 kernels
+    (jatts_resunit_desc.w_layout = 1, csrc/resunit_emul16_impl.h): [tap][c / 32][n / 16][lane = 16 ((c % 32) / 8) + n % 16][b0 x8 | b1 x8 | b2 x8] over c % 8."""
+    n_out, c_in, k = w.shape
+    if n_out % 16 or c_in % 32:
+        raise ValueError("pack_unit_weight_bf16x3_k32: channels must be a multiple of 32")
+    planes = []
+    for t in bf16x3_terms(w):
+        # (n, c, k) -> [k][c / 32][c % 32 / 8][c % 8][n / 16][n % 16] -> [k][c / 32][n / 16][c % 32 / 8][n % 16][c % 8]
+        v = t.permute(2, 1, 0).reshape(k, c_in // 32, 4, 8, n_out // 16, 16).permute(0, 1, 4, 2, 5, 3)
+        planes.append(v.reshape(-1, 8))
+    return torch.stack(planes, dim=1).reshape(-1).contiguous()
+
+
 class SplitWeight:
     """A conv weight prepared for JATTS_F32S (the pair of pack_conv_weight_split).  hip.conv1d recognises it in place of a packed f32
     weight -- call sites stay `dtype=hip.F32` -- and takes the split kernel; shapes the split kernel does not cover (a halo beyond 32
@@ -616,9 +630,12 @@ def _check_unit_weights(who, dtype, channels, k_w, *ws):
                              f"pack_conv_weight_bf16x3 with c_mult=32), got {w.numel()} x {w.dtype}")
 
 
-def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype, add=None, out_scale=1.0, ws=None):
+def hifigan_resunit(rb, len_mul, x, y, w1, b1, w2, b2, channels, k_w, dil, slope, dtype, add=None, out_scale=1.0, ws=None, w_layout=0):
+    """jatts_hifigan_resunit.  w_layout (F32E / F32E6): 0 = weights from pack_conv_weight_bf16x3(w, 32) (32 x 32 x 16 kernels), 1 = from
+    pack_unit_weight_bf16x3_k32 (16 x 16 x 32 kernels)."""
     lib = _abi.load()
     d = _abi.ResUnitDesc()
+    d.w_layout = w_layout
     d.rg = rb.struct(len_mul)
     d.dtype, d.channels, d.k_w, d.dil, d.slope = dtype, channels, k_w, dil, slope
     rows = rb.total * len_mul
@@ -1599,7 +1616,7 @@ def mfma_ceiling(dtype=F32E, feed=1, target_ms=60.0, device=None, seed=0):
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator().manual_seed(seed)
     v = torch.randn(1 << 16, generator=g)
-    if dtype in EMUL:
+    if dtype in EMUL or dtype == 16 + F32E:
         ops = torch.cat([t.reshape(-1) for t in bf16x3_terms(v)])
     elif dtype in (F16, F32S):
         ops = v.half()

@@ -31,12 +31,20 @@ class PackedSplitConv:
         self.b = b.detach().float().contiguous()
 
 
-class PackedEmulConv:
-    """A ResBlock conv packed for the JATTS_F32E unit: the three exact bf16 terms of every weight (hip.pack_conv_weight_bf16x3), no scales."""
+# fragment order of the emulated units' weights: "16" = the v_mfma_f32_16x16x32_bf16 kernels (round 6: the power-limited matrix pipe sustains 14 % more of that
+# form, csrc/resunit_emul16_impl.h), "32" = the round-5 v_mfma_f32_32x32x16_bf16 kernels (A/B runs; the fused ResBlock launches always take them)
+EMUL_UNIT_FORM = os.environ.get("JATTS_RESUNIT_EMUL_FORM", "16")
 
-    def __init__(self, w, b):
+
+class PackedEmulConv:
+    """A ResBlock conv packed for the JATTS_F32E unit: the three exact bf16 terms of every weight, no scales; ``k32``: in the fragment order of the
+    16 x 16 x 32 kernels (hip.pack_unit_weight_bf16x3_k32, w_layout 1) instead of the 32 x 32 x 16 ones' (hip.pack_conv_weight_bf16x3, w_layout 0)."""
+
+    def __init__(self, w, b, k32=False, also32=False):
         self.n_out, self.c_in, self.k = w.shape
-        self.w, self.inv = hip.pack_conv_weight_bf16x3(w, 32), None
+        self.layout = 1 if k32 else 0
+        self.w, self.inv = (hip.pack_unit_weight_bf16x3_k32(w) if k32 else hip.pack_conv_weight_bf16x3(w, 32)), None
+        self.w32 = hip.pack_conv_weight_bf16x3(w, 32) if (k32 and also32) else self.w      # what a fused ResBlock launch takes (always the 32 x 32 x 16 order)
         self.b = b.detach().float().contiguous()
 
 
@@ -187,7 +195,9 @@ class HiFiGANGenerator(torch.nn.Module):
                 units = []
                 for di, d in enumerate(self.resblock_dilations[j]):
                     q = f"blocks.{i * nb + j}."
-                    mk = PackedSplitConv if split else PackedEmulConv if emul else (lambda w, b: PackedConv(w, b, dt, dev, c_mult=32))   # fused unit takes c_in == channels
+                    k32 = EMUL_UNIT_FORM == "16" and c_out % 32 == 0
+                    mk = (PackedSplitConv if split else (lambda w, b: PackedEmulConv(w, b, k32, (c_out, rk) in self.fused_blocks_emul)) if emul
+                          else (lambda w, b: PackedConv(w, b, dt, dev, c_mult=32)))   # fused unit takes c_in == channels
                     c1 = mk(padw(sd[q + f"convs1.{di}.1.weight"], c_out, c_out).to(dev), padb(sd[q + f"convs1.{di}.1.bias"], c_out).to(dev))
                     c2 = mk(padw(sd[q + f"convs2.{di}.1.weight"], c_out, c_out).to(dev), padb(sd[q + f"convs2.{di}.1.bias"], c_out).to(dev))
                     units.append((c1, c2, rk, d))
@@ -285,7 +295,7 @@ class HiFiGANGenerator(torch.nn.Module):
                 if (c_out, units[0][2]) in fset and len(units) <= 3 and st is None \
                         and sum((units[0][2] - 1) // 2 * (u[3] + 1) for u in units) <= (64 if (dt == hip.F16 or udt == hip.F32S or udt in hip.EMUL) else 16):
                     lastb = fuse_mean and j == len(blocks) - 1
-                    hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(c1.w, c1.b, c2.w, c2.b, d) for c1, c2, _, d in units],
+                    hip.hifigan_resblock(rb, rate, cur, bufs[j][0], [(getattr(c1, "w32", c1.w), c1.b, getattr(c2, "w32", c2.w), c2.b, d) for c1, c2, _, d in units],
                                          c_out, units[0][2], self.slope, udt, add=outs if lastb else None,
                                          out_scale=1.0 / len(blocks) if lastb else 1.0,
                                          ws=[(c1.inv, c2.inv) for c1, c2, _, _ in units] if udt == hip.F32S else None)
@@ -304,7 +314,7 @@ class HiFiGANGenerator(torch.nn.Module):
                         # the last unit of the last ResBlock writes the MRF mean (cs / num_blocks) directly
                         hip.hifigan_resunit(rb, rate, cur, nxt, c1.w, c1.b, c2.w, c2.b, c_out, rk, d, self.slope, udt,
                                             add=outs if last else None, out_scale=1.0 / len(blocks) if last else 1.0,
-                                            ws=(c1.inv, c2.inv) if udt == hip.F32S else None)
+                                            ws=(c1.inv, c2.inv) if udt == hip.F32S else None, w_layout=getattr(c1, "layout", 0))
                         cur = nxt
                     if st is not None:
                         ev = torch.cuda.Event()

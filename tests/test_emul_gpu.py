@@ -151,14 +151,33 @@ def test_conv1d_emul(cuda, lib, case, xkind, np_):
         assert torch.equal(y0, y[:L0])
 
 
+def _pack_unit(hip, w, layout):
+    """The emulated unit's weight operand in fragment order `layout` (jatts_resunit_desc.w_layout): 0 = the v_mfma_f32_32x32x16_bf16 kernels, 1 = the
+    v_mfma_f32_16x16x32_bf16 kernels (round 6, csrc/resunit_emul16_impl.h)."""
+    return hip.pack_unit_weight_bf16x3_k32(w) if layout else hip.pack_conv_weight_bf16x3(w, 32)
+
+
+def test_unit_weight_index_k32_matches_the_packer(cuda, lib):
+    """jatts_unit_weight_index_k32 (the header's definition of w_layout = 1) against hip.pack_unit_weight_bf16x3_k32, element by element."""
+    from jatts_amd import hip
+    C, k = 64, 3
+    w = torch.arange(C * C * k, dtype=torch.float32).reshape(C, C, k) % 251            # exactly representable in bf16: b0 = w, b1 = b2 = 0
+    p = hip.pack_unit_weight_bf16x3_k32(w.to(cuda)).view(-1, 3, 8).float().cpu()
+    assert not p[:, 1:].any()
+    for n, c, tap in [(0, 0, 0), (17, 5, 1), (63, 63, 2), (16, 32, 0), (31, 40, 2), (48, 9, 1)]:
+        i = lib.jatts_unit_weight_index_k32(n, tap, c, C)
+        assert float(p[i // 8, 0, i % 8]) == float(w[n, c, tap]), (n, c, tap)
+
+
+@pytest.mark.parametrize("layout", [0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
 @pytest.mark.parametrize("np_", ["7", "6"])
 @pytest.mark.parametrize("xkind", ["unit", "tiny", "large", "wide", "single"])
 @pytest.mark.parametrize("C,k,d,lens", [
     (32, 3, 1, [700, 3, 250]), (32, 11, 5, [600, 31]), (64, 7, 3, [513]), (64, 11, 5, [260, 9]), (128, 3, 5, [300, 40]),
     (128, 11, 1, [129]), (128, 11, 5, [300]), (128, 7, 3, [140, 139]), (256, 7, 5, [150, 64]), (256, 11, 5, [70]), (256, 3, 1, [200]),
 ])
-def test_hifigan_resunit_emul(cuda, lib, C, k, d, lens, xkind, np_):
-    """JATTS_F32E / JATTS_F32E6 fused dilation unit: the exact-f32 kernel's tolerance against fp64, at most twice its maximum error on the
+def test_hifigan_resunit_emul(cuda, lib, C, k, d, lens, xkind, np_, layout):
+    """JATTS_F32E / JATTS_F32E6 fused dilation unit, both MFMA forms: the exact-f32 kernel's tolerance against fp64, at most twice its maximum error on the
     same inputs -- at unit, tiny (1e-6), large (3e3), mixed (8 orders of magnitude between rows) magnitudes; with single-non-zero weight
     rows at most twice its relative-L2 error."""
     from jatts_amd import hip
@@ -185,9 +204,9 @@ def test_hifigan_resunit_emul(cuda, lib, C, k, d, lens, xkind, np_):
     ref = _ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, False)
     rb = _ragged(lens, cuda)
     xd = x.to(cuda)
-    p1, p2 = hip.pack_conv_weight_bf16x3(w1.to(cuda), 32), hip.pack_conv_weight_bf16x3(w2.to(cuda), 32)
+    p1, p2 = _pack_unit(hip, w1.to(cuda), layout), _pack_unit(hip, w2.to(cuda), layout)
     y = torch.full_like(xd, float("nan"))
-    hip.hifigan_resunit(rb, 1, xd, y, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, code)
+    hip.hifigan_resunit(rb, 1, xd, y, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, code, w_layout=layout)
     y32 = torch.full_like(xd, float("nan"))
     hip.hifigan_resunit(rb, 1, xd, y32, hip.pack_conv_weight(w1.to(cuda), hip.F32, 32), b1.to(cuda),
                         hip.pack_conv_weight(w2.to(cuda), hip.F32, 32), b2.to(cuda), C, k, d, 0.1, hip.F32)
@@ -205,11 +224,12 @@ def test_hifigan_resunit_emul(cuda, lib, C, k, d, lens, xkind, np_):
     if len(lens) > 1:      # an utterance alone == inside the batch, bit for bit
         L0 = lens[0]
         y0 = torch.empty(L0, C, device=cuda)
-        hip.hifigan_resunit(_ragged([L0], cuda), 1, xd[:L0].contiguous(), y0, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, code)
+        hip.hifigan_resunit(_ragged([L0], cuda), 1, xd[:L0].contiguous(), y0, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, code, w_layout=layout)
         assert torch.equal(y0, y[:L0])
 
 
-def test_hifigan_resunit_emul_mrf_mean(cuda, lib):
+@pytest.mark.parametrize("layout", [0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
+def test_hifigan_resunit_emul_mrf_mean(cuda, lib, layout):
     """The fused MRF mean of the unit's output pass ((unit(x) + add0 + add1) * out_scale) and an all-zero input."""
     from jatts_amd import hip
     g = torch.Generator().manual_seed(12)
@@ -220,13 +240,14 @@ def test_hifigan_resunit_emul_mrf_mean(cuda, lib):
     b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
     ref = (_ref_unit(x, w1, b1, w2, b2, lens, k, d, 0.1, False) + a0.double() + a1.double()) / 3.0
     rb = _ragged(lens, cuda)
-    p1, p2 = hip.pack_conv_weight_bf16x3(w1.to(cuda), 32), hip.pack_conv_weight_bf16x3(w2.to(cuda), 32)
+    p1, p2 = _pack_unit(hip, w1.to(cuda), layout), _pack_unit(hip, w2.to(cuda), layout)
     y = torch.empty(R, C, device=cuda)
-    hip.hifigan_resunit(rb, 1, x.to(cuda), y, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, hip.F32E, add=[a0.to(cuda), a1.to(cuda)], out_scale=1.0 / 3.0)
+    hip.hifigan_resunit(rb, 1, x.to(cuda), y, p1, b1.to(cuda), p2, b2.to(cuda), C, k, d, 0.1, hip.F32E, add=[a0.to(cuda), a1.to(cuda)], out_scale=1.0 / 3.0,
+                        w_layout=layout)
     assert relerr(y, ref) <= TOL["fp32"]
     z = torch.zeros(R, C, device=cuda)
     zb = torch.zeros(C, device=cuda)
-    hip.hifigan_resunit(rb, 1, z, y, p1, zb, p2, zb, C, k, d, 0.1, hip.F32E)
+    hip.hifigan_resunit(rb, 1, z, y, p1, zb, p2, zb, C, k, d, 0.1, hip.F32E, w_layout=layout)
     assert not y.any()
 
 

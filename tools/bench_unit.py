@@ -12,6 +12,9 @@ import torch  # noqa: E402
 from jatts_amd import hip  # noqa: E402
 
 
+LAYOUT = [1]      # emulated units: 1 = the v_mfma_f32_16x16x32_bf16 kernels (the product form), 0 = the 32 x 32 x 16 ones (--layout 0)
+
+
 def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
     dev = torch.device("cuda:0")
     rb = hip.RaggedBatch([T] * B, dev)
@@ -26,7 +29,11 @@ def run(C, k, d, rate, iters, B=64, T=768, dtype=hip.F16):
         (w1, i1), (w2, i2) = hip.pack_conv_weight_split(wa, 32), hip.pack_conv_weight_split(wb, 32)
         kw["ws"] = (i1, i2)
     elif dtype in hip.EMUL:
-        w1, w2 = hip.pack_conv_weight_bf16x3(wa, 32), hip.pack_conv_weight_bf16x3(wb, 32)
+        if LAYOUT[0]:
+            w1, w2 = hip.pack_unit_weight_bf16x3_k32(wa), hip.pack_unit_weight_bf16x3_k32(wb)
+            kw["w_layout"] = 1
+        else:
+            w1, w2 = hip.pack_conv_weight_bf16x3(wa, 32), hip.pack_conv_weight_bf16x3(wb, 32)
     else:
         w1, w2 = hip.pack_conv_weight(wa, dtype, 32), hip.pack_conv_weight(wb, dtype, 32)
     b1 = torch.zeros(C, device=dev)
@@ -106,9 +113,11 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split", "emul", "emul6"])
     ap.add_argument("--resblock", action="store_true", help="fused ResBlock launches vs per-unit launches (f16)")
+    ap.add_argument("--layout", type=int, default=1, choices=[0, 1], help="emulated units: 1 = v_mfma_f32_16x16x32_bf16 kernels (product), 0 = 32x32x16")
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}  # HiFi-GAN v1 22.05 kHz stage rates
     dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E, "emul6": hip.F32E6}[a.dtype]
+    LAYOUT[0] = a.layout
     if a.resblock:
         for C in ((32, 64, 128) if dt == hip.F16 else (32, 64)):
             for k in ((3, 7) if dt != hip.F32 else (3,)):

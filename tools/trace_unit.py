@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dil", type=int, default=1)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "split", "emul", "emul6"])
+    ap.add_argument("--layout", type=int, default=1, choices=[0, 1], help="emulated units: 1 = v_mfma_f32_16x16x32_bf16 kernels (product), 0 = 32x32x16")
     a = ap.parse_args()
     rates = {256: 8, 128: 64, 64: 128, 32: 256}
     dev = torch.device("cuda:0")
@@ -40,8 +41,8 @@ def main():
         (w0, i0), (w1, i1) = (hip.pack_conv_weight_split(v, 32) for v in wf)
         run = lambda: hip.hifigan_resunit(rb, rate, x, y, w0, b, w1, b, a.C, a.k, a.dil, 0.1, dt, ws=(i0, i1))
     elif dt in hip.EMUL:
-        w = [hip.pack_conv_weight_bf16x3(v, 32) for v in wf]
-        run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, dt)
+        w = [hip.pack_unit_weight_bf16x3_k32(v) if a.layout else hip.pack_conv_weight_bf16x3(v, 32) for v in wf]
+        run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, dt, w_layout=a.layout)
     else:
         w = [hip.pack_conv_weight(v, dt, 32) for v in wf]
         run = lambda: hip.hifigan_resunit(rb, rate, x, y, w[0], b, w[1], b, a.C, a.k, a.dil, 0.1, dt)
