@@ -101,5 +101,5 @@ def test_traffic_lookup_answers_null_with_a_reason():
         v, why = bench.lookup_traffic(table, prec, 128)
         assert v and v > 1e9 and why is None, (prec, why)
     v, why = bench.lookup_traffic({"some_other_kernel": {"hbm_bytes": 1.0, "launches": 1}}, "fp32_bf16x3", 128)
-    assert v is None and "resunit_emul_kernel" in why
+    assert v is None and "resunit_emul16_kernel" in why
     assert bench.lookup_traffic(None, "fp32", 128) == (None, "no traffic table")
