@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops, jatts_conv_desc + n_split / ldy2 / y2 / y2_seq_col0 and jatts_resunit_desc + w_layout (appended), jatts_unit_weight_index_k32; 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
+#define JATTS_ABI_VERSION 4   /* 4 (round 6): + jatts_mfma_probe / jatts_mfma_probe_flops, jatts_conv_desc + n_split / ldy2 / y2 / y2_seq_col0 / w_layout and jatts_resunit_desc + w_layout (appended), jatts_unit_weight_index_k32; 3 (round 5): jatts_ragged + total_rows AND host_lens -- the struct grew from 24 to 32 bytes,
                                 * so every descriptor that embeds it (jatts_conv_desc, jatts_resunit_desc, jatts_resblock_desc, jatts_relattn_desc) shifted by 8 bytes; JATTS_F32E; 2 (round 4): jatts_conv_desc + w_inv / act_a / act_b, jatts_resunit_desc + ws1 / ws2, jatts_resblock_desc + ws1 / ws2;
                                 * bumped whenever a descriptor's layout or an entry point's signature changes: a stale library is refused at load */
 
@@ -156,6 +156,10 @@ typedef struct jatts_conv_desc {
   int32_t ldy2;
   void* y2;
   const int32_t* y2_seq_col0;
+  /* (ABI 4) JATTS_F32E / JATTS_F32E6 only: fragment order of w.  0: the order of jatts_conv_weight_index ([tap][c / 16][n / 32][lane][c % 8], v_mfma_f32_32x32x16_bf16
+   * kernels); 1: [tap][c / 32][n / 16][lane = 16 ((c % 32) / 8) + n % 16][c % 8] x (b0 | b1 | b2) with n padded to 32 and c to 64 (v_mfma_f32_16x16x32_bf16 kernels,
+   * csrc/conv1d_emul16.h: the form the power-limited matrix pipe sustains 14 % more of; jatts_amd.hip.pack_conv_weight_bf16x3_k32). */
+  int32_t w_layout;
 } jatts_conv_desc;
 
 int jatts_conv1d(const jatts_conv_desc* d, void* stream);

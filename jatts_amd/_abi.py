@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("alpha", C.c_float), ("resid", C.c_void_p), ("ldr", C.c_int32), ("y", C.c_void_p),
         ("ldy", C.c_int32), ("y_is_f32", C.c_int32), ("y_transposed", C.c_int32), ("y_seq_col0", C.c_void_p),
         ("pad_mode", C.c_int32), ("variant", C.c_int32), ("w_inv", C.c_void_p), ("act_a", C.c_void_p), ("act_b", C.c_void_p),
-        ("n_split", C.c_int32), ("ldy2", C.c_int32), ("y2", C.c_void_p), ("y2_seq_col0", C.c_void_p),
+        ("n_split", C.c_int32), ("ldy2", C.c_int32), ("y2", C.c_void_p), ("y2_seq_col0", C.c_void_p), ("w_layout", C.c_int32),
     ]
 
 

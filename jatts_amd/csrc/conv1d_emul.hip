@@ -2,7 +2,7 @@
 // partial products; conv1d_emul.h).
 #include <stdlib.h>
 
-#include "conv1d_emul.h"
+#include "conv1d_emul16.h"
 
 // The arithmetic has no tile-dependent scale, so -- unlike the split kernels -- the tile may follow the launch: every variant gives the
 // same bits for a row.  (variants: JATTS_CONV_EMUL_VARIANT, measured by tools/bench_conv.py --dtype emul)
@@ -45,4 +45,21 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
   else return launch_conv_emul<T, 2, 2, 2, 2, 1, 32, 2>(d, s);                        // 128 n x 128 t, two workgroups per CU
 }
 
-int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s) { return d.dtype == JATTS_F32E6 ? conv1d_emul<bf3f>(d, s) : conv1d_emul<bf3>(d, s); }
+// The 16 x 16 x 32 form (w_layout = 1; conv1d_emul16.h).  Every tile walks the contraction in 64-channel chunks, so -- in BOTH arithmetics -- a row's bits do
+// not depend on the tile and the choice may follow the launch.
+template <typename T>
+static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
+  static const int variant = [] { const char* e = getenv("JATTS_CONV_EMUL16_VARIANT"); return e ? atoi(e) : 0; }();
+  if (d.n_in > 1) return launch_conv_emul16<T, 4, 4, 2, 2, 3, 64, 1>(d, s);           // summed inputs (rare): 128 n x 128 t, four waves, one workgroup per CU
+  if (d.n_out <= 64) return launch_conv_emul16<T, 2, 2, 2, 2, 1, 64, 2>(d, s);        // 64 n x 64 t, four waves, two workgroups per CU: the HBM-bound last upsampling conv
+  const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
+  const int64_t wgs128 = ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128);
+  // 128 n x 64 t, four waves side by side in n (32 n x 64 t each), two workgroups per CU: k = 1, and launches that cannot give every CU a 128 x 128 workgroup
+  if (variant == 1 || (variant == 0 && (d.k_w == 1 || wgs128 <= 128))) return launch_conv_emul16<T, 2, 4, 4, 1, 1, 64, 2>(d, s);
+  return launch_conv_emul16<T, 2, 4, 4, 2, 1, 64, 1>(d, s);                           // 128 n x 128 t, eight waves, one workgroup per CU
+}
+
+int jatts_conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
+  if (d.w_layout == 1) return d.dtype == JATTS_F32E6 ? conv1d_emul16<bf3f>(d, s) : conv1d_emul16<bf3>(d, s);
+  return d.dtype == JATTS_F32E6 ? conv1d_emul<bf3f>(d, s) : conv1d_emul<bf3>(d, s);
+}

@@ -51,6 +51,7 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_ACT_SNAKEBETA needs 16-byte aligned act_a / act_b and n_out % 4 == 0");
   if (d->n_split != 0 && (d->n_split < 0 || d->n_split % 256 || d->n_split >= d->n_out || !d->y2 || d->y_transposed || d->resid || d->ldy2 <= 0))
     return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: n_split must be a multiple of 256 below n_out, with y2 / ldy2 set, y row-major and no residual");
+  if (d->w_layout != 0 && d->dtype != JATTS_F32E && d->dtype != JATTS_F32E6) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: w_layout = 1 goes with JATTS_F32E / JATTS_F32E6 only");
   if (d->rg.max_len <= 0) return JATTS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == JATTS_F16) return jatts_conv1d_f16(*d, s);
@@ -62,6 +63,7 @@ extern "C" int jatts_conv1d(const jatts_conv_desc* d, void* stream) {
   }
   if (d->dtype == JATTS_F32E || d->dtype == JATTS_F32E6) {
     if (!d->y_is_f32) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: JATTS_F32E / JATTS_F32E6 write f32 (y_is_f32 = 1)");
+    if (d->w_layout != 0 && d->w_layout != 1) return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: w_layout must be 0 or 1");
     return jatts_conv1d_emul(*d, s);
   }
   return jatts_set_error_msg(JATTS_ERR_ARG, "conv1d: unknown dtype");

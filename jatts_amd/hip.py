@@ -417,6 +417,20 @@ def pack_unit_weight_bf16x3_k32(w):
     return torch.stack(planes, dim=1).reshape(-1).contiguous()
 
 
+def pack_conv_weight_bf16x3_k32(w, c_mult=64):
+    """(n_out, c_in, k) f32 -> the JATTS_F32E / JATTS_F32E6 conv operand in the fragment order of the v_mfma_f32_16x16x32_bf16 kernels (jatts_conv_desc.w_layout = 1,
+    csrc/conv1d_emul16.h): output channels zero-padded to 32, input channels to c_mult, then pack_unit_weight_bf16x3_k32's order."""
+    n, c, k = w.shape
+    n_pad, c_pad = round_up(n, 32), round_up(c, c_mult)
+    wp = torch.zeros(n_pad, c_pad, k, dtype=torch.float32, device=w.device)
+    wp[:n, :c] = w.detach().float()
+    return pack_unit_weight_bf16x3_k32(wp)
+
+
+# fragment order of the emulated convs' weights: "16" = the v_mfma_f32_16x16x32_bf16 kernels (round 6), "32" = the round-5 32 x 32 x 16 kernels (A/B runs)
+CONV_EMUL_FORM = os.environ.get("JATTS_CONV_EMUL_FORM", "16")
+
+
 class SplitWeight:
     """A conv weight prepared for JATTS_F32S (the pair of pack_conv_weight_split).  hip.conv1d recognises it in place of a packed f32
     weight -- call sites stay `dtype=hip.F32` -- and takes the split kernel; shapes the split kernel does not cover (a halo beyond 32
@@ -437,9 +451,10 @@ class EmulWeight:
     seven or six partial products).  hip.conv1d recognises it in place of a packed f32 weight -- call sites stay `dtype=hip.F32` -- and takes the
     emulated kernel; a halo beyond its staging registers (32 rows) takes the exact-f32 kernel on a lazily packed f32 copy of the same weight."""
 
-    def __init__(self, w, c_mult=64, code=F32E):
+    def __init__(self, w, c_mult=64, code=F32E, layout=None):
         self.code = code
-        self.packed = pack_conv_weight_bf16x3(w, c_mult)
+        self.layout = (1 if CONV_EMUL_FORM == "16" and c_mult % 64 == 0 else 0) if layout is None else layout      # jatts_conv_desc.w_layout
+        self.packed = pack_conv_weight_bf16x3_k32(w, c_mult) if self.layout else pack_conv_weight_bf16x3(w, c_mult)
         self._src, self._c_mult, self._f32 = w.detach(), c_mult, None
 
     def f32(self):
@@ -523,7 +538,7 @@ def convtranspose_as_conv(w, stride, padding):
 def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=None, act=ACT_NONE,
            alpha=1.0, resid=None, out=None, out_f32=False, transposed=False, pre_lrelu=None,
            in_scale=1.0, ldx=None, x_col0=0, len_mul=1, out_ld=None, out_col0=0, out_rows=None, resid_col0=0,
-           y_seq_col0=None, reflect=False, variant=0, w_inv=None, snake=None, split=None):
+           y_seq_col0=None, reflect=False, variant=0, w_inv=None, snake=None, split=None, w_layout=0):
     """See jatts_conv1d in include/jatts_hip.h.  ``xs`` is a tensor or list of <=3 tensors.  dtype F32S: f32 tensors, ``w_packed`` / ``w_inv``
     from pack_conv_weight_split (c_mult 64).  ``snake`` = (exp(alpha), 1 / (exp(beta) + 1e-9)) f32 vectors of n_out: the SnakeBeta
     activation (the ``snakebeta`` op) applied in the epilogue instead of ``act``.  ``split`` = (n_split, ld2, seq_col0): TWO outputs from one launch
@@ -543,7 +558,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
         if dtype != F32:
             raise ValueError("conv1d: an EmulWeight goes with dtype F32 tensors")
         if (k_w - 1) * dil <= 32:
-            dtype, w_packed, out_f32 = w_packed.code, w_packed.packed, True
+            dtype, w_layout, w_packed, out_f32 = w_packed.code, w_packed.layout, w_packed.packed, True
         else:
             w_packed = w_packed.f32()
     x0 = _dev(xs[0])
@@ -611,6 +626,7 @@ def conv1d(rb, xs, w_packed, c_in, n_out, k_w, *, dtype, dil=1, pad=None, bias=N
     d.y_is_f32, d.y_transposed = int(odt == torch.float32), int(transposed)
     d.y_seq_col0 = _ptr(y_seq_col0) if transposed else None
     d.w_inv = _ptr(w_inv) if dtype == F32S else None
+    d.w_layout = w_layout if dtype in EMUL else 0
     if out2 is not None:
         d.n_split, d.ldy2, d.y2, d.y2_seq_col0 = split[0], split[1], out2.data_ptr(), _ptr(split[2])
     _count(2.0 * c_in * n_out * k_w * rows)

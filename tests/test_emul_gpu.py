@@ -88,12 +88,16 @@ EMUL_CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("layout", [0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
 @pytest.mark.parametrize("np_", ["7", "6"])
 @pytest.mark.parametrize("xkind", ["unit", "wide", "single"])
 @pytest.mark.parametrize("case", EMUL_CONV_CASES)
-def test_conv1d_emul(cuda, lib, case, xkind, np_):
+def test_conv1d_emul(cuda, lib, case, xkind, np_, layout):
+    """JATTS_F32E / JATTS_F32E6 conv in both MFMA forms (jatts_conv_desc.w_layout: 0 = v_mfma_f32_32x32x16_bf16 kernels, 1 = the 16 x 16 x 32 kernels of
+    round 6, csrc/conv1d_emul16.h): the exact-f32 kernel's bounds against fp64."""
     import torch.nn.functional as F
     from jatts_amd import hip
+    packw = (lambda t: hip.pack_conv_weight_bf16x3_k32(t, 64)) if layout else (lambda t: hip.pack_conv_weight_bf16x3(t, 64))
     if np_ == "6" and xkind == "wide":
         pytest.skip("six products: unit and single only")
     code = getattr(hip, CODES[np_])
@@ -120,7 +124,7 @@ def test_conv1d_emul(cuda, lib, case, xkind, np_):
     xd = [F.pad(x, (0, c_pad - c_in)).to(cuda).contiguous() for x in xs]
     kw = dict(dil=dil, bias=b.to(cuda), act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], alpha=alpha,
               resid=None if res is None else res.to(cuda), out_f32=True, transposed=transposed, pre_lrelu=pre, in_scale=in_scale)
-    y = hip.conv1d(rb, xd, hip.pack_conv_weight_bf16x3(w.to(cuda), 64), c_pad, n_out, k, dtype=code, **kw)
+    y = hip.conv1d(rb, xd, packw(w.to(cuda)), c_pad, n_out, k, dtype=code, w_layout=layout, **kw)
     y32 = hip.conv1d(rb, xd, hip.pack_conv_weight(w.to(cuda), hip.F32), c_pad, n_out, k, dtype=hip.F32, **kw)
     torch.cuda.synchronize()
     y, y32 = (y.t(), y32.t()) if transposed else (y, y32)
@@ -140,14 +144,14 @@ def test_conv1d_emul(cuda, lib, case, xkind, np_):
         assert m <= 2.0 * m32 + 1e-30, f"emulated conv1d {case} {xkind}: max err {m:.3e} vs exact f32 {m32:.3e}"
     # the EmulWeight route of the models (dtype stays F32 at the call site) is the same launch
     if n_in == 1 and not transposed:
-        y2 = hip.conv1d(rb, xd, hip.EmulWeight(w.to(cuda), 64, code), c_pad, n_out, k, dtype=hip.F32, **kw)
+        y2 = hip.conv1d(rb, xd, hip.EmulWeight(w.to(cuda), 64, code, layout=layout), c_pad, n_out, k, dtype=hip.F32, **kw)
         assert torch.equal(y2, y)
     # a sequence alone == inside the batch, bit for bit
     if len(lens) > 1 and not transposed:
         L0 = lens[0]
         kw0 = dict(kw, resid=None if res is None else res[:L0].to(cuda).contiguous())
-        y0 = hip.conv1d(_ragged([L0], cuda), [x[:L0].contiguous() for x in xd], hip.pack_conv_weight_bf16x3(w.to(cuda), 64), c_pad, n_out, k,
-                        dtype=code, **kw0)
+        y0 = hip.conv1d(_ragged([L0], cuda), [x[:L0].contiguous() for x in xd], packw(w.to(cuda)), c_pad, n_out, k,
+                        dtype=code, w_layout=layout, **kw0)
         assert torch.equal(y0, y[:L0])
 
 

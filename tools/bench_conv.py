@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     ap.add_argument("--variant", type=int, default=0, help="jatts_conv_desc.variant (0 = the product heuristic)")
     ap.add_argument("--pre-lrelu", type=float, default=None, help="LeakyReLU prologue slope (the HiFi-GAN upsampling convs)")
+    ap.add_argument("--layout", type=int, default=1, choices=[0, 1], help="emulated convs: 1 = v_mfma_f32_16x16x32_bf16 kernels (product), 0 = 32x32x16")
     a = ap.parse_args()
     dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E, "emul6": hip.F32E6}[a.dtype]
     dev = torch.device("cuda:0")
@@ -37,14 +38,16 @@ def main():
         rows = rb.total
         x = (torch.randn(rows, c, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
         wf = (torch.randn(n, c, k, generator=g) / (c * k) ** 0.5).to(dev)
-        w, winv = (hip.pack_conv_weight_split(wf, 64) if dt == hip.F32S else (hip.pack_conv_weight_bf16x3(wf, 64), None) if dt in hip.EMUL
+        lay = a.layout if dt in hip.EMUL else 0
+        w, winv = (hip.pack_conv_weight_split(wf, 64) if dt == hip.F32S
+                   else ((hip.pack_conv_weight_bf16x3_k32(wf, 64) if lay else hip.pack_conv_weight_bf16x3(wf, 64)), None) if dt in hip.EMUL
                    else (hip.pack_conv_weight(wf, dt), None))
         b = torch.zeros(n, device=dev)
         r = torch.zeros(rows, n, device=dev) if res else None
 
         def run():
             return hip.conv1d(rb, x, w, c, n, k, dtype=dt, bias=b, resid=r, out=r, out_f32=res or dt in (hip.F32S,) + hip.EMUL, variant=a.variant,
-                              pre_lrelu=a.pre_lrelu, w_inv=winv)
+                              pre_lrelu=a.pre_lrelu, w_inv=winv, w_layout=lay)
         for _ in range(2):
             run()
         torch.cuda.synchronize()
