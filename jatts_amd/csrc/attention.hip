@@ -362,11 +362,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
       }
     }
   };
+  // LOAD-BEARING: a wave's `buffer_load ... lds` pieces must have LANDED before the barrier that lets OTHER waves read those LDS rows.  A workgroup barrier
+  // does not wait for vector-memory traffic (LDS-DMA requests stay in flight across s_barrier), and nothing orders another wave's ds_read behind them.  The
+  // compiler happens to put s_waitcnt vmcnt(0) in front of these barriers today (checked in the gfx950 ISA); this makes it explicit.
+  auto dma_landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   TileRegs<T, DK, KBT, NW> tr;
   if (PREFETCH) tile_load<T, DK, KBT, 3, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
   if constexpr (DMA) {
     dma_k(j_start);
     ku_commit();
+    dma_landed();
     __syncthreads();
   } else if constexpr (HALFPF) {
     tile_load<T, DK, KBT, 1, NW, REL>(tr, d, kg, vtg, row0, h, j_start, Tn, vt_vec, rk, rv);
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
     }
 
     if constexpr (DMA) {
+      dma_landed();
       __syncthreads();            // V^T(t) landed (vmcnt(0) in front of the barrier) and visible; the K buffer is free
       if (j0 + KBT > Tn) {        // the sequence's last, partial tile: zero the columns past its end (never multiply P = 0 by stray bits)
         const int mf = Tn - j0;
@@ -586,7 +592,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (((DK <= 256 && sizeof(T) ==
         mma16(a, pb, ot[f]);
       }
     }
-    if constexpr (DMA) ku_commit();          // (every wave is past this tile's softmax since the barrier in front of the P V MFMAs)
+    if constexpr (DMA) {
+      ku_commit();          // (every wave is past this tile's softmax since the barrier in front of the P V MFMAs)
+      dma_landed();         // K(t + 1) before the barrier that publishes it
+    }
     if constexpr (HALFPF && !DMA) {
       __builtin_amdgcn_sched_barrier(0);   // (the same for K(t + 1) and the P V MFMAs)
       if (!(DIAG & 4) && j0 + KBT < Tk) tile_store<T, DK, KBT, 1, NW, REL>(tr, ks, vs, kus, KP, VP);

@@ -278,10 +278,13 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void resunit_emul16_kernel(jatts_
         Vec8IO<T>::sts(xs + (size_t)(r_in + ro) * pitch + (size_t)cu * 48, to_planes(xk[j]));
       }
     } else {
-      for (int base = threadIdx.x; base < total; base += NTHR * UB) {
-        f32x8 v[UB];
+      // the WHOLE tile in one batch of loads (halos up to 32 rows a side; longer ones take a second pass): the accumulators are not live yet, and a second
+      // batch is a second serial HBM round trip -- 3.5 k of a C = 128 workgroup's 138 k cycles
+      constexpr int UBX = ((WGCOLS + 64) * UPR + NTHR - 1) / NTHR;
+      for (int base = threadIdx.x; base < total; base += NTHR * UBX) {
+        f32x8 v[UBX];
 #pragma unroll
-        for (int j = 0; j < UB; ++j) {
+        for (int j = 0; j < UBX; ++j) {
           const int u = base + j * NTHR;
           const int r = u / UPR, cu = u - r * UPR;
           const int pos = pos0 + r;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void resunit_emul16_kernel(jatts_
           else v[j] = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
-        for (int j = 0; j < UB; ++j) {
+        for (int j = 0; j < UBX; ++j) {
           const int u = base + j * NTHR;
           if (u >= total) continue;
           const int r = u / UPR, cu = u - r * UPR;

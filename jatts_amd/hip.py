@@ -167,7 +167,9 @@ WS_BYTES = 64 * 1024 + 96 * 1024 * 1024
 
 
 def _ws(device):
-    """Register this device's scratch with the library before a kernel that reduces across workgroups (LayerNorm / GroupNorm / SnakeBeta
+    """(Graph replays: a captured step bakes the scratch in and is ordered against other users only on the stream it was CAPTURED on -- replay a trainer's
+    graph on its capture stream, which is what jatts_amd.training does; ownership is not tracked for replays on other streams.)
+    Register this device's scratch with the library before a kernel that reduces across workgroups (LayerNorm / GroupNorm / SnakeBeta
     parameter gradients, column sums, depthwise-conv weights, the gradient norm): allocated once, outside any graph capture (the trainers'
     first step of a signature runs eagerly), kept alive for the life of the process -- a captured step bakes its address in."""
     key = str(device)
@@ -205,8 +207,10 @@ def _ws_done():
 
 
 def _ws_check(rc, name):
-    _abi.check(rc, name)
-    _ws_done()
+    try:
+        _abi.check(rc, name)
+    finally:          # a failed launch must not leave the pending marker behind: the next reduction would record its event on the wrong stream
+        _ws_done()
 
 
 def _ptr(t, col0=0):

@@ -255,9 +255,11 @@ def test_hifigan_resunit_emul_mrf_mean(cuda, lib, layout):
     assert not y.any()
 
 
+@pytest.mark.parametrize("layout", [0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
 @pytest.mark.parametrize("products", [7, 6])
-def test_emul_sweep_bound(cuda, lib, products):
-    """A randomised draw of tools/emul_sweep.py (its own seed; the committed 1 100-case tables are profiles/r05_emul_sweep*.json).  Seven products:
+def test_emul_sweep_bound(cuda, lib, products, layout):
+    """A randomised draw of tools/emul_sweep.py (its own seed; the committed 1 100-case tables are profiles/r06_emul_sweep*.json for the 16 x 16 x 32 kernels
+    the product runs, profiles/r05_emul_sweep*.json for the 32 x 32 x 16 ones), both MFMA forms.  Seven products:
     in EVERY case, single-non-zero rows included, the maximum error against fp64 is at most twice the exact-f32 kernel's (VERDICT r4's acceptance
     test), so is the relative-L2 error, and every element of every single-non-zero conv lies within 2 x 2^-24 |w x|.  Six products: relative L2 at
     most twice (dense inputs) / three times (few-term cases), elements within 4 x 2^-24 -- tools/emul_sweep.violates."""
@@ -265,6 +267,7 @@ def test_emul_sweep_bound(cuda, lib, products):
     from tools import emul_sweep as sw
     g = torch.Generator().manual_seed(2025)
     code = hip.F32E if products == 7 else hip.F32E6
+    sw.LAYOUT[0] = layout
     rows = sw.sweep_units(60 if products == 7 else 30, g, cuda, code) + sw.sweep_convs(120 if products == 7 else 60, g, cuda, code)
     bad = [r for r in rows if sw.violates(r, products)]
     assert not bad, f"{bad[0]['case']}: emulated {bad[0]['max_emul']:.3e} / {bad[0]['rel_emul']:.3e} vs exact f32 {bad[0]['max_f32']:.3e} / {bad[0]['rel_f32']:.3e}"

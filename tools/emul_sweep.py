@@ -65,8 +65,8 @@ def unit_case(g, dev, C, k, d, lens, kind, single, code=None):
     rb = hip.RaggedBatch(lens, dev)
     xd = x.to(dev)
     y, y32 = torch.empty_like(xd), torch.empty_like(xd)
-    hip.hifigan_resunit(rb, 1, xd, y, hip.pack_conv_weight_bf16x3(w1.to(dev), 32), b1.to(dev), hip.pack_conv_weight_bf16x3(w2.to(dev), 32), b2.to(dev),
-                        C, k, d, 0.1, code)
+    pk = hip.pack_unit_weight_bf16x3_k32 if LAYOUT[0] else (lambda t: hip.pack_conv_weight_bf16x3(t, 32))
+    hip.hifigan_resunit(rb, 1, xd, y, pk(w1.to(dev)), b1.to(dev), pk(w2.to(dev)), b2.to(dev), C, k, d, 0.1, code, w_layout=LAYOUT[0])
     hip.hifigan_resunit(rb, 1, xd, y32, hip.pack_conv_weight(w1.to(dev), hip.F32, 32), b1.to(dev), hip.pack_conv_weight(w2.to(dev), hip.F32, 32), b2.to(dev),
                         C, k, d, 0.1, hip.F32)
     (m, e), (m32, e32) = errs(y, ref), errs(y32, ref)
@@ -88,7 +88,8 @@ def conv_case(g, dev, c_in, n_out, k, dil, act, lens, kind, single, code=None):
     rb = hip.RaggedBatch(lens, dev)
     xd = x.to(dev)
     actc = {"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act]
-    y = hip.conv1d(rb, xd, hip.pack_conv_weight_bf16x3(w.to(dev), 64), c_in, n_out, k, dtype=code, dil=dil, bias=b.to(dev), act=actc)
+    pk = (lambda t: hip.pack_conv_weight_bf16x3_k32(t, 64)) if LAYOUT[0] else (lambda t: hip.pack_conv_weight_bf16x3(t, 64))
+    y = hip.conv1d(rb, xd, pk(w.to(dev)), c_in, n_out, k, dtype=code, dil=dil, bias=b.to(dev), act=actc, w_layout=LAYOUT[0])
     y32 = hip.conv1d(rb, xd, hip.pack_conv_weight(w.to(dev), hip.F32), c_in, n_out, k, dtype=hip.F32, dil=dil, bias=b.to(dev), act=actc)
     (m, e), (m32, e32) = errs(y, ref), errs(y32, ref)
     row = dict(case=f"{c_in}->{n_out} k{k} d{dil} {act} {lens} {kind}{' single' if single else ''}", kind=kind, single=single, max_emul=m, max_f32=m32,
@@ -198,18 +199,23 @@ def summary(rows, products=7):
     return out
 
 
+LAYOUT = [1]      # the MFMA form under test: 1 = the v_mfma_f32_16x16x32_bf16 kernels (the product form since round 6), 0 = 32 x 32 x 16 (--layout 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--layout", type=int, default=1, choices=[0, 1], help="1 = v_mfma_f32_16x16x32_bf16 kernels (product), 0 = the 32 x 32 x 16 kernels")
     ap.add_argument("--units", type=int, default=400)
     ap.add_argument("--convs", type=int, default=700)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--products", type=int, default=7, choices=[6, 7], help="partial products per product: 7 = JATTS_F32E, 6 = JATTS_F32E6")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    LAYOUT[0] = a.layout
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(a.seed)
     code = hip.F32E if a.products == 7 else hip.F32E6
-    out = {"seed": a.seed, "products": a.products,
+    out = {"seed": a.seed, "products": a.products, "mfma_form": "16x16x32" if a.layout else "32x32x16",
            "what": "err_emul / err_f32, both = max |y - fp64 reference| on the same random inputs (JATTS_F32E / JATTS_F32E6 vs JATTS_F32 kernels); "
                    "rel_l2 = ||y - ref|| / ||ref||; every third case has ONE non-zero weight per output channel (K_eff = 1)"}
     bad = 0
