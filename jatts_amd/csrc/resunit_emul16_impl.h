@@ -23,6 +23,13 @@
 
 #include "resunit_emul_impl.h"
 
+#ifndef JATTS_U16_ROWS
+#define JATTS_U16_ROWS 1   // 1: the fragment groups but the last walk all NT column fragments in turn (row16); 0: column pairs everywhere (A/B builds)
+#endif
+#ifndef JATTS_U16_DIAG
+#define JATTS_U16_DIAG 0   // timing probes only (wrong results; separate DIAG builds): 1 = no B (LDS) refills in the K-loop, 2 = no A (L2) refills, 3 = neither
+#endif
+
 namespace {
 
 struct acc2x4 { f32x4 big, small; };
@@ -93,6 +100,28 @@ __device__ __forceinline__ void pair16(typename Acc16<T>::type (&acc)[NF][NT], c
   if constexpr (NP == 7) { mma16p<6>(a, rb[t0_], c0); mma16p<6>(a, rb[t0_ + 1], c1); }
 }
 
+// NP MFMAs each of the NT fragment pairs (f, 0 .. NT - 1), interleaved: an accumulator is touched every NT-th MFMA
+template <typename T, int NF, int NT>
+__device__ __forceinline__ void row16(typename Acc16<T>::type (&acc)[NF][NT], const typename Elem<T>::vec8& a, typename Elem<T>::vec8 (&rb)[NT], int f_) {
+  constexpr int NP = NProd<T>::value;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mma16p<0>(a, rb[t], acc[f_][t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mma16p<1>(a, rb[t], acc[f_][t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mma16p<2>(a, rb[t], acc[f_][t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mma16p<3>(a, rb[t], acc[f_][t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mma16p<4>(a, rb[t], acc[f_][t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mma16p<5>(a, rb[t], acc[f_][t]);
+  if constexpr (NP == 7) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mma16p<6>(a, rb[t], acc[f_][t]);
+  }
+}
+
 // One K-step of the 16 x 16 x 32 form: NF NT NP MFMAs, ONE body for every step (no buffer parity: with two alternating register buffers the compiler
 // rotated them through the accumulator file, ~3 v_accvgpr moves per MFMA).  The A fragments (weights, L2 -> registers) are single-buffered and walked
 // fragment-major: fragment f's NT NP MFMAs, then its register is refilled with the NEXT step's fragment f -- NF - 1 fragment groups (>= 1 300 pipe cycles at
@@ -102,18 +131,24 @@ template <typename T, int NF, int NT>
 __device__ __forceinline__ void step16(typename Acc16<T>::type (&acc)[NF][NT], typename Elem<T>::vec8 (&ra)[NF], typename Elem<T>::vec8 (&rb)[NT], const T* pa,
                                        const char* pb, int pitch) {
   static_assert(NT % 2 == 0, "column fragments come in pairs");
+  constexpr bool ROWS16 = JATTS_U16_ROWS != 0;
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-#pragma unroll
-    for (int tp = 0; tp < NT; tp += 2) {
-      pair16<T, NF, NT>(acc, ra[f], rb, f, tp);
-      if (f == NF - 1) {      // the step's last use of these two B fragments: the next step's
-        rb[tp] = Vec8IO<T>::lds(pb + (size_t)(tp * 16) * pitch);
-        rb[tp + 1] = Vec8IO<T>::lds(pb + (size_t)((tp + 1) * 16) * pitch);
-      }
+    if (f < NF - 1 && ROWS16) {       // every column fragment in turn: an accumulator every NT-th MFMA
+      row16<T, NF, NT>(acc, ra[f], rb, f);
       __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int tp = 0; tp < NT; tp += 2) {
+        pair16<T, NF, NT>(acc, ra[f], rb, f, tp);
+        if (f == NF - 1 && !(JATTS_U16_DIAG & 1)) {      // the step's last use of these two B fragments: the next step's
+          rb[tp] = Vec8IO<T>::lds(pb + (size_t)(tp * 16) * pitch);
+          rb[tp + 1] = Vec8IO<T>::lds(pb + (size_t)((tp + 1) * 16) * pitch);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    ra[f] = Vec8IO<T>::ldg(pa + f * 512);
+    if (!(JATTS_U16_DIAG & 2)) ra[f] = Vec8IO<T>::ldg(pa + f * 512);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
