@@ -134,7 +134,7 @@ def test_self_launch_starts_the_ranks_as_children(tmp_path):
     from jatts_amd.distributed import self_launch
     script = tmp_path / "rank.py"
     script.write_text("import os, sys\n"
-                      "print('rank', os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], sys.argv[1], flush=True)\n"
+                      "os.write(1, ('rank %s %s %s %s\\n' % (os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], sys.argv[1])).encode())\n"     # ONE write per line: the ranks share the pipe
                       "sys.exit(3 if sys.argv[1] == 'fail' and os.environ['RANK'] == '1' else 0)\n")
     seen = []
     rc = self_launch(2, str(script), ["ok"], relay=lambda ln: seen.append(ln.strip()) or True)

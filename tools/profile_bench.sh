@@ -6,5 +6,5 @@ TAG=${1:-r03_bench_prof}; shift
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-configs --no-train --no-fast-mode --no-ragged --no-detail --steps 7 --warmup 2 "$@" > $OUT.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-configs --no-train --no-fast-mode --no-ragged --no-24k --no-b1 --no-detail --steps 7 --warmup 2 "$@" > $OUT.log 2>&1
 find $OUT -name "*kernel_stats.csv" | head -3
