@@ -10,17 +10,19 @@
 #pragma once
 #include "conv1d_impl.h"
 #ifndef JATTS_CEMUL_DIAG
-#define JATTS_CEMUL_DIAG 0   // timing probes only (wrong results): 1 = no split arithmetic in the commit, 2 = no activation loads in the chunk loop, 4 = no barriers in it
+#define JATTS_CEMUL_DIAG 0   // timing probes only (wrong results): 1 = no split arithmetic in the commit, 2 = no activation loads in the chunk loop, 4 = no barriers in it;
+                             // 16 x 16 x 32 kernel only: 8 = no weight refills, 16 = no B (LDS) refills, 32 = no epilogue, 64 = no commit at all
 #endif
 
 namespace {
 
-// commit of the emulated pipeline: combine the staged f32 inputs (sum, in_scale, LeakyReLU), three bf16 planes, LDS
-template <typename T, int MAXU, int NIN, int UPR, int NTHR>
-__device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in, float in_scale,
-                                            int pre_act, float slope) {
+// commit of the emulated pipeline: combine the staged f32 inputs (sum, in_scale, LeakyReLU), three bf16 planes, LDS.  PLAIN (one input, no scale, no
+// activation -- every conv but the HiFi-GAN upsampling ones) skips the combine: 7.5 instead of 12.5 VALU instructions per element (round 6: the commit is
+// 12 - 26 % of a workgroup's life, profiles/r06_conv16_trace.txt).
+template <typename T, int MAXU, int NIN, int UPR, int NTHR, bool PLAIN>
+__device__ __forceinline__ void emul_commit_as(StageRegs<float, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in, float in_scale,
+                                               int pre_act, float slope) {
   const int total = rows * UPR;
-  const bool plain = n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE;
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
     const int u = threadIdx.x + j * NTHR;
@@ -30,7 +32,7 @@ __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, cha
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = sr.v[0][j][e];
-      if (!plain) {
+      if (!PLAIN) {
         if (NIN > 1 && n_in > 1) t += sr.v[NIN > 1 ? 1 : 0][j][e];
         if (NIN > 2 && n_in > 2) t += sr.v[NIN > 2 ? 2 : 0][j][e];
         t *= in_scale;
@@ -46,6 +48,12 @@ __device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, cha
     }
     Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
   }
+}
+template <typename T, int MAXU, int NIN, int UPR, int NTHR>
+__device__ __forceinline__ void emul_commit(StageRegs<float, MAXU, NIN>& sr, char* lds, int pitch, int rows, int n_in, float in_scale,
+                                            int pre_act, float slope) {
+  if (n_in == 1 && in_scale == 1.f && pre_act == JATTS_PRE_NONE) emul_commit_as<T, MAXU, NIN, UPR, NTHR, true>(sr, lds, pitch, rows, n_in, in_scale, pre_act, slope);
+  else emul_commit_as<T, MAXU, NIN, UPR, NTHR, false>(sr, lds, pitch, rows, n_in, in_scale, pre_act, slope);
 }
 
 // HALO: rows beyond the time tile the staging registers must cover; RD: weight ring depth in K-steps (divides KCHT / 16).

@@ -54,7 +54,12 @@ static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
   if (d.n_out <= 64) return launch_conv_emul16<T, 2, 2, 2, 2, 1, 64, 2>(d, s);        // 64 n x 64 t, four waves, two workgroups per CU: the HBM-bound last upsampling conv
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
   const int64_t wgs128 = ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128);
-  // 128 n x 64 t, four waves side by side in n (32 n x 64 t each), two workgroups per CU: k = 1, and launches that cannot give every CU a 128 x 128 workgroup
+  // 128 n x 64 t, four waves side by side in n (32 n x 64 t each), two workgroups per CU: k = 1, and launches that cannot give every CU a 128 x 128 workgroup.
+  // (k = 1, round 6 -- profiles/r06_conv16_diag.txt, r06_conv16_trace.txt: with every non-MFMA piece compiled out the tile runs at 230 - 240 TFLOP/s, 0.9 of
+  //  the LDS-fed ceiling; the pieces ADD instead of overlapping -- activation loads + split 23 %, weight / B refills 17 %, epilogue 10 % -- and the shader
+  //  clock sits at 1.36 - 1.5 GHz against 1.85 in the MFMA-only probe: 8 - 9 TB/s of L2 -> CU operand traffic (weights 128 n x c_in x 6 B per 64 columns,
+  //  x re-read per n tile) is what the power budget goes to.  The eight-wave 128 x 128 tile halves the weight traffic (1.56 - 1.76 GHz) but converts with the
+  //  pipe idle; the anti-phase staging below gives it +3 - 5 % at k = 1, still behind this tile.)
   if (variant == 1 || (variant == 0 && (d.k_w == 1 || wgs128 <= 128))) return launch_conv_emul16<T, 2, 4, 4, 1, 1, 64, 2>(d, s);
   return launch_conv_emul16<T, 2, 4, 4, 2, 1, 64, 1>(d, s);                           // 128 n x 128 t, eight waves, one workgroup per CU
 }

@@ -13,6 +13,18 @@
 #include "conv1d_emul.h"
 #include "resunit_emul16_impl.h"
 
+#ifndef JATTS_CEMUL_ANTIPHASE
+#define JATTS_CEMUL_ANTIPHASE 1   // A/B switch of the anti-phase staging of the eight-wave tiles (conv1d_emul16_kernel)
+#endif
+#ifndef JATTS_CEMUL_TRACE
+#define JATTS_CEMUL_TRACE 0   // DIAG builds only: phase clocks of the chunk loop into jatts_debug_trace's buffer (tools/trace_conv16.py)
+#endif
+#if JATTS_CEMUL_TRACE
+#define JATTS_CEMUL_TRACE_PARAMS , unsigned long long* trace, unsigned trace_cap
+#else
+#define JATTS_CEMUL_TRACE_PARAMS
+#endif
+
 namespace {
 
 // Weight-fragment ring of the 16 x 16 x 32 form: D slots of NF fragments, consumed in the order  for chunk: for tap: for kk (32-channel steps) ; the producer
@@ -88,13 +100,13 @@ __device__ __forceinline__ void conv_stage16(typename Acc16<T>::type (&acc)[NF][
 #pragma unroll
         for (int tp = 0; tp < NT; tp += 2) {
           pair16<T, NF, NT>(acc, ring.r[j][f], rb, f, tp);
-          if (f == NF - 1) {
+          if (f == NF - 1 && !(JATTS_CEMUL_DIAG & 16)) {
             rb[tp] = Vec8IO<T>::lds(pb + (size_t)(tp * 16) * pitch);
             rb[tp + 1] = Vec8IO<T>::lds(pb + (size_t)((tp + 1) * 16) * pitch);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        ring.fetch_frag(j, f);       // this slot's fragment f of the step D ahead
+        if (!(JATTS_CEMUL_DIAG & 8)) ring.fetch_frag(j, f);       // this slot's fragment f of the step D ahead
         __builtin_amdgcn_sched_barrier(0);
       }
       ring.advance();
@@ -201,11 +213,19 @@ __device__ __forceinline__ void conv_epilogue_lds16(const jatts_conv_desc& d, f3
 
 // WN x WT waves, a wave's tile NF x NT fragments of 16 x 16; HALO: rows beyond the time tile the staging registers must cover; D: ring depth in 32-channel steps
 template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int D = 2>      // T = bf3 (seven products) / bf3f (six)
-__global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul16_kernel(jatts_conv_desc d, int f32_tile, XcdOrder xo) {
+__global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul16_kernel(jatts_conv_desc d, int f32_tile, XcdOrder xo JATTS_CEMUL_TRACE_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = WT * NT * 16, NTHR = WN * WT * 64, BN = WN * NF * 16;
   int bx, b, bz;
   if (!xo.decode(blockIdx.x, bx, b, bz, d.rg, BT)) return;
+#if JATTS_CEMUL_TRACE     // DIAG builds only (tools/trace_conv16.py): per workgroup, the clocks wave 0 spends in each phase of the chunk loop
+  const bool tracing = trace != nullptr && blockIdx.x < trace_cap && threadIdx.x == 0;
+  unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = tq, rt_begin = __builtin_amdgcn_s_memrealtime();
+#define JATTS_PH(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph[i] += n_ - tq; tq = n_; } while (0)
+#else
+#define JATTS_PH(i) do {} while (0)
+#endif
   const int row_b = d.rg.cu_rows[b];
   const int L = (d.rg.cu_rows[b + 1] - row_b) * d.rg.len_mul;
   const int t0 = bx * BT;
@@ -254,16 +274,63 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul16_kernel(jatts_c
   ring.init((const T*)d.w, KC32, NFR16, nf0, d.k_w, KCHT / 32, n_chunks, lane);
   const size_t buf_bytes = (size_t)rows * pitch;
   StageRegs<float, MAXU, NIN> sr;
-  stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, 0, reflect);
-  emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
+  // the staging plan: a unit's row does not change from chunk to chunk -- offsets and masks once (round 6: "issue loads" was 3.5 - 8 % of a workgroup's life)
+  int64_t soff[MAXU];
+  bool sok[MAXU];
+  {
+    const int total = rows * UPRC;
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+      const int u = threadIdx.x + j * NTHR;
+      const int r = u / UPRC, cu = u % UPRC;
+      int pos = t0 - d.pad + r;
+      if (reflect) pos = reflect_pos(pos, L);
+      sok[j] = u < total && pos >= 0 && pos < L;
+      soff[j] = (seq_row0 + (sok[j] ? pos : 0)) * (int64_t)d.ldx + cu * 8;
+#pragma unroll
+      for (int i = 0; i < NIN; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sr.v[i][j][e] = 0.f;     // a unit outside the sequence stays zero
+    }
+  }
+  auto issue = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j)
+#pragma unroll
+      for (int i = 0; i < NIN; ++i)
+        if (i < d.n_in && sok[j]) sr.v[i][j] = Vec8IO<float>::ldg(xin[i] + soff[j] + c0);
+  };
+  auto commit = [&](int ci) {
+    emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)(ci & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
+  };
+  // Eight-wave tiles (two waves per SIMD, ONE workgroup per CU): the second wave of every SIMD runs its staging in ANTI-PHASE -- it commits chunk c + 1 (loads
+  // issued a whole chunk earlier) and issues chunk c + 2 BEFORE its K-steps of chunk c, the first wave after them: a wave's split arithmetic runs under its
+  // neighbour's MFMAs instead of all eight waves converting at once with the matrix pipe idle.
+  const bool early = JATTS_CEMUL_ANTIPHASE && WN * WT == 8 && OCC == 1 && wave >= 4;
+  issue(0);
+  commit(0);
+  if (early && n_chunks > 1) issue(KCHT);
   __syncthreads();
+  JATTS_PH(0);      // prologue: bias, ring fill, first chunk staged
   for (int ci = 0; ci < n_chunks; ++ci) {
     const bool more = ci + 1 < n_chunks;
-    if (more) stage_issue<float, MAXU, NIN, UPRC, NTHR>(sr, rows, t0 - d.pad, L, seq_row0, xin, d.n_in, d.ldx, (ci + 1) * KCHT, reflect);
+    if (early) {
+      if (more) commit(ci + 1);
+      if (ci + 2 < n_chunks) issue((ci + 2) * KCHT);
+    } else if (more && !(JATTS_CEMUL_DIAG & 2)) issue((ci + 1) * KCHT);
+    JATTS_PH(1);    // issue of the next chunk's loads (early waves: the commit too)
     conv_stage16<T, NF, NT, D>(accx, ring, KCHT / 32, d.k_w, d.dil, smem + (size_t)(ci & 1) * buf_bytes, pitch, col0, lane);
-    if (more) emul_commit<T, MAXU, NIN, UPRC, NTHR>(sr, smem + (size_t)((ci + 1) & 1) * buf_bytes, pitch, rows, d.n_in, d.in_scale, d.pre_act, d.pre_slope);
-    __syncthreads();
+    JATTS_PH(2);    // K-steps
+#if JATTS_CEMUL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    JATTS_PH(3);    // waiting for the loads (and the ring's look-ahead: L2 hits)
+#endif
+    if (!early && more && !(JATTS_CEMUL_DIAG & 64)) commit(ci + 1);
+    JATTS_PH(4);    // split + LDS writes
+    if (!(JATTS_CEMUL_DIAG & 4)) __syncthreads();
+    JATTS_PH(5);    // barrier
   }
+  if (JATTS_CEMUL_DIAG & 4) __syncthreads();
 
   // close the accumulators (seven products: one correctly rounded add per element): from here on f32 epilogues
   f32x4 acc[NF][NT];
@@ -275,6 +342,29 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul16_kernel(jatts_c
       acc[f][t] = acc16_val(accx[f][t]);
     }
   if (d.act == JATTS_ACT_SNAKEBETA) snake_acc16<NF, NT>(acc, d.act_a, d.act_b, nf0, d.n_out, lane);
+#if JATTS_CEMUL_TRACE
+  auto trace_out = [&]() {
+    JATTS_PH(6);    // epilogue
+    if (!tracing) return;
+    unsigned long long* o = trace + (size_t)blockIdx.x * 16;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[0] = ((unsigned long long)(xcc & 0xF) << 32) | hwid;
+    for (int i = 0; i < 7; ++i) o[1 + i] = ph[i];
+    o[8] = rt_begin; o[9] = __builtin_amdgcn_s_memrealtime(); o[10] = t_begin; o[11] = tq;
+  };
+#else
+  auto trace_out = []() {};
+#endif
+  if (JATTS_CEMUL_DIAG & 32) {     // DIAG: no epilogue (the sum keeps every accumulator live)
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) s += acc[f][t][0] + acc[f][t][1] + acc[f][t][2] + acc[f][t][3];
+    if (s != 12345.678f) return;
+  }
   {
     const int n_base = bz * BN;
     const bool rowmajor = !d.y_transposed && (d.n_out & 7) == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0;
@@ -286,6 +376,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul16_kernel(jatts_c
         case JATTS_ACT_MISH: conv_epilogue_lds16<JATTS_ACT_MISH, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
         default: conv_epilogue_lds16<JATTS_ACT_NONE, NF, NT, BN>(d, acc, smem, t0, col0, wn * NF, n_base, lane, L, seq_row0, BT); break;
       }
+      trace_out();
       return;
     }
   }
@@ -296,6 +387,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void conv1d_emul16_kernel(jatts_c
     case JATTS_ACT_MISH: conv_epilogue16<JATTS_ACT_MISH, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
     default: conv_epilogue16<JATTS_ACT_NONE, NF, NT>(d, acc, t0, col0, nf0, lane, L, seq_row0, b); break;
   }
+  trace_out();
 }
 
 template <typename T, int NF, int NT, int WN, int WT, int NIN, int KCHT, int OCC, int HALO = 32, int D = 2>
@@ -321,7 +413,11 @@ int launch_conv_emul16(const jatts_conv_desc& d, hipStream_t s) {
   XcdOrder xo;
   const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * 6, ragged_tiles_1d(d.rg, BT));
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");
+#if JATTS_CEMUL_TRACE
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WN * WT * 64), lds, s, d, f32_tile, xo, jatts_g_trace, jatts_g_trace_cap);
+#else
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WN * WT * 64), lds, s, d, f32_tile, xo);
+#endif
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
 }

@@ -29,11 +29,12 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="jatts_conv_desc.variant (0 = the product heuristic)")
     ap.add_argument("--pre-lrelu", type=float, default=None, help="LeakyReLU prologue slope (the HiFi-GAN upsampling convs)")
     ap.add_argument("--layout", type=int, default=1, choices=[0, 1], help="emulated convs: 1 = v_mfma_f32_16x16x32_bf16 kernels (product), 0 = 32x32x16")
+    ap.add_argument("--shapes", default="", help="comma-separated indices into SHAPES")
     a = ap.parse_args()
     dt = {"f16": hip.F16, "f32": hip.F32, "split": hip.F32S, "emul": hip.F32E, "emul6": hip.F32E6}[a.dtype]
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    for c, n, k, T, res in (SHAPES if a.only < 0 else [SHAPES[a.only]]):
+    for c, n, k, T, res in ([SHAPES[int(i)] for i in a.shapes.split(',')] if a.shapes else SHAPES if a.only < 0 else [SHAPES[a.only]]):
         rb = hip.RaggedBatch([T] * a.batch, dev)
         rows = rb.total
         x = (torch.randn(rows, c, generator=g) * 0.5).to(dev).to(hip.torch_dtype(dt))
