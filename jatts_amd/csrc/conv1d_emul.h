@@ -29,6 +29,7 @@ __device__ __forceinline__ void emul_commit_as(StageRegs<float, MAXU, NIN>& sr, 
     if (u >= total) continue;
     const int r = u / UPR, cu = u % UPR;
     typename Elem<T>::vec8 o;
+    f32x8 tv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = sr.v[0][j][e];
@@ -38,14 +39,14 @@ __device__ __forceinline__ void emul_commit_as(StageRegs<float, MAXU, NIN>& sr, 
         t *= in_scale;
         if (pre_act == JATTS_PRE_LRELU) t = fmaxf(t, t * slope);     // 0 <= slope <= 1
       }
-      bf16 a, b, c;
-#if JATTS_CEMUL_DIAG & 1
-      a = b = c = __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(t) >> 16));
-#else
-      bf3_split(t, a, b, c);
-#endif
-      o.b0[e] = a; o.b1[e] = b; o.b2[e] = c;
+      tv[e] = t;
     }
+#if JATTS_CEMUL_DIAG & 1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.b0[e] = o.b1[e] = o.b2[e] = __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(tv[e]) >> 16));
+#else
+    bf3_split8(tv, o);
+#endif
     Vec8IO<T>::sts(lds + (size_t)r * pitch + (size_t)cu * 48, o);
   }
 }

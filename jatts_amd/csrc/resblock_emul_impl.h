@@ -97,12 +97,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resblock_em
       if (u >= total) continue;
       lrelu8(xv[j], d.slope);
       V8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bf16 a, bq, c;
-        bf3_split(xv[j][e], a, bq, c);
-        o.b0[e] = a; o.b1[e] = bq; o.b2[e] = c;
-      }
+      bf3_split8(xv[j], o);
       Vec8IO<T>::sts(smem + (size_t)(u / UPR) * pitch + (size_t)(u % UPR) * 48, o);
     }
   }

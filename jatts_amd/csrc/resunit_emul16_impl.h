@@ -258,12 +258,7 @@ __global__ __launch_bounds__(WN* WT * 64, OCC) void resunit_emul16_kernel(jatts_
   auto to_planes = [&](f32x8 v) {
     lrelu8(v, d.slope);
     V8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bf16 a, bq, c;
-      bf3_split(v[e], a, bq, c);
-      o.b0[e] = a; o.b1[e] = bq; o.b2[e] = c;
-    }
+    bf3_split8(v, o);
     return o;
   };
   const float* x = (const float*)d.x;

@@ -16,10 +16,10 @@ namespace {
 // 4 values -> the three bf16 planes of a channel quad
 __device__ __forceinline__ void bf3_split4(const float (&v)[4], bf16x4& p0, bf16x4& p1, bf16x4& p2) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    bf16 a, b, c;
-    bf3_split(v[e], a, b, c);
-    p0[e] = a; p1[e] = b; p2[e] = c;
+  for (int e = 0; e < 4; e += 2) {
+    bf16x2 a, b, c;
+    bf3_split2(v[e], v[e + 1], a, b, c);
+    p0[e] = a[0]; p0[e + 1] = a[1]; p1[e] = b[0]; p1[e + 1] = b[1]; p2[e] = c[0]; p2[e + 1] = c[1];
   }
 }
 
@@ -133,12 +133,7 @@ __global__ __launch_bounds__(WN*(WGCOLS / (NT * 32)) * 64, OCC) void resunit_emu
   auto to_planes = [&](f32x8 v) {
     lrelu8(v, d.slope);
     V8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bf16 a, bq, c;
-      bf3_split(v[e], a, bq, c);
-      o.b0[e] = a; o.b1[e] = bq; o.b2[e] = c;
-    }
+    bf3_split8(v, o);
     return o;
   };
   const float* x = (const float*)d.x;
