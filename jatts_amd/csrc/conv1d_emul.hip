@@ -60,7 +60,15 @@ static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
   //  clock sits at 1.36 - 1.5 GHz against 1.85 in the MFMA-only probe: 8 - 9 TB/s of L2 -> CU operand traffic (weights 128 n x c_in x 6 B per 64 columns,
   //  x re-read per n tile) is what the power budget goes to.  The eight-wave 128 x 128 tile halves the weight traffic (1.56 - 1.76 GHz) but converts with the
   //  pipe idle; the anti-phase staging below gives it +3 - 5 % at k = 1, still behind this tile.)
+  // 256 n x 64 t, eight waves side by side in n, one workgroup per CU (round 6, late): a staged x chunk serves twice the output channels -- half the activation
+  // loads, split arithmetic and LDS writes per MFMA, the piece the k = 1 DIAG table prices highest -- for n_out in whole 256s and launches of at least one
+  // round of such workgroups: +2 - 6 % on the 512 / 1024 / 1536 / 2048-wide shapes at k = 1 and k = 3, +15 % on 2048 -> 512 (profiles/r06_conv16_wide_tiles.txt);
+  // a 384-wide output would leave a quarter of the second tile idle (-16 .. -21 %).
+  const int64_t wgs256 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 256);
+  if (variant == 3 || (variant == 0 && d.n_out % 256 == 0 && wgs256 >= 256)) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1>(d, s);
   if (variant == 1 || (variant == 0 && (d.k_w == 1 || wgs128 <= 128))) return launch_conv_emul16<T, 2, 4, 4, 1, 1, 64, 2>(d, s);
+  if (variant == 4) return launch_conv_emul16<T, 4, 4, 4, 1, 1, 64, 1>(d, s);         // (A/B) 256 n x 64 t, four waves of 4 x 4 fragments
+  if (variant == 5) return launch_conv_emul16<T, 4, 4, 2, 2, 1, 64, 1>(d, s);         // (A/B) 128 n x 128 t, four waves of 4 x 4 fragments
   return launch_conv_emul16<T, 2, 4, 4, 2, 1, 64, 1>(d, s);                           // 128 n x 128 t, eight waves, one workgroup per CU
 }
 
