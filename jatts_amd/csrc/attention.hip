@@ -622,10 +622,10 @@ int launch_attn_kb(const jatts_relattn_desc& d, hipStream_t s) {
   if (total >= ((int64_t)1 << 31) - 8) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "relpos_attention: more than 2^31 query blocks (split the batch)");
   dim3 grid((unsigned)(8 * ((total + 7) / 8)));    // 1-D, decoded in XCD-aware order by the kernel
   auto kern = relattn_kernel<T, DK, KBT, REL, NW>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
-  }
+  // the dynamic-LDS limit ONCE per kernel (function-local static of this template instantiation), not per launch: the per-launch call was seen to stall the
+  // host for ~20 ms now and then (profiles/r06_notes.md section 8)
+  static const hipError_t lds_attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (lds_attr != hipSuccess) return jatts_set_error(lds_attr, __FILE__, __LINE__);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, d);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;

@@ -65,6 +65,12 @@ static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
   // round of such workgroups: +2 - 6 % on the 512 / 1024 / 1536 / 2048-wide shapes at k = 1 and k = 3, +15 % on 2048 -> 512 (profiles/r06_conv16_wide_tiles.txt);
   // a 384-wide output would leave a quarter of the second tile idle (-16 .. -21 %).
   const int64_t wgs256 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 256);
+  // ... and 384 n x 64 t (eight waves of 3 x 4 fragments, a ONE-step weight ring to stay inside 256 registers) where n_out is whole 384s -- the FastSpeech2
+  // widths: a 1536 -> 384 conv stages its input once instead of three times.  384 -> 384 k1 119 -> 142, 1536 -> 384 k3 174 -> 200, 384 -> 1536 k3 184 -> 194 TFLOP/s
+  // (profiles/r06_conv16_384_tile.txt); launches of fewer than 256 such workgroups lose 13 - 15 % and keep the smaller tiles.
+  const int64_t wgs384 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 384);
+  if (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && wgs384 >= 256)) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
+  if (variant == 7) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);  // (A/B) the 256-wide tile with the one-step ring
   if (variant == 3 || (variant == 0 && d.n_out % 256 == 0 && wgs256 >= 256)) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1>(d, s);
   if (variant == 1 || (variant == 0 && (d.k_w == 1 || wgs128 <= 128))) return launch_conv_emul16<T, 2, 4, 4, 1, 1, 64, 2>(d, s);
   if (variant == 4) return launch_conv_emul16<T, 4, 4, 4, 1, 1, 64, 1>(d, s);         // (A/B) 256 n x 64 t, four waves of 4 x 4 fragments

@@ -200,10 +200,10 @@ int launch_conv_split(const jatts_conv_desc& d, hipStream_t s) {
   lds += 64;                                                              // one amax slot per wave
   if (lds > 160 * 1024) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d (split): tile exceeds 160 KiB LDS");
   auto kern = conv1d_split_kernel<NF, NT, WN, WT, NIN, KCHT, OCC, HALO, RD>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
-  }
+  // the dynamic-LDS limit ONCE per kernel (function-local static of this template instantiation), not per launch: the per-launch call was seen to stall the
+  // host for ~20 ms now and then (profiles/r06_notes.md section 8)
+  static const hipError_t lds_attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (lds_attr != hipSuccess) return jatts_set_error(lds_attr, __FILE__, __LINE__);
   XcdOrder xo;
   const int64_t total = xo.plan((int)grid.x, (int)grid.y, (int)grid.z, (int64_t)BN * d.c_in * d.k_w * 4, ragged_tiles_1d(d.rg, BT));
   if (total >= (int64_t)1 << 31) return jatts_set_error_msg(JATTS_ERR_UNSUPPORTED, "conv1d: launch too large");

@@ -254,10 +254,10 @@ int launch_resblock_split(const jatts_resblock_desc& d, hipStream_t s) {
   dim3 grid((unsigned)((maxL + tt_out - 1) / tt_out), (unsigned)d.rg.n_seq);
   if (const int64_t n1 = ragged_tiles_1d(d.rg, tt_out)) grid = dim3((unsigned)n1);
   auto kern = resblock_split_kernel<C, WGCOLS, WN, NT, KCG, OCC>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return jatts_set_error(e, __FILE__, __LINE__);
-  }
+  // the dynamic-LDS limit ONCE per kernel (function-local static of this template instantiation), not per launch: the per-launch call was seen to stall the
+  // host for ~20 ms now and then (profiles/r06_notes.md section 8)
+  static const hipError_t lds_attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (lds_attr != hipSuccess) return jatts_set_error(lds_attr, __FILE__, __LINE__);
   hipLaunchKernelGGL(kern, grid, dim3(WN * WT * 64), lds, s, d, bias_off);
   JATTS_CHECK_LAUNCH();
   return JATTS_OK;
