@@ -71,7 +71,13 @@ static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
   const int64_t wgs384 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 384);
   if (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && wgs384 >= 256)) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
   if (variant == 7) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);  // (A/B) the 256-wide tile with the one-step ring
+  if (variant == 8) return launch_conv_emul16<T, 2, 2, 2, 1, 1, 64, 3>(d, s);         // (A/B) 64 n x 32 t, two waves, three workgroups per CU: one-utterance launches
   if (variant == 3 || (variant == 0 && d.n_out % 256 == 0 && wgs256 >= 256)) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1>(d, s);
+  // one-utterance launches (the B = 1 drop-in path: 768 rows): even the 128 n x 64 t tile leaves most CUs idle -- 36 workgroups for a 1536 -> 384 conv, each walking
+  // 144 K-steps.  128 n x 32 t (four waves of 2 x 2 fragments, two workgroups per CU) when the 64-row tiling gives at most one workgroup per CU:
+  // 1536 -> 384 k3 110 -> 67 us, 384 -> 1536 k3 35 -> 29 us, 384 -> 384 k1 16 -> 12 us (profiles/r06_conv16_b1_tiles.txt)
+  const int64_t wgs64 = ((maxL + 63) / 64) * d.rg.n_seq * ((d.n_out + 127) / 128);
+  if (variant == 9 || (variant == 0 && wgs64 <= 256)) return launch_conv_emul16<T, 2, 2, 4, 1, 1, 64, 2>(d, s);
   if (variant == 1 || (variant == 0 && (d.k_w == 1 || wgs128 <= 128))) return launch_conv_emul16<T, 2, 4, 4, 1, 1, 64, 2>(d, s);
   if (variant == 4) return launch_conv_emul16<T, 4, 4, 4, 1, 1, 64, 1>(d, s);         // (A/B) 256 n x 64 t, four waves of 4 x 4 fragments
   if (variant == 5) return launch_conv_emul16<T, 4, 4, 2, 2, 1, 64, 1>(d, s);         // (A/B) 128 n x 128 t, four waves of 4 x 4 fragments
