@@ -71,6 +71,8 @@ static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
   const int64_t wgs384 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 384);
   if (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && wgs384 >= 256)) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
   if (variant == 7) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);  // (A/B) the 256-wide tile with the one-step ring
+  // (measured and dropped: 192 n x 64 t, four waves of 3 x 4 fragments, two workgroups per CU -- +6 % on 1536 -> 384 k3 at 8 192 rows, +13 % on 192 -> 768, -2 .. -35 %
+  //  elsewhere: profiles/r06_conv16_192_tile.txt)
   if (variant == 8) return launch_conv_emul16<T, 2, 2, 2, 1, 1, 64, 3>(d, s);         // (A/B) 64 n x 32 t, two waves, three workgroups per CU: one-utterance launches
   if (variant == 3 || (variant == 0 && d.n_out % 256 == 0 && wgs256 >= 256)) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1>(d, s);
   // one-utterance launches (the B = 1 drop-in path: 768 rows): even the 128 n x 64 t tile leaves most CUs idle -- 36 workgroups for a 1536 -> 384 conv, each walking
