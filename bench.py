@@ -481,6 +481,13 @@ def measure_ceilings(dev, precisions):
     out = {}
     for name in sorted({PROBE_OF[p][0] for p in precisions}):
         out[name] = {"lds": hip.mfma_ceiling(code[name], 1, device=dev), "registers": hip.mfma_ceiling(code[name], 0, device=dev), "form": "32x32x16" if name != "f32" else "32x32x2"}
+        if name == "f16":
+            # (round 6, late) the same question for the f16 pipe; the f16 / split kernels still issue 32 x 32 x 16, their ceiling is the better form's all the same
+            alt = {"lds": hip.mfma_ceiling(16 + hip.F16, 1, device=dev), "registers": hip.mfma_ceiling(16 + hip.F16, 0, device=dev)}
+            out[name]["form_32x32x16"] = {k: out[name][k] for k in ("lds", "registers")}
+            out[name]["form_16x16x32"] = alt
+            if alt["lds"]["tflops"] > out[name]["lds"]["tflops"]:
+                out[name].update(lds=alt["lds"], registers=alt["registers"], form="16x16x32")
         if name == "bf16":
             # the bf16 pipe has two instruction forms and the power-limited part sustains MORE of v_mfma_f32_16x16x32_bf16 (half the accumulator traffic per
             # flop; the emulated units run on it since round 6): the ceiling a kernel is priced against is the better form's

@@ -413,7 +413,7 @@ int jatts_debug_trace(void* buf, int64_t n_workgroups);
  * part at the clock its power budget allows.  One launch of `workgroups` x 256 threads, every wave issuing 2 x 2 fragments of 32 x 32 per K-step
  * for `iters` K-steps (rounded up to even) with nothing else in the kernel: dtype JATTS_F32E / JATTS_F32E6 -> v_mfma_f32_32x32x16_bf16, JATTS_F16 /
  * JATTS_F32S -> v_mfma_f32_32x32x16_f16, JATTS_F32 -> eight v_mfma_f32_32x32x2_f32 per K-step, 16 + JATTS_F32E -> 4 x 4 fragments of v_mfma_f32_16x16x32_bf16 (the
- * same operand bytes per flop; a comparison of the two bf16 forms under the power limit); feed = 1: both operands re-read from LDS every K-step
+ * same operand bytes per flop; a comparison of the two bf16 forms under the power limit), 16 + JATTS_F16 -> that geometry on v_mfma_f32_16x16x32_f16; feed = 1: both operands re-read from LDS every K-step
  * (ds_read_b128), feed = 0: operands stay in registers.  operands: >= 64 KiB of DEVICE memory, 16-byte aligned, holding operand bits of the dtype (the
  * matrix pipe's power, hence its clock, follows them: zeros run ~19 % faster than random bits); clocks (device, 2 x uint64, may be NULL): s_memtime and
  * s_memrealtime (100 MHz) ticks of workgroup 0 across its MFMA loop; sink: 1 device float, never written.  The caller times the launch on `stream`

@@ -69,7 +69,8 @@ static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
   // widths: a 1536 -> 384 conv stages its input once instead of three times.  384 -> 384 k1 119 -> 142, 1536 -> 384 k3 174 -> 200, 384 -> 1536 k3 184 -> 194 TFLOP/s
   // (profiles/r06_conv16_384_tile.txt); launches of fewer than 256 such workgroups lose 13 - 15 % and keep the smaller tiles.
   const int64_t wgs384 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 384);
-  if (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && wgs384 >= 256)) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
+  // (a two-output launch -- Q | K | V -- splits between workgroups: n_split must be a whole number of tiles; jatts_conv1d checks whole 256s)
+  if (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && wgs384 >= 256 && d.n_split % 384 == 0)) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
   if (variant == 7) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);  // (A/B) the 256-wide tile with the one-step ring
   // (measured and dropped: 192 n x 64 t, four waves of 3 x 4 fragments, two workgroups per CU -- +6 % on 1536 -> 384 k3 at 8 192 rows, +13 % on 192 -> 768, -2 .. -35 %
   //  elsewhere: profiles/r06_conv16_192_tile.txt)

@@ -96,9 +96,15 @@ __global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe_kernel(const c
   if (blockIdx.x == 0 && threadIdx.x == 0 && clocks) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
 }
 
+template <bool F16>
+__device__ __forceinline__ f32x4 probe16_mma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // The same probe on v_mfma_f32_16x16x32_bf16: 4 x 4 fragments of 16 x 16 per wave (the operand bytes per flop of the 2 x 2 x 32 x 32 form), K = 32 per step.
 // Half the accumulator elements written per flop of the 32 x 32 x 16 form: does the power-limited pipe sustain more with it?  (dtype code 16 + JATTS_F32E)
-template <bool LDSFED>
+template <bool LDSFED, bool F16 = false>      // F16: v_mfma_f32_16x16x32_f16 on the same fragment geometry (dtype code 16 + JATTS_F16)
 __global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe16_kernel(const char* __restrict__ src, int64_t src_bytes, int iters,
                                                                             unsigned long long* clocks, float* sink) {
   constexpr int PITCH = PROBE_PITCH;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe16_kernel(const
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[f], b0[t], acc[f][t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[f][t] = probe16_mma<F16>(a0[f], b0[t], acc[f][t]);
     if constexpr (LDSFED) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe16_kernel(const
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[f], b1[t], acc[f][t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[f][t] = probe16_mma<F16>(a1[f], b1[t], acc[f][t]);
     if constexpr (LDSFED) __builtin_amdgcn_sched_barrier(0);
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -180,6 +186,12 @@ extern "C" int jatts_mfma_probe(int32_t dtype, int32_t feed, const void* operand
   if (dtype == 16 + JATTS_F32E) {
     if (feed) hipLaunchKernelGGL((mfma_probe16_kernel<true>), dim3(workgroups), dim3(PROBE_WAVES * 64), 0, s, (const char*)operands, operand_bytes, iters, c, sink);
     else hipLaunchKernelGGL((mfma_probe16_kernel<false>), dim3(workgroups), dim3(PROBE_WAVES * 64), 0, s, (const char*)operands, operand_bytes, iters, c, sink);
+    JATTS_CHECK_LAUNCH();
+    return JATTS_OK;
+  }
+  if (dtype == 16 + JATTS_F16) {
+    if (feed) hipLaunchKernelGGL((mfma_probe16_kernel<true, true>), dim3(workgroups), dim3(PROBE_WAVES * 64), 0, s, (const char*)operands, operand_bytes, iters, c, sink);
+    else hipLaunchKernelGGL((mfma_probe16_kernel<false, true>), dim3(workgroups), dim3(PROBE_WAVES * 64), 0, s, (const char*)operands, operand_bytes, iters, c, sink);
     JATTS_CHECK_LAUNCH();
     return JATTS_OK;
   }

@@ -1638,7 +1638,7 @@ def mfma_ceiling(dtype=F32E, feed=1, target_ms=60.0, device=None, seed=0):
     v = torch.randn(1 << 16, generator=g)
     if dtype in EMUL or dtype == 16 + F32E:
         ops = torch.cat([t.reshape(-1) for t in bf16x3_terms(v)])
-    elif dtype in (F16, F32S):
+    elif dtype in (F16, F32S, 16 + F16):
         ops = v.half()
     else:
         ops = v

@@ -1033,6 +1033,42 @@ def test_conv1d_two_outputs_equal_two_launches(cuda, lib, mode, geom, variant):
         o += T
 
 
+@pytest.mark.parametrize("mode", ["F32E", "F32E6"])
+@pytest.mark.parametrize("geom", [(384, 768, 384, [768] * 8), (512, 1024, 512, [768] * 8), (512, 1024, 512, [768]), (256, 512, 256, [700, 768, 64, 768, 768, 31, 768, 768])],
+                         ids=["fs2-384-batch", "matcha-512-batch", "matcha-512-one", "256-ragged"])
+def test_conv1d_two_outputs_product_tiles(cuda, lib, mode, geom):
+    """The Q | K | V launch on the PRODUCT form of the emulated conv (w_layout = 1, 16 x 16 x 32 kernels) at launch sizes that take its wide tiles (round 6:
+    384 n x 64 t / 256 n x 64 t when the launch fills the chip, 128 n x 32 t for one utterance): a workgroup writes ONE of the two outputs, so n_split has to be
+    a whole number of its tiles -- 1024 is not a multiple of 384 (config 3's 512 -> 1536: the 384-wide tile must not take it; it did for an hour, and only
+    `test_matcha_bench_utterance_matches_the_reference` in a batch of 8 noticed).  Bit-identical to the two launches it replaces."""
+    from jatts_amd import hip
+    c_in, n_split, n_v, lens = geom
+    dt = getattr(hip, mode)
+    g = torch.Generator().manual_seed(c_in + n_v + len(lens))
+    R = sum(lens)
+    x = (torch.randn(R, c_in, generator=g) * 0.7).to(cuda)
+    w = (torch.randn(n_split + n_v, c_in, 1, generator=g) / c_in ** 0.5).to(cuda)
+    b = torch.randn(n_split + n_v, generator=g).to(cuda)
+    pack = lambda wt: hip.pack_conv_weight_bf16x3_k32(wt, 64)  # noqa: E731
+    rb = _ragged(lens, cuda)
+    vcol, ldvt = rb.vt_layout()
+    qk1 = hip.conv1d(rb, x, pack(w[:n_split]), c_in, n_split, 1, dtype=dt, bias=b[:n_split].contiguous(), out_f32=True, w_layout=1)
+    vt1 = torch.full((n_v, ldvt), 7.0, dtype=qk1.dtype, device=cuda)
+    hip.conv1d(rb, x, pack(w[n_split:]), c_in, n_v, 1, dtype=dt, bias=b[n_split:].contiguous(), transposed=True, out=vt1, out_ld=ldvt, y_seq_col0=vcol,
+               out_f32=True, w_layout=1)
+    qk2, vt2 = hip.conv1d(rb, x, pack(w), c_in, n_split + n_v, 1, dtype=dt, bias=b, out_f32=True, split=(n_split, ldvt, vcol), w_layout=1)
+    assert qk2.shape == qk1.shape and torch.equal(qk1, qk2), f"{mode}: Q | K of the one-launch form differs"
+    o = 0
+    for i, T in enumerate(lens):
+        c0 = int(vcol[i])
+        assert torch.equal(vt1[:, c0:c0 + T], vt2[:, c0:c0 + T]), f"{mode}: V^T of sequence {i} differs"
+        ref = (x[o:o + T].double() @ w[n_split:, :, 0].double().t() + b[n_split:].double()).t()
+        assert relerr(vt2[:, c0:c0 + T].float(), ref) <= 1e-5
+        o += T
+    ref_qk = x.double() @ w[:n_split, :, 0].double().t() + b[:n_split].double()
+    assert relerr(qk2.float(), ref_qk) <= 1e-5
+
+
 def test_conv1d_two_outputs_argument_checks(cuda, lib):
     from jatts_amd import hip
     rb = _ragged([10], cuda)
