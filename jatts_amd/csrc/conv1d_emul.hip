@@ -46,44 +46,42 @@ static int conv1d_emul(const jatts_conv_desc& d, hipStream_t s) {
 }
 
 // The 16 x 16 x 32 form (w_layout = 1; conv1d_emul16.h).  Every tile walks the contraction in 64-channel chunks, so -- in BOTH arithmetics -- a row's bits do
-// not depend on the tile and the choice may follow the launch.
+// not depend on the tile and the choice may follow the launch (tests/test_emul_gpu.py: test_conv1d_emul16_tiles_agree forces each tile through
+// jatts_conv_desc.variant and compares bits).  Tiles, by variant number (JATTS_CONV_EMUL16_VARIANT or jatts_conv_desc.variant force one; 0 = the rules below):
+//   6: 384 n x 64 t, eight waves of 3 x 4 fragments, ONE-step weight ring (226 registers), one workgroup per CU
+//   3: 256 n x 64 t, eight waves of 2 x 4 fragments, one workgroup per CU
+//   2: 128 n x 128 t, eight waves of 2 x 4 fragments (anti-phase staging), one workgroup per CU
+//   1: 128 n x 64 t, four waves of 2 x 4 fragments, two workgroups per CU
+//   9: 128 n x 32 t, four waves of 2 x 2 fragments, two workgroups per CU
 template <typename T>
 static int conv1d_emul16(const jatts_conv_desc& d, hipStream_t s) {
-  static const int variant = [] { const char* e = getenv("JATTS_CONV_EMUL16_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int env_variant = [] { const char* e = getenv("JATTS_CONV_EMUL16_VARIANT"); return e ? atoi(e) : 0; }();
+  const int variant = env_variant ? env_variant : d.variant;
   if (d.n_in > 1) return launch_conv_emul16<T, 4, 4, 2, 2, 3, 64, 1>(d, s);           // summed inputs (rare): 128 n x 128 t, four waves, one workgroup per CU
   if (d.n_out <= 64) return launch_conv_emul16<T, 2, 2, 2, 2, 1, 64, 2>(d, s);        // 64 n x 64 t, four waves, two workgroups per CU: the HBM-bound last upsampling conv
   const int64_t maxL = (int64_t)d.rg.max_len * d.rg.len_mul;
+  const int64_t t64 = ((maxL + 63) / 64) * d.rg.n_seq;                                // 64-row time tiles of the launch
   const int64_t wgs128 = ((maxL + 127) / 128) * d.rg.n_seq * ((d.n_out + 127) / 128);
-  // 128 n x 64 t, four waves side by side in n (32 n x 64 t each), two workgroups per CU: k = 1, and launches that cannot give every CU a 128 x 128 workgroup.
-  // (k = 1, round 6 -- profiles/r06_conv16_diag.txt, r06_conv16_trace.txt: with every non-MFMA piece compiled out the tile runs at 230 - 240 TFLOP/s, 0.9 of
-  //  the LDS-fed ceiling; the pieces ADD instead of overlapping -- activation loads + split 23 %, weight / B refills 17 %, epilogue 10 % -- and the shader
-  //  clock sits at 1.36 - 1.5 GHz against 1.85 in the MFMA-only probe: 8 - 9 TB/s of L2 -> CU operand traffic (weights 128 n x c_in x 6 B per 64 columns,
-  //  x re-read per n tile) is what the power budget goes to.  The eight-wave 128 x 128 tile halves the weight traffic (1.56 - 1.76 GHz) but converts with the
-  //  pipe idle; the anti-phase staging below gives it +3 - 5 % at k = 1, still behind this tile.)
-  // 256 n x 64 t, eight waves side by side in n, one workgroup per CU (round 6, late): a staged x chunk serves twice the output channels -- half the activation
-  // loads, split arithmetic and LDS writes per MFMA, the piece the k = 1 DIAG table prices highest -- for n_out in whole 256s and launches of at least one
-  // round of such workgroups: +2 - 6 % on the 512 / 1024 / 1536 / 2048-wide shapes at k = 1 and k = 3, +15 % on 2048 -> 512 (profiles/r06_conv16_wide_tiles.txt);
-  // a 384-wide output would leave a quarter of the second tile idle (-16 .. -21 %).
-  const int64_t wgs256 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 256);
-  // ... and 384 n x 64 t (eight waves of 3 x 4 fragments, a ONE-step weight ring to stay inside 256 registers) where n_out is whole 384s -- the FastSpeech2
-  // widths: a 1536 -> 384 conv stages its input once instead of three times.  384 -> 384 k1 119 -> 142, 1536 -> 384 k3 174 -> 200, 384 -> 1536 k3 184 -> 194 TFLOP/s
-  // (profiles/r06_conv16_384_tile.txt); launches of fewer than 256 such workgroups lose 13 - 15 % and keep the smaller tiles.
-  const int64_t wgs384 = ((maxL + 63) / 64) * d.rg.n_seq * (d.n_out / 384);
-  // (a two-output launch -- Q | K | V -- splits between workgroups: n_split must be a whole number of tiles; jatts_conv1d checks whole 256s)
-  if (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && wgs384 >= 256 && d.n_split % 384 == 0)) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
-  if (variant == 7) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);  // (A/B) the 256-wide tile with the one-step ring
-  // (measured and dropped: 192 n x 64 t, four waves of 3 x 4 fragments, two workgroups per CU -- +6 % on 1536 -> 384 k3 at 8 192 rows, +13 % on 192 -> 768, -2 .. -35 %
-  //  elsewhere: profiles/r06_conv16_192_tile.txt)
-  if (variant == 8) return launch_conv_emul16<T, 2, 2, 2, 1, 1, 64, 3>(d, s);         // (A/B) 64 n x 32 t, two waves, three workgroups per CU: one-utterance launches
-  if (variant == 3 || (variant == 0 && d.n_out % 256 == 0 && wgs256 >= 256)) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1>(d, s);
-  // one-utterance launches (the B = 1 drop-in path: 768 rows): even the 128 n x 64 t tile leaves most CUs idle -- 36 workgroups for a 1536 -> 384 conv, each walking
-  // 144 K-steps.  128 n x 32 t (four waves of 2 x 2 fragments, two workgroups per CU) when the 64-row tiling gives at most one workgroup per CU:
-  // 1536 -> 384 k3 110 -> 67 us, 384 -> 1536 k3 35 -> 29 us, 384 -> 384 k1 16 -> 12 us (profiles/r06_conv16_b1_tiles.txt)
-  const int64_t wgs64 = ((maxL + 63) / 64) * d.rg.n_seq * ((d.n_out + 127) / 128);
-  if (variant == 9 || (variant == 0 && wgs64 <= 256)) return launch_conv_emul16<T, 2, 2, 4, 1, 1, 64, 2>(d, s);
+  // WIDE tiles (round 6, late).  Staging -- the activation loads, the split arithmetic, the LDS writes -- is paid per n tile and is the piece the k = 1 DIAG
+  // table prices highest (profiles/r06_conv16_diag.txt: with every non-MFMA piece compiled out the 128 x 64 tile runs at 230 - 240 TFLOP/s, 0.9 of the LDS-fed
+  // ceiling; staging +23 %, weight / B refills +17 %, epilogue +10 % ADD instead of overlapping, and the clock sits at 1.36 - 1.5 GHz against 1.85 in the probe).
+  // A staged x chunk that serves 384 / 256 output channels halves / thirds it: 384 -> 384 k1 119 -> 142, 1536 -> 384 k3 174 -> 200 (its input staged once
+  // instead of three times), 384 -> 1536 k3 184 -> 194, 2048 -> 512 k1 127 -> 146 TFLOP/s (profiles/r06_conv16_384_tile.txt, r06_conv16_wide_tiles.txt).
+  // Conditions: n_out in whole tiles (a 384-wide output on 256-wide tiles leaves a quarter of the second one idle: -16 .. -21 %), at least one round of such
+  // workgroups (fewer lose 13 - 15 %), and -- a two-output Q | K | V launch splits between workgroups -- n_split in whole tiles (jatts_conv1d checks whole 256s).
+  const bool ok384 = d.n_split % 384 == 0;
+  if (ok384 && (variant == 6 || (variant == 0 && d.n_out % 384 == 0 && t64 * (d.n_out / 384) >= 256))) return launch_conv_emul16<T, 3, 4, 8, 1, 1, 64, 1, 32, 1>(d, s);
+  if (variant == 3 || (variant == 0 && d.n_out % 256 == 0 && t64 * (d.n_out / 256) >= 256)) return launch_conv_emul16<T, 2, 4, 8, 1, 1, 64, 1>(d, s);
+  // (measured and dropped, evidence under profiles/: 192 n x 64 t two workgroups per CU -- r06_conv16_192_tile.txt; 512 n x 32 t -- r06_conv16_512_tile.txt: twice
+  //  the weight bytes per MFMA cost what half the staging saved; the 256-wide tile with the one-step ring: +-2 %; four-wave tiles of 4 x 4 fragments, one wave per
+  //  SIMD, 256 n x 64 t and 128 n x 128 t: -8 .. -25 % -- r06_conv16_wide_tiles.txt; 64 n x 32 t for one utterance: behind 128 n x 32 t -- r06_conv16_b1_tiles.txt)
+  // ONE-UTTERANCE launches (the B = 1 drop-in path: 768 rows): even the 128 n x 64 t tile leaves most CUs idle -- 36 workgroups for a 1536 -> 384 conv, each
+  // walking 144 K-steps.  128 n x 32 t when the 64-row tiling gives at most one workgroup per CU: 1536 -> 384 k3 110 -> 67 us, 384 -> 1536 k3 35 -> 29 us,
+  // 384 -> 384 k1 16 -> 12 us; b1_latency 8.6 -> 7.55 ms (profiles/r06_conv16_b1_tiles.txt)
+  if (variant == 9 || (variant == 0 && t64 * ((d.n_out + 127) / 128) <= 256)) return launch_conv_emul16<T, 2, 2, 4, 1, 1, 64, 2>(d, s);
+  // 128 n x 64 t, two workgroups per CU: k = 1 (the eight-wave 128 x 128 tile halves the weight traffic -- 1.56 - 1.76 GHz -- but converts with the pipe idle; the
+  // anti-phase staging gives it +3 - 5 % at k = 1, still behind this tile), and launches that cannot give every CU a 128 x 128 workgroup
   if (variant == 1 || (variant == 0 && (d.k_w == 1 || wgs128 <= 128))) return launch_conv_emul16<T, 2, 4, 4, 1, 1, 64, 2>(d, s);
-  if (variant == 4) return launch_conv_emul16<T, 4, 4, 4, 1, 1, 64, 1>(d, s);         // (A/B) 256 n x 64 t, four waves of 4 x 4 fragments
-  if (variant == 5) return launch_conv_emul16<T, 4, 4, 2, 2, 1, 64, 1>(d, s);         // (A/B) 128 n x 128 t, four waves of 4 x 4 fragments
   return launch_conv_emul16<T, 2, 4, 4, 2, 1, 64, 1>(d, s);                           // 128 n x 128 t, eight waves, one workgroup per CU
 }
 

@@ -88,6 +88,48 @@ EMUL_CONV_CASES = [
 ]
 
 
+TILE_CASES = [   # (c_in, n_out, k, dil, lens, act, resid): shapes that reach every tile rule of csrc/conv1d_emul.hip: conv1d_emul16
+    (384, 384, 1, 1, [768] * 6 + [700, 31], None, True),
+    (384, 1536, 3, 1, [768] * 8, "relu", False),
+    (1536, 384, 3, 1, [768] * 6 + [5, 767], None, True),
+    (512, 2048, 1, 1, [300, 768, 768, 64], None, False),
+    (192, 200, 5, 2, [130, 1, 77], "tanh", False),          # n_out in no tile's whole multiples: partial last tiles everywhere
+    (384, 768, 1, 1, [768], None, False),                    # one utterance
+]
+
+
+@pytest.mark.parametrize("np_", ["7", "6"])
+@pytest.mark.parametrize("case", TILE_CASES, ids=[f"{c[0]}-{c[1]}-k{c[2]}-{len(c[4])}seq" for c in TILE_CASES])
+def test_conv1d_emul16_tiles_agree(cuda, lib, case, np_):
+    """The product form of the emulated conv picks its tile by the launch (384 / 256 / 128 output channels x 128 / 64 / 32 time steps, round 6) on the promise
+    that a row's bits do not depend on it: every tile walks the contraction in the same 64-channel chunks and K-step order.  Each tile forced through
+    jatts_conv_desc.variant gives the SAME bits as the library's own choice -- and so do a sequence alone and inside the batch, whatever tiles the two launches take."""
+    from jatts_amd import hip
+    code = getattr(hip, CODES[np_])
+    c_in, n_out, k, dil, lens, act, resid = case
+    g = torch.Generator().manual_seed(c_in * 7 + n_out + k)
+    R = sum(lens)
+    x = torch.randn(R, c_in, generator=g).to(cuda)
+    w = (torch.randn(n_out, c_in, k, generator=g) / math.sqrt(c_in * k)).to(cuda)
+    b = (torch.randn(n_out, generator=g) * 0.1).to(cuda)
+    res = torch.randn(R, n_out, generator=g).to(cuda) if resid else None
+    wp = hip.pack_conv_weight_bf16x3_k32(w, 64)
+    rb = _ragged(lens, cuda)
+    kw = dict(dil=dil, bias=b, act={"relu": hip.ACT_RELU, "tanh": hip.ACT_TANH, None: hip.ACT_NONE}[act], out_f32=True, w_layout=1)
+    run = lambda v, rb_=rb, x_=x, r_=res: hip.conv1d(rb_, x_, wp, c_in, n_out, k, dtype=code, variant=v, resid=r_, **kw)  # noqa: E731
+    y0 = run(0)
+    pad = (k - 1) // 2 * dil
+    ref = _ref_conv(x.cpu(), w.cpu(), b.cpu(), lens, dil, pad, k, None, act) + (res.double().cpu() if res is not None else 0)
+    assert relerr(y0, ref) <= TOL["fp32"]
+    for v in (6, 3, 2, 1, 9):
+        assert torch.equal(run(v), y0), f"tile variant {v} differs from the library's choice on {case[:4]}"
+    o = 0
+    for T in lens[:3]:
+        ya = run(0, _ragged([T], cuda), x[o:o + T].contiguous(), None if res is None else res[o:o + T].contiguous())
+        assert torch.equal(ya, y0[o:o + T])
+        o += T
+
+
 @pytest.mark.parametrize("layout", [0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
 @pytest.mark.parametrize("np_", ["7", "6"])
 @pytest.mark.parametrize("xkind", ["unit", "wide", "single"])
