@@ -10,6 +10,7 @@
 //    its last MFMA; ONE set of B fragments, the last fragment group of a step refilling them column pair by column pair (resunit_emul16_impl.h: step16);
 //  * epilogues on the 16 x 16 C / D layout (column = lane & 15, channels 4 (lane >> 4) + {0..3} of the fragment).
 #pragma once
+#include <stdlib.h>
 #include "conv1d_emul.h"
 #include "resunit_emul16_impl.h"
 
@@ -400,7 +401,12 @@ int launch_conv_emul16(const jatts_conv_desc& d, hipStream_t s) {
   const size_t rows = (size_t)BT + (size_t)(d.k_w - 1) * d.dil;
   size_t lds = 2 * rows * (KCHT * 6 + 16);
   int f32_tile = 0;
-  if (!d.y_transposed && (size_t)BT * (BN * 4 + 16) <= 159 * 1024) {     // the coalesced f32 output tile reuses the staging buffers
+  // Row-major outputs WITH a residual go through an f32 tile in LDS (row-contiguous residual reads and stores); without one the accumulators are stored
+  // directly -- a lane's four channels are 16 bytes, a fragment row 64: +2 - 5 % on the wide no-residual shapes, -1 .. -3 % with a residual
+  // (profiles/r06_conv16_direct_epilogue.txt; JATTS_CONV_EMUL16_DIRECT_EPI = 1 / 0 forces one path for A/B).  Same values either way.
+  static const int epi_env = [] { const char* e = getenv("JATTS_CONV_EMUL16_DIRECT_EPI"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool direct_epi = epi_env >= 0 ? epi_env == 1 : d.resid == nullptr;
+  if (!direct_epi && !d.y_transposed && (size_t)BT * (BN * 4 + 16) <= 159 * 1024) {     // the coalesced f32 output tile reuses the staging buffers
     f32_tile = 1;
     if (lds < (size_t)BT * (BN * 4 + 16)) lds = (size_t)BT * (BN * 4 + 16);
   }
