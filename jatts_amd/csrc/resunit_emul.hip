@@ -53,14 +53,12 @@ static int resunit_emul(const jatts_resunit_desc& d, hipStream_t s) {
 template <typename T>
 static int resunit_emul16(const jatts_resunit_desc& d, hipStream_t s) {
   const int halo = (d.k_w - 1) * d.dil;
-  static const int c64_wide_k = [] { const char* e = getenv("JATTS_UNIT16_C64_WIDE_K"); return e ? atoi(e) : 11; }();   // (A/B) smallest k of the one-workgroup-per-CU C = 64 unit
-  static const bool c32_wide = [] { const char* e = getenv("JATTS_UNIT16_C32_WIDE"); return e && atoi(e) != 0; }();
   switch (d.channels) {
-    case 32:
-      if (c32_wide) return launch_resunit_emul16<T, 32, 512, 1, 4, 1, false, true>(d, s);   // (A/B) 512-column windows, 2 x 8 fragments per wave, one workgroup per CU
-      return launch_resunit_emul16<T, 32, 256, 1, 4, 2, false, true>(d, s);
+    // (round 6, measured and dropped -- profiles/r06_unit16_c64_c32_wide.txt: C = 32 with 512-column windows, one workgroup per CU: 9 - 22 % slower; the
+    //  one-workgroup-per-CU C = 64 unit at k = 3 / 7: 10 - 12 % / 4 % slower.  Small-channel units live on the second resident workgroup.)
+    case 32: return launch_resunit_emul16<T, 32, 256, 1, 4, 2, false, true>(d, s);
     case 64:
-      if (d.k_w >= c64_wide_k) return launch_resunit_emul16<T, 64, 256, 1, 4, 1, false, true>(d, s);
+      if (d.k_w >= 11) return launch_resunit_emul16<T, 64, 256, 1, 4, 1, false, true>(d, s);
       return launch_resunit_emul16<T, 64, 128, 2, 2, 2, false, true>(d, s);
     case 128: return launch_resunit_emul16<T, 128, 128, 2, 2, 1>(d, s);
     case 256:
